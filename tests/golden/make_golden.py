@@ -1,0 +1,323 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors (G1-G7) by IMPORTING the reference on CPU.
+
+Run in the build container only (the reference does not exist on the GPU box):
+
+    python tests/golden/make_golden.py            # writes tests/golden/*.npz
+
+Only inputs' seeds and the reference's OUTPUTS are stored; weights and batches are
+re-created on any machine by ``onda_amd.synthetic``.  Three shims let the reference
+import here: stub ``wandb`` / ``addict`` modules (tests/golden/_stubs, own code) and a
+``yaml.load`` wrapper that supplies the Loader PyYAML >= 6 requires.
+"""
+import json
+import os
+import sys
+import tempfile
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = os.environ.get("ONDA_REFERENCE", "/root/reference")
+sys.path[:0] = [REF, os.path.join(HERE, "_stubs"), ROOT]
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import yaml  # noqa: E402
+
+_yaml_load = yaml.load
+yaml.load = lambda f, Loader=None: _yaml_load(f, Loader=Loader or yaml.SafeLoader)
+
+from addict import Dict  # noqa: E402  (stub)
+from framework.model.deeplabv2 import get_deeplab_v2  # noqa: E402
+from framework.domain_adaptation.methods.prototype_handler import prototype_handler  # noqa: E402
+from framework.domain_adaptation.methods.prototypes import regular_loss  # noqa: E402
+from framework.domain_adaptation.methods.prototypes_hybrid_switch import hybrid_proDA, model_select  # noqa: E402
+from framework.domain_adaptation.methods.adaptation_model import switch_batch_statistics  # noqa: E402
+from framework.utils.func import loss_calc  # noqa: E402
+from framework.utils.loss import rce  # noqa: E402
+from framework.utils.monitoring import Monitor  # noqa: E402
+
+from onda_amd.synthetic import fill_state_dict, synth_batch, synth_prototypes  # noqa: E402
+
+torch.set_num_threads(8)
+
+
+def save(name, **arrays):
+    out = {}
+    for k, v in arrays.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = v
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print("wrote", name, {k: getattr(v, "shape", None) for k, v in out.items()})
+
+
+def ref_model(seed, head_scale):
+    m = get_deeplab_v2(num_classes=19, multi_level=True, layers=[3, 4, 6, 3], classifier="ProDA")
+    m.multi_level = False  # model_handler.py:58 with MODEL.MULTI_LEVEL False
+    fill_state_dict(m, seed, head_scale)
+    return m
+
+
+def digest(t, n=256):
+    """(sum, abs-sum, strided sample) of a tensor: pins big tensors in little space."""
+    f = t.detach().double().reshape(-1)
+    idx = (torch.arange(n, dtype=torch.int64) * f.numel()) // n
+    return np.concatenate([[f.sum().item(), f.abs().sum().item()], f[idx].numpy()])
+
+
+def interp_argmax(out, size):
+    up = torch.nn.Upsample(size=size, mode="bilinear", align_corners=True)(out)  # adaptation_model.py:94-98
+    return up, up.softmax(axis=1).argmax(dim=1)  # :145,153
+
+
+# ------------------------------------------------------------------------------------- G1
+def g1():
+    m = ref_model(1, 3.0).eval()
+    b = synth_batch(2, 64, 128, seed=7)
+    with torch.no_grad():
+        _, o = m(b["image"])
+        up, amap = interp_argmax(o["out"], (64, 128))
+    save("g1_eval_small", feat=o["feat"], out=o["out"], up=up, argmax=amap.to(torch.uint8))
+    b = synth_batch(1, 512, 1024, seed=8)
+    with torch.no_grad():
+        _, o = m(b["image"])
+        up, amap = interp_argmax(o["out"], (512, 1024))
+    top2 = up.topk(2, dim=1)[0]
+    margin = (top2[:, 0] - top2[:, 1])
+    save("g1_eval_large", out=o["out"], feat_digest=digest(o["feat"], 4096), argmax=amap.to(torch.uint8),
+         margin_f16=margin.to(torch.float16))
+
+
+# ------------------------------------------------------------------------------------- G2
+def g2():
+    b = synth_batch(2, 64, 128, seed=7)
+    res = {}
+    for track in (True, False):
+        m = ref_model(1, 3.0).train()
+        switch_batch_statistics(m, track)
+        torch.manual_seed(2024)
+        _, o = m(b["image"])
+        loss = loss_calc(o["out"], b["label_res"], "cpu")
+        loss.backward()
+        tag = "track" if track else "frozen"
+        res[f"{tag}_out"], res[f"{tag}_feat"], res[f"{tag}_loss"] = o["out"], o["feat"], loss
+        sd = m.state_dict()
+        for k in ("bn1", "layer1.0.bn1", "layer2.0.downsample.1", "layer3.2.bn2", "layer4.2.bn3"):
+            res[f"{tag}_{k}.running_mean"] = sd[k + ".running_mean"]
+            res[f"{tag}_{k}.running_var"] = sd[k + ".running_var"]
+            res[f"{tag}_{k}.num_batches_tracked"] = sd[k + ".num_batches_tracked"]
+        if track:
+            names, dig = [], []
+            for n, p in m.named_parameters():
+                if p.grad is not None:
+                    names.append(n)
+                    dig.append(digest(p.grad))
+            res["grad_names"] = np.array(names)
+            res["grad_digest"] = np.stack(dig)
+            res["grad_layer6.head.1.weight"] = dict(m.named_parameters())["layer6.head.1.weight"].grad
+            res["grad_layer6.bottleneck.2.weight"] = dict(m.named_parameters())["layer6.bottleneck.2.weight"].grad
+            res["grad_layer6.conv2d_list.0.0.bias"] = dict(m.named_parameters())["layer6.conv2d_list.0.0.bias"].grad
+            res["grad_conv1.weight"] = m.conv1.weight.grad
+    torch.manual_seed(2024)
+    mask = torch.empty(2, 256, 1, 1).bernoulli_(0.9).div_(0.9)
+    res["drop_mask"] = mask
+    save("g2_train_small", **res)
+
+
+# ------------------------------------------------------------------------------------- G3
+def g3():
+    g = torch.Generator().manual_seed(31)
+    res = {}
+    for case, frac in (("mixed", 0.3), ("none_ignored", 0.0), ("all_ignored", 1.0)):
+        logits = (3 * torch.randn(2, 19, 9, 17, generator=g)).requires_grad_(True)
+        target = torch.randint(0, 19, (2, 9, 17), generator=g)
+        target[torch.rand(2, 9, 17, generator=g) < frac] = 255
+        ce = loss_calc(logits, target, "cpu")
+        r = rce(logits, target, "cpu")
+        reg = regular_loss("MRKLD", logits)
+        res[f"{case}_logits"], res[f"{case}_target"] = logits, target
+        res[f"{case}_ce"], res[f"{case}_rce"], res[f"{case}_mrkld"] = ce, r, reg
+        if case != "all_ignored":
+            total = 0.1 * ce + 1.0 * r + 0.1 * reg
+            res[f"{case}_grad"] = torch.autograd.grad(total, logits)[0]
+            res[f"{case}_grad_ce"] = torch.autograd.grad(loss_calc(logits, target, "cpu"), logits)[0]
+    save("g3_losses", **res)
+
+
+# ------------------------------------------------------------------------------------- G4
+def g4():
+    g = torch.Generator().manual_seed(41)
+    res = {}
+    proto, sq, cnt = synth_prototypes()
+    # regime "far": features sit near one prototype each; regime "near": prototypes close
+    # together so that the prior and the threshold decide
+    base = torch.randn(1, 256, generator=g)
+    proto_near = base + 0.15 * torch.randn(19, 256, generator=g)
+    sq_near = proto_near ** 2 + (0.5 + torch.rand(19, 256, generator=g)) ** 2
+    for regime, (P, S) in (("far", (proto, sq)), ("near", (proto_near, sq_near))):
+        cls = torch.randint(0, 19, (2 * 9 * 17,), generator=g)
+        feat_rows = P[cls] + 0.7 * torch.randn(cls.numel(), 256, generator=g)
+        feat = feat_rows.reshape(2, 9, 17, 256).permute(0, 3, 1, 2).contiguous()
+        prior = (2 * torch.randn(2, 19, 9, 17, generator=g)).softmax(1)
+        out = torch.randn(2, 19, 9, 17, generator=g)
+        res[f"{regime}_proto"], res[f"{regime}_sqmean"], res[f"{regime}_counter"] = P, S, cnt
+        res[f"{regime}_feat"], res[f"{regime}_prior"], res[f"{regime}_out"] = feat, prior, out
+        for metric in ("mahalanobis", "euclidean"):
+            for tau in (1, 2):
+                for thresh in (0, 0.3):
+                    h = prototype_handler(0.9995, tau, thresh, metric)
+                    h.prototypes, h.squared_mean, h.counter = P.clone(), S.clone(), cnt.clone()
+                    tag = f"{regime}_{metric}_t{tau}_th{thresh}"
+                    res[tag + "_labels"] = h.pseudo_labels(feat, prior)
+                    res[tag + "_soft"] = h.pseudo_labels(feat, prior, soft=True)
+        h = prototype_handler(0.9995, 1, 0.3, "mahalanobis")
+        h.prototypes, h.squared_mean, h.counter = P.clone(), S.clone(), cnt.clone()
+        res[f"{regime}_global_var"] = h.global_var()
+        h.ma(feat, out)
+        res[f"{regime}_ma_proto"], res[f"{regime}_ma_sqmean"] = h.prototypes, h.squared_mean
+        h2 = prototype_handler(0.9995, 1, 0.3, "mahalanobis")
+        h2.append(feat, out)
+        h2.append(feat * 0.5 + 0.1, out.flip(0))
+        res[f"{regime}_append_proto"], res[f"{regime}_append_sqmean"], res[f"{regime}_append_counter"] = \
+            h2.prototypes, h2.squared_mean, h2.counter
+    save("g4_prototypes", **res)
+
+
+# ------------------------------------------------------------------------------------- G5
+def g5():
+    rng = np.random.RandomState(5)
+    n = 520
+    t = np.arange(n)
+    seq = 0.865 + 0.05 * np.sin(t / 60.0) + 0.004 * rng.randn(n)
+    mon = Monitor(200, 0.003, "hamming")
+    sel = model_select(model_select.static, [0.83, 0.9], 0.0002)
+    avg, exp, dev, cur = [], [], [], []
+    for v in seq:
+        mon.add({"prior static": float(v)})
+        a, d = mon.avg("prior static"), mon.dev_avg("prior static")
+        sel.evaluate(a, d)
+        avg.append(a); exp.append(mon.exp("prior static")); dev.append(d); cur.append(sel.current)
+    save("g5_switch", seq=seq, avg=np.array(avg), exp=np.array(exp), dev=np.array(dev, dtype=np.float64),
+         current=np.array(cur, dtype=np.int64), missing_avg=np.array(mon.avg("nope")), missing_dev=np.array(mon.dev_avg("nope")))
+
+
+# ------------------------------------------------------------------------------------- G6
+def g6():
+    g = torch.Generator().manual_seed(61)
+    w3 = torch.nn.Parameter(torch.randn(5, 4, generator=g))
+    w4 = torch.nn.Parameter(torch.randn(7, generator=g))
+    w1 = torch.nn.Parameter(torch.randn(3, 3, generator=g))
+    h1 = torch.nn.Parameter(torch.randn(6, generator=g))
+    init = [p.detach().clone() for p in (w3, w4, w1, h1)]
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        opt = torch.optim.SGD([{"params": [w3, w4, w1, w3, w4, w3, w4, w4], "lr": 8e-4},
+                               {"params": [h1], "lr": 1e-4}], lr=1e-5, momentum=0.9, weight_decay=1e-4, foreach=False)
+    grads, traj = [], []
+    for _ in range(3):
+        gs = [torch.randn(p.shape, generator=g) for p in (w3, w4, w1, h1)]
+        for p, gr in zip((w3, w4, w1, h1), gs):
+            p.grad = gr.clone()
+        opt.step()
+        grads.append(gs)
+        traj.append([p.detach().clone() for p in (w3, w4, w1, h1)])
+    res = {}
+    for i, n in enumerate(("w3", "w4", "w1", "h1")):
+        res[n + "_init"] = init[i]
+        for s in range(3):
+            res[f"{n}_grad{s}"], res[f"{n}_after{s}"] = grads[s][i], traj[s][i]
+    # multiplicity pattern of the reference's own parameter groups
+    m = ref_model(1, 1.0)
+    name_of = {id(p): n for n, p in m.named_parameters()}
+    groups = m.optim_parameters(1.0)
+    c0 = {}
+    for p in groups[0]["params"]:
+        c0[name_of[id(p)]] = c0.get(name_of[id(p)], 0) + 1
+    g1names = [name_of[id(p)] for p in groups[1]["params"]]
+    res["group0_json"] = np.array(json.dumps(c0))
+    res["group1_json"] = np.array(json.dumps(g1names))
+    save("g6_optimizer", **res)
+
+
+# ------------------------------------------------------------------------------------- G7
+def make_cfg(tmp):
+    from framework.domain_adaptation import config_ouda
+    cwd = os.getcwd()
+    os.chdir(REF)
+    try:
+        y = Dict(yaml.load(open("configs/hybrid_switch.yml")))
+    finally:
+        os.chdir(cwd)
+    cfg = Dict()
+    cfg.SCHEME.RESOLUTION = [128, 64]
+    cfg.MODEL.LR_RATIO = "80:10"
+    cfg.MODEL.MULTI_LEVEL = False
+    cfg.TRAINING.REPLAY_BUFFER = 1000
+    cfg.TRAINING.BATCH_SIZE = 2
+    cfg.TRAINING.BUFFER_DYNAMIC = False
+    cfg.OTHERS.DEVICE = "cpu"
+    cfg.OTHERS.SNAPSHOT_DIR = tmp
+    cfg.OTHERS.ECE_SKIP = True
+    cfg.NUM_CLASSES = 19
+    spec = y.METHOD.ADAPTATION.PROTO_ONLINE_HYBRIDSWITCH
+    spec.LOAD_PROTO = None
+    spec.set_ = (25,)
+    return cfg, spec
+
+
+def tolog(d):
+    out = {}
+    for k, v in d.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().double().item() if v.numel() == 1 else v.detach().numpy()
+        out[k] = float(v) if np.isscalar(v) else v
+    return out
+
+
+def g7():
+    for tag, head_scale in (("static", 40.0), ("dynamic", 3.0)):
+        with tempfile.TemporaryDirectory() as tmp:
+            cfg, spec = make_cfg(tmp)
+            model = ref_model(1, head_scale)
+            da = hybrid_proDA(model, cfg, spec)
+            src = [synth_batch(2, 64, 128, seed=100 + i) for i in range(2)]
+            trg = [synth_batch(2, 64, 128, seed=200 + i) for i in range(2)]
+            torch.manual_seed(123)
+            da.update_dynamic()
+            switch_batch_statistics(da.model, False)
+            da.calculate_prototypes(src)
+            switch_batch_statistics(da.model, True)
+            res = {"proto0": da.prototypes.prototypes.clone(), "sqmean0": da.prototypes.squared_mean.clone(),
+                   "counter0": da.prototypes.counter.clone()}
+            da.optimizer.zero_grad()
+            import warnings
+            for s in range(2):
+                da.adjust_learning_rate(s, 6)
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    log = da.step([src[s]], trg[s])
+                da.update_ema()
+                lg = tolog(log)
+                res[f"log{s}_json"] = np.array(json.dumps({k: v for k, v in lg.items() if np.isscalar(v)}))
+                res[f"labels{s}"] = trg[s]["stored_predictions"].argmax(1).to(torch.uint8)
+                res[f"soft{s}"] = trg[s]["stored_predictions"].to(torch.float32)
+                res[f"proto{s + 1}"] = da.prototypes.prototypes.clone()
+                res[f"sqmean{s + 1}"] = da.prototypes.squared_mean.clone()
+                res[f"branch{s}"] = np.array(da.model_select.current)
+                names, dig = [], []
+                for (n, p) in da.model.state_dict().items():
+                    names.append("student." + n); dig.append(digest(p.float(), 64))
+                for (n, p) in da.ema_model.state_dict().items():
+                    names.append("teacher." + n); dig.append(digest(p.float(), 64))
+                res[f"state_names{s}"] = np.array(names)
+                res[f"state_digest{s}"] = np.stack(dig)
+            save(f"g7_step_{tag}", **res)
+            print(tag, "branch", res["branch0"], res["branch1"], json.loads(str(res["log1_json"]))["pseudolabel_pixel_num"])
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7"]
+    for w in which:
+        globals()[w]()

@@ -1,0 +1,185 @@
+"""CPU: the oracle restatement against the golden vectors captured from the reference
+(tests/golden/make_golden.py).  This is what pins the oracle."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import digest
+from oracle import losses, model, monitor, optim, prototypes
+from oracle.step import OracleAdapter
+from onda_amd.synthetic import synth_batch, synth_tensor
+
+torch.set_num_threads(8)
+
+
+def oracle_sd(seed, head_scale):
+    """state_dict of the reference architecture without instantiating the reference: the
+    key/shape list is part of the oracle (oracle.model.state_spec)."""
+    return {k: synth_tensor(k, torch.empty(shape, dtype=dt), seed, head_scale).to(dt)
+            for k, shape, dt in model.state_spec()}
+
+
+def test_state_spec_counts():
+    spec = model.state_spec()
+    assert len(spec) == 376
+    assert sum(1 for k, _, _ in spec if "running_" in k or k.endswith("tracked")) == 159
+
+
+def test_g1_eval_small(golden):
+    g = golden("g1_eval_small")
+    sd = oracle_sd(1, 3.0)
+    x = synth_batch(2, 64, 128, seed=7)["image"]
+    with torch.no_grad():
+        _, o = model.forward(x, sd, model.BNMode(False))
+        up, amap = model.upsample_argmax(o["out"], (64, 128))
+    np.testing.assert_allclose(o["feat"].numpy(), g["feat"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(o["out"].numpy(), g["out"], rtol=0, atol=2e-5)
+    assert np.array_equal(amap.numpy().astype(np.uint8), g["argmax"])
+
+
+def test_g2_train_small(golden):
+    g = golden("g2_train_small")
+    x = synth_batch(2, 64, 128, seed=7)
+    mask = torch.from_numpy(g["drop_mask"])
+    torch.manual_seed(2024)
+    assert torch.equal(model.draw_drop_mask(2), mask)
+    for track, tag in ((True, "track"), (False, "frozen")):
+        sd = oracle_sd(1, 3.0)
+        names = [k for k, v in sd.items() if v.dim() > 0 and "running" not in k and not _is_bn_affine(k)]
+        for k in names:
+            sd[k].requires_grad_(True)
+        _, o = model.forward(x["image"], sd, model.BNMode(True, track, 0.1), mask)
+        loss = losses.ce_hard(o["out"], x["label_res"])
+        scale = np.abs(g[f"{tag}_out"]).max()
+        assert np.abs(o["out"].detach().numpy() - g[f"{tag}_out"]).max() <= 1e-3 * scale
+        assert abs(loss.item() - g[f"{tag}_loss"]) <= 1e-4 * abs(g[f"{tag}_loss"])
+        for k in ("bn1", "layer1.0.bn1", "layer2.0.downsample.1", "layer3.2.bn2", "layer4.2.bn3"):
+            np.testing.assert_allclose(sd[k + ".running_mean"].numpy(), g[f"{tag}_{k}.running_mean"], rtol=1e-3, atol=1e-5)
+            np.testing.assert_allclose(sd[k + ".running_var"].numpy(), g[f"{tag}_{k}.running_var"], rtol=1e-3, atol=1e-5)
+            assert int(sd[k + ".num_batches_tracked"]) == int(g[f"{tag}_{k}.num_batches_tracked"])
+        if track:
+            gnames = [n for n in g["grad_names"]]
+            grads = torch.autograd.grad(loss, [sd[n] for n in gnames])
+            for n, gr, dg in zip(gnames, grads, g["grad_digest"]):
+                mine = digest(gr)
+                ref_scale = max(np.abs(dg[2:]).max(), 1e-12)
+                assert np.abs(mine[2:] - dg[2:]).max() <= 2e-2 * ref_scale + 1e-7, n
+                assert abs(mine[1] - dg[1]) <= 1e-2 * dg[1] + 1e-7, n
+
+
+def _is_bn_affine(k):
+    return ".bn" in k or k.startswith("bn1.") or ".downsample.1." in k
+
+
+@pytest.mark.parametrize("case", ["mixed", "none_ignored", "all_ignored"])
+def test_g3_losses(golden, case):
+    g = golden("g3_losses")
+    logits = torch.from_numpy(g[f"{case}_logits"]).requires_grad_(True)
+    target = torch.from_numpy(g[f"{case}_target"])
+    ce, r, reg = losses.ce_hard(logits, target), losses.rce_hard(logits, target), losses.mrkld(logits)
+    if case == "all_ignored":
+        assert np.isnan(g["all_ignored_ce"]) and torch.isnan(ce)
+    else:
+        np.testing.assert_allclose(ce.item(), g[f"{case}_ce"], rtol=1e-6)
+        total = losses.target_loss(logits, target)["Total target loss"]
+        grad = torch.autograd.grad(total, logits)[0]
+        np.testing.assert_allclose(grad.numpy(), g[f"{case}_grad"], rtol=1e-4, atol=1e-8)
+    np.testing.assert_allclose(r.item(), g[f"{case}_rce"], rtol=1e-6)
+    np.testing.assert_allclose(reg.item(), g[f"{case}_mrkld"], rtol=1e-6)
+
+
+@pytest.mark.parametrize("regime", ["far", "near"])
+def test_g4_prototypes(golden, regime):
+    g = golden("g4_prototypes")
+    t = lambda k: torch.from_numpy(g[f"{regime}_{k}"])
+    state = (t("proto"), t("sqmean"), t("counter"))
+    feat, prior, out = t("feat"), t("prior"), t("out")
+    np.testing.assert_allclose(prototypes.global_std(state).numpy(), g[f"{regime}_global_var"], rtol=1e-6)
+    for metric in ("mahalanobis", "euclidean"):
+        for tau in (1, 2):
+            for th in (0, 0.3):
+                labels, soft, _ = prototypes.assign(feat, prior, state, tau, th, metric)
+                tag = f"{regime}_{metric}_t{tau}_th{th}"
+                assert np.array_equal(labels.numpy(), g[tag + "_labels"]), tag
+                np.testing.assert_allclose(soft.numpy(), g[tag + "_soft"], rtol=1e-5, atol=1e-7)
+    p, s, _ = prototypes.ema_update(state, feat, out, 0.9995)
+    np.testing.assert_allclose(p.numpy(), g[f"{regime}_ma_proto"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(s.numpy(), g[f"{regime}_ma_sqmean"], rtol=1e-6, atol=1e-7)
+    st = prototypes.running_append(None, feat, out)
+    st = prototypes.running_append(st, feat * 0.5 + 0.1, out.flip(0))
+    np.testing.assert_allclose(st[0].numpy(), g[f"{regime}_append_proto"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(st[1].numpy(), g[f"{regime}_append_sqmean"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(st[2].numpy(), g[f"{regime}_append_counter"])
+
+
+def test_g4_bad_metric():
+    with pytest.raises(ValueError):
+        prototypes.distances(torch.zeros(1, 4), (torch.zeros(2, 4),) * 3, "cosine")
+
+
+def test_g5_switch(golden):
+    g = golden("g5_switch")
+    mon = monitor.WindowStats(200, 0.003, "hamming")
+    sel = monitor.SwitchState([0.83, 0.9], 0.0002)
+    for i, v in enumerate(g["seq"]):
+        mon.add({"prior static": float(v)})
+        a, d = mon.avg("prior static"), mon.dev_avg("prior static")
+        sel.evaluate(a, d)
+        assert a == g["avg"][i] and mon.exp("prior static") == g["exp"][i]
+        assert d == g["dev"][i] and sel.current == g["current"][i]
+    assert set(np.unique(g["current"])) == {0, 1}
+    assert mon.avg("nope") == g["missing_avg"] and mon.dev_avg("nope") == g["missing_dev"]
+
+
+def test_g6_optimizer(golden):
+    g = golden("g6_optimizer")
+    for name, times, lr in (("w3", 3, 8e-4), ("w4", 4, 8e-4), ("w1", 1, 8e-4), ("h1", 1, 1e-4)):
+        p, buf = torch.from_numpy(g[name + "_init"]).clone(), None
+        for s in range(3):
+            buf = optim.sgd_apply(p, torch.from_numpy(g[f"{name}_grad{s}"]), buf, lr, times, 0.9, 1e-4, "torch2")
+            np.testing.assert_allclose(p.numpy(), g[f"{name}_after{s}"], rtol=1e-6, atol=1e-7)
+    c0 = json.loads(str(g["group0_json"]))
+    g1 = json.loads(str(g["group1_json"]))
+    names = [k for k, _, _ in model.state_spec()]
+    mine0, mine1 = optim.param_groups(names)
+    assert dict(mine0) == c0 and len(c0) == 53 and sum(c0.values()) == 161
+    assert mine1 == g1 and len(g1) == 29
+
+
+@pytest.mark.parametrize("tag,head_scale", [("static", 40.0), ("dynamic", 3.0)])
+def test_g7_full_step(golden, tag, head_scale):
+    g = golden(f"g7_step_{tag}")
+    sd = oracle_sd(1, head_scale)
+    src = [synth_batch(2, 64, 128, seed=100 + i) for i in range(2)]
+    trg = [synth_batch(2, 64, 128, seed=200 + i) for i in range(2)]
+    torch.manual_seed(123)
+    ad = OracleAdapter(sd, (torch.zeros(19, 256), torch.zeros(19, 256), torch.zeros(19)))
+    ad.refresh_dynamic()
+    ad.proto = ad.initial_prototypes(src)
+    np.testing.assert_allclose(ad.proto[0].numpy(), g["proto0"], rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(ad.proto[2].numpy(), g["counter0"])
+    for s in range(2):
+        masks = tuple(model.draw_drop_mask(2) for _ in range(3))
+        log = ad.step(src[s], trg[s], masks)
+        ad.update_ema()
+        ref = json.loads(str(g[f"log{s}_json"]))
+        assert int(g[f"branch{s}"]) == ad.switch.current
+        labels = ad.last["labels"].reshape(2, 9, 17)
+        kept = labels != 255
+        ref_soft = torch.from_numpy(g[f"soft{s}"])
+        assert (ad.last["soft"].reshape(2, 9, 17, 19).permute(0, 3, 1, 2) - ref_soft).abs().max() < 2e-3
+        assert (labels[kept] == torch.from_numpy(g[f"labels{s}"]).long()[kept]).float().mean() > 0.99
+        for k, v in ref.items():
+            mine = log[k]
+            mine = mine.item() if isinstance(mine, torch.Tensor) else float(mine)
+            assert mine == pytest.approx(v, rel=5e-3, abs=1e-5), (s, k)
+        np.testing.assert_allclose(ad.proto[0].numpy(), g[f"proto{s + 1}"], rtol=1e-3, atol=1e-4)
+        names = list(g[f"state_names{s}"])
+        dg = g[f"state_digest{s}"]
+        for who, state in (("student.", ad.student), ("teacher.", ad.ema)):
+            for k, v in state.items():
+                row = dg[names.index(who + k)]
+                mine = digest(v.float(), 64)
+                assert np.abs(mine[2:] - row[2:]).max() <= 1e-3 * max(np.abs(row[2:]).max(), 1e-6) + 1e-6, (s, who + k)
