@@ -1,0 +1,208 @@
+/*
+ * onda_hip.h -- C ABI of libonda_hip.so, the MI355X (gfx950) kernels behind the OnDA
+ * adaptation hot path.
+ *
+ * The reference (theo2021/OnDA) has no FFI: every entry point below replaces the ATen /
+ * cuDNN work that one of its Python call sites triggers implicitly (file:line cited per
+ * function, relative to the reference root).  Conventions (SURVEY 8b "Error / ownership /
+ * threading"):
+ *   - plain pointers and sizes only; all device buffers, including workspaces, are owned
+ *     by the caller (torch's caching allocator) -- nothing here allocates or frees;
+ *   - every call takes the hipStream_t to launch on, holds no thread-local state and is
+ *     re-entrant (backward runs on torch's autograd thread);
+ *   - return value: 0 on success, a negative ONDA_E* code for bad arguments, a positive
+ *     hipError_t if the launch failed.  The Python wrapper raises RuntimeError on != 0;
+ *   - activations are NHWC ("pixel-major rows": row m = (b*H + h)*W + w holds C channels,
+ *     row stride `ld*` floats), fp32 throughout; labels are int64 with 255 = ignore.
+ */
+#ifndef ONDA_HIP_H
+#define ONDA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* onda_stream_t; /* hipStream_t */
+
+#define ONDA_OK 0
+#define ONDA_EINVAL (-1)  /* unsupported shape / null pointer */
+#define ONDA_EALIGN (-2)  /* pointer or leading dimension not 16-byte aligned */
+
+/* Geometry of one convolution.  Replaces nn.Conv2d as used by
+ * framework/model/deeplabv2.py:22-44 (bottleneck 1x1 / dilated 3x3), :129-184 (ASPP),
+ * :201-208 (head), :283 (stem, through onda_stem_im2col). */
+typedef struct OndaConv {
+  int B, Hi, Wi, Cin;   /* input grid; Cin multiple of 32 (stem/head are padded by the packers) */
+  int Ho, Wo, Cout;     /* output grid; Cout multiple of 4 */
+  int kh, kw, stride, dil, pad;
+  int ldx;              /* input row stride (floats), >= Cin, multiple of 4 */
+  int ldy;              /* output row stride (floats): > Cout when writing a concat slice */
+  int ldr;              /* residual row stride */
+  int out_os;           /* output pixel (ho,wo) is stored at (ho*out_os, wo*out_os) of an   */
+  int Hf, Wf;           /* [B,Hf,Wf] grid (out_os=1,Hf=Ho,Wf=Wo normally; 2 for the dgrad of */
+                        /* the stride-2 1x1 convs, deeplabv2.py:22-24,351-357)              */
+  int relu;
+} OndaConv;
+
+/* Number of float partials conv_fwd writes when `stats` != NULL: tiles_m * 2 * Cout, where
+ * tiles_m = onda_conv_tiles_m(M). */
+int onda_conv_tiles_m(int M);
+
+/* y = epilogue(conv(x, w)).  w is packed [Cout][kh*kw][Cin] (onda_pack_weight_fwd).
+ * Epilogue, in order: per-channel sum / sum-of-squares partials of the raw result into
+ * `stats` (BatchNorm batch statistics, deeplabv2.py:25,40,45 in train mode); v*scale[n]
+ * + shift[n] (folded eval-mode BatchNorm or conv bias); + residual (deeplabv2.py:65);
+ * ReLU (:57,60,66).  scale, shift, residual, stats may each be NULL.  The same entry runs
+ * data gradients: pass dy as x and weights packed by onda_pack_weight_dgrad. */
+int onda_conv2d_fwd(const float* x, const float* w, float* y, const float* scale, const float* shift,
+                    const float* residual, float* stats, const OndaConv* c, onda_stream_t s);
+
+/* Weight gradient, split over `splitk` pixel ranges: slabs[ks][Cout][kh*kw][Cin] partial
+ * sums of dy[m][n] * x[pix(m,tap)][c]  (autograd of F.conv2d w.r.t. weight).  Then
+ * onda_wgrad_reduce sums the slabs in a fixed order (deterministic) into the OIHW
+ * gradient dw[Cout_real][Cin_real][kh][kw] (flat_k: stem layout where the packed K index is
+ * tap*Cin_real + c). */
+int onda_conv2d_wgrad(const float* x, const float* dy, float* slabs, int lddy, int splitk,
+                      const OndaConv* c, onda_stream_t s);
+int onda_wgrad_reduce(const float* slabs, float* dw, int splitk, int Cout, int taps, int Cin,
+                      int Cout_real, int Cin_real, int flat_k, onda_stream_t s);
+
+/* OIHW -> kernel layouts.  fwd: dst[n][tap*Cin_real + c] rows of length Kp (zero padded),
+ * Cout_pad rows.  dgrad: dst[c][taps-1-tap][n] with rows of Cout_pad, for stride-1 convs
+ * the data gradient is then a plain convolution of dy with dst. */
+int onda_pack_weight_fwd(const float* w_oihw, float* dst, int Cout, int Cin, int taps, int Cout_pad, int Kp,
+                         onda_stream_t s);
+int onda_pack_weight_dgrad(const float* w_oihw, float* dst, int Cout, int Cin, int taps, int Cout_pad,
+                           onda_stream_t s);
+
+/* Stem patches: col[m][ (r*7+s)*3 + c ] (zero padded to Kp) from the NCHW image
+ * f32[B,3,H,W] for the 7x7 stride-2 pad-3 stem (deeplabv2.py:283). */
+int onda_stem_im2col(const float* x_nchw, float* col, int B, int H, int W, int Ho, int Wo, int Kp, onda_stream_t s);
+
+/* ---- BatchNorm2d (eps 1e-5, affine frozen) ------------------------------------------------
+ * train-mode semantics of torch.nn.BatchNorm2d as the reference toggles it
+ * (adaptation_model.py:29-36, prototypes.py:104-110): */
+/* partials [tiles][2][C] -> mean[C], invstd[C]; if running_mean != NULL also the momentum
+ * update with the unbiased variance and num_batches_tracked += 1. */
+int onda_bn_finalize(const float* partials, int tiles, int C, int64_t count, float eps, float* mean, float* invstd,
+                     float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum,
+                     onda_stream_t s);
+/* per-channel sum / sumsq partials of x[M][C] (when the producer could not emit them) */
+int onda_bn_stats(const float* x, int64_t M, int C, int ldx, float* partials, int* tiles_out, onda_stream_t s);
+/* out = [relu]( (x-mean)*invstd*gamma + beta [+ residual] ) */
+int onda_bn_apply(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                  const float* residual, float* out, int64_t M, int C, int relu, onda_stream_t s);
+/* eval-mode fold: scale = gamma/sqrt(var+eps), shift = beta - mean*scale (for conv_fwd's epilogue) */
+int onda_bn_fold(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                 float eps, float* scale, float* shift, int C, onda_stream_t s);
+/* backward of bn_apply (+ReLU, + residual fan-out): g = dout * (out > 0 if relu);
+ * dres = g (if dres != NULL); dx = gamma*invstd*(g - mean_m(g) - xhat*mean_m(g*xhat)).
+ * ws: float workspace of onda_bn_bwd_ws(M, C) floats. */
+int64_t onda_bn_bwd_ws(int64_t M, int C);
+int onda_bn_bwd(const float* dout, const float* out, const float* x, const float* mean, const float* invstd,
+                const float* gamma, float* dx, float* dres, float* ws, int64_t M, int C, int relu, onda_stream_t s);
+
+/* ---- GroupNorm(32 groups, eps 1e-5, trainable affine) [+ReLU] [* Dropout2d mask] -----------
+ * deeplabv2.py:141,163,182 and :203,250 (feat is taken after the dropout). x[B][HW][C]
+ * rows of stride ldx; out rows of stride ldo (concat slice).  chmul: f32[B][C] or NULL. */
+int64_t onda_gn_ws(int B, int64_t HW, int C);
+int onda_gn_fwd(const float* x, int ldx, const float* gamma, const float* beta, const float* chmul, float* out, int ldo,
+                float* mean, float* rstd, float* ws, int B, int64_t HW, int C, int groups, float eps, int relu,
+                onda_stream_t s);
+int onda_gn_bwd(const float* dout, int lddo, const float* out, int ldo, const float* x, int ldx, const float* gamma,
+                const float* chmul, const float* mean, const float* rstd, float* dx, float* dgamma, float* dbeta,
+                float* ws, int B, int64_t HW, int C, int groups, int relu, onda_stream_t s);
+
+/* ---- MaxPool 3x3 s2 p1 ceil_mode (deeplabv2.py:289-291), NHWC; idx = winning window slot -- */
+int onda_maxpool_fwd(const float* x, float* y, uint8_t* idx, int B, int Hi, int Wi, int C, int Ho, int Wo,
+                     onda_stream_t s);
+int onda_maxpool_bwd(const float* dy, const uint8_t* idx, float* dx, int B, int Hi, int Wi, int C, int Ho, int Wo,
+                     onda_stream_t s);
+
+/* ---- SE block (deeplabv2.py:99-114): pooled mean, two linears, sigmoid, channel scale ------ */
+int64_t onda_colsum_ws(int B, int64_t HW, int C);
+/* out[b][c] = alpha * sum_px x[b][px][c] (* y[b][px][c] if y != NULL) */
+int onda_colsum(const float* x, int ldx, const float* y, int ldy, float* out, float alpha, float* ws, int B,
+                int64_t HW, int C, onda_stream_t s);
+int onda_se_fc_fwd(const float* pooled, const float* w1, const float* b1, const float* w2, const float* b2,
+                   float* hidden, float* gate, int B, int C, int R, onda_stream_t s);
+/* ws: B*R floats.  dpooled is returned multiplied by dpooled_scale (1/HW of the mean pool). */
+int onda_se_fc_bwd(const float* dgate, const float* pooled, const float* hidden, const float* gate, const float* w1,
+                   const float* w2, float* dw1, float* db1, float* dw2, float* db2, float* dpooled, float* ws,
+                   float dpooled_scale, int B, int C, int R, onda_stream_t s);
+/* out[b][px][c] = x[b][px][c] * gate[b][c] (+ add[b][c] if add != NULL) */
+int onda_chan_scale(const float* x, const float* gate, const float* add, float* out, int B, int64_t HW, int C,
+                    onda_stream_t s);
+
+/* ---- bilinear upsample, align_corners=True (adaptation_model.py:94-98) -------------------
+ * logits NHWC [B,h,w] rows of stride ldl holding K classes -> NCHW f32[B,K,H,W]. */
+int onda_upsample_fwd(const float* logits, int ldl, float* out_nchw, int B, int h, int w, int K, int H, int W,
+                      onda_stream_t s);
+/* gradient w.r.t. the low-res logits (gather form, deterministic); dlogits rows of stride ldl */
+int onda_upsample_bwd(const float* dout_nchw, float* dlogits, int ldl, int B, int h, int w, int K, int H, int W,
+                      onda_stream_t s);
+/* fused evaluation tail: upsample -> (softmax) -> argmax class map u8[B,H,W]
+ * (adaptation_model.py:145-153) without materialising the upsampled tensor */
+int onda_upsample_argmax(const float* logits, int ldl, uint8_t* cls, int B, int h, int w, int K, int H, int W,
+                         onda_stream_t s);
+
+/* ---- per-pixel softmax statistics --------------------------------------------------------
+ * probs (optional, rows of stride ldp) = softmax(logits row); argmax (optional int32);
+ * result[0] = mean over pixels of the max probability (the "prior ..." / "model" monitor
+ * values of prototypes.py:289, prototypes_hybrid_switch.py:55,62).  ws: N/256+1 floats. */
+int onda_softmax_stats(const float* logits, int ldl, float* probs, int ldp, int32_t* argmax, float* result,
+                       float* ws, int64_t N, int K, onda_stream_t s);
+
+/* ---- target losses (loss.py:16-45 hard CE, :88-112 hard RCE, prototypes.py:29-39 MRKLD) ---
+ * fwd: result[0..3] = {ce, rce, mrkld, n_valid}; bwd: dlogits = g * d(w_ce*ce + w_rce*rce +
+ * w_reg*mrkld)/dlogits, using the normalisers left in `result` (8 floats: ce, rce, mrkld,
+ * n_valid, n_mask) by fwd; columns K..ldl-1 of dlogits are zeroed.  ws: 8*(N/256+1). */
+int onda_seg_loss_fwd(const float* logits, int ldl, const int64_t* labels, float* result, float* ws, int64_t N, int K,
+                      onda_stream_t s);
+int onda_seg_loss_bwd(const float* logits, int ldl, const int64_t* labels, const float* result, const float* gscale,
+                      float w_ce, float w_rce, float w_reg, float* dlogits, int64_t N, int K, onda_stream_t s);
+
+/* ---- prototypes (framework/domain_adaptation/methods/prototype_handler.py) ----------------
+ * sigma (:53-60) from the state; then per pixel (:111-166): D[k] = || (f - p_k) / sigma ||
+ * (mahalanobis=1) or || f - p_k ||, minus its minimum; P = softmax(-D/tau); P *= prior;
+ * P /= sum P; label = argmax P, 255 if max P < thresh.  One pass emits the hard labels, the
+ * soft map and the three monitor sums result[0..2] = mean max softmax(-D/tau), mean max P,
+ * mean max prior.  prior may be NULL.  ws: 3*onda_proto_assign_blocks(N) floats.  C == 256. */
+int onda_proto_assign_blocks(int64_t N);
+int onda_proto_sigma(const float* proto, const float* sqmean, const float* counter, float* sigma, int K, int C,
+                     onda_stream_t s);
+int onda_proto_assign(const float* feat, int ldf, const float* prior, int ldp, const float* proto, const float* sigma,
+                      int mahalanobis, float tau, float thresh, int64_t* labels, float* soft, float* result,
+                      float* ws, int64_t N, int C, int K, onda_stream_t s);
+/* per-class sums of feat and feat^2 under `cls` (:76-86): sums[2][K][C], counts[K].
+ * ws: onda_proto_sums_ws(N, C, K) floats. */
+int64_t onda_proto_sums_ws(int64_t N, int C, int K);
+int onda_proto_class_sums(const float* feat, int ldf, const int32_t* cls, float* sums, float* counts, float* ws,
+                          int64_t N, int C, int K, onda_stream_t s);
+/* EMA blend (:88-99): classes with counts > 0 move to lam*p + (1-lam)*sum/count */
+int onda_proto_ema(float* proto, float* sqmean, const float* sums, const float* counts, float lam, int K, int C,
+                   onda_stream_t s);
+/* running mean (:62-74) */
+int onda_proto_append(float* proto, float* sqmean, float* counter, const float* sums, const float* counts, int K,
+                      int C, onda_stream_t s);
+
+/* ---- optimizer / teacher (adaptation_model.py:88-93 SGD with duplicated entries;
+ * prototypes.py:407-416 EMA teacher).  Tables are device arrays of n entries. ---------------- */
+typedef struct OndaSgdEntry {
+  float* p; const float* g; float* buf; int64_t n; float lr; int times; int fresh;
+} OndaSgdEntry;
+int onda_sgd_multi(const OndaSgdEntry* table, int n, float momentum, float weight_decay, int64_t max_n,
+                   onda_stream_t s);
+/* k = k*keep + q*blend  (keep=0, blend=1 copies a buffer, prototypes.py:415-416) */
+typedef struct OndaEmaEntry { float* k; const float* q; int64_t n; float keep; float blend; } OndaEmaEntry;
+int onda_ema_multi(const OndaEmaEntry* table, int n, int64_t max_n, onda_stream_t s);
+
+/* library identity, for the loader's sanity check */
+const char* onda_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,111 @@
+"""ctypes binding of libonda_hip.so (the C ABI declared in include/onda_hip.h).
+
+The library is the product: if it is missing or a symbol is absent this module raises --
+there is no eager / CPU fallback anywhere in ``onda_amd``.
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int64, c_void_p
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libonda_hip.so")
+
+P = c_void_p  # device pointers travel as integers (tensor.data_ptr())
+I, L, F = c_int, c_int64, c_float
+
+
+class OndaConv(Structure):
+    _fields_ = [(n, c_int) for n in ("B Hi Wi Cin Ho Wo Cout kh kw stride dil pad ldx ldy ldr out_os Hf Wf relu").split()]
+
+
+class OndaSgdEntry(Structure):
+    _fields_ = [("p", c_void_p), ("g", c_void_p), ("buf", c_void_p), ("n", c_int64), ("lr", c_float),
+                ("times", c_int), ("fresh", c_int)]
+
+
+class OndaEmaEntry(Structure):
+    _fields_ = [("k", c_void_p), ("q", c_void_p), ("n", c_int64), ("keep", c_float), ("blend", c_float)]
+
+
+# name -> (restype, argtypes); mirrors include/onda_hip.h one to one
+SIGNATURES = {
+    "onda_conv_tiles_m": (I, [I]),
+    "onda_conv2d_fwd": (I, [P, P, P, P, P, P, P, POINTER(OndaConv), P]),
+    "onda_conv2d_wgrad": (I, [P, P, P, I, I, POINTER(OndaConv), P]),
+    "onda_wgrad_reduce": (I, [P, P, I, I, I, I, I, I, I, P]),
+    "onda_pack_weight_fwd": (I, [P, P, I, I, I, I, I, P]),
+    "onda_pack_weight_dgrad": (I, [P, P, I, I, I, I, P]),
+    "onda_stem_im2col": (I, [P, P, I, I, I, I, I, I, P]),
+    "onda_bn_finalize": (I, [P, I, I, L, F, P, P, P, P, P, F, P]),
+    "onda_bn_stats": (I, [P, L, I, I, P, POINTER(c_int), P]),
+    "onda_bn_apply": (I, [P, P, P, P, P, P, P, L, I, I, P]),
+    "onda_bn_fold": (I, [P, P, P, P, F, P, P, I, P]),
+    "onda_bn_bwd_ws": (L, [L, I]),
+    "onda_bn_bwd": (I, [P, P, P, P, P, P, P, P, P, L, I, I, P]),
+    "onda_gn_ws": (L, [I, L, I]),
+    "onda_gn_fwd": (I, [P, I, P, P, P, P, I, P, P, P, I, L, I, I, F, I, P]),
+    "onda_gn_bwd": (I, [P, I, P, I, P, I, P, P, P, P, P, P, P, P, I, L, I, I, I, P]),
+    "onda_maxpool_fwd": (I, [P, P, P, I, I, I, I, I, I, P]),
+    "onda_maxpool_bwd": (I, [P, P, P, I, I, I, I, I, I, P]),
+    "onda_colsum_ws": (L, [I, L, I]),
+    "onda_colsum": (I, [P, I, P, I, P, F, P, I, L, I, P]),
+    "onda_se_fc_fwd": (I, [P, P, P, P, P, P, P, I, I, I, P]),
+    "onda_se_fc_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, P, F, I, I, I, P]),
+    "onda_chan_scale": (I, [P, P, P, P, I, L, I, P]),
+    "onda_upsample_fwd": (I, [P, I, P, I, I, I, I, I, I, P]),
+    "onda_upsample_bwd": (I, [P, P, I, I, I, I, I, I, I, P]),
+    "onda_upsample_argmax": (I, [P, I, P, I, I, I, I, I, I, P]),
+    "onda_softmax_stats": (I, [P, I, P, I, P, P, P, L, I, P]),
+    "onda_seg_loss_fwd": (I, [P, I, P, P, P, L, I, P]),
+    "onda_seg_loss_bwd": (I, [P, I, P, P, P, F, F, F, P, L, I, P]),
+    "onda_proto_sigma": (I, [P, P, P, P, I, I, P]),
+    "onda_proto_assign_blocks": (I, [L]),
+    "onda_proto_assign": (I, [P, I, P, I, P, P, I, F, F, P, P, P, P, L, I, I, P]),
+    "onda_proto_sums_ws": (L, [L, I, I]),
+    "onda_proto_class_sums": (I, [P, I, P, P, P, P, L, I, I, P]),
+    "onda_proto_ema": (I, [P, P, P, P, F, I, I, P]),
+    "onda_proto_append": (I, [P, P, P, P, P, I, I, P]),
+    "onda_sgd_multi": (I, [P, I, F, F, L, P]),
+    "onda_ema_multi": (I, [P, I, L, P]),
+    "onda_version": (c_char_p, []),
+}
+
+_lib = None
+
+
+class OndaLibraryError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen the in-tree library once and attach the prototypes."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OndaLibraryError(
+            f"{LIB_PATH} is missing: build it with `python -m onda_amd.build` (hipcc --offload-arch=gfx950). "
+            "onda_amd has no fallback path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise OndaLibraryError(f"{LIB_PATH} does not export {name}") from e
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def call(name, *args):
+    """Invoke an int-returning entry point; non-zero -> RuntimeError."""
+    rc = getattr(load(), name)(*args)
+    if rc != 0:
+        kind = {-1: "ONDA_EINVAL (unsupported shape / null pointer)", -2: "ONDA_EALIGN (16-byte alignment)"}.get(
+            rc, f"hipError_t {rc}")
+        raise RuntimeError(f"{name} failed: {kind}")
+
+
+def query(name, *args):
+    """Invoke a value-returning helper (workspace sizes, tile counts)."""
+    return getattr(load(), name)(*args)

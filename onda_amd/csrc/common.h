@@ -1,0 +1,39 @@
+// Shared helpers for the gfx950 kernels of libonda_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "onda_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define ONDA_STREAM(s) (reinterpret_cast<hipStream_t>(s))
+#define ONDA_REQUIRE(cond) \
+  do {                     \
+    if (!(cond)) return ONDA_EINVAL; \
+  } while (0)
+#define ONDA_ALIGNED16(p) ((reinterpret_cast<uintptr_t>(p) & 15u) == 0)
+#define ONDA_LAUNCH_RESULT() static_cast<int>(hipGetLastError())
+
+static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// Sum over the 256 threads of a block; result valid in thread 0. `red` holds >= 4 floats.
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}

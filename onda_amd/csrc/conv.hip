@@ -1,0 +1,508 @@
+// Convolutions of the DeepLabV2/ResNet-50 hot path as fp32 MFMA implicit GEMMs for gfx950.
+//
+// Data layout: activations NHWC (row m = one pixel, channels contiguous), weights packed
+// [Cout][tap][Cin], so both GEMM operands are "row-major with K contiguous" and every
+// global load is a 16-byte chunk of one pixel's channels / one filter's channels.
+//
+//   forward / data-gradient  out[m][n] = sum_{tap,c} X[pix(m,tap)][c] * W[n][tap][c]
+//   weight-gradient          dW[n][tap][c] = sum_m dY[m][n] * X[pix(m,tap)][c]
+//
+// The contraction runs on v_mfma_f32_32x32x2_f32 (exact fp32, 64 cycles per SIMD issue):
+// LDS bandwidth is not the limiter at that rate, so tiles are register-staged
+// (global_load_dwordx4 -> ds_write_b128) into padded rows and double-buffered with one
+// barrier per 32-deep K step.  Workgroup = 256 threads = 4 waves, one wave per SIMD, two
+// workgroups per CU.  The blockIdx -> tile map hands each XCD a contiguous band of
+// M-tiles so the N-tiles that re-read one activation band share an L2.
+#include "common.h"
+
+namespace {
+
+struct ConvK {
+  const float* x;
+  const float* w;
+  float* y;
+  const float* scale;
+  const float* shift;
+  const float* res;
+  float* stats;
+  OndaConv c;
+  int M, tilesM, tilesN, taps, kcper;
+};
+
+constexpr int BK = 32;
+constexpr int LDS_ROW = 36;  // 32 floats + 4 pad: ds_read_b128 of 16 distinct rows is conflict-free
+
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvK a) {
+  constexpr int TM = BM / (32 * WAVES_M), TN = BN / (32 * WAVES_N);
+  constexpr int AL = BM / 32, BL = BN / 32;
+  constexpr int STAGE = (BM + BN) * LDS_ROW;
+  __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
+
+  const OndaConv& c = a.c;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+
+  // XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch), give each
+  // XCD a contiguous run of tiles; N-tiles of one M-tile are adjacent in that run.
+  const int nblk = a.tilesM * a.tilesN, bid = blockIdx.x;
+  const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
+  const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  const int tile_n = swz % a.tilesN, tile_m = swz / a.tilesN;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const int ccol = (t & 7) * 4, rbase = t >> 3;
+  int hi0[AL], wi0[AL], bH[AL];
+#pragma unroll
+  for (int u = 0; u < AL; ++u) {
+    const int m = m0 + rbase + 32 * u;
+    const bool vm = m < a.M;
+    const int mm = vm ? m : 0;
+    const int wo = mm % c.Wo, tq = mm / c.Wo;
+    const int ho = tq % c.Ho, b = tq / c.Ho;
+    hi0[u] = vm ? ho * c.stride - c.pad : -(1 << 28);
+    wi0[u] = wo * c.stride - c.pad;
+    bH[u] = b * c.Hi;
+  }
+  const float* wrow[BL];
+  bool vn[BL];
+  const int wstride = a.taps * c.Cin;
+#pragma unroll
+  for (int u = 0; u < BL; ++u) {
+    const int n = n0 + rbase + 32 * u;
+    vn[u] = n < c.Cout;
+    wrow[u] = a.w + (size_t)(vn[u] ? n : 0) * wstride + ccol;
+  }
+
+  long long aofs[AL];
+  f32x4 ar[AL], br[BL];
+  int tap = 0, c0 = 0;
+  auto set_tap = [&](int tp) {
+    const int rr = tp / c.kw, ss = tp - rr * c.kw;
+#pragma unroll
+    for (int u = 0; u < AL; ++u) {
+      const int hi = hi0[u] + rr * c.dil, wi = wi0[u] + ss * c.dil;
+      const bool ok = (unsigned)hi < (unsigned)c.Hi && (unsigned)wi < (unsigned)c.Wi;
+      aofs[u] = ok ? ((long long)(bH[u] + hi) * c.Wi + wi) * c.ldx + ccol : -1;
+    }
+  };
+  auto gload = [&]() {
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < AL; ++u) ar[u] = aofs[u] >= 0 ? *reinterpret_cast<const f32x4*>(a.x + aofs[u] + c0) : z;
+#pragma unroll
+    for (int u = 0; u < BL; ++u)
+      br[u] = vn[u] ? *reinterpret_cast<const f32x4*>(wrow[u] + tap * c.Cin + c0) : z;
+  };
+  auto sstore = [&](int buf) {
+    float* Ab = lds + buf * STAGE;
+    float* Bb = Ab + BM * LDS_ROW;
+#pragma unroll
+    for (int u = 0; u < AL; ++u) *reinterpret_cast<f32x4*>(&Ab[(rbase + 32 * u) * LDS_ROW + ccol]) = ar[u];
+#pragma unroll
+    for (int u = 0; u < BL; ++u) *reinterpret_cast<f32x4*>(&Bb[(rbase + 32 * u) * LDS_ROW + ccol]) = br[u];
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  set_tap(0);
+  gload();
+  sstore(0);
+  __syncthreads();
+
+  const int KT = a.taps * a.kcper;
+  for (int kt = 0; kt < KT; ++kt) {
+    const int cur = kt & 1;
+    const bool more = kt + 1 < KT;
+    if (more) {
+      c0 += BK;
+      if (c0 == c.Cin) {
+        c0 = 0;
+        ++tap;
+        set_tap(tap);
+      }
+      gload();
+    }
+    const float* Ab = lds + cur * STAGE + (wm * TM * 32 + li) * LDS_ROW + 4 * lh;
+    const float* Bb = lds + cur * STAGE + BM * LDS_ROW + (wn * TN * 32 + li) * LDS_ROW + 4 * lh;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f32x4 af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDS_ROW + 8 * j);
+#pragma unroll
+      for (int i = 0; i < TN; ++i) bf[i] = *reinterpret_cast<const f32x4*>(Bb + i * 32 * LDS_ROW + 8 * j);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int jn = 0; jn < TN; ++jn)
+            acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[jn][e], acc[i][jn], 0, 0, 0);
+    }
+    if (more) sstore(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue --------------------------------------------------------------------------
+  if (a.stats != nullptr) {
+    float* red = lds;  // [WAVES_M][BN][2]
+#pragma unroll
+    for (int jn = 0; jn < TN; ++jn) {
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const float v = acc[i][jn][e];
+          s1 += v;
+          s2 += v * v;
+        }
+      s1 += __shfl_xor(s1, 32, 64);
+      s2 += __shfl_xor(s2, 32, 64);
+      if (lh == 0) {
+        const int col = wn * TN * 32 + jn * 32 + li;
+        red[(wm * BN + col) * 2 + 0] = s1;
+        red[(wm * BN + col) * 2 + 1] = s2;
+      }
+    }
+    __syncthreads();
+    if (t < BN && n0 + t < c.Cout) {
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int w_ = 0; w_ < WAVES_M; ++w_) {
+        s1 += red[(w_ * BN + t) * 2 + 0];
+        s2 += red[(w_ * BN + t) * 2 + 1];
+      }
+      a.stats[((size_t)tile_m * 2 + 0) * c.Cout + n0 + t] = s1;
+      a.stats[((size_t)tile_m * 2 + 1) * c.Cout + n0 + t] = s2;
+    }
+  }
+
+  const bool plain = (c.out_os == 1 && c.Hf == c.Ho && c.Wf == c.Wo);
+#pragma unroll
+  for (int jn = 0; jn < TN; ++jn) {
+    const int n = n0 + wn * TN * 32 + jn * 32 + li;
+    if (n >= c.Cout) continue;
+    const float sc = a.scale ? a.scale[n] : 1.f;
+    const float sh = a.shift ? a.shift[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = (e & 3) + 8 * (e >> 2) + 4 * lh;
+        const int m = m0 + wm * TM * 32 + i * 32 + row;
+        if (m >= a.M) continue;
+        float v = acc[i][jn][e] * sc + sh;
+        if (a.res) v += a.res[(size_t)m * c.ldr + n];
+        if (c.relu) v = fmaxf(v, 0.f);
+        size_t orow = m;
+        if (!plain) {
+          const int wo = m % c.Wo, tq = m / c.Wo;
+          const int ho = tq % c.Ho, b = tq / c.Ho;
+          orow = ((size_t)b * c.Hf + (size_t)ho * c.out_os) * c.Wf + (size_t)wo * c.out_os;
+        }
+        a.y[orow * c.ldy + n] = v;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+struct WgradK {
+  const float* x;
+  const float* dy;
+  float* slabs;
+  OndaConv c;
+  int M, lddy, splitk, mchunk, tilesN, tilesC, taps;
+};
+
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK a) {
+  constexpr int TM = BM / (32 * WAVES_M), TN = BN / (32 * WAVES_N);
+  constexpr int SA = BM + 4, SB = BN + 4;
+  constexpr int CHA = BM / 4, CHB = BN / 4;      // 16-byte chunks per tile row
+  constexpr int RPA = 256 / CHA, RPB = 256 / CHB;  // tile rows covered by one pass of the block
+  constexpr int AL = BK / RPA, BL = BK / RPB;
+  constexpr int STAGE = BK * (SA + SB);
+  __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
+
+  const OndaConv& c = a.c;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+
+  int bid = blockIdx.x;
+  const int tile_c = bid % a.tilesC;
+  bid /= a.tilesC;
+  const int tap = bid % a.taps;
+  bid /= a.taps;
+  const int tile_n = bid % a.tilesN;
+  const int ks = bid / a.tilesN;
+  const int n0 = tile_n * BM, c0 = tile_c * BN;
+  const int mbeg = ks * a.mchunk;
+  const int mend = min(a.M, mbeg + a.mchunk);
+  const int KT = mend > mbeg ? (mend - mbeg + BK - 1) / BK : 0;
+  const int rr = tap / c.kw, ss = tap - rr * c.kw;
+  const int dh = rr * c.dil - c.pad, dw = ss * c.dil - c.pad;
+  const bool direct = (c.kh == 1 && c.kw == 1 && c.stride == 1 && c.pad == 0);
+
+  const int acol = (t % CHA) * 4, arow = t / CHA;
+  const int bcol = (t % CHB) * 4, brow = t / CHB;
+  const bool va = n0 + acol < c.Cout, vb = c0 + bcol < c.Cin;
+
+  f32x4 ar[AL], br[BL];
+  auto gload = [&](int mb) {
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < AL; ++u) {
+      const int m = mb + arow + RPA * u;
+      ar[u] = (va && m < mend) ? *reinterpret_cast<const f32x4*>(a.dy + (size_t)m * a.lddy + n0 + acol) : z;
+    }
+#pragma unroll
+    for (int u = 0; u < BL; ++u) {
+      const int m = mb + brow + RPB * u;
+      bool ok = vb && m < mend;
+      size_t pix = m;
+      if (!direct && ok) {
+        const int wo = m % c.Wo, tq = m / c.Wo;
+        const int ho = tq % c.Ho, b = tq / c.Ho;
+        const int hi = ho * c.stride + dh, wi = wo * c.stride + dw;
+        ok = (unsigned)hi < (unsigned)c.Hi && (unsigned)wi < (unsigned)c.Wi;
+        pix = ((size_t)b * c.Hi + hi) * c.Wi + wi;
+      }
+      br[u] = ok ? *reinterpret_cast<const f32x4*>(a.x + pix * c.ldx + c0 + bcol) : z;
+    }
+  };
+  auto sstore = [&](int buf) {
+    float* Ab = lds + buf * STAGE;
+    float* Bb = Ab + BK * SA;
+#pragma unroll
+    for (int u = 0; u < AL; ++u) *reinterpret_cast<f32x4*>(&Ab[(arow + RPA * u) * SA + acol]) = ar[u];
+#pragma unroll
+    for (int u = 0; u < BL; ++u) *reinterpret_cast<f32x4*>(&Bb[(brow + RPB * u) * SB + bcol]) = br[u];
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  if (KT > 0) {
+    gload(mbeg);
+    sstore(0);
+  }
+  __syncthreads();
+  for (int kt = 0; kt < KT; ++kt) {
+    const int cur = kt & 1;
+    const bool more = kt + 1 < KT;
+    if (more) gload(mbeg + (kt + 1) * BK);
+    const float* Ab = lds + cur * STAGE + lh * SA + wm * TM * 32 + li;
+    const float* Bb = lds + cur * STAGE + BK * SA + lh * SB + wn * TN * 32 + li;
+#pragma unroll
+    for (int kk = 0; kk < BK / 2; ++kk) {
+      float af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = Ab[2 * kk * SA + i * 32];
+#pragma unroll
+      for (int i = 0; i < TN; ++i) bf[i] = Bb[2 * kk * SB + i * 32];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int jn = 0; jn < TN; ++jn)
+          acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[jn], acc[i][jn], 0, 0, 0);
+    }
+    if (more) sstore(cur ^ 1);
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int jn = 0; jn < TN; ++jn) {
+    const int cc = c0 + wn * TN * 32 + jn * 32 + li;
+    if (cc >= c.Cin) continue;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = (e & 3) + 8 * (e >> 2) + 4 * lh;
+        const int n = n0 + wm * TM * 32 + i * 32 + row;
+        if (n >= c.Cout) continue;
+        a.slabs[(((size_t)ks * c.Cout + n) * a.taps + tap) * c.Cin + cc] = acc[i][jn][e];
+      }
+  }
+}
+
+__global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw, int splitk, int Cout,
+                                    int taps, int Cin, int Cout_real, int Cin_real, int flat_k) {
+  const size_t total = (size_t)Cout * taps * Cin;
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  float s = 0.f;
+  for (int k = 0; k < splitk; ++k) s += slabs[(size_t)k * total + e];
+  const int cc = (int)(e % Cin);
+  const size_t q = e / Cin;
+  const int tap = (int)(q % taps);
+  const int n = (int)(q / taps);
+  if (n >= Cout_real) return;
+  if (flat_k > 0) {  // stem: packed K index = tap7*Cin_real + c3, OIHW = [n][c3][tap7]
+    const int tap7 = cc / Cin_real, c3 = cc - tap7 * Cin_real;
+    if (tap7 < flat_k) dw[((size_t)n * Cin_real + c3) * flat_k + tap7] = s;
+  } else if (cc < Cin_real) {
+    dw[((size_t)n * Cin_real + cc) * taps + tap] = s;
+  }
+}
+
+__global__ void pack_fwd_kernel(const float* __restrict__ w, float* __restrict__ dst, int Cout, int Cin, int taps,
+                                int Cout_pad, int Kp) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (size_t)Cout_pad * Kp) return;
+  const int k = (int)(e % Kp), n = (int)(e / Kp);
+  float v = 0.f;
+  if (n < Cout && k < taps * Cin) {
+    const int tap = k / Cin, cc = k - tap * Cin;
+    v = w[((size_t)n * Cin + cc) * taps + tap];
+  }
+  dst[e] = v;
+}
+
+__global__ void pack_dgrad_kernel(const float* __restrict__ w, float* __restrict__ dst, int Cout, int Cin, int taps,
+                                  int Cout_pad) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (size_t)Cin * taps * Cout_pad) return;
+  const int n = (int)(e % Cout_pad);
+  const size_t q = e / Cout_pad;
+  const int tap = (int)(q % taps), cc = (int)(q / taps);
+  dst[e] = n < Cout ? w[((size_t)n * Cin + cc) * taps + (taps - 1 - tap)] : 0.f;
+}
+
+__global__ void stem_im2col_kernel(const float* __restrict__ x, float* __restrict__ col, int B, int H, int W, int Ho,
+                                   int Wo, int Kp) {
+  const int k4 = Kp / 4;
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t M = (size_t)B * Ho * Wo;
+  if (e >= M * k4) return;
+  const int kq = (int)(e % k4);
+  const size_t m = e / k4;
+  const int wo = (int)(m % Wo);
+  const size_t tq = m / Wo;
+  const int ho = (int)(tq % Ho), b = (int)(tq / Ho);
+  f32x4 v;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int k = kq * 4 + j;
+    float val = 0.f;
+    if (k < 147) {
+      const int tap = k / 3, cc = k - tap * 3;
+      const int r = tap / 7, s = tap - r * 7;
+      const int hi = ho * 2 - 3 + r, wi = wo * 2 - 3 + s;
+      if ((unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W) val = x[(((size_t)b * 3 + cc) * H + hi) * W + wi];
+    }
+    v[j] = val;
+  }
+  *reinterpret_cast<f32x4*>(col + m * Kp + kq * 4) = v;
+}
+
+}  // namespace
+
+extern "C" {
+
+int onda_conv_tiles_m(int M) { return (M + 127) / 128; }
+
+int onda_conv2d_fwd(const float* x, const float* w, float* y, const float* scale, const float* shift,
+                    const float* residual, float* stats, const OndaConv* c, onda_stream_t s) {
+  ONDA_REQUIRE(x && w && y && c);
+  ONDA_REQUIRE(c->Cin > 0 && c->Cin % 32 == 0 && c->Cout > 0 && c->ldx % 4 == 0 && c->ldx >= c->Cin);
+  ONDA_REQUIRE(c->kh >= 1 && c->kw >= 1 && c->stride >= 1 && c->dil >= 1 && c->out_os >= 1);
+  if (!ONDA_ALIGNED16(x) || !ONDA_ALIGNED16(w)) return ONDA_EALIGN;
+  ConvK k;
+  k.x = x; k.w = w; k.y = y; k.scale = scale; k.shift = shift; k.res = residual; k.stats = stats;
+  k.c = *c;
+  const long long M = (long long)c->B * c->Ho * c->Wo;
+  ONDA_REQUIRE(M > 0 && M < (1ll << 31));
+  k.M = (int)M;
+  k.taps = c->kh * c->kw;
+  k.kcper = c->Cin / 32;
+  k.tilesM = (k.M + 127) / 128;
+  if (c->Cout > 64) {
+    k.tilesN = (c->Cout + 127) / 128;
+    hipLaunchKernelGGL((conv_fwd_kernel<128, 128, 2, 2>), dim3(k.tilesM * k.tilesN), dim3(256), 0, ONDA_STREAM(s), k);
+  } else {
+    k.tilesN = (c->Cout + 63) / 64;
+    hipLaunchKernelGGL((conv_fwd_kernel<128, 64, 2, 2>), dim3(k.tilesM * k.tilesN), dim3(256), 0, ONDA_STREAM(s), k);
+  }
+  return ONDA_LAUNCH_RESULT();
+}
+
+int onda_conv2d_wgrad(const float* x, const float* dy, float* slabs, int lddy, int splitk, const OndaConv* c,
+                      onda_stream_t s) {
+  ONDA_REQUIRE(x && dy && slabs && c && splitk >= 1);
+  ONDA_REQUIRE(c->Cin % 4 == 0 && c->Cout % 4 == 0 && c->ldx % 4 == 0 && lddy % 4 == 0);
+  if (!ONDA_ALIGNED16(x) || !ONDA_ALIGNED16(dy)) return ONDA_EALIGN;
+  WgradK k;
+  k.x = x; k.dy = dy; k.slabs = slabs; k.c = *c;
+  const long long M = (long long)c->B * c->Ho * c->Wo;
+  ONDA_REQUIRE(M > 0 && M < (1ll << 31));
+  k.M = (int)M;
+  k.lddy = lddy;
+  k.splitk = splitk;
+  k.mchunk = (int)(((M + splitk - 1) / splitk + 31) / 32 * 32);
+  k.taps = c->kh * c->kw;
+  if (c->Cout > 64 && c->Cin > 64) {
+    k.tilesN = (c->Cout + 127) / 128;
+    k.tilesC = (c->Cin + 127) / 128;
+    hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 2, 2>), dim3(k.tilesN * k.tilesC * k.taps * splitk), dim3(256), 0,
+                       ONDA_STREAM(s), k);
+  } else {
+    k.tilesN = (c->Cout + 63) / 64;
+    k.tilesC = (c->Cin + 63) / 64;
+    hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, 2, 2>), dim3(k.tilesN * k.tilesC * k.taps * splitk), dim3(256), 0,
+                       ONDA_STREAM(s), k);
+  }
+  return ONDA_LAUNCH_RESULT();
+}
+
+int onda_wgrad_reduce(const float* slabs, float* dw, int splitk, int Cout, int taps, int Cin, int Cout_real,
+                      int Cin_real, int flat_k, onda_stream_t s) {
+  ONDA_REQUIRE(slabs && dw && splitk >= 1);
+  const size_t total = (size_t)Cout * taps * Cin;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ONDA_STREAM(s), slabs,
+                     dw, splitk, Cout, taps, Cin, Cout_real, Cin_real, flat_k);
+  return ONDA_LAUNCH_RESULT();
+}
+
+int onda_pack_weight_fwd(const float* w, float* dst, int Cout, int Cin, int taps, int Cout_pad, int Kp,
+                         onda_stream_t s) {
+  ONDA_REQUIRE(w && dst && Kp >= taps * Cin && Cout_pad >= Cout);
+  const size_t total = (size_t)Cout_pad * Kp;
+  hipLaunchKernelGGL(pack_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ONDA_STREAM(s), w, dst, Cout,
+                     Cin, taps, Cout_pad, Kp);
+  return ONDA_LAUNCH_RESULT();
+}
+
+int onda_pack_weight_dgrad(const float* w, float* dst, int Cout, int Cin, int taps, int Cout_pad, onda_stream_t s) {
+  ONDA_REQUIRE(w && dst && Cout_pad >= Cout);
+  const size_t total = (size_t)Cin * taps * Cout_pad;
+  hipLaunchKernelGGL(pack_dgrad_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ONDA_STREAM(s), w, dst,
+                     Cout, Cin, taps, Cout_pad);
+  return ONDA_LAUNCH_RESULT();
+}
+
+int onda_stem_im2col(const float* x, float* col, int B, int H, int W, int Ho, int Wo, int Kp, onda_stream_t s) {
+  ONDA_REQUIRE(x && col && Kp % 4 == 0 && Kp >= 147);
+  const size_t total = (size_t)B * Ho * Wo * (Kp / 4);
+  hipLaunchKernelGGL(stem_im2col_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ONDA_STREAM(s), x, col, B,
+                     H, W, Ho, Wo, Kp);
+  return ONDA_LAUNCH_RESULT();
+}
+
+}  // extern "C"

@@ -1,0 +1,484 @@
+// Per-pixel class-vector kernels: softmax statistics, the fused target losses and their
+// gradient, prototype distances / pseudo-labels, prototype statistics and EMA, plus the
+// multi-tensor SGD and teacher-EMA updates.  All HBM-bound; reductions are two-stage with a
+// fixed order (bitwise reproducible).
+#include "common.h"
+
+namespace {
+
+constexpr int KMAX = 32;              // class vectors are kept in registers, K <= 32
+constexpr float LOG_CLAMP = -9.21034037f;  // log(1e-4): loss.py:104-106 clamps the one-hot to [1e-4, 1]
+
+__global__ void sum_partials_kernel(const float* __restrict__ ws, int nblocks, int nvals, float scale,
+                                    float* __restrict__ result) {
+  const int j = threadIdx.x;
+  if (j >= nvals) return;
+  double s = 0.0;
+  for (int b = 0; b < nblocks; ++b) s += (double)ws[(size_t)b * nvals + j];
+  result[j] = (float)(s * (double)scale);
+}
+
+// ---- softmax statistics ----------------------------------------------------------------------
+__global__ __launch_bounds__(256) void softmax_stats_kernel(const float* __restrict__ logits, int ldl,
+                                                            float* __restrict__ probs, int ldp,
+                                                            int32_t* __restrict__ argmax, float* __restrict__ ws,
+                                                            int64_t N, int K) {
+  __shared__ float red[4];
+  const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  float pmax = 0.f;
+  if (n < N) {
+    const float* row = logits + (size_t)n * ldl;
+    float v[KMAX];
+    float m = -INFINITY;
+    int am = 0;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k)
+      if (k < K) {
+        v[k] = row[k];
+        if (v[k] > m) {
+          m = v[k];
+          am = k;
+        }
+      }
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k)
+      if (k < K) {
+        v[k] = expf(v[k] - m);
+        sum += v[k];
+      }
+    const float inv = 1.f / sum;
+    if (probs) {
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k)
+        if (k < K) probs[(size_t)n * ldp + k] = v[k] / sum;
+    }
+    if (argmax) argmax[n] = am;
+    pmax = inv;  // exp(0)/sum at the maximum
+  }
+  const float tot = block_sum_256(pmax, red);
+  if (threadIdx.x == 0) ws[blockIdx.x] = tot;
+}
+
+// ---- CE + RCE + MRKLD ------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void seg_loss_fwd_kernel(const float* __restrict__ logits, int ldl,
+                                                           const int64_t* __restrict__ labels,
+                                                           float* __restrict__ ws, int64_t N, int K) {
+  __shared__ float red[4];
+  const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  float ce = 0.f, rce = 0.f, kld = 0.f, nv = 0.f, nm = 0.f;
+  if (n < N) {
+    const float* row = logits + (size_t)n * ldl;
+    float v[KMAX];
+    float m = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k)
+      if (k < K) {
+        v[k] = row[k];
+        m = fmaxf(m, v[k]);
+      }
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k)
+      if (k < K) sum += expf(v[k] - m);
+    const float lse = m + logf(sum);
+    const int64_t tl = labels[n];
+    const bool valid = tl >= 0 && tl != 255 && tl < K;
+    const bool mask = tl != 255;
+    float others = 0.f;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k)
+      if (k < K) {
+        const float lp = v[k] - lse;
+        kld -= lp;
+        if (valid && k == (int)tl) ce = -lp;
+        if (mask && k != (int)tl) others += expf(lp);
+      }
+    rce = mask ? -LOG_CLAMP * others : 0.f;
+    nv = valid ? 1.f : 0.f;
+    nm = mask ? 1.f : 0.f;
+  }
+  float r;
+  r = block_sum_256(ce, red);
+  if (threadIdx.x == 0) ws[(size_t)blockIdx.x * 8 + 0] = r;
+  r = block_sum_256(rce, red);
+  if (threadIdx.x == 0) ws[(size_t)blockIdx.x * 8 + 1] = r;
+  r = block_sum_256(kld, red);
+  if (threadIdx.x == 0) ws[(size_t)blockIdx.x * 8 + 2] = r;
+  r = block_sum_256(nv, red);
+  if (threadIdx.x == 0) ws[(size_t)blockIdx.x * 8 + 3] = r;
+  r = block_sum_256(nm, red);
+  if (threadIdx.x == 0) ws[(size_t)blockIdx.x * 8 + 4] = r;
+}
+
+__global__ void seg_loss_finalize_kernel(const float* __restrict__ ws, int nblocks, double total_elems,
+                                         float* __restrict__ result) {
+  if (threadIdx.x != 0) return;
+  double s[5] = {0, 0, 0, 0, 0};
+  for (int b = 0; b < nblocks; ++b)
+    for (int j = 0; j < 5; ++j) s[j] += (double)ws[(size_t)b * 8 + j];
+  result[0] = (float)(s[0] / s[3]);  // mean over kept pixels; 0/0 = NaN as in the reference
+  result[1] = (float)(s[1] / (s[4] + 1e-6));
+  result[2] = (float)(s[2] / total_elems);
+  result[3] = (float)s[3];
+  result[4] = (float)s[4];
+}
+
+__global__ __launch_bounds__(256) void seg_loss_bwd_kernel(const float* __restrict__ logits, int ldl,
+                                                           const int64_t* __restrict__ labels,
+                                                           const float* __restrict__ result,
+                                                           const float* __restrict__ gscale, float w_ce, float w_rce,
+                                                           float w_reg, float* __restrict__ dl, int64_t N, int K) {
+  const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (n >= N) return;
+  const float gs = gscale ? gscale[0] : 1.f;
+  const float nvalid = result[3], nmask = result[4];
+  const float a_ce = nvalid > 0.f ? gs * w_ce / nvalid : 0.f;
+  const float a_rce = gs * w_rce * (-LOG_CLAMP) / (nmask + 1e-6f);
+  const float a_reg = gs * w_reg / ((float)N * (float)K);
+  const float* row = logits + (size_t)n * ldl;
+  float v[KMAX];
+  float m = -INFINITY;
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k)
+    if (k < K) {
+      v[k] = row[k];
+      m = fmaxf(m, v[k]);
+    }
+  float sum = 0.f;
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k)
+    if (k < K) {
+      v[k] = expf(v[k] - m);
+      sum += v[k];
+    }
+  const int64_t tl = labels[n];
+  const bool valid = tl >= 0 && tl != 255 && tl < K;
+  const bool mask = tl != 255;
+  float pt = 0.f;
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k)
+    if (k < K) {
+      v[k] = v[k] / sum;
+      if (k == (int)tl) pt = v[k];
+    }
+  float* out = dl + (size_t)n * ldl;
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) {
+    if (k >= ldl) break;
+    float g = 0.f;
+    if (k < K) {
+      const float onehot = (k == (int)tl) ? 1.f : 0.f;
+      if (valid) g += a_ce * (v[k] - onehot);
+      if (mask) g += a_rce * pt * (v[k] - onehot);
+      g += a_reg * ((float)K * v[k] - 1.f);
+    }
+    out[k] = g;
+  }
+}
+
+// ---- prototypes ---------------------------------------------------------------------------
+__global__ void proto_sigma_kernel(const float* __restrict__ proto, const float* __restrict__ sqmean,
+                                   const float* __restrict__ counter, float* __restrict__ sigma, int K, int C) {
+  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ch >= C) return;
+  float total = 0.f;
+  for (int k = 0; k < K; ++k) total += counter[k];
+  float gsq = 0.f, gm = 0.f;
+  for (int k = 0; k < K; ++k) {
+    gsq += sqmean[(size_t)k * C + ch] * counter[k] / total;
+    gm += proto[(size_t)k * C + ch] * counter[k] / total;
+  }
+  sigma[ch] = sqrtf(gsq - gm * gm);
+}
+
+// One wave per pixel; lane l owns channels 4l..4l+3 (C == 256).
+__global__ __launch_bounds__(256) void proto_assign_kernel(const float* __restrict__ feat, int ldf,
+                                                           const float* __restrict__ prior, int ldp,
+                                                           const float* __restrict__ proto,
+                                                           const float* __restrict__ sigma, int mahalanobis,
+                                                           float tau, float thresh, int64_t* __restrict__ labels,
+                                                           float* __restrict__ soft, float* __restrict__ ws, int64_t N,
+                                                           int K) {
+  __shared__ __attribute__((aligned(16))) float sp[KMAX * 256];
+  __shared__ float red[3][4];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  for (int i = t; i < K * 64; i += 256) reinterpret_cast<f32x4*>(sp)[i] = reinterpret_cast<const f32x4*>(proto)[i];
+  __syncthreads();
+  f32x4 sg = {1.f, 1.f, 1.f, 1.f};
+  if (mahalanobis) sg = *reinterpret_cast<const f32x4*>(sigma + lane * 4);
+  float a_conf = 0.f, a_soft = 0.f, a_prior = 0.f;
+  const int64_t wstride = (int64_t)gridDim.x * 4;
+  for (int64_t n = (int64_t)blockIdx.x * 4 + wave; n < N; n += wstride) {
+    const f32x4 f = *reinterpret_cast<const f32x4*>(feat + (size_t)n * ldf + lane * 4);
+    float d[KMAX];
+    float dmin = INFINITY;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k)
+      if (k < K) {
+        f32x4 df = f - reinterpret_cast<const f32x4*>(sp)[k * 64 + lane];
+        if (mahalanobis) df = df / sg;
+        float s = df[0] * df[0] + df[1] * df[1] + df[2] * df[2] + df[3] * df[3];
+        s = wave_sum(s);
+        d[k] = sqrtf(s);
+        dmin = fminf(dmin, d[k]);
+      }
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k)
+      if (k < K) {
+        d[k] = expf(-(d[k] - dmin) / tau);
+        sum += d[k];
+      }
+    float conf = 0.f, psum = 0.f, prmax = 0.f;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k)
+      if (k < K) {
+        float p = d[k] / sum;
+        conf = fmaxf(conf, p);
+        if (prior) {
+          const float pr = prior[(size_t)n * ldp + k];
+          prmax = fmaxf(prmax, pr);
+          p *= pr;
+        }
+        d[k] = p;
+        psum += p;
+      }
+    float best = -INFINITY;
+    int arg = 0;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k)
+      if (k < K) {
+        d[k] = d[k] / psum;
+        if (d[k] > best) {
+          best = d[k];
+          arg = k;
+        }
+      }
+    if (lane == 0) labels[n] = best < thresh ? 255 : arg;
+    if (soft) {
+      float mine = 0.f;
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k)
+        if (k < K && k == lane) mine = d[k];
+      if (lane < K) soft[(size_t)n * K + lane] = mine;
+    }
+    a_conf += conf;
+    a_soft += best;
+    a_prior += prmax;
+  }
+  if (lane == 0) {
+    red[0][wave] = a_conf;
+    red[1][wave] = a_soft;
+    red[2][wave] = a_prior;
+  }
+  __syncthreads();
+  if (t < 3) ws[(size_t)blockIdx.x * 3 + t] = red[t][0] + red[t][1] + red[t][2] + red[t][3];
+}
+
+constexpr int SUMS_BLOCKS = 256;
+
+__global__ __launch_bounds__(256) void proto_class_sums_kernel(const float* __restrict__ feat, int ldf,
+                                                               const int32_t* __restrict__ cls,
+                                                               float* __restrict__ ws, int64_t N, int C, int K,
+                                                               int64_t rows_per_block) {
+  extern __shared__ float acc[];  // [2][K][C] + [K]
+  float* cnt = acc + (size_t)2 * K * C;
+  const int t = threadIdx.x;
+  for (int i = t; i < 2 * K * C + K; i += 256) acc[i] = 0.f;
+  __syncthreads();
+  const int64_t n0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t n1 = min(N, n0 + rows_per_block);
+  for (int64_t n = n0; n < n1; ++n) {
+    const int k = cls[n];
+    if ((unsigned)k >= (unsigned)K) continue;
+    for (int ch = t; ch < C; ch += 256) {
+      const float v = feat[(size_t)n * ldf + ch];
+      acc[(size_t)k * C + ch] += v;
+      acc[(size_t)(K + k) * C + ch] += v * v;
+    }
+    if (t == 0) cnt[k] += 1.f;
+  }
+  __syncthreads();
+  float* dst = ws + (size_t)blockIdx.x * (2 * K * C + K);
+  for (int i = t; i < 2 * K * C + K; i += 256) dst[i] = acc[i];
+}
+
+__global__ void proto_sums_finalize_kernel(const float* __restrict__ ws, int nblocks, int KC2, int K,
+                                           float* __restrict__ sums, float* __restrict__ counts) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= KC2 + K) return;
+  float s = 0.f;
+  for (int b = 0; b < nblocks; ++b) s += ws[(size_t)b * (KC2 + K) + i];
+  if (i < KC2)
+    sums[i] = s;
+  else
+    counts[i - KC2] = s;
+}
+
+__global__ void proto_ema_kernel(float* __restrict__ proto, float* __restrict__ sqmean, const float* __restrict__ sums,
+                                 const float* __restrict__ counts, float lam, int K, int C) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= K * C) return;
+  const int k = i / C;
+  const float n = counts[k];
+  const float keep = n > 0.f ? lam : 1.f;
+  const float denom = n > 0.f ? n : 1.f;
+  proto[i] = proto[i] * keep + (1.f - keep) * (sums[i] / denom);
+  sqmean[i] = sqmean[i] * keep + (1.f - keep) * (sums[(size_t)K * C + i] / denom);
+}
+
+__global__ void proto_append_kernel(float* __restrict__ proto, float* __restrict__ sqmean, float* __restrict__ counter,
+                                    const float* __restrict__ sums, const float* __restrict__ counts, int K, int C) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= K * C) return;
+  const int k = i / C;
+  const float n = counts[k];
+  const float tot = counter[k] + n;
+  const float denom = tot > 0.f ? tot : 1.f;
+  proto[i] += (sums[i] - proto[i] * n) / denom;
+  sqmean[i] += (sums[(size_t)K * C + i] - sqmean[i] * n) / denom;
+}
+__global__ void proto_append_counter_kernel(float* __restrict__ counter, const float* __restrict__ counts, int K) {
+  const int k = threadIdx.x;
+  if (k < K) counter[k] += counts[k];
+}
+
+// ---- multi-tensor optimizer / teacher ---------------------------------------------------------
+__global__ __launch_bounds__(256) void sgd_multi_kernel(const OndaSgdEntry* __restrict__ table, float momentum,
+                                                        float wd) {
+  const OndaSgdEntry e = table[blockIdx.y];
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < e.n; i += (int64_t)gridDim.x * 256) {
+    float p = e.p[i], b = e.fresh ? 0.f : e.buf[i];
+    const float g = e.g[i];
+    for (int r = 0; r < e.times; ++r) {
+      const float d = g + wd * p;
+      b = e.fresh ? d : b * momentum + d;
+      p = p - e.lr * b;
+    }
+    e.p[i] = p;
+    e.buf[i] = b;
+  }
+}
+
+__global__ __launch_bounds__(256) void ema_multi_kernel(const OndaEmaEntry* __restrict__ table) {
+  const OndaEmaEntry e = table[blockIdx.y];
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < e.n; i += (int64_t)gridDim.x * 256)
+    e.k[i] = e.k[i] * e.keep + e.q[i] * e.blend;
+}
+
+}  // namespace
+
+extern "C" {
+
+int onda_softmax_stats(const float* logits, int ldl, float* probs, int ldp, int32_t* argmax, float* result, float* ws,
+                       int64_t N, int K, onda_stream_t s) {
+  ONDA_REQUIRE(logits && result && ws && K >= 1 && K <= KMAX && N >= 1);
+  const int nb = (int)((N + 255) / 256);
+  hipLaunchKernelGGL(softmax_stats_kernel, dim3(nb), dim3(256), 0, ONDA_STREAM(s), logits, ldl, probs, ldp, argmax, ws,
+                     N, K);
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(64), 0, ONDA_STREAM(s), ws, nb, 1, (float)(1.0 / (double)N),
+                     result);
+  return ONDA_LAUNCH_RESULT();
+}
+
+int onda_seg_loss_fwd(const float* logits, int ldl, const int64_t* labels, float* result, float* ws, int64_t N, int K,
+                      onda_stream_t s) {
+  ONDA_REQUIRE(logits && labels && result && ws && K >= 1 && K <= KMAX && N >= 1);
+  const int nb = (int)((N + 255) / 256);
+  hipLaunchKernelGGL(seg_loss_fwd_kernel, dim3(nb), dim3(256), 0, ONDA_STREAM(s), logits, ldl, labels, ws, N, K);
+  hipLaunchKernelGGL(seg_loss_finalize_kernel, dim3(1), dim3(64), 0, ONDA_STREAM(s), ws, nb, (double)N * K, result);
+  return ONDA_LAUNCH_RESULT();
+}
+
+int onda_seg_loss_bwd(const float* logits, int ldl, const int64_t* labels, const float* result, const float* gscale,
+                      float w_ce, float w_rce, float w_reg, float* dlogits, int64_t N, int K, onda_stream_t s) {
+  ONDA_REQUIRE(logits && labels && result && dlogits && K >= 1 && K <= KMAX && ldl <= KMAX && N >= 1);
+  const int nb = (int)((N + 255) / 256);
+  hipLaunchKernelGGL(seg_loss_bwd_kernel, dim3(nb), dim3(256), 0, ONDA_STREAM(s), logits, ldl, labels, result, gscale,
+                     w_ce, w_rce, w_reg, dlogits, N, K);
+  return ONDA_LAUNCH_RESULT();
+}
+
+int onda_proto_sigma(const float* proto, const float* sqmean, const float* counter, float* sigma, int K, int C,
+                     onda_stream_t s) {
+  ONDA_REQUIRE(proto && sqmean && counter && sigma);
+  hipLaunchKernelGGL(proto_sigma_kernel, dim3((C + 255) / 256), dim3(256), 0, ONDA_STREAM(s), proto, sqmean, counter,
+                     sigma, K, C);
+  return ONDA_LAUNCH_RESULT();
+}
+
+int onda_proto_assign_blocks(int64_t N) {
+  int64_t nb = (N + 3) / 4;
+  if (nb > 2048) nb = 2048;
+  return (int)nb;
+}
+
+int onda_proto_assign(const float* feat, int ldf, const float* prior, int ldp, const float* proto, const float* sigma,
+                      int mahalanobis, float tau, float thresh, int64_t* labels, float* soft, float* result, float* ws,
+                      int64_t N, int C, int K, onda_stream_t s) {
+  ONDA_REQUIRE(feat && proto && labels && result && ws && C == 256 && K >= 1 && K <= KMAX && N >= 1 && ldf % 4 == 0);
+  ONDA_REQUIRE(!mahalanobis || sigma);
+  if (!ONDA_ALIGNED16(feat) || !ONDA_ALIGNED16(proto)) return ONDA_EALIGN;
+  const int nb = onda_proto_assign_blocks(N);
+  hipLaunchKernelGGL(proto_assign_kernel, dim3(nb), dim3(256), 0, ONDA_STREAM(s), feat, ldf, prior, ldp, proto, sigma,
+                     mahalanobis, tau, thresh, labels, soft, ws, N, K);
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(64), 0, ONDA_STREAM(s), ws, nb, 3, (float)(1.0 / (double)N),
+                     result);
+  return ONDA_LAUNCH_RESULT();
+}
+
+int64_t onda_proto_sums_ws(int64_t N, int C, int K) { return (int64_t)SUMS_BLOCKS * (2 * K * C + K); }
+
+int onda_proto_class_sums(const float* feat, int ldf, const int32_t* cls, float* sums, float* counts, float* ws,
+                          int64_t N, int C, int K, onda_stream_t s) {
+  ONDA_REQUIRE(feat && cls && sums && counts && ws && N >= 1);
+  const size_t lds = ((size_t)2 * K * C + K) * sizeof(float);
+  ONDA_REQUIRE(lds <= 64 * 1024);
+  const int64_t rpb = (N + SUMS_BLOCKS - 1) / SUMS_BLOCKS;
+  hipLaunchKernelGGL(proto_class_sums_kernel, dim3(SUMS_BLOCKS), dim3(256), lds, ONDA_STREAM(s), feat, ldf, cls, ws, N,
+                     C, K, rpb);
+  const int tot = 2 * K * C + K;
+  hipLaunchKernelGGL(proto_sums_finalize_kernel, dim3((tot + 255) / 256), dim3(256), 0, ONDA_STREAM(s), ws, SUMS_BLOCKS,
+                     2 * K * C, K, sums, counts);
+  return ONDA_LAUNCH_RESULT();
+}
+
+int onda_proto_ema(float* proto, float* sqmean, const float* sums, const float* counts, float lam, int K, int C,
+                   onda_stream_t s) {
+  ONDA_REQUIRE(proto && sqmean && sums && counts);
+  hipLaunchKernelGGL(proto_ema_kernel, dim3((K * C + 255) / 256), dim3(256), 0, ONDA_STREAM(s), proto, sqmean, sums,
+                     counts, lam, K, C);
+  return ONDA_LAUNCH_RESULT();
+}
+
+int onda_proto_append(float* proto, float* sqmean, float* counter, const float* sums, const float* counts, int K, int C,
+                      onda_stream_t s) {
+  ONDA_REQUIRE(proto && sqmean && counter && sums && counts && K <= 64);
+  hipLaunchKernelGGL(proto_append_kernel, dim3((K * C + 255) / 256), dim3(256), 0, ONDA_STREAM(s), proto, sqmean,
+                     counter, sums, counts, K, C);
+  hipLaunchKernelGGL(proto_append_counter_kernel, dim3(1), dim3(64), 0, ONDA_STREAM(s), counter, counts, K);
+  return ONDA_LAUNCH_RESULT();
+}
+
+int onda_sgd_multi(const OndaSgdEntry* table, int n, float momentum, float weight_decay, int64_t max_n,
+                   onda_stream_t s) {
+  ONDA_REQUIRE(table && n >= 1 && max_n >= 1);
+  int64_t gx = (max_n + 1023) / 1024;
+  if (gx > 128) gx = 128;
+  hipLaunchKernelGGL(sgd_multi_kernel, dim3((unsigned)gx, n), dim3(256), 0, ONDA_STREAM(s), table, momentum,
+                     weight_decay);
+  return ONDA_LAUNCH_RESULT();
+}
+
+int onda_ema_multi(const OndaEmaEntry* table, int n, int64_t max_n, onda_stream_t s) {
+  ONDA_REQUIRE(table && n >= 1 && max_n >= 1);
+  int64_t gx = (max_n + 1023) / 1024;
+  if (gx > 128) gx = 128;
+  hipLaunchKernelGGL(ema_multi_kernel, dim3((unsigned)gx, n), dim3(256), 0, ONDA_STREAM(s), table);
+  return ONDA_LAUNCH_RESULT();
+}
+
+const char* onda_version(void) { return "onda_hip 0.1 (gfx950)"; }
+
+}  // extern "C"

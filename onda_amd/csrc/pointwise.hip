@@ -1,0 +1,346 @@
+// HBM-bound pointwise / stencil kernels of the hot path: ceil-mode max-pool, the SE gate,
+// channel scaling, align_corners bilinear upsampling (plain, gradient, fused argmax).
+#include "common.h"
+
+namespace {
+
+#define LD4(p) (*reinterpret_cast<const f32x4*>(p))
+
+// ---- MaxPool 3x3 / s2 / p1 / ceil_mode, NHWC -------------------------------------------
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                          uint8_t* __restrict__ idx, int B, int Hi, int Wi, int C,
+                                                          int Ho, int Wo) {
+  const int c4 = C / 4;
+  const size_t total = (size_t)B * Ho * Wo * c4;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const int col = (int)(e % c4) * 4;
+    size_t q = e / c4;
+    const int wo = (int)(q % Wo);
+    q /= Wo;
+    const int ho = (int)(q % Ho), b = (int)(q / Ho);
+    f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    int slot[4] = {0, 0, 0, 0};
+    bool first = true;
+    for (int r = 0; r < 3; ++r) {
+      const int hi = ho * 2 - 1 + r;
+      if ((unsigned)hi >= (unsigned)Hi) continue;
+      for (int s = 0; s < 3; ++s) {
+        const int wi = wo * 2 - 1 + s;
+        if ((unsigned)wi >= (unsigned)Wi) continue;
+        const f32x4 v = LD4(x + (((size_t)b * Hi + hi) * Wi + wi) * C + col);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          // ATen's scan: strict '>' keeps the first maximum, NaN always wins
+          if (first || v[j] > best[j] || v[j] != v[j]) {
+            best[j] = v[j];
+            slot[j] = r * 3 + s;
+          }
+        }
+        first = false;
+      }
+    }
+    *reinterpret_cast<f32x4*>(y + e * 4) = best;
+    *reinterpret_cast<uint32_t*>(idx + e * 4) =
+        (uint32_t)slot[0] | ((uint32_t)slot[1] << 8) | ((uint32_t)slot[2] << 16) | ((uint32_t)slot[3] << 24);
+  }
+}
+
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ idx,
+                                                          float* __restrict__ dx, int B, int Hi, int Wi, int C, int Ho,
+                                                          int Wo) {
+  const int c4 = C / 4;
+  const size_t total = (size_t)B * Hi * Wi * c4;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const int col = (int)(e % c4) * 4;
+    size_t q = e / c4;
+    const int wi = (int)(q % Wi);
+    q /= Wi;
+    const int hi = (int)(q % Hi), b = (int)(q / Hi);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int ho_lo = hi / 2, ho_hi = (hi + 1) / 2;  // windows with 2*ho-1 <= hi <= 2*ho+1
+    const int wo_lo = wi / 2, wo_hi = (wi + 1) / 2;
+    for (int ho = ho_lo; ho <= ho_hi; ++ho) {
+      if (ho >= Ho) continue;
+      for (int wo = wo_lo; wo <= wo_hi; ++wo) {
+        if (wo >= Wo) continue;
+        const int slot = (hi - (ho * 2 - 1)) * 3 + (wi - (wo * 2 - 1));
+        const size_t o = (((size_t)b * Ho + ho) * Wo + wo) * C + col;
+        const uint32_t pk = *reinterpret_cast<const uint32_t*>(idx + o);
+        const f32x4 g = LD4(dy + o);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if ((int)((pk >> (8 * j)) & 0xff) == slot) acc[j] += g[j];
+      }
+    }
+    *reinterpret_cast<f32x4*>(dx + e * 4) = acc;
+  }
+}
+
+// ---- SE gate -------------------------------------------------------------------------------
+// one block per image: hidden = relu(W1 pooled + b1) (R rows), gate = sigmoid(W2 hidden + b2)
+__global__ __launch_bounds__(256) void se_fc_fwd_kernel(const float* __restrict__ pooled, const float* __restrict__ w1,
+                                                        const float* __restrict__ b1, const float* __restrict__ w2,
+                                                        const float* __restrict__ b2, float* __restrict__ hidden,
+                                                        float* __restrict__ gate, int C, int R) {
+  extern __shared__ float hid[];
+  const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const float* p = pooled + (size_t)b * C;
+  for (int r = wave; r < R; r += 4) {
+    float s = 0.f;
+    for (int ch = lane; ch < C; ch += 64) s += w1[(size_t)r * C + ch] * p[ch];
+    s = wave_sum(s);
+    if (lane == 0) {
+      const float h = fmaxf(s + b1[r], 0.f);
+      hid[r] = h;
+      hidden[(size_t)b * R + r] = h;
+    }
+  }
+  __syncthreads();
+  for (int ch = t; ch < C; ch += 256) {
+    float s = b2[ch];
+    for (int r = 0; r < R; ++r) s += w2[(size_t)ch * R + r] * hid[r];
+    gate[(size_t)b * C + ch] = 1.f / (1.f + expf(-s));
+  }
+}
+
+// dpre2[b][c] = dgate*gate*(1-gate);  dw2[c][r] = sum_b dpre2[b][c]*hidden[b][r]; db2[c]
+__global__ void se_bwd_w2_kernel(const float* __restrict__ dgate, const float* __restrict__ gate,
+                                 const float* __restrict__ hidden, float* __restrict__ dw2, float* __restrict__ db2,
+                                 int B, int C, int R) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= C * R) return;
+  const int ch = i / R, r = i % R;
+  float s = 0.f, sb = 0.f;
+  for (int b = 0; b < B; ++b) {
+    const float g = gate[(size_t)b * C + ch];
+    const float d = dgate[(size_t)b * C + ch] * g * (1.f - g);
+    s += d * hidden[(size_t)b * R + r];
+    sb += d;
+  }
+  dw2[i] = s;
+  if (r == 0) db2[ch] = sb;
+}
+
+// dpre1[b][r] = (sum_c dpre2[b][c]*w2[c][r]) * (hidden>0)   -> ws[b][r]
+__global__ __launch_bounds__(256) void se_bwd_hidden_kernel(const float* __restrict__ dgate,
+                                                            const float* __restrict__ gate,
+                                                            const float* __restrict__ hidden,
+                                                            const float* __restrict__ w2, float* __restrict__ dpre1,
+                                                            int C, int R) {
+  const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  for (int r = wave; r < R; r += 4) {
+    float s = 0.f;
+    for (int ch = lane; ch < C; ch += 64) {
+      const float g = gate[(size_t)b * C + ch];
+      s += dgate[(size_t)b * C + ch] * g * (1.f - g) * w2[(size_t)ch * R + r];
+    }
+    s = wave_sum(s);
+    if (lane == 0) dpre1[(size_t)b * R + r] = hidden[(size_t)b * R + r] > 0.f ? s : 0.f;
+  }
+}
+
+// dw1[r][c] = sum_b dpre1[b][r]*pooled[b][c]; db1[r]; dpooled[b][c] = scale * sum_r dpre1[b][r]*w1[r][c]
+__global__ void se_bwd_w1_kernel(const float* __restrict__ dpre1, const float* __restrict__ pooled,
+                                 const float* __restrict__ w1, float* __restrict__ dw1, float* __restrict__ db1,
+                                 float* __restrict__ dpooled, int B, int C, int R, float scale) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < R * C) {
+    const int r = i / C, ch = i % C;
+    float s = 0.f, sb = 0.f;
+    for (int b = 0; b < B; ++b) {
+      s += dpre1[(size_t)b * R + r] * pooled[(size_t)b * C + ch];
+      sb += dpre1[(size_t)b * R + r];
+    }
+    dw1[i] = s;
+    if (ch == 0) db1[r] = sb;
+  }
+  if (i < B * C) {
+    const int b = i / C, ch = i % C;
+    float s = 0.f;
+    for (int r = 0; r < R; ++r) s += dpre1[(size_t)b * R + r] * w1[(size_t)r * C + ch];
+    dpooled[i] = s * scale;
+  }
+}
+
+__global__ __launch_bounds__(256) void chan_scale_kernel(const float* __restrict__ x, const float* __restrict__ gate,
+                                                         const float* __restrict__ add, float* __restrict__ out,
+                                                         int64_t HW, int C, size_t total4) {
+  const int c4 = C / 4;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total4; e += (size_t)gridDim.x * blockDim.x) {
+    const int col = (int)(e % c4) * 4;
+    const int b = (int)((e / c4) / HW);
+    f32x4 v = LD4(x + e * 4) * LD4(gate + (size_t)b * C + col);
+    if (add) v += LD4(add + (size_t)b * C + col);
+    *reinterpret_cast<f32x4*>(out + e * 4) = v;
+  }
+}
+
+// ---- bilinear, align_corners=True ----------------------------------------------------------
+struct Lerp {
+  int i0, i1;
+  float l0, l1;
+};
+__device__ __forceinline__ Lerp lerp_index(int dst, float scale, int in_size) {
+  const float src = scale * (float)dst;
+  Lerp o;
+  o.i0 = (int)src;
+  o.i1 = o.i0 + (o.i0 < in_size - 1 ? 1 : 0);
+  o.l1 = src - (float)o.i0;
+  o.l0 = 1.f - o.l1;
+  return o;
+}
+
+template <bool ARGMAX>
+__global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__ logits, int ldl,
+                                                       float* __restrict__ out, uint8_t* __restrict__ cls, int B, int h,
+                                                       int w, int K, int H, int W, float sy, float sx) {
+  const size_t total = (size_t)B * H * W;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const int X = (int)(e % W);
+    const size_t q = e / W;
+    const int Y = (int)(q % H), b = (int)(q / H);
+    const Lerp ly = lerp_index(Y, sy, h), lx = lerp_index(X, sx, w);
+    const float* p00 = logits + (((size_t)b * h + ly.i0) * w + lx.i0) * ldl;
+    const float* p01 = logits + (((size_t)b * h + ly.i0) * w + lx.i1) * ldl;
+    const float* p10 = logits + (((size_t)b * h + ly.i1) * w + lx.i0) * ldl;
+    const float* p11 = logits + (((size_t)b * h + ly.i1) * w + lx.i1) * ldl;
+    float best = -INFINITY;
+    int arg = 0;
+    for (int k = 0; k < K; ++k) {
+      const float v = ly.l0 * (lx.l0 * p00[k] + lx.l1 * p01[k]) + ly.l1 * (lx.l0 * p10[k] + lx.l1 * p11[k]);
+      if (ARGMAX) {
+        if (v > best) {
+          best = v;
+          arg = k;
+        }
+      } else {
+        out[(((size_t)b * K + k) * H + Y) * W + X] = v;
+      }
+    }
+    if (ARGMAX) cls[e] = (uint8_t)arg;
+  }
+}
+
+__global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restrict__ dout, float* __restrict__ dl,
+                                                           int ldl, int B, int h, int w, int K, int H, int W, float sy,
+                                                           float sx, float inv_sy, float inv_sx) {
+  const size_t total = (size_t)B * h * w * K;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const int k = (int)(e % K);
+    size_t q = e / K;
+    const int x = (int)(q % w);
+    q /= w;
+    const int y = (int)(q % h), b = (int)(q / h);
+    // destination rows whose source coordinate falls in (y-1, y+1), with one row of slack
+    int Y0 = (int)floorf((float)(y - 1) * inv_sy) - 1, Y1 = (int)ceilf((float)(y + 1) * inv_sy) + 1;
+    int X0 = (int)floorf((float)(x - 1) * inv_sx) - 1, X1 = (int)ceilf((float)(x + 1) * inv_sx) + 1;
+    Y0 = max(Y0, 0);
+    X0 = max(X0, 0);
+    Y1 = min(Y1, H - 1);
+    X1 = min(X1, W - 1);
+    float acc = 0.f;
+    for (int Y = Y0; Y <= Y1; ++Y) {
+      const Lerp ly = lerp_index(Y, sy, h);
+      const float wy = (ly.i0 == y ? ly.l0 : 0.f) + (ly.i1 == y ? ly.l1 : 0.f);
+      if (wy == 0.f) continue;
+      const float* row = dout + (((size_t)b * K + k) * H + Y) * W;
+      float racc = 0.f;
+      for (int X = X0; X <= X1; ++X) {
+        const Lerp lx = lerp_index(X, sx, w);
+        const float wx = (lx.i0 == x ? lx.l0 : 0.f) + (lx.i1 == x ? lx.l1 : 0.f);
+        racc += wx * row[X];
+      }
+      acc += wy * racc;
+    }
+    dl[(((size_t)b * h + y) * w + x) * ldl + k] = acc;
+  }
+}
+
+static inline unsigned ew_grid(size_t total) {
+  size_t g = (total + 255) / 256;
+  if (g > 16384) g = 16384;
+  if (g < 1) g = 1;
+  return (unsigned)g;
+}
+
+// align_corners scale exactly as ATen computes it (float division, 0 when out size is 1)
+static inline float ac_scale(int in, int out) { return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f; }
+
+}  // namespace
+
+extern "C" {
+
+int onda_maxpool_fwd(const float* x, float* y, uint8_t* idx, int B, int Hi, int Wi, int C, int Ho, int Wo,
+                     onda_stream_t s) {
+  ONDA_REQUIRE(x && y && idx && C % 4 == 0);
+  const size_t total = (size_t)B * Ho * Wo * (C / 4);
+  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(ew_grid(total)), dim3(256), 0, ONDA_STREAM(s), x, y, idx, B, Hi, Wi, C, Ho,
+                     Wo);
+  return ONDA_LAUNCH_RESULT();
+}
+
+int onda_maxpool_bwd(const float* dy, const uint8_t* idx, float* dx, int B, int Hi, int Wi, int C, int Ho, int Wo,
+                     onda_stream_t s) {
+  ONDA_REQUIRE(dy && dx && idx && C % 4 == 0);
+  const size_t total = (size_t)B * Hi * Wi * (C / 4);
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, ONDA_STREAM(s), dy, idx, dx, B, Hi, Wi, C,
+                     Ho, Wo);
+  return ONDA_LAUNCH_RESULT();
+}
+
+int onda_se_fc_fwd(const float* pooled, const float* w1, const float* b1, const float* w2, const float* b2,
+                   float* hidden, float* gate, int B, int C, int R, onda_stream_t s) {
+  ONDA_REQUIRE(pooled && w1 && b1 && w2 && b2 && hidden && gate && R <= 4096);
+  hipLaunchKernelGGL(se_fc_fwd_kernel, dim3(B), dim3(256), R * sizeof(float), ONDA_STREAM(s), pooled, w1, b1, w2, b2,
+                     hidden, gate, C, R);
+  return ONDA_LAUNCH_RESULT();
+}
+
+int onda_se_fc_bwd(const float* dgate, const float* pooled, const float* hidden, const float* gate, const float* w1,
+                   const float* w2, float* dw1, float* db1, float* dw2, float* db2, float* dpooled, float* ws,
+                   float dpooled_scale, int B, int C, int R, onda_stream_t s) {
+  ONDA_REQUIRE(dgate && pooled && hidden && gate && w1 && w2 && dw1 && db1 && dw2 && db2 && dpooled && ws);
+  hipLaunchKernelGGL(se_bwd_w2_kernel, dim3((C * R + 255) / 256), dim3(256), 0, ONDA_STREAM(s), dgate, gate, hidden, dw2,
+                     db2, B, C, R);
+  hipLaunchKernelGGL(se_bwd_hidden_kernel, dim3(B), dim3(256), 0, ONDA_STREAM(s), dgate, gate, hidden, w2, ws, C, R);
+  const int n = (R > B ? R : B) * C;
+  hipLaunchKernelGGL(se_bwd_w1_kernel, dim3((n + 255) / 256), dim3(256), 0, ONDA_STREAM(s), ws, pooled, w1, dw1, db1,
+                     dpooled, B, C, R, dpooled_scale);
+  return ONDA_LAUNCH_RESULT();
+}
+
+int onda_chan_scale(const float* x, const float* gate, const float* add, float* out, int B, int64_t HW, int C,
+                    onda_stream_t s) {
+  ONDA_REQUIRE(x && gate && out && C % 4 == 0);
+  const size_t total4 = (size_t)B * HW * C / 4;
+  hipLaunchKernelGGL(chan_scale_kernel, dim3(ew_grid(total4)), dim3(256), 0, ONDA_STREAM(s), x, gate, add, out, HW, C,
+                     total4);
+  return ONDA_LAUNCH_RESULT();
+}
+
+int onda_upsample_fwd(const float* logits, int ldl, float* out, int B, int h, int w, int K, int H, int W,
+                      onda_stream_t s) {
+  ONDA_REQUIRE(logits && out && K <= ldl);
+  hipLaunchKernelGGL((upsample_kernel<false>), dim3(ew_grid((size_t)B * H * W)), dim3(256), 0, ONDA_STREAM(s), logits,
+                     ldl, out, (uint8_t*)nullptr, B, h, w, K, H, W, ac_scale(h, H), ac_scale(w, W));
+  return ONDA_LAUNCH_RESULT();
+}
+
+int onda_upsample_argmax(const float* logits, int ldl, uint8_t* cls, int B, int h, int w, int K, int H, int W,
+                         onda_stream_t s) {
+  ONDA_REQUIRE(logits && cls && K <= ldl && K <= 255);
+  hipLaunchKernelGGL((upsample_kernel<true>), dim3(ew_grid((size_t)B * H * W)), dim3(256), 0, ONDA_STREAM(s), logits,
+                     ldl, (float*)nullptr, cls, B, h, w, K, H, W, ac_scale(h, H), ac_scale(w, W));
+  return ONDA_LAUNCH_RESULT();
+}
+
+int onda_upsample_bwd(const float* dout, float* dlogits, int ldl, int B, int h, int w, int K, int H, int W,
+                      onda_stream_t s) {
+  ONDA_REQUIRE(dout && dlogits && K <= ldl && h > 1 && w > 1 && H > 1 && W > 1);
+  const float sy = ac_scale(h, H), sx = ac_scale(w, W);
+  hipLaunchKernelGGL(upsample_bwd_kernel, dim3(ew_grid((size_t)B * h * w * K)), dim3(256), 0, ONDA_STREAM(s), dout,
+                     dlogits, ldl, B, h, w, K, H, W, sy, sx, 1.f / sy, 1.f / sx);
+  return ONDA_LAUNCH_RESULT();
+}
+
+}  // extern "C"

@@ -1,0 +1,340 @@
+"""Drop-in for ``framework/domain_adaptation/methods/prototypes.py``: ``online_proDA`` -- the
+online prototype adaptation loop whose ``step()`` (:418-450) is the unit BASELINE.json
+measures -- plus ``regular_loss`` (:29-39).
+
+Control flow, state and log keys follow the reference; what changes is where the work runs:
+every forward/backward is HIP kernels, the three target losses are one fused kernel, the
+teacher's softmax / argmax / confidence means come from one kernel per logits map, the
+pseudo-labels + soft map + monitor means come from one pass over the features, optimizer
+and teacher EMA are single multi-tensor launches, and the target batch is uploaded once.
+With ``torch.distributed`` initialised, gradients, prototype statistics and the switch
+scalars are all-reduced (RCCL) so every rank takes the same decisions.
+"""
+from copy import deepcopy
+
+import numpy as np
+import torch
+from torch import nn
+from torch.functional import F
+
+from onda_amd import dist as odist
+from onda_amd import ops
+from onda_amd.config import unset
+from onda_amd.framework.domain_adaptation.methods.adaptation_model import da_model, switch_batch_statistics
+from onda_amd.framework.domain_adaptation.methods.prototype_handler import prototype_handler
+from onda_amd.framework.utils.func import loss_calc
+from onda_amd.framework.utils.loss import rce
+from onda_amd.framework.utils.monitoring import Monitor
+
+
+def regular_loss(regularizer, activation):
+    """"MRKLD": -mean(log_softmax(activation)) over every element (reference :35-38)."""
+    if regularizer == "MRKLD":
+        return ops.seg_losses(activation, torch.zeros(activation.shape[0], *activation.shape[2:], dtype=torch.int64,
+                                                      device=activation.device), 0.0, 0.0, 1.0)[0]
+    if regularizer == "MRENT":
+        raise NotImplementedError("onda_amd: the MRENT regulariser is not used by the BASELINE configs")
+    return 0
+
+
+class online_proDA(da_model):
+    def __init__(self, model, cfg, cfg_spec) -> None:
+        super(online_proDA, self).__init__(model, cfg, cfg_spec)
+        self.ema_model = deepcopy(model)
+        self.dynamic_model = deepcopy(model)
+        self.static_model = deepcopy(model)
+        args = [cfg_spec.AVG_MONITOR_SIZE]
+        if not unset(cfg_spec.EXP_MONITOR_CONST):
+            args.append(cfg_spec.EXP_MONITOR_CONST)
+        if not unset(cfg_spec.DEV_MONITOR_FUNC):
+            args.append(cfg_spec.DEV_MONITOR_FUNC)
+        self.intensity_ma = Monitor(*args)
+        for module in self.static_model.modules():
+            if isinstance(module, nn.BatchNorm2d):
+                module.momentum = cfg_spec.BN_MOMENTUM
+        self.models_default_config()
+        self.prototypes = prototype_handler(
+            ma_lambda=cfg_spec.MA_LAMBDA, tau=cfg_spec.TAU, thresh=cfg_spec.PSEUDO_THRESH,
+            distance_metric=cfg_spec.DISTANCE_MEASURE,
+            confidence_regularization_threshold=cfg_spec.CONFIDENCE_REGULARIZATION_THRESHOLD)
+        self.skip_proto = False
+        if isinstance(cfg_spec.LOAD_PROTO, str):
+            self.prototypes.load(cfg_spec.LOAD_PROTO)
+            self.prototypes.to(self.device)
+            self.skip_proto = True
+        self.proto_loc = cfg.OTHERS.SNAPSHOT_DIR + f"/proto_{cfg_spec.set_}.pickle"
+        self.proto_cur = cfg.OTHERS.SNAPSHOT_DIR + "/proto_current.pickle"
+        self.probability_per_step = 0 if unset(cfg.TRAINING.PERC_FILL_PER_DOMAIN) else cfg.TRAINING.PERC_FILL_PER_DOMAIN
+        self.probability_per_step *= 1.0 * cfg.TRAINING.REPLAY_BUFFER / cfg.TRAINING.BATCH_SIZE
+        if not unset(self.cfg_spec.MODEL_REGULARIZATION) and self.cfg_spec.MODEL_REGULARIZATION > 0:
+            raise NotImplementedError("onda_amd: EWC model regularisation is disabled in every shipped config")
+        self.model_regularization = None
+        if isinstance(cfg_spec.BN_POLICY, dict):
+            self.cfg_spec.BN_POLICY = "freeze"
+        if not unset(cfg_spec.LOAD_MODEL) and cfg_spec.LOAD_MODEL:
+            super().load_model(cfg_spec.LOAD_MODEL)
+        self.dynamic_update_counter = 0
+        self._grad_sync = odist.GradSync(self.model)
+
+    # ---- model bookkeeping -----------------------------------------------------------------
+    def update_dynamic(self):
+        self.dynamic_model = deepcopy(self.model)
+        self.models_default_config()
+
+    def models_default_config(self):
+        self.model.train()
+        self.ema_model.train()
+        self.dynamic_model.eval()
+        self.static_model.eval()
+        self.intensity_ma.train()
+
+    def models_eval(self):
+        self.model.eval()
+        self.ema_model.eval()
+        self.dynamic_model.eval()
+        self.static_model.eval()
+        self.intensity_ma.eval()
+
+    def update_cfg_spec(self, new_cfg):
+        super().update_cfg_spec(new_cfg)
+        self.proto_loc = self.cfg.OTHERS.SNAPSHOT_DIR + f"/proto_{new_cfg.set_}.pickle"
+
+    def save_model(self):
+        super().save_model(prefix="current")
+        self.prototypes.save(self.proto_loc)
+
+    def calculate_prototypes(self, dataloader, save=True):
+        """Initial prototypes as running class means over a loader (reference :128-155)."""
+        with torch.no_grad():
+            buffered = isinstance(self.cfg.TRAINING.BUFFER_DYNAMIC, bool) and self.cfg.TRAINING.BUFFER_DYNAMIC
+            for batch in (dataloader.sequential() if buffered else dataloader):
+                _, pred = self.model(batch["image"].to(self.device))
+                feat, out = pred["feat"], pred["out"]
+                if self.cfg_spec.STARTING_PROTO == "source":
+                    # classes from the nearest-resized ground truth; 255 matches no class, so the
+                    # sums kernel drops those pixels (the reference masks them out, :144-153)
+                    _, channels, height, width = out.size()
+                    labels = F.interpolate(batch["label"].unsqueeze(1).float(), size=(height, width)).view(-1)
+                    self.prototypes.append(feat, channels, classes=labels)
+                else:
+                    self.prototypes.append(feat, out)
+        if save:
+            import os
+            os.makedirs(self.cfg.OTHERS.SNAPSHOT_DIR, exist_ok=True)
+            self.prototypes.save(self.proto_cur)
+
+    # ---- losses ---------------------------------------------------------------------------------
+    def supervised_loss(self, batch):
+        """CE (and optionally RCE) of the student on a source-replay batch (reference :157-189)."""
+        _, pred = self.model(batch["image"].to(self.device))
+        out = pred["out"]
+        label = batch["stored_predictions"] if "stored_predictions" in batch.keys() else batch["label_res"]
+        w_ce = self.cfg_spec.BUFF_CE if self.cfg_spec.BUFF_CE > 0 else 0.0
+        w_rce = self.cfg_spec.BUFF_RCE if self.cfg_spec.BUFF_RCE > 0 else 0.0
+        total, ce, rc, _ = ops.seg_losses(out, label.long().to(self.device), w_ce, w_rce, 0.0)
+        return {"buff_ce_loss": ce if w_ce > 0 else 0, "buff_rce_loss": rc if w_rce > 0 else 0, "buff_loss": total}
+
+    def _prior_of(self, model, image, key):
+        """softmax prior of one no-grad model pass + its mean max-probability (device scalar)."""
+        _, pred = model(image)
+        conf, probs, am = ops.softmax_stats(pred["out"], want_probs=True, want_argmax=(key == "prior EMA"))
+        return pred, probs, conf, am
+
+    def prototype_predictions(self, batch):
+        """Teacher / static / dynamic priors and prototype pseudo-labels (reference :208-273)."""
+        with torch.no_grad():
+            image = self._device_image(batch)
+            pred_ema, prior_ema, conf_ema, cls_ema = self._prior_of(self.ema_model, image, "prior EMA")
+            self.intensity_ma.add({"prior EMA": conf_ema})
+            prior = self.cfg_spec.EMA_LAMBDA * prior_ema
+            if self.cfg_spec.STATIC_LAMBDA > 0:
+                _, prior_static, conf_static, _ = self._prior_of(self.static_model, image, "prior static")
+                self.intensity_ma.add({"prior static": conf_static})
+                prior += self.cfg_spec.STATIC_LAMBDA * prior_static
+            calculate_dyn, replace_dyn = True, False
+            thr = self.cfg_spec.SWITCH_PRIOR_THRESH
+            thr = 0 if unset(thr) else thr
+            if thr > 0 and self.intensity_ma.avg("prior static") < thr:
+                replace_dyn = True
+            elif thr > 0:
+                calculate_dyn = False
+            if self.cfg_spec.DYNAMIC_LAMBDA > 0 and calculate_dyn:
+                _, prior_dynamic, conf_dyn, _ = self._prior_of(self.dynamic_model, image, "prior dynamic")
+                self.intensity_ma.add({"prior dynamic": conf_dyn})
+                prior = self.cfg_spec.DYNAMIC_LAMBDA * prior_dynamic if replace_dyn else \
+                    prior + self.cfg_spec.DYNAMIC_LAMBDA * prior_dynamic
+        return self._labels_from(pred_ema, prior, cls_ema)
+
+    def _labels_from(self, pred_ema, prior, cls_ema):
+        feat = pred_ema["feat"]
+        # one pass + one read-back: [prototype confidence, posterior confidence, prior confidence]
+        labels, soft, s = self.prototypes.assign_stats(feat, prior)
+        self.intensity_ma.add({"prior": s[2]})
+        pseudolabels = self.prototypes.pseudo_labels(feat, prior, confidence_monitor=self.intensity_ma)
+        soft_predictions = self.prototypes.pseudo_labels(feat, prior, soft=True)
+        self.intensity_ma.add({"pseudolabel confidence": s[1]})
+        return {"ema_model": pred_ema, "pseudolabels": pseudolabels, "soft_predictions": soft_predictions,
+                "ema_classes": cls_ema}
+
+    def _device_image(self, batch):
+        img = batch["image"]
+        cached = getattr(self, "_img_cache", None)
+        if cached is not None and cached[0] is img:
+            return cached[1]
+        dev = img.to(self.device, non_blocking=True)
+        self._img_cache = (img, dev)
+        return dev
+
+    def pseudolabel_loss(self, batch):
+        """Target loss from prototype pseudo-labels (reference :275-372)."""
+        if not unset(self.cfg_spec.SOFT_LABELS) and self.cfg_spec.SOFT_LABELS:
+            raise NotImplementedError("onda_amd: SOFT_LABELS is unset in the BASELINE configs; hard labels only")
+        if not unset(self.cfg_spec.PREDICTION_SAVE):
+            raise NotImplementedError("onda_amd: PREDICTION_SAVE is a logging feature outside the hot path")
+        image = self._device_image(batch)
+        _, pred = self.model(image)
+        out = pred["out"]
+        with torch.no_grad():
+            conf_model, _, cls_model = ops.softmax_stats(out, want_argmax=True)
+        self.intensity_ma.add({"model": conf_model})
+        proto_pred = self.prototype_predictions(batch)
+        ema = proto_pred["ema_model"]
+        self._prototype_ema(ema["feat"], ema["out"], proto_pred.get("ema_classes"))
+        batch_size, channels, w, h = out.size()
+        predictions = proto_pred["pseudolabels"].reshape(batch_size, w, h)
+        w_ce = self.cfg_spec.RCE_ALPHA if self.cfg_spec.RCE_ALPHA > 0 else 0.0
+        w_rce = self.cfg_spec.RCE_BETA if self.cfg_spec.RCE_BETA > 0 else 0.0
+        w_reg = self.cfg_spec.REGULARIZER_WEIGHT if self.cfg_spec.REGULARIZER_WEIGHT > 0 else 0.0
+        if w_reg > 0 and self.cfg_spec.REGULARIZER != "MRKLD":
+            raise NotImplementedError("onda_amd: only the MRKLD regulariser is implemented")
+        if self.cfg_spec.JS_D > 0:
+            raise NotImplementedError("onda_amd: JS_D is 0 in every shipped config")
+        total, ce_loss, rce_loss, reg_loss = ops.seg_losses(out, predictions, w_ce, w_rce, w_reg)
+        flat = proto_pred["pseudolabels"].reshape(-1)
+        current_losses = {
+            "ce_loss": ce_loss if w_ce > 0 else 0,
+            "pseudolabel_pixel_num": ((flat >= 0) * (flat != 255)).float().sum(),
+            "output & prototype agreement": (flat == cls_model.long()).float().mean(),
+            "mean_prototype_intensity_values": (self.prototypes.prototypes ** 2).mean(),
+            "rce_loss": rce_loss if w_rce > 0 else 0,
+            "sym_loss": total,  # the reference aliases total_loss = sym_loss
+            "regularization_loss": reg_loss if w_reg > 0 else 0,
+            "JS Divergance loss": 0,
+            "Total target loss": total,
+            "model regularization": 0,
+        }
+        for name, value in self.intensity_ma.avg().items():
+            current_losses[f"{name} confidence ma"] = value
+        for name, value in self.intensity_ma.exp().items():
+            current_losses[f"{name} exp confidence ma"] = value
+        current_losses["dev avg prior static"] = self.intensity_ma.dev_avg("prior static")
+        batch["stored_predictions"] = proto_pred["soft_predictions"].reshape(batch_size, w, h, channels).permute(0, 3, 1, 2)
+        return current_losses
+
+    def _prototype_ema(self, feat, out, classes=None):
+        """prototypes.ma with the batch statistics summed over all ranks first."""
+        flat, K, C = self.prototypes.class_statistics(feat, out)
+        odist.all_reduce_sum(flat)
+        self.prototypes.ma_from_statistics(flat, K, C)
+
+    def evaluate(self, validation_loader):
+        def proto_func(batch):
+            proto_pred = self.prototype_predictions(batch)
+            b, k, h, w = proto_pred["ema_model"]["out"].size()
+            return proto_pred["soft_predictions"].reshape(b, h, w, k).permute(0, 3, 1, 2)
+
+        if isinstance(self.cfg_spec.SKIP_PROTO_EVAL, bool) and self.cfg_spec.SKIP_PROTO_EVAL:
+            return super().evaluate(validation_loader)
+        return super().evaluate(validation_loader, {"proto": proto_func})
+
+    def evaluate_update_dynamic(self):
+        if not unset(self.cfg_spec.AUTO_DYNAMIC) and self.cfg_spec.AUTO_DYNAMIC:
+            self.dynamic_update_counter += 1
+            if self.dynamic_update_counter > 500:
+                x = self.intensity_ma.dev_avg("prior static")
+                if np.abs(x) > self.cfg_spec.DEV_THRESH:
+                    self.update_dynamic()
+                    self.dynamic_update_counter = 0
+
+    @torch.no_grad()
+    def update_ema(self):
+        """teacher = keep*teacher + (1-keep)*student for all 217 parameters, buffers copied
+        (reference :407-416), as one multi-tensor launch."""
+        keep = self.cfg_spec.EMA_UPDATE
+        items = [(k, q, keep, 1.0 - keep) for q, k in zip(self.model.parameters(), self.ema_model.parameters())]
+        ints_q, ints_k = [], []
+        for bq, bk in zip(self.model.buffers(), self.ema_model.buffers()):
+            if bq.dtype == torch.float32:
+                items.append((bk, bq, 0.0, 1.0))
+            else:
+                ints_q.append(bq)
+                ints_k.append(bk)
+        ops.ema_multi(items)
+        if ints_k:
+            torch._foreach_copy_(ints_k, ints_q)
+
+    def step(self, batches_source, batch_target):
+        """One adaptation step: source replay fwd+bwd (BN statistics frozen), target fwd, teacher /
+        static / (dynamic) fwd, pseudo-labels, prototype EMA, target bwd, optimizer step."""
+        loss_seg_src_main = {}
+        if self.cfg_spec.BN_POLICY == "freeze":
+            switch_batch_statistics(self.model, False)
+        elif self.cfg_spec.BN_POLICY == "double":
+            self.bn.exchange()
+        for batch_source in batches_source:
+            if self.cfg.TRAINING.REPLAY_BUFFER > 0:
+                loss_seg_src_main = self.supervised_loss(batch_source)
+                loss_seg_src_main["buff_loss"].backward()
+        if self.cfg_spec.BN_POLICY == "freeze":
+            switch_batch_statistics(self.model, True)
+        elif self.cfg_spec.BN_POLICY == "double":
+            self.bn.exchange()
+        pseudolabel_losses = self.pseudolabel_loss(batch_target)
+        pseudolabel_losses["Total target loss"].backward()
+        pseudolabel_losses["encoder_lr"] = self.optimizer.param_groups[0]["lr"]
+        pseudolabel_losses.update(loss_seg_src_main)
+        self._grad_sync.all_reduce()  # no-op on one GPU; one bucketed RCCL all-reduce otherwise
+        self.optimizer.step()
+        self.optimizer.zero_grad()
+        self._img_cache = None
+        return pseudolabel_losses
+
+    def train(self, trainloader, targetloader, validation_loaders, log_fn=None):
+        """The per-domain loop (reference :466-520); `log_fn(dict)` replaces wandb.log."""
+        if unset(self.cfg_spec.AUTO_DYNAMIC) or self.cfg_spec.AUTO_DYNAMIC is False:
+            self.update_dynamic()
+        if not self.cfg_spec.SKIP_CALC:
+            if not self.skip_proto:
+                switch_batch_statistics(self.model, False)
+                self.calculate_prototypes(targetloader if self.cfg_spec.STARTING_PROTO == "target" else trainloader)
+                switch_batch_statistics(self.model, True)
+                self.skip_proto = True
+            if log_fn and validation_loaders:
+                log_fn(self.evaluate_all(validation_loaders))
+        steps = self.cfg_spec.EPOCHS * len(targetloader)
+        src_iter, trg_iter = iter(trainloader), iter(targetloader)
+        self.optimizer.zero_grad()
+        for i_iter in range(steps):
+            self.adjust_learning_rate(i_iter, steps)
+            source_samples = []
+            for _ in range(self.cfg_spec.SOURCE_REPEAT):
+                try:
+                    sample = next(src_iter)
+                except StopIteration:
+                    src_iter = iter(trainloader)
+                    sample = next(src_iter)
+                source_samples.append(sample)
+            try:
+                target_sample = next(trg_iter)
+            except StopIteration:
+                trg_iter = iter(targetloader)
+                target_sample = next(trg_iter)
+            log = self.step(source_samples, target_sample)
+            self.evaluate_update_dynamic()
+            self.update_ema()
+            if (i_iter + 1) % len(targetloader) == 0 and validation_loaders:
+                log.update(self.evaluate_all(validation_loaders))
+                self.save_model()
+            if log_fn:
+                log_fn(log)
+        self.save_model()

@@ -1,0 +1,562 @@
+"""Host-side operator layer: torch tensors in, HIP kernels (through the C ABI) underneath.
+
+PyTorch supplies device memory (the caching allocator owns every buffer, workspaces
+included), the current HIP stream and the autograd graph; all arithmetic of the hot path
+runs in ``libonda_hip.so``.  Activations are dense NHWC tensors ``[B, H, W, C]`` (or channel
+slices of one, row stride ``ld``); parameters keep the reference's shapes (OIHW conv weights)
+so state_dicts, ``deepcopy`` and optimizers behave exactly as with the reference modules.
+
+Nothing here falls back to eager torch math: a missing library raises at first use.
+"""
+import ctypes
+from ctypes import byref
+
+import torch
+
+from . import _lib
+from ._lib import OndaConv, call, query
+
+BN_EPS = 1e-5
+GN_EPS = 1e-5
+GN_GROUPS = 32
+HEAD_PAD = 32  # the 19-class head is computed as a 32-wide GEMM (padded rows are zero)
+STEM_K = 160   # 7*7*3 = 147 patch values padded to a multiple of 32
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _require_cuda(t, what):
+    if not t.is_cuda:
+        raise RuntimeError(f"onda_amd: {what} must live on the GPU (got {t.device}); the HIP path has no CPU fallback")
+
+
+def nhwc_ld(t):
+    """Row stride of a dense-pixel NHWC view; raises if the view is not pixel-dense."""
+    b, h, w, c = t.shape
+    ld = t.stride(2)
+    if t.stride(3) != 1 or t.stride(1) != w * ld or (b > 1 and t.stride(0) != h * w * ld) or ld < c:
+        raise RuntimeError(f"onda_amd: tensor is not a pixel-dense NHWC view: shape {tuple(t.shape)} strides {t.stride()}")
+    return ld
+
+
+def as_nhwc(t):
+    """Return `t` (logical [B,H,W,C]) as something the kernels accept, copying only if needed."""
+    b, h, w, c = t.shape
+    ld = t.stride(2)
+    if t.stride(3) == 1 and t.stride(1) == w * ld and (b == 1 or t.stride(0) == h * w * ld) and ld >= c and ld % 4 == 0:
+        return t
+    return t.contiguous()
+
+
+def conv_out_size(n, k, stride, dil, pad):
+    return (n + 2 * pad - dil * (k - 1) - 1) // stride + 1
+
+
+# ------------------------------------------------------------------------------- conv plumbing
+def _desc(B, Hi, Wi, Cin, Ho, Wo, Cout, k, stride, dil, pad, ldx, ldy, ldr=0, out_os=1, Hf=None, Wf=None, relu=0):
+    return OndaConv(B, Hi, Wi, Cin, Ho, Wo, Cout, k, k, stride, dil, pad, ldx, ldy, ldr, out_os,
+                    Ho if Hf is None else Hf, Wo if Wf is None else Wf, int(relu))
+
+
+def pack_weight_fwd(weight, cout_pad=None, kp=None):
+    """OIHW -> [Cout_pad][tap*Cin + c] rows of length kp (zero padded)."""
+    cout, cin, kh, kw = weight.shape
+    taps = kh * kw
+    cout_pad = cout_pad or cout
+    kp = kp or taps * cin
+    dst = torch.empty(cout_pad, kp, device=weight.device, dtype=torch.float32)
+    call("onda_pack_weight_fwd", _p(weight.detach().contiguous()), _p(dst), cout, cin, taps, cout_pad, kp, _stream())
+    return dst
+
+
+def pack_weight_dgrad(weight, cout_pad=None):
+    """OIHW -> [Cin][taps (flipped)][Cout_pad]: the data gradient of a stride-1 conv is a conv of dy with this."""
+    cout, cin, kh, kw = weight.shape
+    cout_pad = cout_pad or cout
+    dst = torch.empty(cin, kh * kw, cout_pad, device=weight.device, dtype=torch.float32)
+    call("onda_pack_weight_dgrad", _p(weight.detach().contiguous()), _p(dst), cout, cin, kh * kw, cout_pad, _stream())
+    return dst
+
+
+def conv_forward(x, wp, k, stride, dil, pad, cout, out=None, scale=None, shift=None, residual=None, relu=False,
+                 want_stats=False):
+    """x NHWC view, wp packed [cout][k*k*Cin].  Returns (y, stats partials or None, tiles)."""
+    _require_cuda(x, "conv input")
+    B, Hi, Wi, Cin = x.shape
+    ldx = nhwc_ld(x)
+    Ho, Wo = conv_out_size(Hi, k, stride, dil, pad), conv_out_size(Wi, k, stride, dil, pad)
+    if out is None:
+        out = torch.empty(B, Ho, Wo, cout, device=x.device, dtype=torch.float32)
+    ldy = nhwc_ld(out)
+    ldr = nhwc_ld(residual) if residual is not None else 0
+    stats, tiles = None, 0
+    if want_stats:
+        tiles = query("onda_conv_tiles_m", B * Ho * Wo)
+        stats = torch.empty(tiles, 2, cout, device=x.device, dtype=torch.float32)
+    d = _desc(B, Hi, Wi, Cin, Ho, Wo, cout, k, stride, dil, pad, ldx, ldy, ldr, relu=relu)
+    call("onda_conv2d_fwd", _p(x), _p(wp), _p(out), _p(scale), _p(shift), _p(residual), _p(stats), byref(d), _stream())
+    return out, stats, tiles
+
+
+def conv_dgrad(dy, wpd, k, stride, dil, pad, cin, in_hw):
+    """Data gradient.  dy NHWC [B,Ho,Wo,Cout(_pad)], wpd = pack_weight_dgrad(weight)."""
+    B, Ho, Wo, Co = dy.shape
+    Hi, Wi = in_hw
+    ldy = nhwc_ld(dy)
+    if stride == 1:
+        dx = torch.empty(B, Hi, Wi, cin, device=dy.device, dtype=torch.float32)
+        d = _desc(B, Ho, Wo, Co, Hi, Wi, cin, k, 1, dil, dil * (k - 1) - pad, ldy, cin)
+    else:
+        if k != 1 or pad != 0:
+            raise RuntimeError("onda_amd: strided data gradient is implemented for 1x1 convs only")
+        dx = torch.zeros(B, Hi, Wi, cin, device=dy.device, dtype=torch.float32)
+        d = _desc(B, Ho, Wo, Co, Ho, Wo, cin, 1, 1, 1, 0, ldy, cin, out_os=stride, Hf=Hi, Wf=Wi)
+    call("onda_conv2d_fwd", _p(dy), _p(wpd), _p(dx), None, None, None, None, byref(d), _stream())
+    return dx
+
+
+def _wgrad_splitk(M, cout, cin, taps):
+    t = 128 if (cout > 64 and cin > 64) else 64
+    tiles = -(-cout // t) * -(-cin // t) * taps
+    sk = max(1, -(-1024 // tiles))
+    sk = min(sk, max(1, M // 256))
+    budget = (256 << 20) // (4 * cout * cin * taps)
+    return max(1, min(sk, max(1, budget)))
+
+
+def conv_wgrad(x, dy, k, stride, dil, pad, cout_real, cin_real, flat_k=0):
+    """Weight gradient in OIHW.  x NHWC input of the conv, dy NHWC output gradient."""
+    B, Hi, Wi, Cin = x.shape
+    _, Ho, Wo, Co = dy.shape
+    taps = k * k
+    M = B * Ho * Wo
+    sk = _wgrad_splitk(M, Co, Cin, taps)
+    slabs = torch.empty(sk, Co, taps, Cin, device=x.device, dtype=torch.float32)
+    d = _desc(B, Hi, Wi, Cin, Ho, Wo, Co, k, stride, dil, pad, nhwc_ld(x), Co)
+    call("onda_conv2d_wgrad", _p(x), _p(dy), _p(slabs), nhwc_ld(dy), sk, byref(d), _stream())
+    if flat_k:
+        dw = torch.empty(cout_real, cin_real, 7, 7, device=x.device, dtype=torch.float32)
+    else:
+        dw = torch.empty(cout_real, cin_real, k, k, device=x.device, dtype=torch.float32)
+    call("onda_wgrad_reduce", _p(slabs), _p(dw), sk, Co, taps, Cin, cout_real, cin_real, flat_k, _stream())
+    return dw
+
+
+def colsum(x, y=None, alpha=1.0, per_image=False):
+    """sum over pixels of x (*y): [C] (or [B,C] if per_image).  x, y NHWC views."""
+    B, H, W, C = x.shape
+    nb, hw = (B, H * W) if per_image else (1, B * H * W)
+    ws = torch.empty(query("onda_colsum_ws", nb, hw, C), device=x.device, dtype=torch.float32)
+    out = torch.empty(nb, C, device=x.device, dtype=torch.float32)
+    call("onda_colsum", _p(x), nhwc_ld(x), _p(y), nhwc_ld(y) if y is not None else 0, _p(out), float(alpha), _p(ws),
+         nb, hw, C, _stream())
+    return out if per_image else out[0]
+
+
+# ------------------------------------------------------------------------------- autograd ops
+class _PackCache:
+    """Packed copies of one conv weight, rebuilt when the parameter changes (version counter or storage)."""
+
+    def __init__(self):
+        self.key_f = self.key_d = None
+        self.fwd = self.dgrad = None
+
+    @staticmethod
+    def _key(w):
+        return (w.data_ptr(), w._version, w.device)
+
+    def get_fwd(self, w, cout_pad=None, kp=None):
+        k = self._key(w)
+        if self.key_f != k:
+            self.fwd, self.key_f = pack_weight_fwd(w, cout_pad, kp), k
+        return self.fwd
+
+    def get_dgrad(self, w, cout_pad=None):
+        k = self._key(w)
+        if self.key_d != k:
+            self.dgrad, self.key_d = pack_weight_dgrad(w, cout_pad), k
+        return self.dgrad
+
+    def __deepcopy__(self, memo):
+        return _PackCache()
+
+
+class Conv2dFn(torch.autograd.Function):
+    """NHWC convolution (+bias) with optional BatchNorm statistic partials from the epilogue."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, cache, stride, dil, pad, want_stats, cout_pad):
+        cout, cin, k, _ = weight.shape
+        co = cout_pad or cout
+        wp = cache.get_fwd(weight, cout_pad)
+        y, stats, _tiles = conv_forward(x, wp, k, stride, dil, pad, co, shift=_pad_vec(bias, co), want_stats=want_stats)
+        ctx.save_for_backward(x, weight)
+        ctx.cache, ctx.geom, ctx.has_bias = cache, (k, stride, dil, pad, cout, cin, cout_pad), bias is not None
+        if want_stats:
+            ctx.mark_non_differentiable(stats)
+            return y, stats
+        return y, None
+
+    @staticmethod
+    def backward(ctx, dy, _dstats):
+        x, weight = ctx.saved_tensors
+        k, stride, dil, pad, cout, cin, cout_pad = ctx.geom
+        dy = as_nhwc(dy)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = conv_dgrad(dy, ctx.cache.get_dgrad(weight, cout_pad), k, stride, dil, pad, cin, x.shape[1:3])
+        if ctx.needs_input_grad[1]:
+            dw = conv_wgrad(x, dy, k, stride, dil, pad, cout, cin)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = colsum(dy)[:cout]
+        return dx, dw, db, None, None, None, None, None, None
+
+
+def _pad_vec(v, n):
+    if v is None or v.numel() == n:
+        return v
+    out = torch.zeros(n, device=v.device, dtype=v.dtype)
+    out[: v.numel()] = v.detach()
+    return out
+
+
+class StemConvFn(torch.autograd.Function):
+    """7x7 / stride 2 / pad 3 stem on the NCHW image: im2col patches + the same MFMA GEMM."""
+
+    @staticmethod
+    def forward(ctx, x_nchw, weight, cache, want_stats):
+        _require_cuda(x_nchw, "image")
+        x_nchw = x_nchw.contiguous()
+        B, _, H, W = x_nchw.shape
+        Ho, Wo = conv_out_size(H, 7, 2, 1, 3), conv_out_size(W, 7, 2, 1, 3)
+        col = torch.empty(B, Ho, Wo, STEM_K, device=x_nchw.device, dtype=torch.float32)
+        call("onda_stem_im2col", _p(x_nchw), _p(col), B, H, W, Ho, Wo, STEM_K, _stream())
+        wp = cache.get_fwd(weight, None, STEM_K)
+        y, stats, _ = conv_forward(col, wp, 1, 1, 1, 0, weight.shape[0], want_stats=want_stats)
+        if weight.requires_grad and torch.is_grad_enabled():
+            ctx.save_for_backward(col)
+        ctx.cout = weight.shape[0]
+        if want_stats:
+            ctx.mark_non_differentiable(stats)
+            return y, stats
+        return y, None
+
+    @staticmethod
+    def backward(ctx, dy, _dstats):
+        (col,) = ctx.saved_tensors
+        dw = conv_wgrad(col, as_nhwc(dy), 1, 1, 1, 0, ctx.cout, 3, flat_k=49)
+        return None, dw, None, None
+
+
+def stem_eval(x_nchw, weight, cache, scale, shift):
+    """Eval-mode stem: patches -> GEMM with folded BatchNorm + ReLU in the epilogue (no graph)."""
+    _require_cuda(x_nchw, "image")
+    with torch.no_grad():
+        x_nchw = x_nchw.contiguous()
+        B, _, H, W = x_nchw.shape
+        Ho, Wo = conv_out_size(H, 7, 2, 1, 3), conv_out_size(W, 7, 2, 1, 3)
+        col = torch.empty(B, Ho, Wo, STEM_K, device=x_nchw.device, dtype=torch.float32)
+        call("onda_stem_im2col", _p(x_nchw), _p(col), B, H, W, Ho, Wo, STEM_K, _stream())
+        y, _, _ = conv_forward(col, cache.get_fwd(weight, None, STEM_K), 1, 1, 1, 0, weight.shape[0], scale=scale,
+                               shift=shift, relu=True)
+    return y
+
+
+class BNTrainFn(torch.autograd.Function):
+    """Batch-statistics BatchNorm (+residual, +ReLU) on a conv output whose sum / sum-of-squares
+    partials came out of the conv epilogue.  Affine parameters are frozen (no dgamma/dbeta)."""
+
+    @staticmethod
+    def forward(ctx, y, stats, gamma, beta, residual, relu, running, momentum):
+        B, H, W, C = y.shape
+        M = B * H * W
+        mean = torch.empty(C, device=y.device, dtype=torch.float32)
+        invstd = torch.empty_like(mean)
+        rm, rv, nbt = running if running is not None else (None, None, None)
+        call("onda_bn_finalize", _p(stats), stats.shape[0], C, M, BN_EPS, _p(mean), _p(invstd), _p(rm), _p(rv), _p(nbt),
+             float(momentum), _stream())
+        out = torch.empty_like(y)
+        res = as_nhwc(residual) if residual is not None else None
+        if res is not None and nhwc_ld(res) != C:
+            res = res.contiguous()
+        call("onda_bn_apply", _p(y), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(res), _p(out), M, C, int(relu),
+             _stream())
+        ctx.save_for_backward(y, out if relu else None, mean, invstd, gamma)
+        ctx.relu, ctx.has_res = relu, residual is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        y, out, mean, invstd, gamma = ctx.saved_tensors
+        B, H, W, C = y.shape
+        M = B * H * W
+        dout = dout.contiguous()
+        ws = torch.empty(query("onda_bn_bwd_ws", M, C), device=y.device, dtype=torch.float32)
+        dx = torch.empty_like(y)
+        need_res = ctx.has_res and ctx.needs_input_grad[4]
+        dres = None
+        if need_res:
+            dres = torch.empty_like(y) if ctx.relu else dout
+        call("onda_bn_bwd", _p(dout), _p(out), _p(y), _p(mean), _p(invstd), _p(gamma), _p(dx),
+             _p(dres) if (need_res and ctx.relu) else None, _p(ws), M, C, int(ctx.relu), _stream())
+        return dx, None, None, None, dres, None, None, None
+
+
+def bn_eval_fold(gamma, beta, rm, rv):
+    C = gamma.numel()
+    scale = torch.empty(C, device=gamma.device, dtype=torch.float32)
+    shift = torch.empty_like(scale)
+    call("onda_bn_fold", _p(gamma), _p(beta), _p(rm), _p(rv), BN_EPS, _p(scale), _p(shift), C, _stream())
+    return scale, shift
+
+
+class MaxPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        B, Hi, Wi, C = x.shape
+        Ho, Wo = -(-(Hi - 1) // 2) + 1, -(-(Wi - 1) // 2) + 1  # k3 s2 p1 ceil_mode
+        if (Ho - 1) * 2 - 1 >= Hi:
+            Ho -= 1
+        if (Wo - 1) * 2 - 1 >= Wi:
+            Wo -= 1
+        y = torch.empty(B, Ho, Wo, C, device=x.device, dtype=torch.float32)
+        idx = torch.empty(B, Ho, Wo, C, device=x.device, dtype=torch.uint8)
+        x = x.contiguous()
+        call("onda_maxpool_fwd", _p(x), _p(y), _p(idx), B, Hi, Wi, C, Ho, Wo, _stream())
+        ctx.save_for_backward(idx)
+        ctx.in_shape = (B, Hi, Wi, C)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        B, Hi, Wi, C = ctx.in_shape
+        dy = dy.contiguous()
+        dx = torch.empty(B, Hi, Wi, C, device=dy.device, dtype=torch.float32)
+        call("onda_maxpool_bwd", _p(dy), _p(idx), _p(dx), B, Hi, Wi, C, dy.shape[1], dy.shape[2], _stream())
+        return dx
+
+
+class GNConcatFn(torch.autograd.Function):
+    """GroupNorm(32)+ReLU of n conv outputs written side by side into one NHWC buffer
+    (the ASPP concat without the torch.cat copy); with n == 1, optional ReLU and an optional
+    per-(image, channel) multiplier (the Dropout2d mask) it is the bottleneck GroupNorm."""
+
+    @staticmethod
+    def forward(ctx, relu, chmul, *args):
+        n = len(args) // 3
+        ys, gammas, betas = args[:n], args[n:2 * n], args[2 * n:]
+        B, H, W, C = ys[0].shape
+        HW = H * W
+        cat = torch.empty(B, H, W, C * n, device=ys[0].device, dtype=torch.float32)
+        ws = torch.empty(query("onda_gn_ws", B, HW, C), device=cat.device, dtype=torch.float32)
+        means, rstds = [], []
+        for i in range(n):
+            mean = torch.empty(B * GN_GROUPS, device=cat.device, dtype=torch.float32)
+            rstd = torch.empty_like(mean)
+            sl = cat[..., i * C:(i + 1) * C]
+            call("onda_gn_fwd", _p(ys[i]), nhwc_ld(ys[i]), _p(gammas[i]), _p(betas[i]), _p(chmul), _p(sl), C * n,
+                 _p(mean), _p(rstd), _p(ws), B, HW, C, GN_GROUPS, GN_EPS, int(relu), _stream())
+            means.append(mean)
+            rstds.append(rstd)
+        ctx.save_for_backward(cat, chmul, *ys, *gammas, *means, *rstds)
+        ctx.n, ctx.relu = n, relu
+        return cat
+
+    @staticmethod
+    def backward(ctx, dcat):
+        n = ctx.n
+        saved = ctx.saved_tensors
+        cat, chmul = saved[0], saved[1]
+        ys, gammas = saved[2:2 + n], saved[2 + n:2 + 2 * n]
+        means, rstds = saved[2 + 2 * n:2 + 3 * n], saved[2 + 3 * n:2 + 4 * n]
+        B, H, W, C = ys[0].shape
+        HW = H * W
+        dcat = as_nhwc(dcat)
+        ldd = nhwc_ld(dcat)
+        ws = torch.empty(query("onda_gn_ws", B, HW, C), device=cat.device, dtype=torch.float32)
+        dys, dgs, dbs = [], [], []
+        for i in range(n):
+            dx = torch.empty(B, H, W, C, device=cat.device, dtype=torch.float32)
+            dg = torch.empty(C, device=cat.device, dtype=torch.float32)
+            db = torch.empty_like(dg)
+            call("onda_gn_bwd", dcat.data_ptr() + 4 * i * C, ldd, cat.data_ptr() + 4 * i * C, C * n, _p(ys[i]),
+                 nhwc_ld(ys[i]), _p(gammas[i]), _p(chmul), _p(means[i]), _p(rstds[i]), _p(dx), _p(dg), _p(db), _p(ws),
+                 B, HW, C, GN_GROUPS, int(ctx.relu), _stream())
+            dys.append(dx)
+            dgs.append(dg)
+            dbs.append(db)
+        return (None, None, *dys, *dgs, *dbs)
+
+
+class SEScaleFn(torch.autograd.Function):
+    """SEBlock: x * sigmoid(W2 relu(W1 mean_px(x) + b1) + b2)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2):
+        B, H, W, C = x.shape
+        R = w1.shape[0]
+        pooled = colsum(x, alpha=1.0 / (H * W), per_image=True)
+        hidden = torch.empty(B, R, device=x.device, dtype=torch.float32)
+        gate = torch.empty(B, C, device=x.device, dtype=torch.float32)
+        call("onda_se_fc_fwd", _p(pooled), _p(w1), _p(b1), _p(w2), _p(b2), _p(hidden), _p(gate), B, C, R, _stream())
+        out = torch.empty_like(x)
+        call("onda_chan_scale", _p(x), _p(gate), None, _p(out), B, H * W, C, _stream())
+        ctx.save_for_backward(x, pooled, hidden, gate, w1, w2)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, pooled, hidden, gate, w1, w2 = ctx.saved_tensors
+        B, H, W, C = x.shape
+        R = w1.shape[0]
+        dout = dout.contiguous()
+        dgate = colsum(dout, x, per_image=True)
+        dw1, db1 = torch.empty_like(w1), torch.empty(R, device=x.device, dtype=torch.float32)
+        dw2, db2 = torch.empty_like(w2), torch.empty(C, device=x.device, dtype=torch.float32)
+        dpooled = torch.empty(B, C, device=x.device, dtype=torch.float32)
+        ws = torch.empty(B * R, device=x.device, dtype=torch.float32)
+        call("onda_se_fc_bwd", _p(dgate), _p(pooled), _p(hidden), _p(gate), _p(w1), _p(w2), _p(dw1), _p(db1), _p(dw2),
+             _p(db2), _p(dpooled), _p(ws), 1.0 / (H * W), B, C, R, _stream())
+        dx = torch.empty_like(x)
+        call("onda_chan_scale", _p(dout), _p(gate), _p(dpooled), _p(dx), B, H * W, C, _stream())
+        return dx, dw1, db1, dw2, db2
+
+
+class ClassSliceFn(torch.autograd.Function):
+    """[B,h,w,32] padded head output -> the reference's NCHW `out` f32[B,K,h,w] (a view)."""
+
+    @staticmethod
+    def forward(ctx, out_pad, k):
+        ctx.k, ctx.pad = k, out_pad.shape[3]
+        return out_pad[..., :k].permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, dout):
+        B, K, H, W = dout.shape
+        g = torch.zeros(B, H, W, ctx.pad, device=dout.device, dtype=torch.float32)
+        g[..., :K].copy_(dout.permute(0, 2, 3, 1))
+        return g, None
+
+
+def logits_rows(out):
+    """(tensor, ld, N, K) of an NCHW logits tensor laid out pixel-major (as this model
+    returns it); copies into a padded pixel-major buffer otherwise."""
+    B, K, H, W = out.shape
+    ld = out.stride(3)
+    if out.stride(1) == 1 and out.stride(2) == W * ld and (B == 1 or out.stride(0) == H * W * ld) and ld >= K:
+        return out, ld, B * H * W, K
+    buf = torch.zeros(B, H, W, HEAD_PAD, device=out.device, dtype=torch.float32)
+    buf[..., :K].copy_(out.detach().permute(0, 2, 3, 1))
+    return buf, HEAD_PAD, B * H * W, K
+
+
+class SegLossFn(torch.autograd.Function):
+    """w_ce*CE + w_rce*RCE + w_reg*MRKLD over hard labels, one pass; returns
+    (total, ce, rce, mrkld) with gradients flowing through `total` only."""
+
+    @staticmethod
+    def forward(ctx, out, labels, w_ce, w_rce, w_reg):
+        rows, ld, N, K = logits_rows(out)
+        labels = labels.reshape(-1).to(device=out.device, dtype=torch.int64).contiguous()
+        result = torch.empty(8, device=out.device, dtype=torch.float32)
+        ws = torch.empty(8 * (N // 256 + 1), device=out.device, dtype=torch.float32)
+        call("onda_seg_loss_fwd", _p(rows), ld, _p(labels), _p(result), _p(ws), N, K, _stream())
+        ctx.save_for_backward(rows, labels, result)
+        ctx.meta = (ld, N, K, w_ce, w_rce, w_reg, tuple(out.shape))
+        ce, rce, reg = result[0], result[1], result[2]
+        total = w_ce * ce + w_rce * rce + w_reg * reg
+        ctx.mark_non_differentiable(ce, rce, reg)
+        return total, ce, rce, reg
+
+    @staticmethod
+    def backward(ctx, gtotal, _a, _b, _c):
+        rows, labels, result = ctx.saved_tensors
+        ld, N, K, w_ce, w_rce, w_reg, shape = ctx.meta
+        B, _, H, W = shape
+        dl = torch.empty(B, H, W, ld, device=rows.device, dtype=torch.float32)
+        g = gtotal.reshape(1).to(torch.float32).contiguous()
+        call("onda_seg_loss_bwd", _p(rows), ld, _p(labels), _p(result), _p(g), w_ce, w_rce, w_reg, _p(dl), N, K,
+             _stream())
+        return dl[..., :K].permute(0, 3, 1, 2), None, None, None, None
+
+
+def seg_losses(out, labels, w_ce=1.0, w_rce=0.0, w_reg=0.0):
+    return SegLossFn.apply(out, labels, float(w_ce), float(w_rce), float(w_reg))
+
+
+def softmax_stats(out, want_probs=False, want_argmax=False):
+    """Per-pixel softmax of NCHW logits: (mean max-prob 0-dim tensor, probs [N,K] or None, argmax i32[N] or None)."""
+    rows, ld, N, K = logits_rows(out)
+    probs = torch.empty(N, K, device=out.device, dtype=torch.float32) if want_probs else None
+    am = torch.empty(N, device=out.device, dtype=torch.int32) if want_argmax else None
+    result = torch.empty(1, device=out.device, dtype=torch.float32)
+    ws = torch.empty(N // 256 + 1, device=out.device, dtype=torch.float32)
+    call("onda_softmax_stats", _p(rows), ld, _p(probs), K, _p(am), _p(result), _p(ws), N, K, _stream())
+    return result[0], probs, am
+
+
+class UpsampleFn(torch.autograd.Function):
+    """nn.Upsample(size, bilinear, align_corners=True) on the pixel-major logits -> NCHW."""
+
+    @staticmethod
+    def forward(ctx, out, size):
+        rows, ld, _, K = logits_rows(out)
+        B, _, h, w = out.shape
+        H, W = size
+        up = torch.empty(B, K, H, W, device=out.device, dtype=torch.float32)
+        call("onda_upsample_fwd", _p(rows), ld, _p(up), B, h, w, K, H, W, _stream())
+        ctx.meta = (B, h, w, K, H, W)
+        return up
+
+    @staticmethod
+    def backward(ctx, dup):
+        B, h, w, K, H, W = ctx.meta
+        dup = dup.contiguous()
+        dl = torch.zeros(B, h, w, HEAD_PAD, device=dup.device, dtype=torch.float32)
+        call("onda_upsample_bwd", _p(dup), _p(dl), HEAD_PAD, B, h, w, K, H, W, _stream())
+        return dl[..., :K].permute(0, 3, 1, 2), None
+
+
+def upsample_argmax(out, size):
+    """Fused evaluation tail: class map u8[B,H,W] of interp(out).softmax(1).argmax(1)."""
+    rows, ld, _, K = logits_rows(out)
+    B, _, h, w = out.shape
+    H, W = size
+    cls = torch.empty(B, H, W, device=out.device, dtype=torch.uint8)
+    call("onda_upsample_argmax", _p(rows), ld, _p(cls), B, h, w, K, H, W, _stream())
+    return cls
+
+
+# ------------------------------------------------------------------------------- multi-tensor
+def _table(entries, struct):
+    arr = (struct * len(entries))(*entries)
+    host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+    return host
+
+
+def sgd_multi(items, momentum, weight_decay):
+    """items: list of (param, grad, buf, lr, times, fresh).  One launch for all tensors."""
+    ents = [_lib.OndaSgdEntry(p.data_ptr(), g.data_ptr(), b.data_ptr(), p.numel(), float(lr), int(times), int(fresh))
+            for p, g, b, lr, times, fresh in items]
+    dev = items[0][0].device
+    table = _table(ents, _lib.OndaSgdEntry).to(dev, non_blocking=False)
+    call("onda_sgd_multi", _p(table), len(ents), float(momentum), float(weight_decay), max(e.n for e in ents), _stream())
+    for p, *_ in items:
+        torch.autograd.graph.increment_version(p)
+
+
+def ema_multi(items):
+    """items: list of (k, q, keep, blend): k = k*keep + q*blend, one launch."""
+    ents = [_lib.OndaEmaEntry(k.data_ptr(), q.data_ptr(), k.numel(), float(keep), float(blend)) for k, q, keep, blend in items]
+    dev = items[0][0].device
+    table = _table(ents, _lib.OndaEmaEntry).to(dev, non_blocking=False)
+    call("onda_ema_multi", _p(table), len(ents), max(e.n for e in ents), _stream())
+    for k, *_ in items:
+        torch.autograd.graph.increment_version(k)

@@ -1,0 +1,447 @@
+"""GPU parity of every HIP kernel family, called through the C ABI (ctypes), against plain
+fp32 torch on the CPU / the oracle on the same seeded inputs.  Integer outputs (labels,
+argmax maps, pool indices) must match exactly; floating point within the stated tolerance."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(t):
+    return t.permute(0, 3, 1, 2).contiguous()
+
+
+def close(a, b, rel=1e-4, what=""):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    scale = max(b.abs().max().item(), 1e-20)
+    err = (a - b).abs().max().item()
+    assert err <= rel * scale, f"{what}: max err {err:.3e} vs scale {scale:.3e}"
+
+
+CONV_CASES = [
+    # cin, cout, k, stride, dil, pad, H, W, bias
+    (64, 64, 1, 1, 1, 0, 17, 33, False),
+    (64, 256, 1, 1, 1, 0, 17, 33, False),
+    (256, 64, 1, 1, 1, 0, 9, 17, False),
+    (256, 128, 1, 2, 1, 0, 17, 33, False),
+    (256, 512, 1, 2, 1, 0, 17, 33, False),
+    (64, 64, 3, 1, 1, 1, 17, 33, False),
+    (128, 128, 3, 1, 1, 1, 9, 17, False),
+    (256, 256, 3, 1, 2, 2, 9, 17, False),
+    (512, 512, 3, 1, 4, 4, 9, 17, False),
+    (2048, 256, 3, 1, 6, 6, 9, 17, True),
+    (2048, 256, 3, 1, 24, 24, 9, 17, True),
+    (2048, 256, 1, 1, 1, 0, 9, 17, True),
+    (1280, 256, 3, 1, 1, 1, 9, 17, True),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "x".join(map(str, c[:6])))
+def test_conv_fwd_bwd(case):
+    from onda_amd import ops
+    cin, cout, k, stride, dil, pad, H, W, bias = case
+    g = torch.Generator().manual_seed(hash(case) & 0xFFFF)
+    B = 2
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    b = torch.randn(cout, generator=g) if bias else None
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True) if bias else None
+    yr = F.conv2d(xr, wr, br, stride, pad, dil)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+
+    xd = nhwc(x).to(DEV).requires_grad_(True)
+    wd = w.to(DEV).requires_grad_(True)
+    bd = b.to(DEV).requires_grad_(True) if bias else None
+    cache = ops._PackCache()
+    y, stats = ops.Conv2dFn.apply(xd, wd, bd, cache, stride, dil, pad, not bias, None)
+    close(nchw(y), yr, 2e-5, "conv fwd")
+    if stats is not None:
+        s = stats.sum(0).cpu()
+        close(s[0], yr.sum((0, 2, 3)), 1e-4, "stats sum")
+        close(s[1], (yr ** 2).sum((0, 2, 3)), 1e-4, "stats sumsq")
+    y.backward(nhwc(gy).to(DEV))
+    close(nchw(xd.grad), xr.grad, 2e-5, "dgrad")
+    close(wd.grad, wr.grad, 5e-5, "wgrad")
+    if bias:
+        close(bd.grad, br.grad, 5e-5, "bias grad")
+
+
+def test_conv_fused_epilogue_and_slice():
+    """eval-mode fold: scale/shift + residual + ReLU in the epilogue, written into a channel slice."""
+    from onda_amd import ops
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 128, 9, 17, generator=g)
+    w = torch.randn(256, 128, 3, 3, generator=g) / 34.0
+    sc, sh = torch.rand(256, generator=g) + 0.5, torch.randn(256, generator=g)
+    res = torch.randn(2, 256, 9, 17, generator=g)
+    ref = F.relu(F.conv2d(x, w, None, 1, 2, 2) * sc[None, :, None, None] + sh[None, :, None, None] + res)
+    buf = torch.zeros(2, 9, 17, 512, device=DEV)
+    out = buf[..., 256:]
+    ops.conv_forward(nhwc(x).to(DEV), ops.pack_weight_fwd(w.to(DEV)), 3, 1, 2, 2, 256, out=out, scale=sc.to(DEV),
+                     shift=sh.to(DEV), residual=nhwc(res).to(DEV), relu=True)
+    close(nchw(out), ref, 2e-5, "fused epilogue")
+    assert buf[..., :256].abs().max().item() == 0
+
+
+def test_head_and_stem():
+    from onda_amd import ops
+    g = torch.Generator().manual_seed(6)
+    # 19-class head through the padded 32-wide GEMM
+    feat = torch.randn(2, 256, 9, 17, generator=g)
+    w = torch.randn(19, 256, 1, 1, generator=g) / 16
+    fr, wr = feat.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    yr = F.conv2d(fr, wr)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    fd, wd = nhwc(feat).to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
+    out_pad, _ = ops.Conv2dFn.apply(fd, wd, None, ops._PackCache(), 1, 1, 0, False, ops.HEAD_PAD)
+    out = ops.ClassSliceFn.apply(out_pad, 19)
+    close(out, yr, 2e-5, "head fwd")
+    assert out_pad[..., 19:].abs().max().item() == 0
+    out.backward(gy.to(DEV))
+    close(nchw(fd.grad), fr.grad, 2e-5, "head dgrad")
+    close(wd.grad, wr.grad, 5e-5, "head wgrad")
+    # stem 7x7 s2 p3 from the NCHW image
+    x = torch.randn(2, 3, 64, 128, generator=g)
+    w = torch.randn(64, 3, 7, 7, generator=g) / 12
+    wr = w.clone().requires_grad_(True)
+    yr = F.conv2d(x, wr, None, 2, 3)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    wd = w.to(DEV).requires_grad_(True)
+    y, stats = ops.StemConvFn.apply(x.to(DEV), wd, ops._PackCache(), True)
+    close(nchw(y), yr, 2e-5, "stem fwd")
+    y.backward(nhwc(gy).to(DEV))
+    close(wd.grad, wr.grad, 5e-5, "stem wgrad")
+
+
+@pytest.mark.parametrize("C,H,W,relu,res,track", [(64, 17, 33, True, False, True), (256, 9, 17, True, True, False),
+                                                    (512, 9, 17, False, False, True), (2048, 5, 9, True, True, True)])
+def test_batchnorm_train(C, H, W, relu, res, track):
+    from onda_amd import ops
+    g = torch.Generator().manual_seed(C + H)
+    B = 2
+    x = torch.randn(B, C, H, W, generator=g) * 2 + 0.5
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    r = torch.randn(B, C, H, W, generator=g) if res else None
+    rm, rv = torch.randn(C, generator=g) * 0.1, torch.rand(C, generator=g) + 0.5
+    xr = x.clone().requires_grad_(True)
+    rr = r.clone().requires_grad_(True) if res else None
+    rm_r, rv_r = rm.clone(), rv.clone()
+    y = F.batch_norm(xr, rm_r if track else None, rv_r if track else None, gamma, beta, True, 0.1, 1e-5)
+    if res:
+        y = y + rr
+    if relu:
+        y = F.relu(y)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+
+    xd = nhwc(x).to(DEV).requires_grad_(True)
+    rd = nhwc(r).to(DEV).requires_grad_(True) if res else None
+    parts = torch.empty(64 * 2 * C, device=DEV)
+    import ctypes
+    from onda_amd._lib import call
+    tiles = ctypes.c_int(0)
+    call("onda_bn_stats", xd.data_ptr(), B * H * W, C, C, parts.data_ptr(), ctypes.byref(tiles), ops._stream())
+    stats = parts[: tiles.value * 2 * C].reshape(tiles.value, 2, C)
+    rm_d, rv_d, nbt = rm.to(DEV), rv.to(DEV), torch.zeros((), dtype=torch.int64, device=DEV)
+    out = ops.BNTrainFn.apply(xd, stats, gamma.to(DEV), beta.to(DEV), rd, relu, (rm_d, rv_d, nbt) if track else None, 0.1)
+    close(nchw(out), y, 2e-5, "bn fwd")
+    out.backward(nhwc(gy).to(DEV))
+    close(nchw(xd.grad), xr.grad, 1e-4, "bn dx")
+    if res:
+        close(nchw(rd.grad), rr.grad, 1e-5, "bn dres")
+    if track:
+        close(rm_d, rm_r, 1e-5, "running mean")
+        close(rv_d, rv_r, 1e-5, "running var")
+        assert int(nbt) == 1
+    else:
+        assert torch.equal(rm_d.cpu(), rm)
+
+
+def test_bn_fold_matches_eval_batchnorm():
+    from onda_amd import ops
+    g = torch.Generator().manual_seed(9)
+    C = 256
+    x = torch.randn(2, C, 9, 17, generator=g)
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    rm, rv = torch.randn(C, generator=g), torch.rand(C, generator=g) + 0.5
+    ref = F.batch_norm(x, rm, rv, gamma, beta, False, 0.1, 1e-5)
+    sc, sh = ops.bn_eval_fold(gamma.to(DEV), beta.to(DEV), rm.to(DEV), rv.to(DEV))
+    got = x * sc.cpu()[None, :, None, None] + sh.cpu()[None, :, None, None]
+    close(got, ref, 1e-6, "bn fold")
+
+
+@pytest.mark.parametrize("n,relu,drop", [(5, True, False), (1, False, True), (1, False, False)])
+def test_groupnorm_concat(n, relu, drop):
+    from onda_amd import ops
+    g = torch.Generator().manual_seed(n * 7 + relu)
+    B, C, H, W = 2, 256, 9, 17
+    xs = [torch.randn(B, C, H, W, generator=g) * (i + 1) + 0.3 for i in range(n)]
+    gs = [torch.rand(C, generator=g) + 0.5 for _ in range(n)]
+    bs = [torch.randn(C, generator=g) for _ in range(n)]
+    mask = (torch.empty(B, C, 1, 1).bernoulli_(0.9, generator=g) / 0.9) if drop else None
+    xr = [x.clone().requires_grad_(True) for x in xs]
+    gr = [t.clone().requires_grad_(True) for t in gs]
+    br = [t.clone().requires_grad_(True) for t in bs]
+    outs = []
+    for i in range(n):
+        y = F.group_norm(xr[i], 32, gr[i], br[i], 1e-5)
+        y = F.relu(y) if relu else y
+        outs.append(y * mask if drop else y)
+    ref = torch.cat(outs, 1)
+    gy = torch.randn(ref.shape, generator=g)
+    ref.backward(gy)
+    xd = [nhwc(x).to(DEV).requires_grad_(True) for x in xs]
+    gd = [t.to(DEV).requires_grad_(True) for t in gs]
+    bd = [t.to(DEV).requires_grad_(True) for t in bs]
+    chmul = mask.reshape(B, C).to(DEV) if drop else None
+    cat = ops.GNConcatFn.apply(relu, chmul, *xd, *gd, *bd)
+    close(nchw(cat), ref, 2e-5, "gn fwd")
+    cat.backward(nhwc(gy).to(DEV))
+    for i in range(n):
+        close(nchw(xd[i].grad), xr[i].grad, 2e-4, f"gn dx{i}")
+        close(gd[i].grad, gr[i].grad, 1e-4, f"gn dgamma{i}")
+        close(bd[i].grad, br[i].grad, 1e-4, f"gn dbeta{i}")
+
+
+@pytest.mark.parametrize("H,W", [(64, 128), (33, 65), (8, 9)])
+def test_maxpool_ceil(H, W):
+    from onda_amd import ops
+    g = torch.Generator().manual_seed(H)
+    x = F.relu(torch.randn(2, 64, H, W, generator=g))  # many exact ties at 0, like the post-ReLU stem
+    xr = x.clone().requires_grad_(True)
+    yr = F.max_pool2d(xr, 3, 2, 1, ceil_mode=True)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    xd = nhwc(x).to(DEV).requires_grad_(True)
+    y = ops.MaxPoolFn.apply(xd)
+    assert torch.equal(nchw(y).cpu(), yr.detach())
+    y.backward(nhwc(gy).to(DEV))
+    assert torch.equal(nchw(xd.grad).cpu(), xr.grad)
+
+
+def test_se_block():
+    from onda_amd import ops
+    g = torch.Generator().manual_seed(3)
+    B, C, R, H, W = 2, 1280, 80, 9, 17
+    x = torch.randn(B, C, H, W, generator=g)
+    w1, b1 = torch.randn(R, C, generator=g) / 30, torch.randn(R, generator=g) * 0.1
+    w2, b2 = torch.randn(C, R, generator=g) / 9, torch.randn(C, generator=g) * 0.1
+    ps = [t.clone().requires_grad_(True) for t in (x, w1, b1, w2, b2)]
+    z = torch.sigmoid(F.linear(F.relu(F.linear(ps[0].mean((2, 3)), ps[1], ps[2])), ps[3], ps[4]))
+    ref = ps[0] * z[:, :, None, None]
+    gy = torch.randn(ref.shape, generator=g)
+    ref.backward(gy)
+    ds = [nhwc(x).to(DEV).requires_grad_(True)] + [t.to(DEV).requires_grad_(True) for t in (w1, b1, w2, b2)]
+    out = ops.SEScaleFn.apply(*ds)
+    close(nchw(out), ref, 2e-5, "se fwd")
+    out.backward(nhwc(gy).to(DEV))
+    close(nchw(ds[0].grad), ps[0].grad, 1e-4, "se dx")
+    for i, name in enumerate(("dw1", "db1", "dw2", "db2"), 1):
+        close(ds[i].grad, ps[i].grad, 2e-4, "se " + name)
+
+
+def _head_out(logits_nchw):
+    """Bring CPU logits [B,K,h,w] to the device in the model's own output layout."""
+    B, K, h, w = logits_nchw.shape
+    pad = torch.zeros(B, h, w, 32)
+    pad[..., :K] = logits_nchw.permute(0, 2, 3, 1)
+    return pad.to(DEV)[..., :K].permute(0, 3, 1, 2)
+
+
+@pytest.mark.parametrize("h,w,H,W", [(9, 17, 64, 128), (65, 129, 512, 1024), (5, 7, 11, 13)])
+def test_upsample_align_corners(h, w, H, W):
+    from onda_amd import ops
+    g = torch.Generator().manual_seed(h)
+    lo = torch.randn(2, 19, h, w, generator=g) * 3
+    lr = lo.clone().requires_grad_(True)
+    up = F.interpolate(lr, size=(H, W), mode="bilinear", align_corners=True)
+    gy = torch.randn(up.shape, generator=g)
+    up.backward(gy)
+    ld = _head_out(lo).detach().requires_grad_(True)
+    got = ops.UpsampleFn.apply(ld, (H, W))
+    close(got, up, 2e-6, "upsample fwd")
+    got.backward(gy.to(DEV))
+    close(ld.grad, lr.grad, 2e-5, "upsample bwd")
+    cls = ops.upsample_argmax(_head_out(lo), (H, W)).cpu()
+    ref_cls = up.softmax(1).argmax(1)
+    top2 = up.detach().topk(2, dim=1)[0]
+    decided = (top2[:, 0] - top2[:, 1]) > 1e-5  # exclude numerical ties of the reference itself
+    assert torch.equal(cls.long()[decided], ref_cls[decided])
+    assert (cls.long() != ref_cls).float().mean().item() < 1e-4
+
+
+@pytest.mark.parametrize("case", ["mixed", "none_ignored", "all_ignored"])
+def test_losses_golden(golden, case):
+    """Fused CE/RCE/MRKLD kernel against the reference's own numbers (fixture G3)."""
+    from onda_amd import ops
+    g = golden("g3_losses")
+    logits = torch.from_numpy(g[f"{case}_logits"])
+    target = torch.from_numpy(g[f"{case}_target"])
+    out = _head_out(logits).detach().requires_grad_(True)
+    total, ce, rce, reg = ops.seg_losses(out, target.to(DEV), 0.1, 1.0, 0.1)
+    np.testing.assert_allclose(rce.item(), g[f"{case}_rce"], rtol=2e-6)
+    np.testing.assert_allclose(reg.item(), g[f"{case}_mrkld"], rtol=2e-6)
+    if case == "all_ignored":
+        assert torch.isnan(ce).item() and torch.isnan(total).item()
+        return
+    np.testing.assert_allclose(ce.item(), g[f"{case}_ce"], rtol=2e-6)
+    total.backward()
+    close(out.grad, torch.from_numpy(g[f"{case}_grad"]), 2e-5, "loss grad")
+
+
+def test_losses_full_size_property():
+    """At 4x65x129 pixels: kernel vs oracle, and the gradient sums to zero over classes for CE."""
+    from onda_amd import ops
+    from oracle import losses
+    g = torch.Generator().manual_seed(77)
+    logits = torch.randn(4, 19, 65, 129, generator=g) * 4
+    target = torch.randint(0, 19, (4, 65, 129), generator=g)
+    target[torch.rand(4, 65, 129, generator=g) < 0.4] = 255
+    lr = logits.clone().requires_grad_(True)
+    ref = losses.target_loss(lr, target)
+    ref["Total target loss"].backward()
+    out = _head_out(logits).detach().requires_grad_(True)
+    total, ce, rce, reg = ops.seg_losses(out, target.to(DEV), 0.1, 1.0, 0.1)
+    np.testing.assert_allclose(total.item(), ref["Total target loss"].item(), rtol=1e-5)
+    total.backward()
+    close(out.grad, lr.grad, 1e-4, "loss grad full")
+    out2 = _head_out(logits).detach().requires_grad_(True)
+    ops.seg_losses(out2, target.to(DEV), 1.0, 0.0, 0.0)[0].backward()
+    assert out2.grad.sum(1).abs().max().item() < 1e-9
+
+
+def test_softmax_stats():
+    from onda_amd import ops
+    g = torch.Generator().manual_seed(8)
+    logits = torch.randn(2, 19, 9, 17, generator=g) * 3
+    conf, probs, am = ops.softmax_stats(_head_out(logits), True, True)
+    p = logits.softmax(1)
+    np.testing.assert_allclose(conf.item(), p.max(1)[0].mean().item(), rtol=1e-6)
+    close(probs, p.permute(0, 2, 3, 1).reshape(-1, 19), 1e-6, "softmax probs")
+    assert torch.equal(am.cpu().long(), logits.permute(0, 2, 3, 1).reshape(-1, 19).argmax(1))
+
+
+@pytest.mark.parametrize("regime", ["far", "near"])
+def test_prototypes_golden(golden, regime):
+    """Pseudo-labels bit-exact, soft map / EMA / append / sigma close, against the reference's
+    own outputs (fixture G4)."""
+    from onda_amd.framework.domain_adaptation.methods.prototype_handler import prototype_handler
+    g = golden("g4_prototypes")
+    t = lambda k: torch.from_numpy(g[f"{regime}_{k}"])
+    feat = nhwc(t("feat")).to(DEV).permute(0, 3, 1, 2)  # the model's own layout
+    prior, out = t("prior").to(DEV), t("out").to(DEV)
+    for metric in ("mahalanobis", "euclidean"):
+        for tau in (1, 2):
+            for th in (0, 0.3):
+                h = prototype_handler(0.9995, tau, th, metric)
+                h.prototypes, h.squared_mean, h.counter = t("proto").to(DEV), t("sqmean").to(DEV), t("counter").to(DEV)
+                tag = f"{regime}_{metric}_t{tau}_th{th}"
+                labels = h.pseudo_labels(feat, prior)
+                soft = h.pseudo_labels(feat, prior, soft=True)
+                assert labels.shape == (306, 1) and labels.dtype == torch.int64
+                assert np.array_equal(labels.cpu().numpy(), g[tag + "_labels"]), tag
+                close(soft, torch.from_numpy(g[tag + "_soft"]), 2e-5, tag)
+    h = prototype_handler(0.9995, 1, 0.3, "mahalanobis")
+    h.prototypes, h.squared_mean, h.counter = t("proto").to(DEV), t("sqmean").to(DEV), t("counter").to(DEV)
+    close(h.global_var(), t("global_var"), 1e-5, "sigma")
+    h.ma(feat, out)
+    close(h.prototypes, t("ma_proto"), 1e-6, "ma proto")
+    close(h.squared_mean, t("ma_sqmean"), 1e-6, "ma sqmean")
+    h2 = prototype_handler(0.9995, 1, 0.3, "mahalanobis")
+    h2.append(feat, out)
+    h2.append(feat * 0.5 + 0.1, out.flip(0))
+    close(h2.prototypes, t("append_proto"), 1e-5, "append proto")
+    close(h2.squared_mean, t("append_sqmean"), 1e-5, "append sqmean")
+    assert torch.equal(h2.counter.cpu(), t("append_counter"))
+    with pytest.raises(ValueError):
+        prototype_handler(distance_metric="cosine")
+
+
+def test_prototypes_full_size():
+    """BASELINE size (N = 4*65*129 = 33 540 pixels): labels identical to the oracle except at
+    numerical ties of the threshold / argmax, which are counted and bounded."""
+    from onda_amd.framework.domain_adaptation.methods.prototype_handler import prototype_handler
+    from onda_amd.synthetic import synth_prototypes
+    from oracle import prototypes as op
+    g = torch.Generator().manual_seed(99)
+    proto, sq, cnt = synth_prototypes()
+    N = 4 * 65 * 129
+    cls = torch.randint(0, 19, (N,), generator=g)
+    mix = torch.rand(N, 1, generator=g) * 0.5
+    other = proto[torch.randint(0, 19, (N,), generator=g)]
+    rows = proto[cls] * (1 - mix) + other * mix + 0.8 * torch.randn(N, 256, generator=g)
+    feat = rows.reshape(4, 65, 129, 256)
+    prior = (2 * torch.randn(4, 19, 65, 129, generator=g)).softmax(1)
+    ref_labels, ref_soft, ref_conf = op.assign(feat.permute(0, 3, 1, 2), prior, (proto, sq, cnt), 1.0, 0.3)
+    h = prototype_handler(0.9995, 1, 0.3, "mahalanobis")
+    h.prototypes, h.squared_mean, h.counter = proto.to(DEV), sq.to(DEV), cnt.to(DEV)
+    fd = feat.to(DEV).permute(0, 3, 1, 2)
+    labels, soft, stats = h.assign_stats(fd, prior.to(DEV))
+    mism = (labels.cpu() != ref_labels).reshape(-1)
+    if mism.any():
+        top2 = ref_soft.topk(2, dim=1)[0][mism]
+        near_tie = ((top2[:, 0] - top2[:, 1]).abs() < 1e-5) | ((top2[:, 0] - 0.3).abs() < 1e-5)
+        assert near_tie.all(), "label mismatch away from a numerical tie"
+    assert mism.sum().item() <= 3
+    close(soft, ref_soft, 5e-5, "soft full")
+    np.testing.assert_allclose(stats[0], ref_conf.item(), rtol=1e-5)
+    np.testing.assert_allclose(stats[1], ref_soft.max(1)[0].mean().item(), rtol=1e-5)
+    np.testing.assert_allclose(stats[2], prior.max(1)[0].mean().item(), rtol=1e-5)
+    assert (labels != 255).float().mean().item() > 0.2 and (labels == 255).any().item()
+    # class sums: linearity / counts
+    out = torch.randn(4, 19, 65, 129, generator=g)
+    flat, K, C = h.class_statistics(fd, out.to(DEV))
+    s, n = op.class_sums(feat.permute(0, 3, 1, 2), out)
+    close(flat[: K * C].reshape(K, C), s, 1e-5, "class sums")
+    assert torch.equal(flat[2 * K * C:].cpu(), n) and n.sum().item() == N
+
+
+def test_replay_sgd_golden(golden):
+    """Duplicate-aware SGD against torch's for-loop SGD run on the reference's group layout (G6)."""
+    from onda_amd.optim import ReplaySGD
+    g = golden("g6_optimizer")
+    ps = {n: torch.nn.Parameter(torch.from_numpy(g[n + "_init"]).to(DEV)) for n in ("w3", "w4", "w1", "h1")}
+    w3, w4, w1, h1 = ps["w3"], ps["w4"], ps["w1"], ps["h1"]
+    opt = ReplaySGD([{"params": [w3, w4, w1, w3, w4, w3, w4, w4], "lr": 8e-4}, {"params": [h1], "lr": 1e-4}],
+                    lr=1e-5, momentum=0.9, weight_decay=1e-4)
+    for s in range(3):
+        for n, p in ps.items():
+            p.grad = torch.from_numpy(g[f"{n}_grad{s}"]).to(DEV)
+        v = w3._version
+        opt.step()
+        assert w3._version > v
+        for n, p in ps.items():
+            close(p, torch.from_numpy(g[f"{n}_after{s}"]), 2e-6, f"{n} step {s}")
+
+
+def test_ema_multi():
+    from onda_amd import ops
+    g = torch.Generator().manual_seed(4)
+    ks = [torch.randn(n, generator=g) for n in (7, 1000, 33333)]
+    qs = [torch.randn(n, generator=g) for n in (7, 1000, 33333)]
+    kd, qd = [t.to(DEV) for t in ks], [t.to(DEV) for t in qs]
+    ops.ema_multi([(k, q, 0.999, 1.0 - 0.999) for k, q in zip(kd[:2], qd[:2])] + [(kd[2], qd[2], 0.0, 1.0)])
+    for i in range(2):
+        close(kd[i], ks[i] * 0.999 + qs[i] * (1.0 - 0.999), 1e-6, "ema")
+    assert torch.equal(kd[2].cpu(), qs[2])
+
+
+def test_bad_arguments_raise():
+    from onda_amd import ops
+    with pytest.raises(RuntimeError):
+        ops.conv_forward(torch.zeros(1, 4, 4, 32), torch.zeros(32, 32), 1, 1, 1, 0, 32)  # CPU tensor
+    x = torch.zeros(1, 4, 4, 48, device=DEV)  # Cin not a multiple of 32
+    with pytest.raises(RuntimeError, match="ONDA_EINVAL"):
+        ops.conv_forward(x, torch.zeros(32, 48, device=DEV), 1, 1, 1, 0, 32)

@@ -1,0 +1,189 @@
+"""GPU parity of the drop-in model and of one full adaptation step, against the golden vectors
+captured from the reference (G1, G2, G7) and against the CPU oracle on the same inputs."""
+import itertools
+import json
+from copy import deepcopy
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import digest
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def build_model(seed, head_scale):
+    from onda_amd.framework.model.deeplabv2 import get_deeplab_v2
+    from onda_amd.synthetic import fill_state_dict
+    m = get_deeplab_v2(num_classes=19, multi_level=True, layers=[3, 4, 6, 3], classifier="ProDA")
+    m.multi_level = False
+    fill_state_dict(m, seed, head_scale)
+    return m.to(DEV)
+
+
+def test_eval_forward_small_golden(golden):
+    """Eval-mode forward (folded BN): logits within 1e-3 rel of the reference, argmax map of
+    interp(out) bit-identical (BASELINE north_star)."""
+    from onda_amd import ops
+    from onda_amd.synthetic import synth_batch
+    g = golden("g1_eval_small")
+    m = build_model(1, 3.0).eval()
+    x = synth_batch(2, 64, 128, seed=7)["image"].to(DEV)
+    with torch.no_grad():
+        x1, o = m(x)
+        cls = ops.upsample_argmax(o["out"], (64, 128))
+        up = ops.UpsampleFn.apply(o["out"], (64, 128))
+    assert x1 is None and o["feat"].shape == (2, 256, 9, 17) and o["out"].shape == (2, 19, 9, 17)
+    for key, tol in (("feat", 1e-4), ("out", 1e-4), ):
+        ref = g[key]
+        err = np.abs(o[key].cpu().numpy() - ref).max()
+        assert err <= tol * np.abs(ref).max(), (key, err)
+    assert np.abs(up.cpu().numpy() - g["up"]).max() <= 1e-4 * np.abs(g["up"]).max()
+    assert np.array_equal(cls.cpu().numpy(), g["argmax"])
+
+
+def test_eval_forward_512x1024_golden(golden):
+    """One full-resolution frame (config 1 shape): class map vs the reference's."""
+    from onda_amd import ops
+    from onda_amd.synthetic import synth_batch
+    g = golden("g1_eval_large")
+    m = build_model(1, 3.0).eval()
+    x = synth_batch(1, 512, 1024, seed=8)["image"].to(DEV)
+    with torch.no_grad():
+        _, o = m(x)
+        cls = ops.upsample_argmax(o["out"], (512, 1024)).cpu().numpy()
+    assert o["out"].shape == (1, 19, 65, 129)
+    ref = g["out"]
+    assert np.abs(o["out"].cpu().numpy() - ref).max() <= 1e-3 * np.abs(ref).max()
+    diff = cls != g["argmax"]
+    # any disagreement must sit on a numerical tie of the reference's own top-2 logits
+    assert diff.mean() < 1e-5
+    if diff.any():
+        assert g["margin_f16"].astype(np.float32)[diff].max() < 1e-3
+    np.testing.assert_allclose(digest(o["feat"], 4096)[2:], g["feat_digest"][2:], rtol=0,
+                               atol=1e-3 * np.abs(g["feat_digest"][2:]).max())
+
+
+@pytest.mark.parametrize("track", [True, False])
+def test_train_forward_backward_golden(golden, track):
+    """Train-mode pass (batch-statistics BN, fixed Dropout2d mask): logits within 1e-3 rel,
+    gradients of all 82 trainable tensors and running statistics against the reference (G2)."""
+    from onda_amd import ops
+    from onda_amd.framework.model import deeplabv2
+    from onda_amd.framework.domain_adaptation.methods.adaptation_model import switch_batch_statistics
+    from onda_amd.synthetic import synth_batch
+    g = golden("g2_train_small")
+    tag = "track" if track else "frozen"
+    m = build_model(1, 3.0).train()
+    switch_batch_statistics(m, track)
+    b = synth_batch(2, 64, 128, seed=7)
+    mask = torch.from_numpy(g["drop_mask"])
+    deeplabv2.drop_mask_fn = lambda B, C, p, dev: mask.to(dev)
+    try:
+        _, o = m(b["image"].to(DEV))
+    finally:
+        deeplabv2.drop_mask_fn = deeplabv2._default_drop_mask
+    loss = ops.seg_losses(o["out"], b["label_res"].to(DEV), 1.0, 0.0, 0.0)[0]
+    ref = g[f"{tag}_out"]
+    assert np.abs(o["out"].detach().cpu().numpy() - ref).max() <= 1e-3 * np.abs(ref).max()
+    assert np.abs(o["feat"].detach().cpu().numpy() - g[f"{tag}_feat"]).max() <= 1e-3 * np.abs(g[f"{tag}_feat"]).max()
+    assert abs(loss.item() - g[f"{tag}_loss"]) <= 1e-4 * abs(g[f"{tag}_loss"])
+    sd = m.state_dict()
+    for k in ("bn1", "layer1.0.bn1", "layer2.0.downsample.1", "layer3.2.bn2", "layer4.2.bn3"):
+        np.testing.assert_allclose(sd[k + ".running_mean"].cpu().numpy(), g[f"{tag}_{k}.running_mean"], rtol=1e-3, atol=1e-5)
+        np.testing.assert_allclose(sd[k + ".running_var"].cpu().numpy(), g[f"{tag}_{k}.running_var"], rtol=1e-3, atol=1e-5)
+        assert int(sd[k + ".num_batches_tracked"]) == int(g[f"{tag}_{k}.num_batches_tracked"])
+    if not track:
+        return
+    loss.backward()
+    params = dict(m.named_parameters())
+    names = list(g["grad_names"])
+    assert sorted(names) == sorted(n for n, p in params.items() if p.grad is not None)
+    worst = 0.0
+    for n, dg in zip(names, g["grad_digest"]):
+        mine = digest(params[n].grad)
+        scale = max(np.abs(dg[2:]).max(), 1e-12)
+        err = np.abs(mine[2:] - dg[2:]).max() / scale
+        worst = max(worst, err)
+        assert err <= 2e-2, (n, err)
+        assert abs(mine[1] - dg[1]) <= 1e-2 * dg[1] + 1e-7, n
+    for n in ("layer6.head.1.weight", "layer6.bottleneck.2.weight", "layer6.conv2d_list.0.0.bias", "conv1.weight"):
+        ref = g["grad_" + n]
+        assert np.abs(params[n].grad.cpu().numpy() - ref).max() <= 5e-3 * np.abs(ref).max(), n
+
+
+def test_model_invariants_on_device():
+    """What the reference's callers rely on: deepcopy, per-module BN state_dict,
+    376-key state_dict round trip, BatchNorm2d instances, param/buffer order."""
+    import torch.nn as nn
+    m = build_model(2, 1.0)
+    c = deepcopy(m)
+    sd = m.state_dict()
+    assert len(sd) == 376 and list(sd.keys()) == list(c.state_dict().keys())
+    assert sum(isinstance(x, nn.BatchNorm2d) for x in m.modules()) == 53
+    assert len(list(m.parameters())) == 217 and len(list(m.buffers())) == 159
+    x = torch.randn(1, 3, 64, 128, device=DEV)
+    m.eval(); c.eval()
+    with torch.no_grad():
+        a, b = m(x)[1]["out"], c(x)[1]["out"]
+        assert torch.equal(a, b)
+        c.load_state_dict({k: v * 1.01 if v.dtype == torch.float32 else v for k, v in sd.items()})
+        assert not torch.equal(c(x)[1]["out"], a)  # packed weights follow the parameters
+        c.load_state_dict(sd)
+        assert torch.equal(c(x)[1]["out"], a)
+    with pytest.raises(RuntimeError):
+        m.cpu()(x.cpu())  # no CPU fallback
+
+
+@pytest.mark.parametrize("tag,head_scale", [("static", 40.0), ("dynamic", 3.0)])
+def test_full_step_golden(golden, tmp_path, tag, head_scale):
+    """Two complete hybrid_proDA steps (+update_ema) at 128x64, B=2 against the reference's log
+    dict, labels, prototypes and post-step weights (fixture G7), both switch branches."""
+    from onda_amd.config import hybrid_switch_cfg
+    from onda_amd.framework.handlers import get_adapt_method, get_model
+    from onda_amd.framework.model import deeplabv2
+    from onda_amd.framework.domain_adaptation.methods.adaptation_model import switch_batch_statistics
+    from onda_amd.synthetic import fill_state_dict, synth_batch
+    from oracle import model as omodel
+    g = golden(f"g7_step_{tag}")
+    cfg, spec = hybrid_switch_cfg(128, 64, DEV, str(tmp_path), batch_size=2)
+    model = get_model(cfg, 19)
+    fill_state_dict(model, 1, head_scale)
+    da = get_adapt_method(cfg)(model, cfg, spec)
+    src = [synth_batch(2, 64, 128, seed=100 + i) for i in range(2)]
+    trg = [synth_batch(2, 64, 128, seed=200 + i) for i in range(2)]
+    torch.manual_seed(123)
+    masks = [omodel.draw_drop_mask(2) for _ in range(8)]  # same CPU draws as the reference run
+    it = iter(masks)
+    deeplabv2.drop_mask_fn = lambda B, C, p, dev: next(it).to(dev)
+    try:
+        da.update_dynamic()
+        switch_batch_statistics(da.model, False)
+        da.calculate_prototypes(src, save=False)
+        switch_batch_statistics(da.model, True)
+        np.testing.assert_allclose(da.prototypes.prototypes.cpu().numpy(), g["proto0"], rtol=1e-3, atol=1e-4)
+        np.testing.assert_allclose(da.prototypes.counter.cpu().numpy(), g["counter0"])
+        da.optimizer.zero_grad()
+        for s in range(2):
+            da.adjust_learning_rate(s, 6)
+            log = da.step([src[s]], trg[s])
+            da.update_ema()
+            assert int(g[f"branch{s}"]) == da.model_select.current
+            soft = trg[s]["stored_predictions"]
+            assert (soft.cpu() - torch.from_numpy(g[f"soft{s}"])).abs().max() < 2e-3
+            ref = json.loads(str(g[f"log{s}_json"]))
+            for k, v in ref.items():
+                mine = log[k]
+                mine = mine.item() if isinstance(mine, torch.Tensor) else float(mine)
+                assert mine == pytest.approx(v, rel=5e-3, abs=1e-5), (s, k)
+            np.testing.assert_allclose(da.prototypes.prototypes.cpu().numpy(), g[f"proto{s + 1}"], rtol=1e-3, atol=1e-4)
+            names, dg = list(g[f"state_names{s}"]), g[f"state_digest{s}"]
+            for who, mod in (("student.", da.model), ("teacher.", da.ema_model)):
+                for k, v in mod.state_dict().items():
+                    row = dg[names.index(who + k)]
+                    mine = digest(v.float(), 64)
+                    assert np.abs(mine[2:] - row[2:]).max() <= 1e-3 * max(np.abs(row[2:]).max(), 1e-6) + 1e-6, (s, who + k)
+    finally:
+        deeplabv2.drop_mask_fn = deeplabv2._default_drop_mask

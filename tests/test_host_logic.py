@@ -1,0 +1,131 @@
+"""CPU: host-side logic of the product and the C-ABI surface (no kernel is launched)."""
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT
+
+
+def header_functions():
+    text = open(os.path.join(ROOT, "include", "onda_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(onda_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    import ctypes
+    from onda_amd import _lib
+    lib = _lib.load()
+    names = header_functions()
+    assert len(names) >= 38
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/onda_hip.h but not exported"
+        assert n in _lib.SIGNATURES, f"{n} has no ctypes prototype"
+    assert set(_lib.SIGNATURES) == set(names)
+    assert b"gfx950" in lib.onda_version()
+    assert ctypes.sizeof(_lib.OndaConv) == 19 * 4 and ctypes.sizeof(_lib.OndaSgdEntry) == 48
+    assert lib.onda_conv_tiles_m(33540) == 263
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from onda_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libonda_hip.so")
+    with pytest.raises(_lib.OndaLibraryError, match="no fallback"):
+        _lib.load()
+
+
+def test_cpu_tensors_are_rejected():
+    from onda_amd.framework.model.deeplabv2 import get_deeplab_v2
+    m = get_deeplab_v2(19, True, [3, 4, 6, 3], "ProDA").eval()
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.zeros(1, 3, 64, 128))
+    with pytest.raises(NotImplementedError):
+        get_deeplab_v2(19, True, [3, 4, 6, 3], "normal")
+
+
+def test_model_tree_matches_reference_spec(golden):
+    """376 state_dict keys / shapes / dtypes in the reference's order; parameter groups with the
+    reference's duplicate pattern (fixture G6 holds what the reference's own walk yields)."""
+    from onda_amd.framework.model.deeplabv2 import get_deeplab_v2
+    from oracle import model as omodel
+    m = get_deeplab_v2(19, True, [3, 4, 6, 3], "ProDA")
+    sd = m.state_dict()
+    spec = omodel.state_spec()
+    assert [k for k, _, _ in spec] == list(sd.keys())
+    for k, shape, dt in spec:
+        assert tuple(sd[k].shape) == tuple(shape) and sd[k].dtype == dt, k
+    assert sum(p.numel() for p in m.parameters() if p.requires_grad) == 58882400
+    m.multi_level = False
+    g = golden("g6_optimizer")
+    name_of = {id(p): n for n, p in m.named_parameters()}
+    groups = m.optim_parameters(1e-5)
+    c0 = {}
+    for p in groups[0]["params"]:
+        c0[name_of[id(p)]] = c0.get(name_of[id(p)], 0) + 1
+    assert c0 == json.loads(str(g["group0_json"]))
+    assert [name_of[id(p)] for p in groups[1]["params"]] == json.loads(str(g["group1_json"]))
+    assert groups[1]["lr"] == pytest.approx(1e-4)
+
+
+def test_feature_grid_formula():
+    from onda_amd.synthetic import feature_hw
+    assert feature_hw(512, 1024) == (65, 129) and feature_hw(1024, 2048) == (129, 257)
+    assert feature_hw(64, 128) == (9, 17)
+
+
+def test_monitor_and_switch_golden(golden):
+    from onda_amd.framework.utils.monitoring import Monitor
+    from onda_amd.framework.domain_adaptation.methods.prototypes_hybrid_switch import model_select
+    g = golden("g5_switch")
+    mon = Monitor(200, 0.003, "hamming")
+    sel = model_select(model_select.static, [0.83, 0.9], 0.0002)
+    for i, v in enumerate(g["seq"]):
+        mon.add({"prior static": torch.tensor(float(v), dtype=torch.float64) if i % 2 else float(v)})
+        a, d = mon.avg("prior static"), mon.dev_avg("prior static")
+        sel.evaluate(a, d)
+        assert a == g["avg"][i] and mon.exp("prior static") == g["exp"][i] and d == g["dev"][i]
+        assert sel.current == g["current"][i]
+    mon.eval(); sel.eval()
+    mon.add({"prior static": 0.0}); sel.evaluate(0.0, -1.0)
+    assert len(mon.current_dict["prior static"]) == 200 and sel.current == g["current"][-1]
+    assert mon.avg("nope") == 1 and mon.dev_avg("nope") == 0 and mon.exp("nope") == 1
+
+
+def test_cfg_semantics():
+    from onda_amd.config import Cfg, hybrid_switch_cfg, unset
+    cfg, spec = hybrid_switch_cfg()
+    assert spec.SOFT_LABELS == {} and unset(spec.AUTO_DYNAMIC) and not unset(spec.BN_POLICY)
+    assert cfg.SCHEME.RESOLUTION == [1024, 512] and spec.MA_LAMBDA == 0.9995 and spec.set_ == (25,)
+    c = Cfg()
+    c.A.B = 1
+    assert c.A.B == 1 and c.X.Y == {}
+
+
+def test_lr_schedule_and_hist():
+    from onda_amd.framework.utils.func import fast_hist, lr_poly, per_class_iu
+    assert lr_poly(1e-5, 10, 100, 0) == 1e-5
+    assert lr_poly(1.0, 50, 100, 0.9) == pytest.approx(0.5 ** 0.9)
+    a, b = np.array([0, 1, 1, 255, 2]), np.array([0, 1, 2, 1, 2])
+    h = fast_hist(a, b, 3)
+    assert h.sum() == 4 and h[1, 2] == 1
+    np.testing.assert_allclose(per_class_iu(h), [1.0, 0.5, 0.5], rtol=1e-9)
+
+
+def test_prototype_handler_host_side(tmp_path):
+    from onda_amd.framework.domain_adaptation.methods.prototype_handler import prototype_handler
+    with pytest.raises(ValueError):
+        prototype_handler(distance_metric="cosine")
+    h = prototype_handler(0.9995, 1, 0.3, "mahalanobis", confidence_regularization_threshold={})
+    assert h.prototypes == 0 and h.confidence_regularization_threshold == 1
+    assert h.load(str(tmp_path / "missing.pickle")) is False
+    h.prototypes, h.squared_mean, h.counter = torch.ones(19, 256), torch.ones(19, 256) * 2, torch.ones(19)
+    h.save(str(tmp_path / "p.pickle"))
+    h2 = prototype_handler()
+    assert h2.load(str(tmp_path / "p.pickle")) and torch.equal(h2.squared_mean, h.squared_mean)
+    x = torch.arange(2 * 3 * 4 * 5.0).reshape(2, 3, 4, 5)
+    assert torch.equal(h.transform(x), x.permute(0, 2, 3, 1).reshape(-1, 3))
