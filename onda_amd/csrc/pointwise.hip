@@ -181,6 +181,7 @@ struct Lerp {
   float l0, l1;
 };
 __device__ __forceinline__ Lerp lerp_index(int dst, float scale, int in_size) {
+#pragma clang fp contract(off)  // the product is rounded before the subtraction below, as in ATen
   const float src = scale * (float)dst;
   Lerp o;
   o.i0 = (int)src;

@@ -23,8 +23,23 @@ HEAD_PAD = 32  # the 19-class head is computed as a 32-wide GEMM (padded rows ar
 STEM_K = 160   # 7*7*3 = 147 patch values padded to a multiple of 32
 
 
+# bench.py sets this to a list to collect (kernel family, algorithmic flops, start event, end event)
+# around every conv launch; the events are recorded on the launch stream (torch's current stream)
+PROFILE = None
+
+
 def _stream():
     return torch.cuda.current_stream().cuda_stream
+
+
+def _launch(name, flops, fn_name, *args):
+    if PROFILE is None:
+        return call(fn_name, *args)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    call(fn_name, *args)
+    e1.record()
+    PROFILE.append((name, flops, e0, e1))
 
 
 def _p(t):
@@ -100,7 +115,8 @@ def conv_forward(x, wp, k, stride, dil, pad, cout, out=None, scale=None, shift=N
         tiles = query("onda_conv_tiles_m", B * Ho * Wo)
         stats = torch.empty(tiles, 2, cout, device=x.device, dtype=torch.float32)
     d = _desc(B, Hi, Wi, Cin, Ho, Wo, cout, k, stride, dil, pad, ldx, ldy, ldr, relu=relu)
-    call("onda_conv2d_fwd", _p(x), _p(wp), _p(out), _p(scale), _p(shift), _p(residual), _p(stats), byref(d), _stream())
+    _launch("conv_fwd_kernel<128,%d>" % (128 if cout > 64 else 64), 2.0 * B * Ho * Wo * cout * k * k * Cin,
+            "onda_conv2d_fwd", _p(x), _p(wp), _p(out), _p(scale), _p(shift), _p(residual), _p(stats), byref(d), _stream())
     return out, stats, tiles
 
 
@@ -117,7 +133,8 @@ def conv_dgrad(dy, wpd, k, stride, dil, pad, cin, in_hw):
             raise RuntimeError("onda_amd: strided data gradient is implemented for 1x1 convs only")
         dx = torch.zeros(B, Hi, Wi, cin, device=dy.device, dtype=torch.float32)
         d = _desc(B, Ho, Wo, Co, Ho, Wo, cin, 1, 1, 1, 0, ldy, cin, out_os=stride, Hf=Hi, Wf=Wi)
-    call("onda_conv2d_fwd", _p(dy), _p(wpd), _p(dx), None, None, None, None, byref(d), _stream())
+    _launch("conv_fwd_kernel<128,%d>" % (128 if cin > 64 else 64), 2.0 * B * Ho * Wo * cin * k * k * Co,
+            "onda_conv2d_fwd", _p(dy), _p(wpd), _p(dx), None, None, None, None, byref(d), _stream())
     return dx
 
 
@@ -139,7 +156,8 @@ def conv_wgrad(x, dy, k, stride, dil, pad, cout_real, cin_real, flat_k=0):
     sk = _wgrad_splitk(M, Co, Cin, taps)
     slabs = torch.empty(sk, Co, taps, Cin, device=x.device, dtype=torch.float32)
     d = _desc(B, Hi, Wi, Cin, Ho, Wo, Co, k, stride, dil, pad, nhwc_ld(x), Co)
-    call("onda_conv2d_wgrad", _p(x), _p(dy), _p(slabs), nhwc_ld(dy), sk, byref(d), _stream())
+    _launch("conv_wgrad_kernel<%s>" % ("128,128" if (Co > 64 and Cin > 64) else "64,64"), 2.0 * M * Co * taps * Cin,
+            "onda_conv2d_wgrad", _p(x), _p(dy), _p(slabs), nhwc_ld(dy), sk, byref(d), _stream())
     if flat_k:
         dw = torch.empty(cout_real, cin_real, 7, 7, device=x.device, dtype=torch.float32)
     else:
@@ -239,8 +257,7 @@ class StemConvFn(torch.autograd.Function):
         call("onda_stem_im2col", _p(x_nchw), _p(col), B, H, W, Ho, Wo, STEM_K, _stream())
         wp = cache.get_fwd(weight, None, STEM_K)
         y, stats, _ = conv_forward(col, wp, 1, 1, 1, 0, weight.shape[0], want_stats=want_stats)
-        if weight.requires_grad and torch.is_grad_enabled():
-            ctx.save_for_backward(col)
+        ctx.save_for_backward(col)  # dropped again by autograd when no graph is being recorded
         ctx.cout = weight.shape[0]
         if want_stats:
             ctx.mark_non_differentiable(stats)
