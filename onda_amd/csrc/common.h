@@ -29,6 +29,12 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
 // Sum over the 256 threads of a block; result valid in thread 0. `red` holds >= 4 floats.
 __device__ __forceinline__ float block_sum_256(float v, float* red) {
   v = wave_sum(v);

@@ -145,17 +145,22 @@ struct GnBwdRed {
 };
 
 // ---- BatchNorm --------------------------------------------------------------------------
-__global__ void bn_finalize_kernel(const float* __restrict__ partials, int tiles, int C, double count, float eps,
-                                   float* mean, float* invstd, float* rmean, float* rvar, int64_t* nbt,
-                                   float momentum) {
-  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
-  if (ch == 0 && nbt) *nbt += 1;
+// One wave per channel: lanes stride over the tile partials, fp64 wave reduction.
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partials, int tiles, int C,
+                                                          double count, float eps, float* mean, float* invstd,
+                                                          float* rmean, float* rvar, int64_t* nbt, float momentum) {
+  const int lane = threadIdx.x & 63;
+  const int ch = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) *nbt += 1;
   if (ch >= C) return;
   double s1 = 0.0, s2 = 0.0;
-  for (int tl = 0; tl < tiles; ++tl) {
+  for (int tl = lane; tl < tiles; tl += 64) {
     s1 += (double)partials[((size_t)tl * 2 + 0) * C + ch];
     s2 += (double)partials[((size_t)tl * 2 + 1) * C + ch];
   }
+  s1 = wave_sum_d(s1);
+  s2 = wave_sum_d(s2);
+  if (lane != 0) return;
   const double mu = s1 / count;
   double var = s2 / count - mu * mu;
   if (var < 0.0) var = 0.0;
@@ -197,16 +202,22 @@ __global__ void bn_fold_kernel(const float* gamma, const float* beta, const floa
   shift[ch] = beta[ch] - rmean[ch] * sc;
 }
 
-__global__ void bn_bwd_sums_kernel(const float* __restrict__ partials, int chunks, int C, float* sums) {
-  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void bn_bwd_sums_kernel(const float* __restrict__ partials, int chunks, int C,
+                                                          float* sums) {
+  const int lane = threadIdx.x & 63;
+  const int ch = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (ch >= C) return;
   double s1 = 0.0, s2 = 0.0;
-  for (int k = 0; k < chunks; ++k) {
+  for (int k = lane; k < chunks; k += 64) {
     s1 += (double)partials[((size_t)k * 2 + 0) * C + ch];
     s2 += (double)partials[((size_t)k * 2 + 1) * C + ch];
   }
-  sums[ch] = (float)s1;
-  sums[C + ch] = (float)s2;
+  s1 = wave_sum_d(s1);
+  s2 = wave_sum_d(s2);
+  if (lane == 0) {
+    sums[ch] = (float)s1;
+    sums[C + ch] = (float)s2;
+  }
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dout,
@@ -233,18 +244,24 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 }
 
 // ---- GroupNorm --------------------------------------------------------------------------
-__global__ void gn_finalize_kernel(const float* __restrict__ partials, int chunks, int B, int C, int groups,
-                                   double count, float eps, float* mean, float* rstd) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+// One wave per (image, group): lanes stride over chunks x channels-of-the-group.
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ partials, int chunks, int B,
+                                                          int C, int groups, double count, float eps, float* mean,
+                                                          float* rstd) {
+  const int lane = threadIdx.x & 63;
+  const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (idx >= B * groups) return;
   const int b = idx / groups, g = idx % groups, cpg = C / groups;
   double s1 = 0.0, s2 = 0.0;
-  for (int k = 0; k < chunks; ++k)
-    for (int j = 0; j < cpg; ++j) {
-      const size_t base = (((size_t)b * chunks + k) * 2) * C + g * cpg + j;
-      s1 += (double)partials[base];
-      s2 += (double)partials[base + C];
-    }
+  for (int i = lane; i < chunks * cpg; i += 64) {
+    const int k = i / cpg, j = i - k * cpg;
+    const size_t base = (((size_t)b * chunks + k) * 2) * C + g * cpg + j;
+    s1 += (double)partials[base];
+    s2 += (double)partials[base + C];
+  }
+  s1 = wave_sum_d(s1);
+  s2 = wave_sum_d(s2);
+  if (lane != 0) return;
   const double mu = s1 / count;
   double var = s2 / count - mu * mu;
   if (var < 0.0) var = 0.0;
@@ -274,31 +291,36 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
   }
 }
 
-// partials[b][chunk][2][C] -> per (b,c) sums A, Bq (in ws), dgamma/dbeta, group sums
-__global__ void gn_bwd_finalize_kernel(const float* __restrict__ partials, int chunks, int B, int C, int groups,
-                                       const float* __restrict__ gamma, float* __restrict__ dgamma,
-                                       float* __restrict__ dbeta, float* __restrict__ gsum /*[B][groups][2]*/) {
-  // one block, 256 threads
-  extern __shared__ float sh[];  // A[B][C], Bq[B][C]
-  float* A = sh;
-  float* Bq = sh + (size_t)B * C;
-  for (int i = threadIdx.x; i < B * C; i += blockDim.x) {
-    const int b = i / C, ch = i % C;
-    double s1 = 0.0, s2 = 0.0;
-    for (int k = 0; k < chunks; ++k) {
-      const size_t base = (((size_t)b * chunks + k) * 2) * C + ch;
-      s1 += (double)partials[base];
-      s2 += (double)partials[base + C];
-    }
-    A[i] = (float)s1;
-    Bq[i] = (float)s2;
+// partials[b][chunk][2][C] -> AB[b][2][C] (one wave per (b,c))
+__global__ __launch_bounds__(256) void pair_finalize_kernel(const float* __restrict__ partials, int chunks, int B,
+                                                            int C, float* __restrict__ AB) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= B * C) return;
+  const int b = i / C, ch = i % C;
+  double s1 = 0.0, s2 = 0.0;
+  for (int k = lane; k < chunks; k += 64) {
+    const size_t base = (((size_t)b * chunks + k) * 2) * C + ch;
+    s1 += (double)partials[base];
+    s2 += (double)partials[base + C];
   }
-  __syncthreads();
+  s1 = wave_sum_d(s1);
+  s2 = wave_sum_d(s2);
+  if (lane == 0) {
+    AB[((size_t)b * 2 + 0) * C + ch] = (float)s1;
+    AB[((size_t)b * 2 + 1) * C + ch] = (float)s2;
+  }
+}
+
+// AB[b][2][C] -> dgamma/dbeta and the per-(image, group) sums the dx formula needs
+__global__ void gn_bwd_group_kernel(const float* __restrict__ AB, int B, int C, int groups,
+                                    const float* __restrict__ gamma, float* __restrict__ dgamma,
+                                    float* __restrict__ dbeta, float* __restrict__ gsum /*[B][groups][2]*/) {
   for (int ch = threadIdx.x; ch < C; ch += blockDim.x) {
     float da = 0.f, db = 0.f;
     for (int b = 0; b < B; ++b) {
-      db += A[b * C + ch];
-      da += Bq[b * C + ch];
+      db += AB[((size_t)b * 2 + 0) * C + ch];
+      da += AB[((size_t)b * 2 + 1) * C + ch];
     }
     if (dgamma) dgamma[ch] = da;
     if (dbeta) dbeta[ch] = db;
@@ -309,8 +331,8 @@ __global__ void gn_bwd_finalize_kernel(const float* __restrict__ partials, int c
     float ds = 0.f, dq = 0.f;
     for (int j = 0; j < cpg; ++j) {
       const int ch = g * cpg + j;
-      ds += gamma[ch] * A[b * C + ch];
-      dq += gamma[ch] * Bq[b * C + ch];
+      ds += gamma[ch] * AB[((size_t)b * 2 + 0) * C + ch];
+      dq += gamma[ch] * AB[((size_t)b * 2 + 1) * C + ch];
     }
     gsum[i * 2 + 0] = ds;
     gsum[i * 2 + 1] = dq;
@@ -347,14 +369,16 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
   }
 }
 
-__global__ void colsum_finalize_kernel(const float* __restrict__ partials, int chunks, int B, int C, float alpha,
-                                       float* out) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ partials, int chunks, int B,
+                                                              int C, float alpha, float* out) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= B * C) return;
   const int b = i / C, ch = i % C;
   double s = 0.0;
-  for (int k = 0; k < chunks; ++k) s += (double)partials[(((size_t)b * chunks + k) * 2) * C + ch];
-  out[i] = (float)(s * (double)alpha);
+  for (int k = lane; k < chunks; k += 64) s += (double)partials[(((size_t)b * chunks + k) * 2) * C + ch];
+  s = wave_sum_d(s);
+  if (lane == 0) out[i] = (float)(s * (double)alpha);
 }
 
 static inline unsigned ew_grid(size_t total4) {
@@ -371,7 +395,7 @@ extern "C" {
 int onda_bn_finalize(const float* partials, int tiles, int C, int64_t count, float eps, float* mean, float* invstd,
                      float* running_mean, float* running_var, int64_t* nbt, float momentum, onda_stream_t s) {
   ONDA_REQUIRE(partials && mean && invstd && tiles >= 1 && C >= 1 && count >= 1);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, ONDA_STREAM(s), partials, tiles, C,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, ONDA_STREAM(s), partials, tiles, C,
                      (double)count, eps, mean, invstd, running_mean, running_var, nbt, momentum);
   return ONDA_LAUNCH_RESULT();
 }
@@ -414,7 +438,7 @@ int onda_bn_bwd(const float* dout, const float* out, const float* x, const float
   BnBwdRed f{dout, out, x, mean, invstd, dres, C, relu};
   int rc = launch_colreduce(f, 1, M, C, ws, p, ONDA_STREAM(s));
   if (rc) return rc;
-  hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3((C + 255) / 256), dim3(256), 0, ONDA_STREAM(s), ws, p.chunks, C, sums);
+  hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3((C + 3) / 4), dim3(256), 0, ONDA_STREAM(s), ws, p.chunks, C, sums);
   const size_t total4 = (size_t)M * C / 4;
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(total4)), dim3(256), 0, ONDA_STREAM(s), dout, out, x, mean,
                      invstd, gamma, sums, dx, total4, C, (float)(1.0 / (double)M), relu);
@@ -423,7 +447,7 @@ int onda_bn_bwd(const float* dout, const float* out, const float* x, const float
 
 int64_t onda_gn_ws(int B, int64_t HW, int C) {
   const ColPlan p = col_plan(B, HW, C);
-  return (int64_t)B * p.chunks * 2 * C + (int64_t)B * C * 2 + 1024;
+  return (int64_t)B * p.chunks * 2 * C + (int64_t)B * C * 2 + (int64_t)B * 2 * 128 + 64;
 }
 
 int onda_gn_fwd(const float* x, int ldx, const float* gamma, const float* beta, const float* chmul, float* out, int ldo,
@@ -435,7 +459,7 @@ int onda_gn_fwd(const float* x, int ldx, const float* gamma, const float* beta, 
   SqStats f{x, HW, ldx};
   int rc = launch_colreduce(f, B, HW, C, ws, p, ONDA_STREAM(s));
   if (rc) return rc;
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3((B * groups + 255) / 256), dim3(256), 0, ONDA_STREAM(s), ws, p.chunks, B,
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3((B * groups + 3) / 4), dim3(256), 0, ONDA_STREAM(s), ws, p.chunks, B,
                      C, groups, (double)HW * (C / groups), eps, mean, rstd);
   const size_t total4 = (size_t)B * HW * C / 4;
   hipLaunchKernelGGL(gn_apply_kernel, dim3(ew_grid(total4)), dim3(256), 0, ONDA_STREAM(s), x, ldx, gamma, beta, chmul,
@@ -448,14 +472,15 @@ int onda_gn_bwd(const float* dout, int lddo, const float* out, int ldo, const fl
                 float* ws, int B, int64_t HW, int C, int groups, int relu, onda_stream_t s) {
   ONDA_REQUIRE(dout && x && gamma && mean && rstd && dx && ws && (!relu || out));
   ONDA_REQUIRE(C % groups == 0 && (C / groups) % 4 == 0 && ldx % 4 == 0 && lddo % 4 == 0);
-  ONDA_REQUIRE((size_t)B * C * 2 * sizeof(float) <= 160 * 1024);
   const ColPlan p = col_plan(B, HW, C);
-  float* gsum = ws + (size_t)B * p.chunks * 2 * C;
+  float* AB = ws + (size_t)B * p.chunks * 2 * C;
+  float* gsum = AB + (size_t)B * 2 * C;
   GnBwdRed f{dout, out, x, chmul, mean, rstd, HW, lddo, ldo, ldx, C, groups, relu};
   int rc = launch_colreduce(f, B, HW, C, ws, p, ONDA_STREAM(s));
   if (rc) return rc;
-  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(1), dim3(256), (size_t)B * C * 2 * sizeof(float), ONDA_STREAM(s), ws,
-                     p.chunks, B, C, groups, gamma, dgamma, dbeta, gsum);
+  hipLaunchKernelGGL(pair_finalize_kernel, dim3((B * C + 3) / 4), dim3(256), 0, ONDA_STREAM(s), ws, p.chunks, B, C, AB);
+  hipLaunchKernelGGL(gn_bwd_group_kernel, dim3(1), dim3(256), 0, ONDA_STREAM(s), AB, B, C, groups, gamma, dgamma, dbeta,
+                     gsum);
   const size_t total4 = (size_t)B * HW * C / 4;
   hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(ew_grid(total4)), dim3(256), 0, ONDA_STREAM(s), dout, lddo, out, ldo, x,
                      ldx, gamma, chmul, mean, rstd, gsum, dx, HW, C, groups, total4,
@@ -475,7 +500,7 @@ int onda_colsum(const float* x, int ldx, const float* y, int ldy, float* out, fl
   ProdSum f{x, y, HW, ldx, ldy};
   int rc = launch_colreduce(f, B, HW, C, ws, p, ONDA_STREAM(s));
   if (rc) return rc;
-  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((B * C + 255) / 256), dim3(256), 0, ONDA_STREAM(s), ws, p.chunks, B, C,
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((B * C + 3) / 4), dim3(256), 0, ONDA_STREAM(s), ws, p.chunks, B, C,
                      alpha, out);
   return ONDA_LAUNCH_RESULT();
 }

@@ -10,6 +10,10 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# The CPU reference legs are small; on a many-core host (the GPU box has 256) the default
+# one-thread-per-core OpenMP pool makes every tiny op pay a 256-way fork/join.
+torch.set_num_threads(min(16, os.cpu_count() or 1))
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

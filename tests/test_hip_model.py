@@ -119,7 +119,6 @@ def test_train_forward_backward_golden(golden, track):
 def _fp64_oracle_grads(g, batch, mask, names):
     from oracle import losses, model as omodel
     from onda_amd.synthetic import synth_tensor
-    torch.set_num_threads(os.cpu_count() or 1)
     sd = {k: synth_tensor(k, torch.empty(shape, dtype=dt), 1, 3.0).to(dt) for k, shape, dt in omodel.state_spec()}
     sd = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
     for k in names:

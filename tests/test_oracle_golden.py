@@ -11,7 +11,6 @@ from oracle import losses, model, monitor, optim, prototypes
 from oracle.step import OracleAdapter
 from onda_amd.synthetic import synth_batch, synth_tensor
 
-torch.set_num_threads(8)
 
 
 def oracle_sd(seed, head_scale):
