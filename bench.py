@@ -96,7 +96,7 @@ def measure_roofline(da, src, trg, args, steps_done):
     one_step(da, src, trg, steps_done + 1, steps_done + 2)
     torch.cuda.synchronize()
     fam = {}
-    for name, flops, e0, e1 in ops.PROFILE:
+    for name, flops, e0, e1, _tag in ops.PROFILE:
         f = fam.setdefault(name, [0.0, 0.0, 0])
         f[0] += flops
         f[1] += e0.elapsed_time(e1) * 1e-3

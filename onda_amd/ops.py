@@ -32,14 +32,14 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-def _launch(name, flops, fn_name, *args):
+def _launch(name, flops, fn_name, *args, tag=None):
     if PROFILE is None:
         return call(fn_name, *args)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     call(fn_name, *args)
     e1.record()
-    PROFILE.append((name, flops, e0, e1))
+    PROFILE.append((name, flops, e0, e1, tag))
 
 
 def _p(t):
@@ -116,7 +116,8 @@ def conv_forward(x, wp, k, stride, dil, pad, cout, out=None, scale=None, shift=N
         stats = torch.empty(tiles, 2, cout, device=x.device, dtype=torch.float32)
     d = _desc(B, Hi, Wi, Cin, Ho, Wo, cout, k, stride, dil, pad, ldx, ldy, ldr, relu=relu)
     _launch("conv_fwd_kernel<128,%d>" % (128 if cout > 64 else 64), 2.0 * B * Ho * Wo * cout * k * k * Cin,
-            "onda_conv2d_fwd", _p(x), _p(wp), _p(out), _p(scale), _p(shift), _p(residual), _p(stats), byref(d), _stream())
+            "onda_conv2d_fwd", _p(x), _p(wp), _p(out), _p(scale), _p(shift), _p(residual), _p(stats), byref(d), _stream(),
+            tag=("fwd", B * Ho * Wo, cout, Cin, k, stride, dil))
     return out, stats, tiles
 
 
@@ -134,7 +135,8 @@ def conv_dgrad(dy, wpd, k, stride, dil, pad, cin, in_hw):
         dx = torch.zeros(B, Hi, Wi, cin, device=dy.device, dtype=torch.float32)
         d = _desc(B, Ho, Wo, Co, Ho, Wo, cin, 1, 1, 1, 0, ldy, cin, out_os=stride, Hf=Hi, Wf=Wi)
     _launch("conv_fwd_kernel<128,%d>" % (128 if cin > 64 else 64), 2.0 * B * Ho * Wo * cin * k * k * Co,
-            "onda_conv2d_fwd", _p(dy), _p(wpd), _p(dx), None, None, None, None, byref(d), _stream())
+            "onda_conv2d_fwd", _p(dy), _p(wpd), _p(dx), None, None, None, None, byref(d), _stream(),
+            tag=("dgrad", B * Ho * Wo if stride != 1 else B * Hi * Wi, cin, Co, k, stride, dil))
     return dx
 
 
@@ -157,7 +159,8 @@ def conv_wgrad(x, dy, k, stride, dil, pad, cout_real, cin_real, flat_k=0):
     slabs = torch.empty(sk, Co, taps, Cin, device=x.device, dtype=torch.float32)
     d = _desc(B, Hi, Wi, Cin, Ho, Wo, Co, k, stride, dil, pad, nhwc_ld(x), Co)
     _launch("conv_wgrad_kernel<%s>" % ("128,128" if (Co > 64 and Cin > 64) else "64,64"), 2.0 * M * Co * taps * Cin,
-            "onda_conv2d_wgrad", _p(x), _p(dy), _p(slabs), nhwc_ld(dy), sk, byref(d), _stream())
+            "onda_conv2d_wgrad", _p(x), _p(dy), _p(slabs), nhwc_ld(dy), sk, byref(d), _stream(),
+            tag=("wgrad", M, Co, Cin, k, stride, dil, sk))
     if flat_k:
         dw = torch.empty(cout_real, cin_real, 7, 7, device=x.device, dtype=torch.float32)
     else:

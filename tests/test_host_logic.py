@@ -129,3 +129,20 @@ def test_prototype_handler_host_side(tmp_path):
     assert h2.load(str(tmp_path / "p.pickle")) and torch.equal(h2.squared_mean, h.squared_mean)
     x = torch.arange(2 * 3 * 4 * 5.0).reshape(2, 3, 4, 5)
     assert torch.equal(h.transform(x), x.permute(0, 2, 3, 1).reshape(-1, 3))
+
+
+def test_dropin_aliases_reference_names():
+    import sys
+    import onda_amd.dropin as dropin
+    saved = {k: v for k, v in sys.modules.items() if k == "framework" or k.startswith("framework.")}
+    try:
+        dropin.install()
+        from framework.domain_adaptation.methods.prototypes_hybrid_switch import hybrid_proDA, model_select  # noqa
+        from framework.handlers import get_adapt_method, get_model  # noqa
+        from framework.model.deeplabv2 import get_deeplab_v2
+        import onda_amd.framework.model.deeplabv2 as mine
+        assert get_deeplab_v2 is mine.get_deeplab_v2
+    finally:
+        for k in [k for k in sys.modules if k == "framework" or k.startswith("framework.")]:
+            del sys.modules[k]
+        sys.modules.update(saved)
