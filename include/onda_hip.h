@@ -55,9 +55,14 @@ int onda_conv_tiles_m(int M);
  * `stats` (BatchNorm batch statistics, deeplabv2.py:25,40,45 in train mode); v*scale[n]
  * + shift[n] (folded eval-mode BatchNorm or conv bias); + residual (deeplabv2.py:65);
  * ReLU (:57,60,66).  scale, shift, residual, stats may each be NULL.  The same entry runs
- * data gradients: pass dy as x and weights packed by onda_pack_weight_dgrad. */
+ * data gradients: pass dy as x and weights packed by onda_pack_weight_dgrad.
+ * ws: NULL, or onda_conv_ws_floats() floats of scratch; with it, shapes whose tile count
+ * leaves the last round of resident workgroups mostly idle run "stream-K" balanced (the tile x
+ * K-step space is cut evenly over the resident workgroups, partial tiles are combined in a
+ * fixed order by a second launch -- results stay bitwise reproducible). */
+int64_t onda_conv_ws_floats(void);
 int onda_conv2d_fwd(const float* x, const float* w, float* y, const float* scale, const float* shift,
-                    const float* residual, float* stats, const OndaConv* c, onda_stream_t s);
+                    const float* residual, float* stats, float* ws, const OndaConv* c, onda_stream_t s);
 
 /* Weight gradient, split over `splitk` pixel ranges: slabs[ks][Cout][kh*kw][Cin] partial
  * sums of dy[m][n] * x[pix(m,tap)][c]  (autograd of F.conv2d w.r.t. weight).  Then

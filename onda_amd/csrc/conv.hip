@@ -27,12 +27,18 @@ struct ConvK {
   float* stats;
   OndaConv c;
   int M, tilesM, tilesN, taps, kcper;
+  float* ws;  // stream-K partial tiles [grid][2][BM*BN]
 };
 
 constexpr int BK = 32;
 constexpr int LDS_ROW = 36;  // 32 floats + 4 pad: ds_read_b128 of 16 distinct rows is conflict-free
 
-template <int BM, int BN, int WAVES_M, int WAVES_N>
+// SK = false: one workgroup per output tile (grid = tiles).
+// SK = true : "stream-K" -- the tiles x K-steps unit space is cut into gridDim.x equal contiguous
+//             ranges (grid = resident workgroups), so every CU finishes together whatever the
+//             tile count; a range end inside a tile leaves a raw partial tile in `ws`, summed in
+//             fixed order by conv_fixup_kernel (deterministic, no atomics, no inter-block waits).
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool SK>
 __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvK a) {
   constexpr int TM = BM / (32 * WAVES_M), TN = BN / (32 * WAVES_N);
   constexpr int AL = BM / 32, BL = BN / 32;
@@ -44,15 +50,25 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvK a) {
   const int li = lane & 31, lh = lane >> 5;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
 
-  // XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch), give each
-  // XCD a contiguous run of tiles; N-tiles of one M-tile are adjacent in that run.
-  const int nblk = a.tilesM * a.tilesN, bid = blockIdx.x;
+  // XCD-aware order: blocks b and b+8 share an XCD (round-robin dispatch); give each XCD a
+  // contiguous run of tiles (or of the unit space); N-tiles of one M-tile are adjacent in it.
+  const int nblk = gridDim.x, bid = blockIdx.x;
   const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
   const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  const int tile_n = swz % a.tilesN, tile_m = swz / a.tilesN;
+  const int KT = a.taps * a.kcper;
+  const long long U = (long long)a.tilesM * a.tilesN * KT;
+  long long u = SK ? swz * U / nblk : (long long)swz * KT;
+  const long long u_begin = u;
+  const long long u_end = SK ? (swz + 1) * U / nblk : u + KT;
+  const int ccol = (t & 7) * 4, rbase = t >> 3;
+
+  while (u < u_end) {
+  const int tile = (int)(u / KT);
+  const int k_begin = (int)(u - (long long)tile * KT);
+  const int k_end = (int)min((long long)KT, k_begin + (u_end - u));
+  const int tile_n = tile % a.tilesN, tile_m = tile / a.tilesN;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
-  const int ccol = (t & 7) * 4, rbase = t >> 3;
   int hi0[AL], wi0[AL], bH[AL];
 #pragma unroll
   for (int u = 0; u < AL; ++u) {
@@ -77,7 +93,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvK a) {
 
   long long aofs[AL];
   f32x4 ar[AL], br[BL];
-  int tap = 0, c0 = 0;
+  int tap = k_begin / a.kcper, c0 = (k_begin - tap * a.kcper) * BK;
   auto set_tap = [&](int tp) {
     const int rr = tp / c.kw, ss = tp - rr * c.kw;
 #pragma unroll
@@ -112,15 +128,15 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvK a) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  set_tap(0);
+  set_tap(tap);
   gload();
+  __syncthreads();  // the previous tile's LDS reads (main loop / statistics) are done
   sstore(0);
   __syncthreads();
 
-  const int KT = a.taps * a.kcper;
-  for (int kt = 0; kt < KT; ++kt) {
-    const int cur = kt & 1;
-    const bool more = kt + 1 < KT;
+  for (int kt = k_begin; kt < k_end; ++kt) {
+    const int cur = (kt - k_begin) & 1;
+    const bool more = kt + 1 < k_end;
     if (more) {
       c0 += BK;
       if (c0 == c.Cin) {
@@ -149,6 +165,22 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvK a) {
     }
     if (more) sstore(cur ^ 1);
     __syncthreads();
+  }
+
+  u += k_end - k_begin;
+  if (SK && (k_begin != 0 || k_end != KT)) {
+    // partial tile: raw accumulators to this block's slot (0 = its first segment, 1 = its last)
+    float* slot = a.ws + ((size_t)swz * 2 + (u - (k_end - k_begin) == u_begin ? 0 : 1)) * (BM * BN);
+#pragma unroll
+    for (int jn = 0; jn < TN; ++jn)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int row = wm * TM * 32 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+          slot[row * BN + wn * TN * 32 + jn * 32 + li] = acc[i][jn][e];
+        }
+    continue;
   }
 
   // ---- epilogue --------------------------------------------------------------------------
@@ -211,6 +243,67 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvK a) {
         }
         a.y[orow * c.ldy + n] = v;
       }
+    }
+  }
+  }  // tile / segment loop
+}
+
+// Sums the partial tiles stream-K left in `ws` (fixed order: ascending workgroup) and runs the
+// normal epilogue for every tile that was split.  One workgroup per output tile.
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void conv_fixup_kernel(const ConvK a, int G) {
+  __shared__ float red[2][256];
+  const OndaConv& c = a.c;
+  const int KT = a.taps * a.kcper;
+  const long long U = (long long)a.tilesM * a.tilesN * KT;
+  const int tile = blockIdx.x;
+  const long long t0 = (long long)tile * KT, t1 = t0 + KT;
+  const int vs = (int)(((t0 + 1) * G + U - 1) / U - 1), ve = (int)((t1 * G + U - 1) / U - 1);
+  if (vs == ve && vs * U / G <= t0 && (vs + 1) * U / G >= t1) return;  // computed whole by one workgroup
+  const int tile_n = tile % a.tilesN, tile_m = tile / a.tilesN;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int t = threadIdx.x, col = t % BN, rg = t / BN;
+  constexpr int RG = 256 / BN;
+  const int n = n0 + col;
+  const bool vn = n < c.Cout;
+  const float sc = (a.scale && vn) ? a.scale[n] : 1.f;
+  const float sh = (a.shift && vn) ? a.shift[n] : 0.f;
+  const bool plain = (c.out_os == 1 && c.Hf == c.Ho && c.Wf == c.Wo);
+  float s1 = 0.f, s2 = 0.f;
+  for (int row = rg; row < BM; row += RG) {
+    float v = 0.f;
+    for (int vb = vs; vb <= ve; ++vb) {
+      const long long b0 = (long long)vb * U / G, b1 = (long long)(vb + 1) * U / G;
+      const long long g0 = max(b0, t0), g1 = min(b1, t1);
+      if (g1 <= g0) continue;
+      v += a.ws[((size_t)vb * 2 + (g0 == b0 ? 0 : 1)) * (BM * BN) + row * BN + col];
+    }
+    s1 += v;
+    s2 += v * v;
+    const int m = m0 + row;
+    if (m >= a.M || !vn) continue;
+    float o = v * sc + sh;
+    if (a.res) o += a.res[(size_t)m * c.ldr + n];
+    if (c.relu) o = fmaxf(o, 0.f);
+    size_t orow = m;
+    if (!plain) {
+      const int wo = m % c.Wo, tq = m / c.Wo;
+      const int ho = tq % c.Ho, b = tq / c.Ho;
+      orow = ((size_t)b * c.Hf + (size_t)ho * c.out_os) * c.Wf + (size_t)wo * c.out_os;
+    }
+    a.y[orow * c.ldy + n] = o;
+  }
+  if (a.stats != nullptr) {
+    red[0][t] = s1;
+    red[1][t] = s2;
+    __syncthreads();
+    if (rg == 0 && vn) {
+      for (int g = 1; g < RG; ++g) {
+        s1 += red[0][g * BN + col];
+        s2 += red[1][g * BN + col];
+      }
+      a.stats[((size_t)tile_m * 2 + 0) * c.Cout + n] = s1;
+      a.stats[((size_t)tile_m * 2 + 1) * c.Cout + n] = s2;
     }
   }
 }
@@ -418,14 +511,29 @@ extern "C" {
 
 int onda_conv_tiles_m(int M) { return (M + 127) / 128; }
 
+static int resident_workgroups() {
+  static int cached = 0;
+  if (cached == 0) {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) {
+      hipDeviceProp_t prop;
+      if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+    }
+    cached = 2 * cus;  // two 256-thread workgroups of the conv kernel fit one CU (LDS 73.7 KB, 176 registers)
+  }
+  return cached;
+}
+
+int64_t onda_conv_ws_floats(void) { return (int64_t)resident_workgroups() * 2 * 128 * 128; }
+
 int onda_conv2d_fwd(const float* x, const float* w, float* y, const float* scale, const float* shift,
-                    const float* residual, float* stats, const OndaConv* c, onda_stream_t s) {
+                    const float* residual, float* stats, float* ws, const OndaConv* c, onda_stream_t s) {
   ONDA_REQUIRE(x && w && y && c);
   ONDA_REQUIRE(c->Cin > 0 && c->Cin % 32 == 0 && c->Cout > 0 && c->ldx % 4 == 0 && c->ldx >= c->Cin);
   ONDA_REQUIRE(c->kh >= 1 && c->kw >= 1 && c->stride >= 1 && c->dil >= 1 && c->out_os >= 1);
   if (!ONDA_ALIGNED16(x) || !ONDA_ALIGNED16(w)) return ONDA_EALIGN;
   ConvK k;
-  k.x = x; k.w = w; k.y = y; k.scale = scale; k.shift = shift; k.res = residual; k.stats = stats;
+  k.x = x; k.w = w; k.y = y; k.scale = scale; k.shift = shift; k.res = residual; k.stats = stats; k.ws = ws;
   k.c = *c;
   const long long M = (long long)c->B * c->Ho * c->Wo;
   ONDA_REQUIRE(M > 0 && M < (1ll << 31));
@@ -433,12 +541,30 @@ int onda_conv2d_fwd(const float* x, const float* w, float* y, const float* scale
   k.taps = c->kh * c->kw;
   k.kcper = c->Cin / 32;
   k.tilesM = (k.M + 127) / 128;
-  if (c->Cout > 64) {
-    k.tilesN = (c->Cout + 127) / 128;
-    hipLaunchKernelGGL((conv_fwd_kernel<128, 128, 2, 2>), dim3(k.tilesM * k.tilesN), dim3(256), 0, ONDA_STREAM(s), k);
+  const bool wide = c->Cout > 64;
+  k.tilesN = wide ? (c->Cout + 127) / 128 : (c->Cout + 63) / 64;
+  const int tiles = k.tilesM * k.tilesN, KT = k.taps * k.kcper, G = resident_workgroups();
+  // One workgroup per tile wastes the last partial round of the G resident workgroups.  Stream-K
+  // removes that at the price of the fix-up pass (about two partial tiles written and read per
+  // resident workgroup); take it when the modelled saving exceeds the modelled cost.
+  const double eff = ((double)tiles / G) / (double)((tiles + G - 1) / G);
+  const double t_ideal_us = 2.0 * (double)M * c->Cout * k.taps * c->Cin / 1.2e8;  // at ~120 TFLOP/s
+  const double split = tiles < G ? tiles : G;
+  const double fix_us = split * (wide ? 0.09 : 0.045) + 8.0;
+  const bool balanced = ws != nullptr && KT >= 4 && t_ideal_us * (1.0 / eff - 1.0) > fix_us;
+  hipStream_t st = ONDA_STREAM(s);
+  if (balanced) {
+    if (wide) {
+      hipLaunchKernelGGL((conv_fwd_kernel<128, 128, 2, 2, true>), dim3(G), dim3(256), 0, st, k);
+      hipLaunchKernelGGL((conv_fixup_kernel<128, 128>), dim3(tiles), dim3(256), 0, st, k, G);
+    } else {
+      hipLaunchKernelGGL((conv_fwd_kernel<128, 64, 2, 2, true>), dim3(G), dim3(256), 0, st, k);
+      hipLaunchKernelGGL((conv_fixup_kernel<128, 64>), dim3(tiles), dim3(256), 0, st, k, G);
+    }
+  } else if (wide) {
+    hipLaunchKernelGGL((conv_fwd_kernel<128, 128, 2, 2, false>), dim3(tiles), dim3(256), 0, st, k);
   } else {
-    k.tilesN = (c->Cout + 63) / 64;
-    hipLaunchKernelGGL((conv_fwd_kernel<128, 64, 2, 2>), dim3(k.tilesM * k.tilesN), dim3(256), 0, ONDA_STREAM(s), k);
+    hipLaunchKernelGGL((conv_fwd_kernel<128, 64, 2, 2, false>), dim3(tiles), dim3(256), 0, st, k);
   }
   return ONDA_LAUNCH_RESULT();
 }

@@ -79,6 +79,19 @@ def _desc(B, Hi, Wi, Cin, Ho, Wo, Cout, k, stride, dil, pad, ldx, ldy, ldr=0, ou
                     Ho if Hf is None else Hf, Wo if Wf is None else Wf, int(relu))
 
 
+_CONV_WS = {}
+
+
+def _conv_ws(device):
+    """Scratch for the balanced (stream-K) conv schedule: one buffer per (device, stream) --
+    launches on one stream are ordered, so consecutive convs can share it."""
+    key = (str(device), _stream())
+    ws = _CONV_WS.get(key)
+    if ws is None:
+        ws = _CONV_WS[key] = torch.empty(query("onda_conv_ws_floats"), device=device, dtype=torch.float32)
+    return ws
+
+
 def pack_weight_fwd(weight, cout_pad=None, kp=None):
     """OIHW -> [Cout_pad][tap*Cin + c] rows of length kp (zero padded)."""
     cout, cin, kh, kw = weight.shape
@@ -116,7 +129,8 @@ def conv_forward(x, wp, k, stride, dil, pad, cout, out=None, scale=None, shift=N
         stats = torch.empty(tiles, 2, cout, device=x.device, dtype=torch.float32)
     d = _desc(B, Hi, Wi, Cin, Ho, Wo, cout, k, stride, dil, pad, ldx, ldy, ldr, relu=relu)
     _launch("conv_fwd_kernel<128,%d>" % (128 if cout > 64 else 64), 2.0 * B * Ho * Wo * cout * k * k * Cin,
-            "onda_conv2d_fwd", _p(x), _p(wp), _p(out), _p(scale), _p(shift), _p(residual), _p(stats), byref(d), _stream(),
+            "onda_conv2d_fwd", _p(x), _p(wp), _p(out), _p(scale), _p(shift), _p(residual), _p(stats),
+            _p(_conv_ws(x.device)), byref(d), _stream(),
             tag=("fwd", B * Ho * Wo, cout, Cin, k, stride, dil))
     return out, stats, tiles
 
@@ -135,18 +149,30 @@ def conv_dgrad(dy, wpd, k, stride, dil, pad, cin, in_hw):
         dx = torch.zeros(B, Hi, Wi, cin, device=dy.device, dtype=torch.float32)
         d = _desc(B, Ho, Wo, Co, Ho, Wo, cin, 1, 1, 1, 0, ldy, cin, out_os=stride, Hf=Hi, Wf=Wi)
     _launch("conv_fwd_kernel<128,%d>" % (128 if cin > 64 else 64), 2.0 * B * Ho * Wo * cin * k * k * Co,
-            "onda_conv2d_fwd", _p(dy), _p(wpd), _p(dx), None, None, None, None, byref(d), _stream(),
+            "onda_conv2d_fwd", _p(dy), _p(wpd), _p(dx), None, None, None, None, _p(_conv_ws(dy.device)), byref(d),
+            _stream(),
             tag=("dgrad", B * Ho * Wo if stride != 1 else B * Hi * Wi, cin, Co, k, stride, dil))
     return dx
 
 
 def _wgrad_splitk(M, cout, cin, taps):
+    """Split count over the pixel (K) range: pick the one whose workgroup count best fills whole
+    rounds of the resident workgroups (tail effect) net of the slab write+read it costs."""
     t = 128 if (cout > 64 and cin > 64) else 64
     tiles = -(-cout // t) * -(-cin // t) * taps
-    sk = max(1, -(-1024 // tiles))
-    sk = min(sk, max(1, M // 256))
-    budget = (256 << 20) // (4 * cout * cin * taps)
-    return max(1, min(sk, max(1, budget)))
+    G = query("onda_conv_ws_floats") // (2 * 128 * 128) * (1 if t == 128 else 2)
+    t_ideal = 2.0 * M * cout * cin * taps / 1.2e14            # seconds at ~120 TFLOP/s
+    wbytes = 4.0 * cout * cin * taps
+    best, best_t = 1, None
+    for sk in range(1, 129):
+        if sk > 1 and (M // sk < 256 or sk * wbytes > (512 << 20)):
+            break
+        blocks = tiles * sk
+        eff = (blocks / G) / -(-blocks // G)
+        est = t_ideal / eff + 2.0 * sk * wbytes / 3e12
+        if best_t is None or est < best_t * 0.995:
+            best, best_t = sk, est
+    return best
 
 
 def conv_wgrad(x, dy, k, stride, dil, pad, cout_real, cin_real, flat_k=0):
