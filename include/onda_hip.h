@@ -64,6 +64,16 @@ int64_t onda_conv_ws_floats(void);
 int onda_conv2d_fwd(const float* x, const float* w, float* y, const float* scale, const float* shift,
                     const float* residual, float* stats, float* ws, const OndaConv* c, onda_stream_t s);
 
+/* The same convolution evaluated on the bf16 matrix pipe with fp32-level accuracy: each fp32
+ * operand is the exact sum of three bf16 limbs and the six limb products of weight >= 2^-16 are
+ * accumulated in fp32 (csrc/conv_bf3.hip).  w3 = onda_pack_weight_bf3 output: limb planes
+ * [3][rows][K] bf16 with rows = c->Cout and K = kh*kw*c->Cin (dgrad=0: row n, k = tap*Cin + c;
+ * dgrad=1: row c, k = tap'*Cout_pad + n, taps flipped -- the data-gradient operand). */
+int onda_pack_weight_bf3(const float* w_oihw, void* dst, int Cout, int Cin, int taps, int rows_pad, int Kp, int dgrad,
+                         int Cout_pad, onda_stream_t s);
+int onda_conv2d_fwd_bf3(const float* x, const void* w3, float* y, const float* scale, const float* shift,
+                        const float* residual, float* stats, float* ws, const OndaConv* c, onda_stream_t s);
+
 /* Weight gradient, split over `splitk` pixel ranges: slabs[ks][Cout][kh*kw][Cin] partial
  * sums of dy[m][n] * x[pix(m,tap)][c]  (autograd of F.conv2d w.r.t. weight).  Then
  * onda_wgrad_reduce sums the slabs in a fixed order (deterministic) into the OIHW

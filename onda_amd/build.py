@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libonda_hip.so")
-SOURCES = ["conv.hip", "norm.hip", "pointwise.hip", "loss_proto.hip"]
+SOURCES = ["conv.hip", "conv_bf3.hip", "norm.hip", "pointwise.hip", "loss_proto.hip"]
 
 
 def _stale(target, deps):
@@ -23,7 +23,7 @@ def _stale(target, deps):
 
 def build(force=False, verbose=True):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(INCLUDE, "onda_hip.h")]
+    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "conv_common.h"), os.path.join(INCLUDE, "onda_hip.h")]
     objs = []
     for src in SOURCES:
         path = os.path.join(CSRC, src)

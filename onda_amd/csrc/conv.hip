@@ -13,24 +13,10 @@
 // barrier per 32-deep K step.  Workgroup = 256 threads = 4 waves, one wave per SIMD, two
 // workgroups per CU.  The blockIdx -> tile map hands each XCD a contiguous band of
 // M-tiles so the N-tiles that re-read one activation band share an L2.
-#include "common.h"
+#include "conv_common.h"
 
 namespace {
 
-struct ConvK {
-  const float* x;
-  const float* w;
-  float* y;
-  const float* scale;
-  const float* shift;
-  const float* res;
-  float* stats;
-  OndaConv c;
-  int M, tilesM, tilesN, taps, kcper;
-  float* ws;  // stream-K partial tiles [grid][2][BM*BN]
-};
-
-constexpr int BK = 32;
 constexpr int LDS_ROW = 36;  // 32 floats + 4 pad: ds_read_b128 of 16 distinct rows is conflict-free
 
 // SK = false: one workgroup per output tile (grid = tiles).
@@ -88,7 +74,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvK a) {
   for (int u = 0; u < BL; ++u) {
     const int n = n0 + rbase + 32 * u;
     vn[u] = n < c.Cout;
-    wrow[u] = a.w + (size_t)(vn[u] ? n : 0) * wstride + ccol;
+    wrow[u] = static_cast<const float*>(a.w) + (size_t)(vn[u] ? n : 0) * wstride + ccol;
   }
 
   long long aofs[AL];
@@ -171,80 +157,10 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvK a) {
   if (SK && (k_begin != 0 || k_end != KT)) {
     // partial tile: raw accumulators to this block's slot (0 = its first segment, 1 = its last)
     float* slot = a.ws + ((size_t)swz * 2 + (u - (k_end - k_begin) == u_begin ? 0 : 1)) * (BM * BN);
-#pragma unroll
-    for (int jn = 0; jn < TN; ++jn)
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int row = wm * TM * 32 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-          slot[row * BN + wn * TN * 32 + jn * 32 + li] = acc[i][jn][e];
-        }
+    conv_store_partial<BN, TM, TN>(slot, acc, wm, wn, li, lh);
     continue;
   }
-
-  // ---- epilogue --------------------------------------------------------------------------
-  if (a.stats != nullptr) {
-    float* red = lds;  // [WAVES_M][BN][2]
-#pragma unroll
-    for (int jn = 0; jn < TN; ++jn) {
-      float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const float v = acc[i][jn][e];
-          s1 += v;
-          s2 += v * v;
-        }
-      s1 += __shfl_xor(s1, 32, 64);
-      s2 += __shfl_xor(s2, 32, 64);
-      if (lh == 0) {
-        const int col = wn * TN * 32 + jn * 32 + li;
-        red[(wm * BN + col) * 2 + 0] = s1;
-        red[(wm * BN + col) * 2 + 1] = s2;
-      }
-    }
-    __syncthreads();
-    if (t < BN && n0 + t < c.Cout) {
-      float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-      for (int w_ = 0; w_ < WAVES_M; ++w_) {
-        s1 += red[(w_ * BN + t) * 2 + 0];
-        s2 += red[(w_ * BN + t) * 2 + 1];
-      }
-      a.stats[((size_t)tile_m * 2 + 0) * c.Cout + n0 + t] = s1;
-      a.stats[((size_t)tile_m * 2 + 1) * c.Cout + n0 + t] = s2;
-    }
-  }
-
-  const bool plain = (c.out_os == 1 && c.Hf == c.Ho && c.Wf == c.Wo);
-#pragma unroll
-  for (int jn = 0; jn < TN; ++jn) {
-    const int n = n0 + wn * TN * 32 + jn * 32 + li;
-    if (n >= c.Cout) continue;
-    const float sc = a.scale ? a.scale[n] : 1.f;
-    const float sh = a.shift ? a.shift[n] : 0.f;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int row = (e & 3) + 8 * (e >> 2) + 4 * lh;
-        const int m = m0 + wm * TM * 32 + i * 32 + row;
-        if (m >= a.M) continue;
-        float v = acc[i][jn][e] * sc + sh;
-        if (a.res) v += a.res[(size_t)m * c.ldr + n];
-        if (c.relu) v = fmaxf(v, 0.f);
-        size_t orow = m;
-        if (!plain) {
-          const int wo = m % c.Wo, tq = m / c.Wo;
-          const int ho = tq % c.Ho, b = tq / c.Ho;
-          orow = ((size_t)b * c.Hf + (size_t)ho * c.out_os) * c.Wf + (size_t)wo * c.out_os;
-        }
-        a.y[orow * c.ldy + n] = v;
-      }
-    }
-  }
+  conv_epilogue<BM, BN, TM, TN, WAVES_M>(a, acc, lds, tile_m, m0, n0, wm, wn, li, lh);
   }  // tile / segment loop
 }
 
@@ -511,7 +427,18 @@ extern "C" {
 
 int onda_conv_tiles_m(int M) { return (M + 127) / 128; }
 
-static int resident_workgroups() {
+}  // extern "C"
+
+int conv_launch_fixup(const ConvK& k, int G, bool wide, hipStream_t st) {
+  const int tiles = k.tilesM * k.tilesN;
+  if (wide)
+    hipLaunchKernelGGL((conv_fixup_kernel<128, 128>), dim3(tiles), dim3(256), 0, st, k, G);
+  else
+    hipLaunchKernelGGL((conv_fixup_kernel<128, 64>), dim3(tiles), dim3(256), 0, st, k, G);
+  return ONDA_LAUNCH_RESULT();
+}
+
+int conv_resident_workgroups() {
   static int cached = 0;
   if (cached == 0) {
     int dev = 0, cus = 256;
@@ -524,7 +451,9 @@ static int resident_workgroups() {
   return cached;
 }
 
-int64_t onda_conv_ws_floats(void) { return (int64_t)resident_workgroups() * 2 * 128 * 128; }
+extern "C" {
+
+int64_t onda_conv_ws_floats(void) { return (int64_t)conv_resident_workgroups() * 2 * 128 * 128; }
 
 int onda_conv2d_fwd(const float* x, const float* w, float* y, const float* scale, const float* shift,
                     const float* residual, float* stats, float* ws, const OndaConv* c, onda_stream_t s) {
@@ -543,7 +472,7 @@ int onda_conv2d_fwd(const float* x, const float* w, float* y, const float* scale
   k.tilesM = (k.M + 127) / 128;
   const bool wide = c->Cout > 64;
   k.tilesN = wide ? (c->Cout + 127) / 128 : (c->Cout + 63) / 64;
-  const int tiles = k.tilesM * k.tilesN, KT = k.taps * k.kcper, G = resident_workgroups();
+  const int tiles = k.tilesM * k.tilesN, KT = k.taps * k.kcper, G = conv_resident_workgroups();
   // One workgroup per tile wastes the last partial round of the G resident workgroups.  Stream-K
   // removes that at the price of the fix-up pass (about two partial tiles written and read per
   // resident workgroup); take it when the modelled saving exceeds the modelled cost.
@@ -554,13 +483,11 @@ int onda_conv2d_fwd(const float* x, const float* w, float* y, const float* scale
   const bool balanced = ws != nullptr && KT >= 4 && t_ideal_us * (1.0 / eff - 1.0) > fix_us;
   hipStream_t st = ONDA_STREAM(s);
   if (balanced) {
-    if (wide) {
+    if (wide)
       hipLaunchKernelGGL((conv_fwd_kernel<128, 128, 2, 2, true>), dim3(G), dim3(256), 0, st, k);
-      hipLaunchKernelGGL((conv_fixup_kernel<128, 128>), dim3(tiles), dim3(256), 0, st, k, G);
-    } else {
+    else
       hipLaunchKernelGGL((conv_fwd_kernel<128, 64, 2, 2, true>), dim3(G), dim3(256), 0, st, k);
-      hipLaunchKernelGGL((conv_fixup_kernel<128, 64>), dim3(tiles), dim3(256), 0, st, k, G);
-    }
+    return conv_launch_fixup(k, G, wide, st);
   } else if (wide) {
     hipLaunchKernelGGL((conv_fwd_kernel<128, 128, 2, 2, false>), dim3(tiles), dim3(256), 0, st, k);
   } else {

@@ -1,0 +1,284 @@
+// fp32-accurate convolution on the bf16 matrix pipe ("split-3"): every fp32 operand is written as
+// the exact sum of three bf16 limbs, x = x1 + x2 + x3 (8 + 8 + 8 mantissa bits), and the product
+// a*b is evaluated as the six limb products whose weight is >= 2^-16,
+//     a1*b1 + (a1*b2 + a2*b1) + (a1*b3 + a2*b2 + a3*b1),
+// each exact in fp32 and accumulated in fp32 by v_mfma_f32_32x32x16_bf16.  What is dropped
+// (a2*b3 + a3*b2 + a3*b3 and the limb-3 rounding) is <= ~2^-23 |a||b| per product -- the size of
+// an fp32 rounding error -- while the bf16 pipe runs 16x the fp32-MFMA rate, i.e. 16/6 = 2.7x per
+// fp32-equivalent FLOP.  bf16 keeps fp32's exponent range, so no scaling is involved.
+//
+// Same implicit-GEMM geometry, stream-K schedule and epilogue as conv.hip.  Weights arrive
+// pre-split ([3][rows][tap*Cin] bf16, onda_pack_weight_*_bf3); activations are split by the
+// VALU on their way into LDS.  LDS holds the three limb planes of both operand tiles
+// ((128+128) rows x 32 k x 3 limbs, rows padded to 80 B: conflict-free ds_read_b128), single
+// stage with register prefetch, 61.4 KB -> two workgroups per CU.
+#include "conv_common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int ROWB = 80;  // bytes per LDS row: 32 bf16 + 16 B pad
+
+__device__ __forceinline__ unsigned pack2(__bf16 lo, __bf16 hi) {
+  return (unsigned)__builtin_bit_cast(unsigned short, lo) | ((unsigned)__builtin_bit_cast(unsigned short, hi) << 16);
+}
+
+// float4 -> three limbs, each 4 bf16 packed in 8 bytes
+__device__ __forceinline__ void split3(const f32x4 v, u32x2& l1, u32x2& l2, u32x2& l3) {
+  __bf16 a[4], b[4], cc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    a[j] = (__bf16)v[j];
+    const float r1 = v[j] - (float)a[j];
+    b[j] = (__bf16)r1;
+    const float r2 = r1 - (float)b[j];
+    cc[j] = (__bf16)r2;
+  }
+  l1 = u32x2{pack2(a[0], a[1]), pack2(a[2], a[3])};
+  l2 = u32x2{pack2(b[0], b[1]), pack2(b[2], b[3])};
+  l3 = u32x2{pack2(cc[0], cc[1]), pack2(cc[2], cc[3])};
+}
+
+template <int BM, int BN, bool SK>
+__global__ __launch_bounds__(256, 2) void conv_fwd_bf3_kernel(const ConvK a, size_t limb_stride) {
+  constexpr int WAVES_M = 2, WAVES_N = 2;
+  constexpr int TM = BM / (32 * WAVES_M), TN = BN / (32 * WAVES_N);
+  constexpr int AL = BM / 32;          // float4 loads per thread for the A tile
+  constexpr int BL = BN / 64;          // 16-byte loads per thread per limb for the B tile
+  constexpr int PLANE = (BM + BN) * ROWB;  // bytes of one limb plane (A rows then B rows)
+  __shared__ __attribute__((aligned(16))) unsigned char lds[3 * PLANE];
+
+  const OndaConv& c = a.c;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+
+  const int nblk = gridDim.x, bid = blockIdx.x;
+  const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
+  const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  const int KT = a.taps * a.kcper;
+  const long long U = (long long)a.tilesM * a.tilesN * KT;
+  long long u = SK ? swz * U / nblk : (long long)swz * KT;
+  const long long u_begin = u;
+  const long long u_end = SK ? (swz + 1) * U / nblk : u + KT;
+  const int ccol = (t & 7) * 4, rbase = t >> 3;  // A: 4 floats at k=ccol of rows rbase+32u
+  const int brow = t >> 2, bk = (t & 3) * 8;     // B: 8 bf16 at k=bk of rows brow+64v
+  const __bf16* wbase = static_cast<const __bf16*>(a.w);
+  const int wstride = a.taps * c.Cin;
+
+  while (u < u_end) {
+    const int tile = (int)(u / KT);
+    const int k_begin = (int)(u - (long long)tile * KT);
+    const int k_end = (int)min((long long)KT, k_begin + (u_end - u));
+    const int tile_n = tile % a.tilesN, tile_m = tile / a.tilesN;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    int hi0[AL], wi0[AL], bH[AL];
+#pragma unroll
+    for (int i = 0; i < AL; ++i) {
+      const int m = m0 + rbase + 32 * i;
+      const bool vm = m < a.M;
+      const int mm = vm ? m : 0;
+      const int wo = mm % c.Wo, tq = mm / c.Wo;
+      const int ho = tq % c.Ho, b = tq / c.Ho;
+      hi0[i] = vm ? ho * c.stride - c.pad : -(1 << 28);
+      wi0[i] = wo * c.stride - c.pad;
+      bH[i] = b * c.Hi;
+    }
+    const __bf16* wrow[BL];
+    bool vn[BL];
+#pragma unroll
+    for (int v = 0; v < BL; ++v) {
+      const int n = n0 + brow + 64 * v;
+      vn[v] = n < c.Cout;
+      wrow[v] = wbase + (size_t)(vn[v] ? n : 0) * wstride + bk;
+    }
+
+    int aofs[AL];  // element offsets fit 31 bits (checked on the host)
+    f32x4 ar[AL];
+    u32x4 br[3][BL];
+    int tap = k_begin / a.kcper, c0 = (k_begin - tap * a.kcper) * BK;
+    auto set_tap = [&](int tp) {
+      const int rr = tp / c.kw, ss = tp - rr * c.kw;
+#pragma unroll
+      for (int i = 0; i < AL; ++i) {
+        const int hi = hi0[i] + rr * c.dil, wi = wi0[i] + ss * c.dil;
+        const bool ok = (unsigned)hi < (unsigned)c.Hi && (unsigned)wi < (unsigned)c.Wi;
+        aofs[i] = ok ? ((bH[i] + hi) * c.Wi + wi) * c.ldx + ccol : -1;
+      }
+    };
+    auto gload = [&]() {
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      const u32x4 zi = {0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int i = 0; i < AL; ++i) ar[i] = aofs[i] >= 0 ? *reinterpret_cast<const f32x4*>(a.x + aofs[i] + c0) : z;
+#pragma unroll
+      for (int l = 0; l < 3; ++l)
+#pragma unroll
+        for (int v = 0; v < BL; ++v)
+          br[l][v] = vn[v] ? *reinterpret_cast<const u32x4*>(wrow[v] + l * limb_stride + tap * c.Cin + c0) : zi;
+    };
+    auto sstore = [&]() {
+#pragma unroll
+      for (int i = 0; i < AL; ++i) {
+        u32x2 l1, l2, l3;
+        split3(ar[i], l1, l2, l3);
+        const int off = (rbase + 32 * i) * ROWB + ccol * 2;
+        *reinterpret_cast<u32x2*>(lds + 0 * PLANE + off) = l1;
+        *reinterpret_cast<u32x2*>(lds + 1 * PLANE + off) = l2;
+        *reinterpret_cast<u32x2*>(lds + 2 * PLANE + off) = l3;
+      }
+#pragma unroll
+      for (int l = 0; l < 3; ++l)
+#pragma unroll
+        for (int v = 0; v < BL; ++v)
+          *reinterpret_cast<u32x4*>(lds + l * PLANE + (BM + brow + 64 * v) * ROWB + bk * 2) = br[l][v];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    set_tap(tap);
+    gload();
+    for (int kt = k_begin; kt < k_end; ++kt) {
+      __syncthreads();  // LDS free: the previous K-step's (or tile's) reads are done
+      sstore();
+      __syncthreads();
+      if (kt + 1 < k_end) {  // next tile's loads fly while this one is multiplied
+        c0 += BK;
+        if (c0 == c.Cin) {
+          c0 = 0;
+          ++tap;
+          set_tap(tap);
+        }
+        gload();
+      }
+      const unsigned char* Ab = lds + (wm * TM * 32 + li) * ROWB + lh * 16;
+      const unsigned char* Bb = lds + (BM + wn * TN * 32 + li) * ROWB + lh * 16;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        // A limbs stay in registers; B limbs stream 3 -> 2 -> 1 (smallest products first)
+        bf16x8 af[TM][3];
+#pragma unroll
+        for (int l = 0; l < 3; ++l)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+            af[i][l] = *reinterpret_cast<const bf16x8*>(Ab + l * PLANE + i * 32 * ROWB + s * 32);
+#pragma unroll
+        for (int l = 2; l >= 0; --l) {
+          bf16x8 bf[TN];
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            bf[j] = *reinterpret_cast<const bf16x8*>(Bb + l * PLANE + j * 32 * ROWB + s * 32);
+#pragma unroll
+          for (int la = 2 - l; la >= 0; --la)  // a_{la+1} * b_{l+1} with la + l <= 2
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+              for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][la], bf[j], acc[i][j], 0, 0, 0);
+        }
+      }
+    }
+
+    u += k_end - k_begin;
+    if (SK && (k_begin != 0 || k_end != KT)) {
+      float* slot = a.ws + ((size_t)swz * 2 + (u - (k_end - k_begin) == u_begin ? 0 : 1)) * (BM * BN);
+      conv_store_partial<BN, TM, TN>(slot, acc, wm, wn, li, lh);
+      continue;
+    }
+    __syncthreads();  // all waves are past their last LDS read before the statistics reuse it
+    conv_epilogue<BM, BN, TM, TN, WAVES_M>(a, acc, reinterpret_cast<float*>(lds), tile_m, m0, n0, wm, wn, li, lh);
+  }
+}
+
+// OIHW fp32 -> limb planes dst[3][rows_pad][Kp] bf16.  dgrad = 0: row n, k = tap*Cin + c.
+// dgrad = 1: row c, k = tap'*Cout_pad + n with the taps flipped (data-gradient operand).
+__global__ void pack_bf3_kernel(const float* __restrict__ w, __bf16* __restrict__ dst, int Cout, int Cin, int taps,
+                                int rows_pad, int Kp, int dgrad, int Cout_pad) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t plane = (size_t)rows_pad * Kp;
+  if (e >= plane) return;
+  const int k = (int)(e % Kp), row = (int)(e / Kp);
+  float v = 0.f;
+  if (!dgrad) {
+    if (row < Cout && k < taps * Cin) {
+      const int tap = k / Cin, cc = k - tap * Cin;
+      v = w[((size_t)row * Cin + cc) * taps + tap];
+    }
+  } else {
+    const int tap = k / Cout_pad, n = k - tap * Cout_pad;
+    if (row < Cin && tap < taps && n < Cout) v = w[((size_t)n * Cin + row) * taps + (taps - 1 - tap)];
+  }
+  const __bf16 a = (__bf16)v;
+  const float r1 = v - (float)a;
+  const __bf16 b = (__bf16)r1;
+  const float r2 = r1 - (float)b;
+  dst[e] = a;
+  dst[plane + e] = b;
+  dst[2 * plane + e] = (__bf16)r2;
+}
+
+}  // namespace
+
+extern "C" {
+
+int onda_pack_weight_bf3(const float* w_oihw, void* dst, int Cout, int Cin, int taps, int rows_pad, int Kp, int dgrad,
+                         int Cout_pad, onda_stream_t s) {
+  ONDA_REQUIRE(w_oihw && dst && Kp % 8 == 0);
+  ONDA_REQUIRE(dgrad ? (rows_pad >= Cin && Kp >= taps * Cout_pad && Cout_pad >= Cout) : (rows_pad >= Cout && Kp >= taps * Cin));
+  const size_t plane = (size_t)rows_pad * Kp;
+  hipLaunchKernelGGL(pack_bf3_kernel, dim3((unsigned)((plane + 255) / 256)), dim3(256), 0, ONDA_STREAM(s), w_oihw,
+                     static_cast<__bf16*>(dst), Cout, Cin, taps, rows_pad, Kp, dgrad, Cout_pad);
+  return ONDA_LAUNCH_RESULT();
+}
+
+int onda_conv2d_fwd_bf3(const float* x, const void* w3, float* y, const float* scale, const float* shift,
+                        const float* residual, float* stats, float* ws, const OndaConv* c, onda_stream_t s) {
+  ONDA_REQUIRE(x && w3 && y && c);
+  ONDA_REQUIRE(c->Cin > 0 && c->Cin % 32 == 0 && c->Cout > 0 && c->ldx % 4 == 0 && c->ldx >= c->Cin);
+  ONDA_REQUIRE(c->kh >= 1 && c->kw >= 1 && c->stride >= 1 && c->dil >= 1 && c->out_os >= 1);
+  if (!ONDA_ALIGNED16(x) || !ONDA_ALIGNED16(w3)) return ONDA_EALIGN;
+  ConvK k;
+  k.x = x; k.w = w3; k.y = y; k.scale = scale; k.shift = shift; k.res = residual; k.stats = stats; k.ws = ws;
+  k.c = *c;
+  const long long M = (long long)c->B * c->Ho * c->Wo;
+  ONDA_REQUIRE(M > 0 && M < (1ll << 31));
+  ONDA_REQUIRE((long long)c->B * c->Hi * c->Wi * c->ldx < (1ll << 31));  // 32-bit gather offsets
+  k.M = (int)M;
+  k.taps = c->kh * c->kw;
+  k.kcper = c->Cin / 32;
+  k.tilesM = (k.M + 127) / 128;
+  const bool wide = c->Cout > 64;
+  k.tilesN = wide ? (c->Cout + 127) / 128 : (c->Cout + 63) / 64;
+  const size_t limb_stride = (size_t)c->Cout * k.taps * c->Cin;  // planes are [Cout][taps*Cin]
+  const int tiles = k.tilesM * k.tilesN, KT = k.taps * k.kcper, G = conv_resident_workgroups();
+  const double eff = ((double)tiles / G) / (double)((tiles + G - 1) / G);
+  const double t_ideal_us = 2.0 * (double)M * c->Cout * k.taps * c->Cin / 2.5e8;  // at ~250 TFLOP/s equivalent
+  const double split = tiles < G ? tiles : G;
+  const double fix_us = split * (wide ? 0.09 : 0.045) + 8.0;
+  const bool balanced = ws != nullptr && KT >= 4 && t_ideal_us * (1.0 / eff - 1.0) > fix_us;
+  hipStream_t st = ONDA_STREAM(s);
+  if (balanced) {
+    if (wide)
+      hipLaunchKernelGGL((conv_fwd_bf3_kernel<128, 128, true>), dim3(G), dim3(256), 0, st, k, limb_stride);
+    else
+      hipLaunchKernelGGL((conv_fwd_bf3_kernel<128, 64, true>), dim3(G), dim3(256), 0, st, k, limb_stride);
+    return conv_launch_fixup(k, G, wide, st);
+  }
+  if (wide)
+    hipLaunchKernelGGL((conv_fwd_bf3_kernel<128, 128, false>), dim3(tiles), dim3(256), 0, st, k, limb_stride);
+  else
+    hipLaunchKernelGGL((conv_fwd_bf3_kernel<128, 64, false>), dim3(tiles), dim3(256), 0, st, k, limb_stride);
+  return ONDA_LAUNCH_RESULT();
+}
+
+}  // extern "C"

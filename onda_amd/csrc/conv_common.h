@@ -1,0 +1,107 @@
+// Shared between the fp32 and the split-bf16 convolution kernels: argument block, the
+// stream-K partial-tile store and the common epilogue (statistics, scale/shift, residual, ReLU,
+// slice / scatter store) for a 4-wave workgroup of 32x32 MFMA accumulator tiles.
+#pragma once
+#include "common.h"
+
+struct ConvK {
+  const float* x;
+  const void* w;
+  float* y;
+  const float* scale;
+  const float* shift;
+  const float* res;
+  float* stats;
+  OndaConv c;
+  int M, tilesM, tilesN, taps, kcper;
+  float* ws;  // stream-K partial tiles [grid][2][BM*BN]
+};
+
+constexpr int BK = 32;
+
+// raw accumulators of a partial (stream-K) tile -> slot[BM][BN]
+template <int BN, int TM, int TN>
+__device__ __forceinline__ void conv_store_partial(float* slot, const f32x16 (&acc)[TM][TN], int wm, int wn, int li,
+                                                   int lh) {
+#pragma unroll
+  for (int jn = 0; jn < TN; ++jn)
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = wm * TM * 32 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        slot[row * BN + wn * TN * 32 + jn * 32 + li] = acc[i][jn][e];
+      }
+}
+
+// `red`: >= WAVES_M*BN*2 floats of LDS that no wave is still reading.
+template <int BM, int BN, int TM, int TN, int WAVES_M>
+__device__ __forceinline__ void conv_epilogue(const ConvK& a, const f32x16 (&acc)[TM][TN], float* red, int tile_m,
+                                              int m0, int n0, int wm, int wn, int li, int lh) {
+  const OndaConv& c = a.c;
+  const int t = threadIdx.x;
+  if (a.stats != nullptr) {
+#pragma unroll
+    for (int jn = 0; jn < TN; ++jn) {
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const float v = acc[i][jn][e];
+          s1 += v;
+          s2 += v * v;
+        }
+      s1 += __shfl_xor(s1, 32, 64);
+      s2 += __shfl_xor(s2, 32, 64);
+      if (lh == 0) {
+        const int col = wn * TN * 32 + jn * 32 + li;
+        red[(wm * BN + col) * 2 + 0] = s1;
+        red[(wm * BN + col) * 2 + 1] = s2;
+      }
+    }
+    __syncthreads();
+    if (t < BN && n0 + t < c.Cout) {
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int w_ = 0; w_ < WAVES_M; ++w_) {
+        s1 += red[(w_ * BN + t) * 2 + 0];
+        s2 += red[(w_ * BN + t) * 2 + 1];
+      }
+      a.stats[((size_t)tile_m * 2 + 0) * c.Cout + n0 + t] = s1;
+      a.stats[((size_t)tile_m * 2 + 1) * c.Cout + n0 + t] = s2;
+    }
+  }
+
+  const bool plain = (c.out_os == 1 && c.Hf == c.Ho && c.Wf == c.Wo);
+#pragma unroll
+  for (int jn = 0; jn < TN; ++jn) {
+    const int n = n0 + wn * TN * 32 + jn * 32 + li;
+    if (n >= c.Cout) continue;
+    const float sc = a.scale ? a.scale[n] : 1.f;
+    const float sh = a.shift ? a.shift[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = (e & 3) + 8 * (e >> 2) + 4 * lh;
+        const int m = m0 + wm * TM * 32 + i * 32 + row;
+        if (m >= a.M) continue;
+        float v = acc[i][jn][e] * sc + sh;
+        if (a.res) v += a.res[(size_t)m * c.ldr + n];
+        if (c.relu) v = fmaxf(v, 0.f);
+        size_t orow = m;
+        if (!plain) {
+          const int wo = m % c.Wo, tq = m / c.Wo;
+          const int ho = tq % c.Ho, b = tq / c.Ho;
+          orow = ((size_t)b * c.Hf + (size_t)ho * c.out_os) * c.Wf + (size_t)wo * c.out_os;
+        }
+        a.y[orow * c.ldy + n] = v;
+      }
+    }
+  }
+}
+
+// conv.hip: sums stream-K partial tiles and runs the epilogue for split tiles
+int conv_launch_fixup(const ConvK& k, int G, bool wide, hipStream_t st);
+int conv_resident_workgroups();

@@ -9,6 +9,7 @@ so state_dicts, ``deepcopy`` and optimizers behave exactly as with the reference
 Nothing here falls back to eager torch math: a missing library raises at first use.
 """
 import ctypes
+import os
 from ctypes import byref
 
 import torch
@@ -22,6 +23,12 @@ GN_GROUPS = 32
 HEAD_PAD = 32  # the 19-class head is computed as a 32-wide GEMM (padded rows are zero)
 STEM_K = 160   # 7*7*3 = 147 patch values padded to a multiple of 32
 
+
+# How forward / data-gradient convolutions are evaluated:
+#   "bf16x3": fp32 operands split into three bf16 limbs, six products on the bf16 MFMA pipe with
+#             fp32 accumulation (fp32-level accuracy at 16/6 of the fp32-MFMA rate);
+#   "f32"   : v_mfma_f32_32x32x2_f32 (an exact fp32 fmaf chain).
+CONV_MODE = os.environ.get("ONDA_CONV_MODE", "f32")
 
 # bench.py sets this to a list to collect (kernel family, algorithmic flops, start event, end event)
 # around every conv launch; the events are recorded on the launch stream (torch's current stream)
@@ -93,11 +100,17 @@ def _conv_ws(device):
 
 
 def pack_weight_fwd(weight, cout_pad=None, kp=None):
-    """OIHW -> [Cout_pad][tap*Cin + c] rows of length kp (zero padded)."""
+    """OIHW -> [Cout_pad][tap*Cin + c] rows of length kp (zero padded); three bf16 limb planes
+    of the same matrix in "bf16x3" mode."""
     cout, cin, kh, kw = weight.shape
     taps = kh * kw
     cout_pad = cout_pad or cout
     kp = kp or taps * cin
+    if CONV_MODE == "bf16x3":
+        dst = torch.empty(3, cout_pad, kp, device=weight.device, dtype=torch.bfloat16)
+        call("onda_pack_weight_bf3", _p(weight.detach().contiguous()), _p(dst), cout, cin, taps, cout_pad, kp, 0,
+             cout_pad, _stream())
+        return dst
     dst = torch.empty(cout_pad, kp, device=weight.device, dtype=torch.float32)
     call("onda_pack_weight_fwd", _p(weight.detach().contiguous()), _p(dst), cout, cin, taps, cout_pad, kp, _stream())
     return dst
@@ -107,6 +120,11 @@ def pack_weight_dgrad(weight, cout_pad=None):
     """OIHW -> [Cin][taps (flipped)][Cout_pad]: the data gradient of a stride-1 conv is a conv of dy with this."""
     cout, cin, kh, kw = weight.shape
     cout_pad = cout_pad or cout
+    if CONV_MODE == "bf16x3":
+        dst = torch.empty(3, cin, kh * kw * cout_pad, device=weight.device, dtype=torch.bfloat16)
+        call("onda_pack_weight_bf3", _p(weight.detach().contiguous()), _p(dst), cout, cin, kh * kw, cin,
+             kh * kw * cout_pad, 1, cout_pad, _stream())
+        return dst
     dst = torch.empty(cin, kh * kw, cout_pad, device=weight.device, dtype=torch.float32)
     call("onda_pack_weight_dgrad", _p(weight.detach().contiguous()), _p(dst), cout, cin, kh * kw, cout_pad, _stream())
     return dst
@@ -128,8 +146,9 @@ def conv_forward(x, wp, k, stride, dil, pad, cout, out=None, scale=None, shift=N
         tiles = query("onda_conv_tiles_m", B * Ho * Wo)
         stats = torch.empty(tiles, 2, cout, device=x.device, dtype=torch.float32)
     d = _desc(B, Hi, Wi, Cin, Ho, Wo, cout, k, stride, dil, pad, ldx, ldy, ldr, relu=relu)
-    _launch("conv_fwd_kernel<128,%d>" % (128 if cout > 64 else 64), 2.0 * B * Ho * Wo * cout * k * k * Cin,
-            "onda_conv2d_fwd", _p(x), _p(wp), _p(out), _p(scale), _p(shift), _p(residual), _p(stats),
+    bf3 = wp.dtype == torch.bfloat16
+    _launch("conv_fwd%s_kernel<128,%d>" % ("_bf3" if bf3 else "", 128 if cout > 64 else 64),
+            2.0 * B * Ho * Wo * cout * k * k * Cin, "onda_conv2d_fwd_bf3" if bf3 else "onda_conv2d_fwd", _p(x), _p(wp), _p(out), _p(scale), _p(shift), _p(residual), _p(stats),
             _p(_conv_ws(x.device)), byref(d), _stream(),
             tag=("fwd", B * Ho * Wo, cout, Cin, k, stride, dil))
     return out, stats, tiles
@@ -148,8 +167,9 @@ def conv_dgrad(dy, wpd, k, stride, dil, pad, cin, in_hw):
             raise RuntimeError("onda_amd: strided data gradient is implemented for 1x1 convs only")
         dx = torch.zeros(B, Hi, Wi, cin, device=dy.device, dtype=torch.float32)
         d = _desc(B, Ho, Wo, Co, Ho, Wo, cin, 1, 1, 1, 0, ldy, cin, out_os=stride, Hf=Hi, Wf=Wi)
-    _launch("conv_fwd_kernel<128,%d>" % (128 if cin > 64 else 64), 2.0 * B * Ho * Wo * cin * k * k * Co,
-            "onda_conv2d_fwd", _p(dy), _p(wpd), _p(dx), None, None, None, None, _p(_conv_ws(dy.device)), byref(d),
+    bf3 = wpd.dtype == torch.bfloat16
+    _launch("conv_fwd%s_kernel<128,%d>" % ("_bf3" if bf3 else "", 128 if cin > 64 else 64),
+            2.0 * B * Ho * Wo * cin * k * k * Co, "onda_conv2d_fwd_bf3" if bf3 else "onda_conv2d_fwd", _p(dy), _p(wpd), _p(dx), None, None, None, None, _p(_conv_ws(dy.device)), byref(d),
             _stream(),
             tag=("dgrad", B * Ho * Wo if stride != 1 else B * Hi * Wi, cin, Co, k, stride, dil))
     return dx
@@ -216,7 +236,7 @@ class _PackCache:
 
     @staticmethod
     def _key(w):
-        return (w.data_ptr(), w._version, w.device)
+        return (w.data_ptr(), w._version, w.device, CONV_MODE)
 
     def get_fwd(self, w, cout_pad=None, kp=None):
         k = self._key(w)

@@ -44,8 +44,16 @@ CONV_CASES = [
 ]
 
 
+@pytest.fixture(params=["f32", "bf16x3"])
+def conv_mode(request):
+    from onda_amd import ops
+    old, ops.CONV_MODE = ops.CONV_MODE, request.param
+    yield request.param
+    ops.CONV_MODE = old
+
+
 @pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "x".join(map(str, c[:6])))
-def test_conv_fwd_bwd(case):
+def test_conv_fwd_bwd(case, conv_mode):
     from onda_amd import ops
     cin, cout, k, stride, dil, pad, H, W, bias = case
     g = torch.Generator().manual_seed(hash(case) & 0xFFFF)
@@ -76,7 +84,7 @@ def test_conv_fwd_bwd(case):
         close(bd.grad, br.grad, 5e-5, "bias grad")
 
 
-def test_conv_fused_epilogue_and_slice():
+def test_conv_fused_epilogue_and_slice(conv_mode):
     """eval-mode fold: scale/shift + residual + ReLU in the epilogue, written into a channel slice."""
     from onda_amd import ops
     g = torch.Generator().manual_seed(5)
@@ -93,7 +101,7 @@ def test_conv_fused_epilogue_and_slice():
     assert buf[..., :256].abs().max().item() == 0
 
 
-def test_head_and_stem():
+def test_head_and_stem(conv_mode):
     from onda_amd import ops
     g = torch.Generator().manual_seed(6)
     # 19-class head through the padded 32-wide GEMM
