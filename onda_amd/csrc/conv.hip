@@ -168,46 +168,73 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvK a) {
 // normal epilogue for every tile that was split.  One workgroup per output tile.
 template <int BM, int BN>
 __global__ __launch_bounds__(256) void conv_fixup_kernel(const ConvK a, int G) {
-  __shared__ float red[2][256];
+  constexpr int C4 = BN / 4;        // float4 columns of a tile row
+  constexpr int RG = 256 / C4;      // row groups covered by the workgroup at once
+  constexpr int RPT = BM / RG;      // rows per thread
+  __shared__ f32x4 red[2][256];
   const OndaConv& c = a.c;
   const int KT = a.taps * a.kcper;
   const long long U = (long long)a.tilesM * a.tilesN * KT;
   const int tile = blockIdx.x;
   const long long t0 = (long long)tile * KT, t1 = t0 + KT;
   const int vs = (int)(((t0 + 1) * G + U - 1) / U - 1), ve = (int)((t1 * G + U - 1) / U - 1);
-  if (vs == ve && vs * U / G <= t0 && (vs + 1) * U / G >= t1) return;  // computed whole by one workgroup
+  if (vs == ve) return;  // computed whole by one workgroup: its own epilogue already ran
   const int tile_n = tile % a.tilesN, tile_m = tile / a.tilesN;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
-  const int t = threadIdx.x, col = t % BN, rg = t / BN;
-  constexpr int RG = 256 / BN;
+  const int t = threadIdx.x, col = (t % C4) * 4, rg = t / C4;
   const int n = n0 + col;
-  const bool vn = n < c.Cout;
-  const float sc = (a.scale && vn) ? a.scale[n] : 1.f;
-  const float sh = (a.shift && vn) ? a.shift[n] : 0.f;
+  const bool vn = n < c.Cout;  // Cout is a multiple of 4: the 4 columns are valid together
+  f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+  if (vn && a.scale) sc = *reinterpret_cast<const f32x4*>(a.scale + n);
+  if (vn && a.shift) sh = *reinterpret_cast<const f32x4*>(a.shift + n);
   const bool plain = (c.out_os == 1 && c.Hf == c.Ho && c.Wf == c.Wo);
-  float s1 = 0.f, s2 = 0.f;
-  for (int row = rg; row < BM; row += RG) {
-    float v = 0.f;
-    for (int vb = vs; vb <= ve; ++vb) {
-      const long long b0 = (long long)vb * U / G, b1 = (long long)(vb + 1) * U / G;
-      const long long g0 = max(b0, t0), g1 = min(b1, t1);
-      if (g1 <= g0) continue;
-      v += a.ws[((size_t)vb * 2 + (g0 == b0 ? 0 : 1)) * (BM * BN) + row * BN + col];
+
+  // the (at most 3) contributing workgroups and the slot each used, in ascending order
+  const float* src[3];
+  int nsrc = 0;
+  for (int vb = vs; vb <= ve && nsrc < 3; ++vb) {
+    const long long b0 = (long long)vb * U / G, b1 = (long long)(vb + 1) * U / G;
+    const long long g0 = max(b0, t0), g1 = min(b1, t1);
+    if (g1 <= g0) continue;
+    src[nsrc++] = a.ws + ((size_t)vb * 2 + (g0 == b0 ? 0 : 1)) * (BM * BN);
+  }
+  const bool many = (ve - vs + 1) > 3;  // tile cut into more than 3 pieces (tiny problems): slow path below
+
+  f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+  for (int i = 0; i < RPT; ++i) {
+    const int row = rg + RG * i;
+    const int eo = row * BN + col;
+    f32x4 v = *reinterpret_cast<const f32x4*>(src[0] + eo);
+    if (nsrc > 1) v += *reinterpret_cast<const f32x4*>(src[1] + eo);
+    if (nsrc > 2) v += *reinterpret_cast<const f32x4*>(src[2] + eo);
+    if (many) {
+      int seen = 0;
+      for (int vb = vs; vb <= ve; ++vb) {
+        const long long b0 = (long long)vb * U / G, b1 = (long long)(vb + 1) * U / G;
+        const long long g0 = max(b0, t0), g1 = min(b1, t1);
+        if (g1 <= g0) continue;
+        if (seen++ < 3) continue;
+        v += *reinterpret_cast<const f32x4*>(a.ws + ((size_t)vb * 2 + (g0 == b0 ? 0 : 1)) * (BM * BN) + eo);
+      }
     }
     s1 += v;
     s2 += v * v;
     const int m = m0 + row;
     if (m >= a.M || !vn) continue;
-    float o = v * sc + sh;
-    if (a.res) o += a.res[(size_t)m * c.ldr + n];
-    if (c.relu) o = fmaxf(o, 0.f);
+    f32x4 o = v * sc + sh;
+    if (a.res) o += *reinterpret_cast<const f32x4*>(a.res + (size_t)m * c.ldr + n);
+    if (c.relu) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = fmaxf(o[j], 0.f);
+    }
     size_t orow = m;
     if (!plain) {
       const int wo = m % c.Wo, tq = m / c.Wo;
       const int ho = tq % c.Ho, b = tq / c.Ho;
       orow = ((size_t)b * c.Hf + (size_t)ho * c.out_os) * c.Wf + (size_t)wo * c.out_os;
     }
-    a.y[orow * c.ldy + n] = o;
+    *reinterpret_cast<f32x4*>(a.y + orow * c.ldy + n) = o;
   }
   if (a.stats != nullptr) {
     red[0][t] = s1;
@@ -215,11 +242,11 @@ __global__ __launch_bounds__(256) void conv_fixup_kernel(const ConvK a, int G) {
     __syncthreads();
     if (rg == 0 && vn) {
       for (int g = 1; g < RG; ++g) {
-        s1 += red[0][g * BN + col];
-        s2 += red[1][g * BN + col];
+        s1 += red[0][g * C4 + t];
+        s2 += red[1][g * C4 + t];
       }
-      a.stats[((size_t)tile_m * 2 + 0) * c.Cout + n] = s1;
-      a.stats[((size_t)tile_m * 2 + 1) * c.Cout + n] = s2;
+      *reinterpret_cast<f32x4*>(a.stats + ((size_t)tile_m * 2 + 0) * c.Cout + n) = s1;
+      *reinterpret_cast<f32x4*>(a.stats + ((size_t)tile_m * 2 + 1) * c.Cout + n) = s2;
     }
   }
 }
@@ -458,9 +485,11 @@ int64_t onda_conv_ws_floats(void) { return (int64_t)conv_resident_workgroups() *
 int onda_conv2d_fwd(const float* x, const float* w, float* y, const float* scale, const float* shift,
                     const float* residual, float* stats, float* ws, const OndaConv* c, onda_stream_t s) {
   ONDA_REQUIRE(x && w && y && c);
-  ONDA_REQUIRE(c->Cin > 0 && c->Cin % 32 == 0 && c->Cout > 0 && c->ldx % 4 == 0 && c->ldx >= c->Cin);
+  ONDA_REQUIRE(c->Cin > 0 && c->Cin % 32 == 0 && c->Cout > 0 && c->Cout % 4 == 0 && c->ldx % 4 == 0 && c->ldx >= c->Cin);
   ONDA_REQUIRE(c->kh >= 1 && c->kw >= 1 && c->stride >= 1 && c->dil >= 1 && c->out_os >= 1);
   if (!ONDA_ALIGNED16(x) || !ONDA_ALIGNED16(w)) return ONDA_EALIGN;
+  if (ws && (c->ldy % 4 != 0 || !ONDA_ALIGNED16(y) || (residual && (c->ldr % 4 != 0 || !ONDA_ALIGNED16(residual)))))
+    ws = nullptr;  // the fix-up pass stores 16-byte vectors; otherwise stay on the one-tile-per-workgroup path
   ConvK k;
   k.x = x; k.w = w; k.y = y; k.scale = scale; k.shift = shift; k.res = residual; k.stats = stats; k.ws = ws;
   k.c = *c;

@@ -28,7 +28,7 @@ STEM_K = 160   # 7*7*3 = 147 patch values padded to a multiple of 32
 #   "bf16x3": fp32 operands split into three bf16 limbs, six products on the bf16 MFMA pipe with
 #             fp32 accumulation (fp32-level accuracy at 16/6 of the fp32-MFMA rate);
 #   "f32"   : v_mfma_f32_32x32x2_f32 (an exact fp32 fmaf chain).
-CONV_MODE = os.environ.get("ONDA_CONV_MODE", "f32")
+CONV_MODE = os.environ.get("ONDA_CONV_MODE", "bf16x3")
 
 # bench.py sets this to a list to collect (kernel family, algorithmic flops, start event, end event)
 # around every conv launch; the events are recorded on the launch stream (torch's current stream)
