@@ -81,6 +81,9 @@ int onda_conv2d_fwd_bf3(const float* x, const void* w3, float* y, const float* s
  * tap*Cin_real + c). */
 int onda_conv2d_wgrad(const float* x, const float* dy, float* slabs, int lddy, int splitk,
                       const OndaConv* c, onda_stream_t s);
+/* the same slabs from the split-bf16 evaluation (csrc/conv_bf3.hip) */
+int onda_conv2d_wgrad_bf3(const float* x, const float* dy, float* slabs, int lddy, int splitk,
+                          const OndaConv* c, onda_stream_t s);
 int onda_wgrad_reduce(const float* slabs, float* dw, int splitk, int Cout, int taps, int Cin,
                       int Cout_real, int Cin_real, int flat_k, onda_stream_t s);
 

@@ -252,14 +252,6 @@ __global__ __launch_bounds__(256) void conv_fixup_kernel(const ConvK a, int G) {
 }
 
 // ---------------------------------------------------------------------------------------------
-struct WgradK {
-  const float* x;
-  const float* dy;
-  float* slabs;
-  OndaConv c;
-  int M, lddy, splitk, mchunk, tilesN, tilesC, taps;
-};
-
 template <int BM, int BN, int WAVES_M, int WAVES_N>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK a) {
   constexpr int TM = BM / (32 * WAVES_M), TN = BN / (32 * WAVES_N);

@@ -200,6 +200,151 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_bf3_kernel(const ConvK a, siz
   }
 }
 
+// ---- weight gradient on the bf16 pipe ------------------------------------------------------------
+// dW[n][tap][c] = sum_m dY[m][n] * X[pix(m,tap)][c]: both operands have the contraction index
+// (the pixel m) as their SLOW axis in memory, while an MFMA fragment wants 8 consecutive k per
+// lane.  The transposition happens in registers on the way into LDS: a thread owns 8 consecutive
+// pixels of ONE channel column (lanes run over consecutive channels, so every scalar load
+// instruction reads 128 contiguous bytes of one pixel row), splits the 8 values into limbs and
+// writes each limb's 8 bf16 as one ds_write_b128 into the [channel row][k] image (consecutive
+// lanes -> consecutive rows of 80 B: conflict-free).  Threads 0-127 stage dY, 128-255 stage X.
+// The consumer side is the forward kernel's: [row][k] limb planes, six limb products.
+template <int BM, int BN>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_bf3_kernel(const WgradK a) {
+  constexpr int WAVES_N = 2;
+  constexpr int TM = BM / 64, TN = BN / 64;
+  constexpr int ROWS = BM + BN;
+  constexpr int PLANE = ROWS * ROWB;
+  constexpr int CPT = (BM > BN ? BM : BN) / 32;  // channel columns per staging thread
+  static_assert(BM == BN, "one staging half per operand");
+  __shared__ __attribute__((aligned(16))) unsigned char lds[3 * PLANE];
+  __shared__ int pofs[32];
+
+  const OndaConv& c = a.c;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+
+  int bid = blockIdx.x;
+  const int tile_c = bid % a.tilesC;
+  bid /= a.tilesC;
+  const int tap = bid % a.taps;
+  bid /= a.taps;
+  const int tile_n = bid % a.tilesN;
+  const int ks = bid / a.tilesN;
+  const int n0 = tile_n * BM, c0 = tile_c * BN;
+  const int mbeg = ks * a.mchunk;
+  const int mend = min(a.M, mbeg + a.mchunk);
+  const int KT = mend > mbeg ? (mend - mbeg + BK - 1) / BK : 0;
+  const int rr = tap / c.kw, ss = tap - rr * c.kw;
+  const int dh = rr * c.dil - c.pad, dw = ss * c.dil - c.pad;
+
+  // staging role of this thread
+  const bool is_x = t >= 128;
+  const int ch_lane = t & 31, kgroup = (t >> 5) & 3;  // 8 pixels kgroup*8 .. +7
+  const float* src = is_x ? a.x : a.dy;
+  const int ld = is_x ? c.ldx : a.lddy;
+  const int ch0 = (is_x ? c0 : n0) + ch_lane;
+  const int chmax = is_x ? c.Cin : c.Cout;
+
+  // offset (in elements, -1 = zero) of pixel mb+i of the X operand for this tap
+  auto pixel_offset = [&](int m) -> int {
+    if (m >= mend) return -1;
+    const int wo = m % c.Wo, tq = m / c.Wo;
+    const int ho = tq % c.Ho, b = tq / c.Ho;
+    const int hi = ho * c.stride + dh, wi = wo * c.stride + dw;
+    if ((unsigned)hi >= (unsigned)c.Hi || (unsigned)wi >= (unsigned)c.Wi) return -1;
+    return ((b * c.Hi + hi) * c.Wi + wi) * c.ldx;
+  };
+
+  float v[CPT][8];
+  auto gload = [&](int mb) {
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      const int m = mb + kgroup * 8 + p;
+      const int off = is_x ? pofs[kgroup * 8 + p] : (m < mend ? m * ld : -1);
+#pragma unroll
+      for (int j = 0; j < CPT; ++j) {
+        const int ch = ch0 + 32 * j;
+        v[j][p] = (off >= 0 && ch < chmax) ? src[off + ch] : 0.f;
+      }
+    }
+  };
+  auto sstore = [&]() {
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) {
+      u32x2 a1, a2, a3, b1, b2, b3;
+      split3(f32x4{v[j][0], v[j][1], v[j][2], v[j][3]}, a1, a2, a3);
+      split3(f32x4{v[j][4], v[j][5], v[j][6], v[j][7]}, b1, b2, b3);
+      unsigned char* dst = lds + ((is_x ? BM : 0) + ch_lane + 32 * j) * ROWB + kgroup * 16;
+      *reinterpret_cast<u32x4*>(dst + 0 * PLANE) = u32x4{a1[0], a1[1], b1[0], b1[1]};
+      *reinterpret_cast<u32x4*>(dst + 1 * PLANE) = u32x4{a2[0], a2[1], b2[0], b2[1]};
+      *reinterpret_cast<u32x4*>(dst + 2 * PLANE) = u32x4{a3[0], a3[1], b3[0], b3[1]};
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  if (KT > 0) {
+    if (t < 32) pofs[t] = pixel_offset(mbeg + t);
+    __syncthreads();
+    gload(mbeg);
+  }
+  for (int kt = 0; kt < KT; ++kt) {
+    __syncthreads();  // LDS image and pofs are free
+    sstore();
+    if (t < 32 && kt + 1 < KT) pofs[t] = pixel_offset(mbeg + (kt + 1) * BK + t);
+    __syncthreads();
+    if (kt + 1 < KT) gload(mbeg + (kt + 1) * BK);
+    const unsigned char* Ab = lds + (wm * TM * 32 + li) * ROWB + lh * 16;
+    const unsigned char* Bb = lds + (BM + wn * TN * 32 + li) * ROWB + lh * 16;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 af[TM][3];
+#pragma unroll
+      for (int l = 0; l < 3; ++l)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+          af[i][l] = *reinterpret_cast<const bf16x8*>(Ab + l * PLANE + i * 32 * ROWB + s * 32);
+#pragma unroll
+      for (int l = 2; l >= 0; --l) {
+        bf16x8 bf[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          bf[j] = *reinterpret_cast<const bf16x8*>(Bb + l * PLANE + j * 32 * ROWB + s * 32);
+#pragma unroll
+        for (int la = 2 - l; la >= 0; --la)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][la], bf[j], acc[i][j], 0, 0, 0);
+      }
+    }
+  }
+
+#pragma unroll
+  for (int jn = 0; jn < TN; ++jn) {
+    const int cc = c0 + wn * TN * 32 + jn * 32 + li;
+    if (cc >= c.Cin) continue;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = (e & 3) + 8 * (e >> 2) + 4 * lh;
+        const int n = n0 + wm * TM * 32 + i * 32 + row;
+        if (n >= c.Cout) continue;
+        a.slabs[(((size_t)ks * c.Cout + n) * a.taps + tap) * c.Cin + cc] = acc[i][jn][e];
+      }
+  }
+}
+
 // OIHW fp32 -> limb planes dst[3][rows_pad][Kp] bf16.  dgrad = 0: row n, k = tap*Cin + c.
 // dgrad = 1: row c, k = tap'*Cout_pad + n with the taps flipped (data-gradient operand).
 __global__ void pack_bf3_kernel(const float* __restrict__ w, __bf16* __restrict__ dst, int Cout, int Cin, int taps,
@@ -280,6 +425,33 @@ int onda_conv2d_fwd_bf3(const float* x, const void* w3, float* y, const float* s
     hipLaunchKernelGGL((conv_fwd_bf3_kernel<128, 128, false>), dim3(tiles), dim3(256), 0, st, k, limb_stride);
   else
     hipLaunchKernelGGL((conv_fwd_bf3_kernel<128, 64, false>), dim3(tiles), dim3(256), 0, st, k, limb_stride);
+  return ONDA_LAUNCH_RESULT();
+}
+
+int onda_conv2d_wgrad_bf3(const float* x, const float* dy, float* slabs, int lddy, int splitk, const OndaConv* c,
+                          onda_stream_t s) {
+  ONDA_REQUIRE(x && dy && slabs && c && splitk >= 1);
+  const long long M = (long long)c->B * c->Ho * c->Wo;
+  ONDA_REQUIRE(M > 0 && M < (1ll << 31));
+  ONDA_REQUIRE((long long)c->B * c->Hi * c->Wi * c->ldx < (1ll << 31) && M * lddy < (1ll << 31));
+  WgradK k;
+  k.x = x; k.dy = dy; k.slabs = slabs; k.c = *c;
+  k.M = (int)M;
+  k.lddy = lddy;
+  k.splitk = splitk;
+  k.mchunk = (int)(((M + splitk - 1) / splitk + 31) / 32 * 32);
+  k.taps = c->kh * c->kw;
+  if (c->Cout > 64 && c->Cin > 64) {
+    k.tilesN = (c->Cout + 127) / 128;
+    k.tilesC = (c->Cin + 127) / 128;
+    hipLaunchKernelGGL((conv_wgrad_bf3_kernel<128, 128>), dim3(k.tilesN * k.tilesC * k.taps * splitk), dim3(256), 0,
+                       ONDA_STREAM(s), k);
+  } else {
+    k.tilesN = (c->Cout + 63) / 64;
+    k.tilesC = (c->Cin + 63) / 64;
+    hipLaunchKernelGGL((conv_wgrad_bf3_kernel<64, 64>), dim3(k.tilesN * k.tilesC * k.taps * splitk), dim3(256), 0,
+                       ONDA_STREAM(s), k);
+  }
   return ONDA_LAUNCH_RESULT();
 }
 

@@ -17,6 +17,14 @@ struct ConvK {
   float* ws;  // stream-K partial tiles [grid][2][BM*BN]
 };
 
+struct WgradK {
+  const float* x;
+  const float* dy;
+  float* slabs;
+  OndaConv c;
+  int M, lddy, splitk, mchunk, tilesN, tilesC, taps;
+};
+
 constexpr int BK = 32;
 
 // raw accumulators of a partial (stream-K) tile -> slot[BM][BN]

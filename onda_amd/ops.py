@@ -204,8 +204,9 @@ def conv_wgrad(x, dy, k, stride, dil, pad, cout_real, cin_real, flat_k=0):
     sk = _wgrad_splitk(M, Co, Cin, taps)
     slabs = torch.empty(sk, Co, taps, Cin, device=x.device, dtype=torch.float32)
     d = _desc(B, Hi, Wi, Cin, Ho, Wo, Co, k, stride, dil, pad, nhwc_ld(x), Co)
-    _launch("conv_wgrad_kernel<%s>" % ("128,128" if (Co > 64 and Cin > 64) else "64,64"), 2.0 * M * Co * taps * Cin,
-            "onda_conv2d_wgrad", _p(x), _p(dy), _p(slabs), nhwc_ld(dy), sk, byref(d), _stream(),
+    bf3 = CONV_MODE == "bf16x3"
+    _launch("conv_wgrad%s_kernel<%s>" % ("_bf3" if bf3 else "", "128,128" if (Co > 64 and Cin > 64) else "64,64"),
+            2.0 * M * Co * taps * Cin, "onda_conv2d_wgrad_bf3" if bf3 else "onda_conv2d_wgrad", _p(x), _p(dy), _p(slabs), nhwc_ld(dy), sk, byref(d), _stream(),
             tag=("wgrad", M, Co, Cin, k, stride, dil, sk))
     if flat_k:
         dw = torch.empty(cout_real, cin_real, 7, 7, device=x.device, dtype=torch.float32)
