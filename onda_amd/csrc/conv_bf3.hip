@@ -22,28 +22,45 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int ROWB = 80;  // bytes per LDS row: 32 bf16 + 16 B pad
 
-__device__ __forceinline__ unsigned pack2(__bf16 lo, __bf16 hi) {
-  return (unsigned)__builtin_bit_cast(unsigned short, lo) | ((unsigned)__builtin_bit_cast(unsigned short, hi) << 16);
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+// two floats -> two bf16 (round to nearest even) in one dword: a single v_cvt_pk_bf16_f32
+__device__ __forceinline__ unsigned cvt2(float lo, float hi) {
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{lo, hi}, bf16x2));
 }
 
-// float4 -> three limbs, each 4 bf16 packed in 8 bytes
+// float4 -> three limbs, each 4 bf16 packed in 8 bytes (4.5 VALU per element)
 __device__ __forceinline__ void split3(const f32x4 v, u32x2& l1, u32x2& l2, u32x2& l3) {
-  __bf16 a[4], b[4], cc[4];
+  unsigned p[2], q[2], r[2];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    a[j] = (__bf16)v[j];
-    const float r1 = v[j] - (float)a[j];
-    b[j] = (__bf16)r1;
-    const float r2 = r1 - (float)b[j];
-    cc[j] = (__bf16)r2;
+  for (int h = 0; h < 2; ++h) {
+    const float x0 = v[2 * h], x1 = v[2 * h + 1];
+    p[h] = cvt2(x0, x1);
+    const float r0 = x0 - __builtin_bit_cast(float, p[h] << 16);
+    const float r1 = x1 - __builtin_bit_cast(float, p[h] & 0xFFFF0000u);
+    q[h] = cvt2(r0, r1);
+    const float s0 = r0 - __builtin_bit_cast(float, q[h] << 16);
+    const float s1 = r1 - __builtin_bit_cast(float, q[h] & 0xFFFF0000u);
+    r[h] = cvt2(s0, s1);
   }
-  l1 = u32x2{pack2(a[0], a[1]), pack2(a[2], a[3])};
-  l2 = u32x2{pack2(b[0], b[1]), pack2(b[2], b[3])};
-  l3 = u32x2{pack2(cc[0], cc[1]), pack2(cc[2], cc[3])};
+  l1 = u32x2{p[0], p[1]};
+  l2 = u32x2{q[0], q[1]};
+  l3 = u32x2{r[0], r[1]};
+}
+
+// Buffer resources: loads take a 32-bit per-lane byte offset plus a scalar offset, so the K
+// loop needs no 64-bit address arithmetic, and an offset >= num_records reads as zero without
+// a branch -- which is how padding taps, rows past M and channels past Cout are expressed.
+constexpr unsigned OOB = 0x80000000u;     // every operand is < 2 GiB - 4 KiB (checked on the host)
+constexpr unsigned CH_OOB = 0x7FFFF000u;  // second addend: row + channel never wraps, stays out of range
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
 }
 
 template <int BM, int BN, bool SK>
-__global__ __launch_bounds__(256, 2) void conv_fwd_bf3_kernel(const ConvK a, size_t limb_stride) {
+__global__ __launch_bounds__(256, 2) void conv_fwd_bf3_kernel(const ConvK a, unsigned limb_stride, unsigned x_bytes,
+                                                               unsigned w_bytes) {
   constexpr int WAVES_M = 2, WAVES_N = 2;
   constexpr int TM = BM / (32 * WAVES_M), TN = BN / (32 * WAVES_N);
   constexpr int AL = BM / 32;          // float4 loads per thread for the A tile
@@ -66,8 +83,8 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_bf3_kernel(const ConvK a, siz
   const long long u_end = SK ? (swz + 1) * U / nblk : u + KT;
   const int ccol = (t & 7) * 4, rbase = t >> 3;  // A: 4 floats at k=ccol of rows rbase+32u
   const int brow = t >> 2, bk = (t & 3) * 8;     // B: 8 bf16 at k=bk of rows brow+64v
-  const __bf16* wbase = static_cast<const __bf16*>(a.w);
   const int wstride = a.taps * c.Cin;
+  const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, x_bytes), rw = make_rsrc(a.w, w_bytes);
 
   while (u < u_end) {
     const int tile = (int)(u / KT);
@@ -88,16 +105,16 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_bf3_kernel(const ConvK a, siz
       wi0[i] = wo * c.stride - c.pad;
       bH[i] = b * c.Hi;
     }
-    const __bf16* wrow[BL];
-    bool vn[BL];
+    unsigned wofs[3][BL];  // byte offsets into the limb planes, OOB for rows past Cout
 #pragma unroll
     for (int v = 0; v < BL; ++v) {
       const int n = n0 + brow + 64 * v;
-      vn[v] = n < c.Cout;
-      wrow[v] = wbase + (size_t)(vn[v] ? n : 0) * wstride + bk;
+#pragma unroll
+      for (int l = 0; l < 3; ++l)
+        wofs[l][v] = n < c.Cout ? (l * limb_stride + (unsigned)n * wstride + bk) * 2u : OOB;
     }
 
-    int aofs[AL];  // element offsets fit 31 bits (checked on the host)
+    unsigned aofs[AL];  // byte offsets of this thread's rows for the current tap, OOB = zero row
     f32x4 ar[AL];
     u32x4 br[3][BL];
     int tap = k_begin / a.kcper, c0 = (k_begin - tap * a.kcper) * BK;
@@ -107,19 +124,18 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_bf3_kernel(const ConvK a, siz
       for (int i = 0; i < AL; ++i) {
         const int hi = hi0[i] + rr * c.dil, wi = wi0[i] + ss * c.dil;
         const bool ok = (unsigned)hi < (unsigned)c.Hi && (unsigned)wi < (unsigned)c.Wi;
-        aofs[i] = ok ? ((bH[i] + hi) * c.Wi + wi) * c.ldx + ccol : -1;
+        aofs[i] = ok ? (unsigned)(((bH[i] + hi) * c.Wi + wi) * c.ldx + ccol) * 4u : OOB;
       }
     };
     auto gload = [&]() {
-      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-      const u32x4 zi = {0u, 0u, 0u, 0u};
+      const int sa = c0 * 4, sw = (tap * c.Cin + c0) * 2;  // scalar (wave-uniform) byte offsets
 #pragma unroll
-      for (int i = 0; i < AL; ++i) ar[i] = aofs[i] >= 0 ? *reinterpret_cast<const f32x4*>(a.x + aofs[i] + c0) : z;
+      for (int i = 0; i < AL; ++i)
+        ar[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, aofs[i], sa, 0));
 #pragma unroll
       for (int l = 0; l < 3; ++l)
 #pragma unroll
-        for (int v = 0; v < BL; ++v)
-          br[l][v] = vn[v] ? *reinterpret_cast<const u32x4*>(wrow[v] + l * limb_stride + tap * c.Cin + c0) : zi;
+        for (int v = 0; v < BL; ++v) br[l][v] = __builtin_amdgcn_raw_buffer_load_b128(rw, wofs[l][v], sw, 0);
     };
     auto sstore = [&]() {
 #pragma unroll
@@ -210,7 +226,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_bf3_kernel(const ConvK a, siz
 // lanes -> consecutive rows of 80 B: conflict-free).  Threads 0-127 stage dY, 128-255 stage X.
 // The consumer side is the forward kernel's: [row][k] limb planes, six limb products.
 template <int BM, int BN>
-__global__ __launch_bounds__(256, 2) void conv_wgrad_bf3_kernel(const WgradK a) {
+__global__ __launch_bounds__(256, 2) void conv_wgrad_bf3_kernel(const WgradK a, unsigned x_bytes, unsigned dy_bytes) {
   constexpr int WAVES_N = 2;
   constexpr int TM = BM / 64, TN = BN / 64;
   constexpr int ROWS = BM + BN;
@@ -218,7 +234,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf3_kernel(const WgradK a) 
   constexpr int CPT = (BM > BN ? BM : BN) / 32;  // channel columns per staging thread
   static_assert(BM == BN, "one staging half per operand");
   __shared__ __attribute__((aligned(16))) unsigned char lds[3 * PLANE];
-  __shared__ int pofs[32];
+  __shared__ unsigned pofs[32];
 
   const OndaConv& c = a.c;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -240,21 +256,25 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf3_kernel(const WgradK a) 
   const int dh = rr * c.dil - c.pad, dw = ss * c.dil - c.pad;
 
   // staging role of this thread
-  const bool is_x = t >= 128;
+  // the role is wave-uniform; readfirstlane tells the compiler so (descriptor and scalar offset stay
+  // in SGPRs instead of a per-lane "waterfall" loop around every buffer load)
+  const bool is_x = __builtin_amdgcn_readfirstlane(t >> 7) != 0;
   const int ch_lane = t & 31, kgroup = (t >> 5) & 3;  // 8 pixels kgroup*8 .. +7
-  const float* src = is_x ? a.x : a.dy;
-  const int ld = is_x ? c.ldx : a.lddy;
+  const __amdgpu_buffer_rsrc_t rs = is_x ? make_rsrc(a.x, x_bytes) : make_rsrc(a.dy, dy_bytes);
   const int ch0 = (is_x ? c0 : n0) + ch_lane;
   const int chmax = is_x ? c.Cin : c.Cout;
+  unsigned chofs[CPT];  // byte offset of this thread's channel columns, OOB past the operand's width
+#pragma unroll
+  for (int j = 0; j < CPT; ++j) chofs[j] = ch0 + 32 * j < chmax ? (unsigned)(ch0 + 32 * j) * 4u : CH_OOB;
 
-  // offset (in elements, -1 = zero) of pixel mb+i of the X operand for this tap
-  auto pixel_offset = [&](int m) -> int {
-    if (m >= mend) return -1;
+  // byte offset (OOB = zero row) of pixel m of the X operand for this tap
+  auto pixel_offset = [&](int m) -> unsigned {
+    if (m >= mend) return OOB;
     const int wo = m % c.Wo, tq = m / c.Wo;
     const int ho = tq % c.Ho, b = tq / c.Ho;
     const int hi = ho * c.stride + dh, wi = wo * c.stride + dw;
-    if ((unsigned)hi >= (unsigned)c.Hi || (unsigned)wi >= (unsigned)c.Wi) return -1;
-    return ((b * c.Hi + hi) * c.Wi + wi) * c.ldx;
+    if ((unsigned)hi >= (unsigned)c.Hi || (unsigned)wi >= (unsigned)c.Wi) return OOB;
+    return (unsigned)(((b * c.Hi + hi) * c.Wi + wi) * c.ldx) * 4u;
   };
 
   float v[CPT][8];
@@ -262,12 +282,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf3_kernel(const WgradK a) 
 #pragma unroll
     for (int p = 0; p < 8; ++p) {
       const int m = mb + kgroup * 8 + p;
-      const int off = is_x ? pofs[kgroup * 8 + p] : (m < mend ? m * ld : -1);
+      // X: gathered row from the table; dY: row m itself (scalar part mb*lddy rides in the soffset)
+      const unsigned row = is_x ? pofs[kgroup * 8 + p] : (m < mend ? (unsigned)((kgroup * 8 + p) * a.lddy) * 4u : OOB);
+      const int so = is_x ? 0 : mb * a.lddy * 4;
 #pragma unroll
-      for (int j = 0; j < CPT; ++j) {
-        const int ch = ch0 + 32 * j;
-        v[j][p] = (off >= 0 && ch < chmax) ? src[off + ch] : 0.f;
-      }
+      for (int j = 0; j < CPT; ++j)
+        v[j][p] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, row + chofs[j], so, 0));
     }
   };
   auto sstore = [&]() {
@@ -399,14 +419,17 @@ int onda_conv2d_fwd_bf3(const float* x, const void* w3, float* y, const float* s
   k.c = *c;
   const long long M = (long long)c->B * c->Ho * c->Wo;
   ONDA_REQUIRE(M > 0 && M < (1ll << 31));
-  ONDA_REQUIRE((long long)c->B * c->Hi * c->Wi * c->ldx < (1ll << 31));  // 32-bit gather offsets
+  ONDA_REQUIRE((long long)c->B * c->Hi * c->Wi * c->ldx * 4 < 0x7FFFF000ll);  // 32-bit byte offsets
   k.M = (int)M;
   k.taps = c->kh * c->kw;
   k.kcper = c->Cin / 32;
   k.tilesM = (k.M + 127) / 128;
   const bool wide = c->Cout > 64;
   k.tilesN = wide ? (c->Cout + 127) / 128 : (c->Cout + 63) / 64;
-  const size_t limb_stride = (size_t)c->Cout * k.taps * c->Cin;  // planes are [Cout][taps*Cin]
+  const size_t limb_elems = (size_t)c->Cout * k.taps * c->Cin;  // planes are [Cout][taps*Cin]
+  ONDA_REQUIRE(limb_elems * 6 < (1ull << 31));
+  const unsigned limb_stride = (unsigned)limb_elems;
+  const unsigned x_bytes = (unsigned)((size_t)c->B * c->Hi * c->Wi * c->ldx * 4), w_bytes = (unsigned)(limb_elems * 6);
   const int tiles = k.tilesM * k.tilesN, KT = k.taps * k.kcper, G = conv_resident_workgroups();
   const double eff = ((double)tiles / G) / (double)((tiles + G - 1) / G);
   const double t_ideal_us = 2.0 * (double)M * c->Cout * k.taps * c->Cin / 2.5e8;  // at ~250 TFLOP/s equivalent
@@ -416,15 +439,15 @@ int onda_conv2d_fwd_bf3(const float* x, const void* w3, float* y, const float* s
   hipStream_t st = ONDA_STREAM(s);
   if (balanced) {
     if (wide)
-      hipLaunchKernelGGL((conv_fwd_bf3_kernel<128, 128, true>), dim3(G), dim3(256), 0, st, k, limb_stride);
+      hipLaunchKernelGGL((conv_fwd_bf3_kernel<128, 128, true>), dim3(G), dim3(256), 0, st, k, limb_stride, x_bytes, w_bytes);
     else
-      hipLaunchKernelGGL((conv_fwd_bf3_kernel<128, 64, true>), dim3(G), dim3(256), 0, st, k, limb_stride);
+      hipLaunchKernelGGL((conv_fwd_bf3_kernel<128, 64, true>), dim3(G), dim3(256), 0, st, k, limb_stride, x_bytes, w_bytes);
     return conv_launch_fixup(k, G, wide, st);
   }
   if (wide)
-    hipLaunchKernelGGL((conv_fwd_bf3_kernel<128, 128, false>), dim3(tiles), dim3(256), 0, st, k, limb_stride);
+    hipLaunchKernelGGL((conv_fwd_bf3_kernel<128, 128, false>), dim3(tiles), dim3(256), 0, st, k, limb_stride, x_bytes, w_bytes);
   else
-    hipLaunchKernelGGL((conv_fwd_bf3_kernel<128, 64, false>), dim3(tiles), dim3(256), 0, st, k, limb_stride);
+    hipLaunchKernelGGL((conv_fwd_bf3_kernel<128, 64, false>), dim3(tiles), dim3(256), 0, st, k, limb_stride, x_bytes, w_bytes);
   return ONDA_LAUNCH_RESULT();
 }
 
@@ -433,7 +456,8 @@ int onda_conv2d_wgrad_bf3(const float* x, const float* dy, float* slabs, int ldd
   ONDA_REQUIRE(x && dy && slabs && c && splitk >= 1);
   const long long M = (long long)c->B * c->Ho * c->Wo;
   ONDA_REQUIRE(M > 0 && M < (1ll << 31));
-  ONDA_REQUIRE((long long)c->B * c->Hi * c->Wi * c->ldx < (1ll << 31) && M * lddy < (1ll << 31));
+  ONDA_REQUIRE((long long)c->B * c->Hi * c->Wi * c->ldx * 4 < 0x7FFFF000ll && M * lddy * 4 < 0x7FFFF000ll);
+  const unsigned x_bytes = (unsigned)((size_t)c->B * c->Hi * c->Wi * c->ldx * 4), dy_bytes = (unsigned)(M * lddy * 4);
   WgradK k;
   k.x = x; k.dy = dy; k.slabs = slabs; k.c = *c;
   k.M = (int)M;
@@ -445,12 +469,12 @@ int onda_conv2d_wgrad_bf3(const float* x, const float* dy, float* slabs, int ldd
     k.tilesN = (c->Cout + 127) / 128;
     k.tilesC = (c->Cin + 127) / 128;
     hipLaunchKernelGGL((conv_wgrad_bf3_kernel<128, 128>), dim3(k.tilesN * k.tilesC * k.taps * splitk), dim3(256), 0,
-                       ONDA_STREAM(s), k);
+                       ONDA_STREAM(s), k, x_bytes, dy_bytes);
   } else {
     k.tilesN = (c->Cout + 63) / 64;
     k.tilesC = (c->Cin + 63) / 64;
     hipLaunchKernelGGL((conv_wgrad_bf3_kernel<64, 64>), dim3(k.tilesN * k.tilesC * k.taps * splitk), dim3(256), 0,
-                       ONDA_STREAM(s), k);
+                       ONDA_STREAM(s), k, x_bytes, dy_bytes);
   }
   return ONDA_LAUNCH_RESULT();
 }
