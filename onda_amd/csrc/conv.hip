@@ -13,6 +13,8 @@
 // barrier per 32-deep K step.  Workgroup = 256 threads = 4 waves, one wave per SIMD, two
 // workgroups per CU.  The blockIdx -> tile map hands each XCD a contiguous band of
 // M-tiles so the N-tiles that re-read one activation band share an L2.
+#include <cstdlib>
+
 #include "conv_common.h"
 
 namespace {
@@ -42,16 +44,24 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvK a) {
   const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
   const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   const int KT = a.taps * a.kcper;
-  const long long U = (long long)a.tilesM * a.tilesN * KT;
-  long long u = SK ? swz * U / nblk : (long long)swz * KT;
+  // SK: a.tiles_dp tiles (whole rounds of the grid) are processed one per workgroup, all starting
+  // at k = 0 together -- workgroups of an XCD then stream the SAME weight slices at the same time,
+  // which is what keeps them in its L2.  Only the remaining (< gridDim.x) tiles are cut into
+  // equal unit ranges over all workgroups.
+  const int tiles_all = a.tilesM * a.tilesN;
+  const int tiles_dp = SK ? a.tiles_dp : tiles_all;
+  const long long U = (long long)(tiles_all - tiles_dp) * KT;  // units of the stream-K remainder
+  long long u = SK ? swz * U / nblk : 0;
   const long long u_begin = u;
-  const long long u_end = SK ? (swz + 1) * U / nblk : u + KT;
+  const long long u_end = SK ? (swz + 1) * U / nblk : 0;
+  int dp_tile = swz;  // next data-parallel tile of this workgroup
   const int ccol = (t & 7) * 4, rbase = t >> 3;
 
-  while (u < u_end) {
-  const int tile = (int)(u / KT);
-  const int k_begin = (int)(u - (long long)tile * KT);
-  const int k_end = (int)min((long long)KT, k_begin + (u_end - u));
+  while (dp_tile < tiles_dp || u < u_end) {
+  const bool dp = dp_tile < tiles_dp;
+  const int tile = dp ? dp_tile : tiles_dp + (int)(u / KT);
+  const int k_begin = dp ? 0 : (int)(u - (long long)(tile - tiles_dp) * KT);
+  const int k_end = dp ? KT : (int)min((long long)KT, k_begin + (u_end - u));
   const int tile_n = tile % a.tilesN, tile_m = tile / a.tilesN;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
@@ -153,7 +163,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvK a) {
     __syncthreads();
   }
 
-  u += k_end - k_begin;
+  if (dp) dp_tile += nblk; else u += k_end - k_begin;
   if (SK && (k_begin != 0 || k_end != KT)) {
     // partial tile: raw accumulators to this block's slot (0 = its first segment, 1 = its last)
     float* slot = a.ws + ((size_t)swz * 2 + (u - (k_end - k_begin) == u_begin ? 0 : 1)) * (BM * BN);
@@ -166,17 +176,47 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvK a) {
 
 // Sums the partial tiles stream-K left in `ws` (fixed order: ascending workgroup) and runs the
 // normal epilogue for every tile that was split.  One workgroup per output tile.
+// Stage 1 (only when a remainder tile is cut into many pieces): sum the pieces of 8 tile rows per
+// workgroup -- wide and shallow, so the many small reads run in parallel -- into sums[tile][BM][BN].
 template <int BM, int BN>
-__global__ __launch_bounds__(256) void conv_fixup_kernel(const ConvK a, int G) {
+__global__ __launch_bounds__(256) void conv_piece_sum_kernel(const ConvK a, int G, float* __restrict__ sums) {
+  constexpr int ROWS = 1024 / BN;  // rows per workgroup: 256 threads x float4
+  __shared__ int piece[1024];
+  const int KT = a.taps * a.kcper;
+  const long long U = (long long)(a.tilesM * a.tilesN - a.tiles_dp) * KT;
+  const int lt = blockIdx.x;  // remainder-local tile
+  const long long t0 = (long long)lt * KT, t1 = t0 + KT;
+  const int vs = (int)(((t0 + 1) * G + U - 1) / U - 1), ve = (int)((t1 * G + U - 1) / U - 1);
+  if (vs == ve) return;
+  const int t = threadIdx.x, npieces = ve - vs + 1;
+  for (int p = t; p < npieces; p += 256) {
+    const int vb = vs + p;
+    const long long b0 = (long long)vb * U / G, b1 = (long long)(vb + 1) * U / G;
+    const long long g0 = max(b0, t0), g1 = min(b1, t1);
+    piece[p] = g1 > g0 ? vb * 2 + (g0 == b0 ? 0 : 1) : -1;
+  }
+  __syncthreads();
+  const int eo = (blockIdx.y * ROWS) * BN + t * 4;
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+  for (int p = 0; p < npieces; ++p) {
+    const int pc = piece[p];
+    if (pc >= 0) v += *reinterpret_cast<const f32x4*>(a.ws + (size_t)pc * (BM * BN) + eo);
+  }
+  *reinterpret_cast<f32x4*>(sums + (size_t)lt * (BM * BN) + eo) = v;
+}
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void conv_fixup_kernel(const ConvK a, int G, const float* __restrict__ sums) {
   constexpr int C4 = BN / 4;        // float4 columns of a tile row
   constexpr int RG = 256 / C4;      // row groups covered by the workgroup at once
   constexpr int RPT = BM / RG;      // rows per thread
   __shared__ f32x4 red[2][256];
   const OndaConv& c = a.c;
   const int KT = a.taps * a.kcper;
-  const long long U = (long long)a.tilesM * a.tilesN * KT;
-  const int tile = blockIdx.x;
-  const long long t0 = (long long)tile * KT, t1 = t0 + KT;
+  const long long U = (long long)(a.tilesM * a.tilesN - a.tiles_dp) * KT;  // the stream-K remainder
+  const int tile = a.tiles_dp + blockIdx.x;
+  const long long t0 = (long long)blockIdx.x * KT, t1 = t0 + KT;
   const int vs = (int)(((t0 + 1) * G + U - 1) / U - 1), ve = (int)((t1 * G + U - 1) / U - 1);
   if (vs == ve) return;  // computed whole by one workgroup: its own epilogue already ran
   const int tile_n = tile % a.tilesN, tile_m = tile / a.tilesN;
@@ -189,33 +229,30 @@ __global__ __launch_bounds__(256) void conv_fixup_kernel(const ConvK a, int G) {
   if (vn && a.shift) sh = *reinterpret_cast<const f32x4*>(a.shift + n);
   const bool plain = (c.out_os == 1 && c.Hf == c.Ho && c.Wf == c.Wo);
 
-  // the (at most 3) contributing workgroups and the slot each used, in ascending order
-  const float* src[3];
-  int nsrc = 0;
-  for (int vb = vs; vb <= ve && nsrc < 3; ++vb) {
+  // contributing workgroups (ascending = the fixed summation order) and the slot each used
+  __shared__ int piece[1024];
+  const int npieces = ve - vs + 1;  // <= gridDim of the conv kernel <= 1024 (checked on the host)
+  for (int p = t; p < npieces; p += 256) {
+    const int vb = vs + p;
     const long long b0 = (long long)vb * U / G, b1 = (long long)(vb + 1) * U / G;
     const long long g0 = max(b0, t0), g1 = min(b1, t1);
-    if (g1 <= g0) continue;
-    src[nsrc++] = a.ws + ((size_t)vb * 2 + (g0 == b0 ? 0 : 1)) * (BM * BN);
+    piece[p] = g1 > g0 ? vb * 2 + (g0 == b0 ? 0 : 1) : -1;
   }
-  const bool many = (ve - vs + 1) > 3;  // tile cut into more than 3 pieces (tiny problems): slow path below
+  __syncthreads();
 
   f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
+#pragma unroll 2
   for (int i = 0; i < RPT; ++i) {
     const int row = rg + RG * i;
     const int eo = row * BN + col;
-    f32x4 v = *reinterpret_cast<const f32x4*>(src[0] + eo);
-    if (nsrc > 1) v += *reinterpret_cast<const f32x4*>(src[1] + eo);
-    if (nsrc > 2) v += *reinterpret_cast<const f32x4*>(src[2] + eo);
-    if (many) {
-      int seen = 0;
-      for (int vb = vs; vb <= ve; ++vb) {
-        const long long b0 = (long long)vb * U / G, b1 = (long long)(vb + 1) * U / G;
-        const long long g0 = max(b0, t0), g1 = min(b1, t1);
-        if (g1 <= g0) continue;
-        if (seen++ < 3) continue;
-        v += *reinterpret_cast<const f32x4*>(a.ws + ((size_t)vb * 2 + (g0 == b0 ? 0 : 1)) * (BM * BN) + eo);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (sums != nullptr) {
+      v = *reinterpret_cast<const f32x4*>(sums + (size_t)blockIdx.x * (BM * BN) + eo);
+    } else {
+#pragma unroll 4
+      for (int p = 0; p < npieces; ++p) {
+        const int pc = piece[p];
+        if (pc >= 0) v += *reinterpret_cast<const f32x4*>(a.ws + (size_t)pc * (BM * BN) + eo);
       }
     }
     s1 += v;
@@ -449,12 +486,23 @@ int onda_conv_tiles_m(int M) { return (M + 127) / 128; }
 }  // extern "C"
 
 int conv_launch_fixup(const ConvK& k, int G, bool wide, hipStream_t st) {
-  const int tiles = k.tilesM * k.tilesN;
-  if (wide)
-    hipLaunchKernelGGL((conv_fixup_kernel<128, 128>), dim3(tiles), dim3(256), 0, st, k, G);
-  else
-    hipLaunchKernelGGL((conv_fixup_kernel<128, 64>), dim3(tiles), dim3(256), 0, st, k, G);
+  const int tiles = k.tilesM * k.tilesN - k.tiles_dp;
+  if (tiles <= 0) return ONDA_LAUNCH_RESULT();
+  // few tiles cut into many pieces: sum the pieces with a wide launch first
+  float* sums = (tiles * 4 < G) ? k.ws + (size_t)G * 2 * 128 * 128 : nullptr;
+  if (wide) {
+    if (sums) hipLaunchKernelGGL((conv_piece_sum_kernel<128, 128>), dim3(tiles, 128 * 128 / 1024), dim3(256), 0, st, k, G, sums);
+    hipLaunchKernelGGL((conv_fixup_kernel<128, 128>), dim3(tiles), dim3(256), 0, st, k, G, sums);
+  } else {
+    if (sums) hipLaunchKernelGGL((conv_piece_sum_kernel<128, 64>), dim3(tiles, 128 * 64 / 1024), dim3(256), 0, st, k, G, sums);
+    hipLaunchKernelGGL((conv_fixup_kernel<128, 64>), dim3(tiles), dim3(256), 0, st, k, G, sums);
+  }
   return ONDA_LAUNCH_RESULT();
+}
+
+int conv_sched_override() {
+  const char* e = getenv("ONDA_CONV_SCHED");
+  return e ? atoi(e) : 0;
 }
 
 int conv_resident_workgroups() {
@@ -472,7 +520,7 @@ int conv_resident_workgroups() {
 
 extern "C" {
 
-int64_t onda_conv_ws_floats(void) { return (int64_t)conv_resident_workgroups() * 2 * 128 * 128; }
+int64_t onda_conv_ws_floats(void) { return (int64_t)conv_resident_workgroups() * 3 * 128 * 128; }  // 2 partial slots per workgroup + summed remainder tiles
 
 int onda_conv2d_fwd(const float* x, const float* w, float* y, const float* scale, const float* shift,
                     const float* residual, float* stats, float* ws, const OndaConv* c, onda_stream_t s) {
@@ -494,14 +542,22 @@ int onda_conv2d_fwd(const float* x, const float* w, float* y, const float* scale
   const bool wide = c->Cout > 64;
   k.tilesN = wide ? (c->Cout + 127) / 128 : (c->Cout + 63) / 64;
   const int tiles = k.tilesM * k.tilesN, KT = k.taps * k.kcper, G = conv_resident_workgroups();
-  // One workgroup per tile wastes the last partial round of the G resident workgroups.  Stream-K
-  // removes that at the price of the fix-up pass (about two partial tiles written and read per
-  // resident workgroup); take it when the modelled saving exceeds the modelled cost.
-  const double eff = ((double)tiles / G) / (double)((tiles + G - 1) / G);
-  const double t_ideal_us = 2.0 * (double)M * c->Cout * k.taps * c->Cin / 1.2e8;  // at ~120 TFLOP/s
-  const double split = tiles < G ? tiles : G;
-  const double fix_us = split * (wide ? 0.09 : 0.045) + 8.0;
-  const bool balanced = ws != nullptr && KT >= 4 && t_ideal_us * (1.0 / eff - 1.0) > fix_us;
+  // One workgroup per tile wastes the last partial round of the G resident workgroups.  The
+  // hybrid schedule runs the whole rounds tile-per-workgroup and spreads only the remaining
+  // tiles evenly over all workgroups (stream-K); its price is the fix-up pass over those tiles.
+  const int rem = tiles % G;
+  k.tiles_dp = tiles - rem;
+  const double t_tile_us = 2.0 * 128.0 * (wide ? 128.0 : 64.0) * k.taps * c->Cin / 0.2e6;  // one tile, half a CU, ~100 TF/s chip
+  const double fix_us = 8.0 + (G + 2.0 * rem) * (wide ? 0.03 : 0.015);  // partial tiles written + read
+  bool balanced = ws != nullptr && rem != 0 && KT >= 4 && t_tile_us * (1.0 - (double)rem / G) > fix_us;
+  if (const int force = conv_sched_override()) {  // ONDA_CONV_SCHED: 1 tile-per-workgroup, 2 hybrid, 3 pure stream-K
+    if (force == 1 || ws == nullptr) {
+      balanced = false;
+    } else {
+      balanced = true;
+      if (force == 3) k.tiles_dp = 0;
+    }
+  }
   hipStream_t st = ONDA_STREAM(s);
   if (balanced) {
     if (wide)

@@ -77,19 +77,27 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_bf3_kernel(const ConvK a, uns
   const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
   const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   const int KT = a.taps * a.kcper;
-  const long long U = (long long)a.tilesM * a.tilesN * KT;
-  long long u = SK ? swz * U / nblk : (long long)swz * KT;
+  // SK: a.tiles_dp tiles (whole rounds of the grid) are processed one per workgroup, all starting
+  // at k = 0 together -- workgroups of an XCD then stream the SAME weight slices at the same time,
+  // which is what keeps them in its L2.  Only the remaining (< gridDim.x) tiles are cut into
+  // equal unit ranges over all workgroups.
+  const int tiles_all = a.tilesM * a.tilesN;
+  const int tiles_dp = SK ? a.tiles_dp : tiles_all;
+  const long long U = (long long)(tiles_all - tiles_dp) * KT;  // units of the stream-K remainder
+  long long u = SK ? swz * U / nblk : 0;
   const long long u_begin = u;
-  const long long u_end = SK ? (swz + 1) * U / nblk : u + KT;
+  const long long u_end = SK ? (swz + 1) * U / nblk : 0;
+  int dp_tile = swz;  // next data-parallel tile of this workgroup
   const int ccol = (t & 7) * 4, rbase = t >> 3;  // A: 4 floats at k=ccol of rows rbase+32u
   const int brow = t >> 2, bk = (t & 3) * 8;     // B: 8 bf16 at k=bk of rows brow+64v
   const int wstride = a.taps * c.Cin;
   const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, x_bytes), rw = make_rsrc(a.w, w_bytes);
 
-  while (u < u_end) {
-    const int tile = (int)(u / KT);
-    const int k_begin = (int)(u - (long long)tile * KT);
-    const int k_end = (int)min((long long)KT, k_begin + (u_end - u));
+  while (dp_tile < tiles_dp || u < u_end) {
+    const bool dp = dp_tile < tiles_dp;
+    const int tile = dp ? dp_tile : tiles_dp + (int)(u / KT);
+    const int k_begin = dp ? 0 : (int)(u - (long long)(tile - tiles_dp) * KT);
+    const int k_end = dp ? KT : (int)min((long long)KT, k_begin + (u_end - u));
     const int tile_n = tile % a.tilesN, tile_m = tile / a.tilesN;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
@@ -205,7 +213,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_bf3_kernel(const ConvK a, uns
       }
     }
 
-    u += k_end - k_begin;
+    if (dp) dp_tile += nblk; else u += k_end - k_begin;
     if (SK && (k_begin != 0 || k_end != KT)) {
       float* slot = a.ws + ((size_t)swz * 2 + (u - (k_end - k_begin) == u_begin ? 0 : 1)) * (BM * BN);
       conv_store_partial<BN, TM, TN>(slot, acc, wm, wn, li, lh);
@@ -431,11 +439,19 @@ int onda_conv2d_fwd_bf3(const float* x, const void* w3, float* y, const float* s
   const unsigned limb_stride = (unsigned)limb_elems;
   const unsigned x_bytes = (unsigned)((size_t)c->B * c->Hi * c->Wi * c->ldx * 4), w_bytes = (unsigned)(limb_elems * 6);
   const int tiles = k.tilesM * k.tilesN, KT = k.taps * k.kcper, G = conv_resident_workgroups();
-  const double eff = ((double)tiles / G) / (double)((tiles + G - 1) / G);
-  const double t_ideal_us = 2.0 * (double)M * c->Cout * k.taps * c->Cin / 2.5e8;  // at ~250 TFLOP/s equivalent
-  const double split = tiles < G ? tiles : G;
-  const double fix_us = split * (wide ? 0.09 : 0.045) + 8.0;
-  const bool balanced = ws != nullptr && KT >= 4 && t_ideal_us * (1.0 / eff - 1.0) > fix_us;
+  const int rem = tiles % G;
+  k.tiles_dp = tiles - rem;
+  const double t_tile_us = 2.0 * 128.0 * (wide ? 128.0 : 64.0) * k.taps * c->Cin / 0.3e6;  // one tile, half a CU, ~150 TF/s chip
+  const double fix_us = 8.0 + (G + 2.0 * rem) * (wide ? 0.03 : 0.015);  // partial tiles written + read
+  bool balanced = ws != nullptr && rem != 0 && KT >= 4 && t_tile_us * (1.0 - (double)rem / G) > fix_us;
+  if (const int force = conv_sched_override()) {  // ONDA_CONV_SCHED: 1 tile-per-workgroup, 2 hybrid, 3 pure stream-K
+    if (force == 1 || ws == nullptr) {
+      balanced = false;
+    } else {
+      balanced = true;
+      if (force == 3) k.tiles_dp = 0;
+    }
+  }
   hipStream_t st = ONDA_STREAM(s);
   if (balanced) {
     if (wide)

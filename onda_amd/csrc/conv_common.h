@@ -14,7 +14,8 @@ struct ConvK {
   float* stats;
   OndaConv c;
   int M, tilesM, tilesN, taps, kcper;
-  float* ws;  // stream-K partial tiles [grid][2][BM*BN]
+  float* ws;     // stream-K partial tiles [grid][2][BM*BN]
+  int tiles_dp;  // tiles done one-per-workgroup before the stream-K remainder (multiple of the grid)
 };
 
 struct WgradK {
@@ -113,3 +114,4 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& a, const f32x16 (&acc
 // conv.hip: sums stream-K partial tiles and runs the epilogue for split tiles
 int conv_launch_fixup(const ConvK& k, int G, bool wide, hipStream_t st);
 int conv_resident_workgroups();
+int conv_sched_override();  // debugging aid: environment variable ONDA_CONV_SCHED (0 / unset = automatic)

@@ -180,7 +180,7 @@ def _wgrad_splitk(M, cout, cin, taps):
     rounds of the resident workgroups (tail effect) net of the slab write+read it costs."""
     t = 128 if (cout > 64 and cin > 64) else 64
     tiles = -(-cout // t) * -(-cin // t) * taps
-    G = query("onda_conv_ws_floats") // (2 * 128 * 128) * (1 if t == 128 else 2)
+    G = query("onda_conv_ws_floats") // (3 * 128 * 128) * (1 if t == 128 else 2)
     t_ideal = 2.0 * M * cout * cin * taps / 1.2e14            # seconds at ~120 TFLOP/s
     wbytes = 4.0 * cout * cin * taps
     best, best_t = 1, None
