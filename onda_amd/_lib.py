@@ -90,6 +90,10 @@ def load():
         raise OndaLibraryError(
             f"{LIB_PATH} is missing: build it with `python -m onda_amd.build` (hipcc --offload-arch=gfx950). "
             "onda_amd has no fallback path.")
+    # PyTorch-ROCm ships its own libamdhip64.so.7; importing torch first makes that copy THE HIP
+    # runtime of the process, so our kernels and torch's tensors/streams share one device context
+    # (loaded the other way round, the two runtimes disagree and launches fail with hipErrorNoDevice)
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         try:

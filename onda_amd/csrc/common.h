@@ -9,8 +9,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define ONDA_STREAM(s) (reinterpret_cast<hipStream_t>(s))
-#define ONDA_REQUIRE(cond) \
-  do {                     \
+// Argument check at the top of every entry point.  It also drops any stale error another
+// library left in this thread's HIP error slot, so that the hipGetLastError() after our own
+// launches reports our launches only.
+#define ONDA_REQUIRE(cond)           \
+  do {                               \
+    (void)hipGetLastError();         \
     if (!(cond)) return ONDA_EINVAL; \
   } while (0)
 #define ONDA_ALIGNED16(p) ((reinterpret_cast<uintptr_t>(p) & 15u) == 0)
