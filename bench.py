@@ -19,6 +19,7 @@ steps after the timed region; `cpu_baseline` times the CPU oracle (oracle/step.p
 restatement of the reference pinned by the golden vectors) on the host cores, rank 0, N=1.
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -34,7 +35,8 @@ import torch  # noqa: E402
 # SURVEY 8d / BASELINE.md section 2: exact conv FLOPs per image at 512x1024
 FWD_GFLOP_PER_IMG = 781.05
 BWD_GFLOP_PER_IMG = 1559.64
-FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
+FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32 (the dtype's dense matrix peak)
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak: the pipe the split-precision kernels execute on
 
 
 def parse():
@@ -107,10 +109,39 @@ def measure_roofline(da, src, trg, args, steps_done):
     achieved = flops / secs / 1e12
     detail = {k: {"launches": v[2], "ms_total": round(v[1] * 1e3, 3), "tflops": round(v[0] / v[1] / 1e12, 2)}
               for k, v in fam.items()}
-    return {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
+    roof = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
             "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
             "launches_per_step": n // 2, "avg_launch_ms": round(secs / n * 1e3, 4),
             "avg_launch_gflop": round(flops / n / 1e9, 3), "families": detail}
+    if "bf3" in name:
+        # achieved/peak above are ALGORITHMIC fp32 flops against the fp32 matrix peak; the kernel
+        # executes six bf16 MFMA products per fp32 product, so on the pipe it actually uses:
+        roof["pipe"] = {"what": "bf16 MFMA, 6 limb products per fp32 product, fp32 accumulate",
+                        "executed_tflops": round(6 * achieved, 1), "peak": BF16_MFMA_PEAK_TFLOPS,
+                        "frac": round(6 * achieved / BF16_MFMA_PEAK_TFLOPS, 4)}
+    roof.update(committed_traffic(name))
+    return roof
+
+
+def committed_traffic(kernel_family):
+    """HBM bytes per launch of the dominant kernel from the committed PMC summary (rocprofv3
+    FETCH_SIZE / WRITE_SIZE in separate passes over this same bench.py; tools/pmc_summary.py
+    applies the gfx950 corrections).  Counters cannot be read from inside the process, so the
+    number is the last profiled one and says which file it came from."""
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json"))):
+        try:
+            data = json.load(open(path))["kernels"]
+        except Exception:
+            continue
+        stem = kernel_family.split("<")[0]
+        rows = [(k, v) for k, v in data.items() if stem + "<" in k]
+        if rows:
+            tot = sum(v["hbm_bytes_per_launch"] * v["launches"] for _, v in rows)
+            n = sum(v["launches"] for _, v in rows)
+            best = {"traffic": round(tot / n), "traffic_unit": "bytes per launch (HBM + Infinity-Cache side of L2)",
+                    "traffic_source": os.path.relpath(path, ROOT)}
+    return best or {}
 
 
 def cpu_baseline(args):
@@ -137,6 +168,14 @@ def cpu_baseline(args):
     return {"value": round(b / dt, 5), "unit": "images/s", "cores": cores, "kind": "port",
             "sample": f"1 hybrid step (+update_ema) of the CPU oracle, B={b} at {w}x{h}, "
                       f"branch={'dynamic' if ad.switch.current else 'static'}, {dt:.1f} s, torch CPU fp32, {cores} threads"}
+
+
+def conv_mode_note():
+    from onda_amd import ops
+    if ops.CONV_MODE == "bf16x3":
+        return ("bf16x3: fp32 operands split exactly into 3 bf16 limbs, 6 limb products on the bf16 MFMA pipe, "
+                "fp32 accumulation (2e-7 relative to the exact-fp32 MFMA kernels; same parity tests)")
+    return "f32: v_mfma_f32_32x32x2_f32 (exact fp32 fmaf chain)"
 
 
 def main():
@@ -187,7 +226,7 @@ def main():
             "config": {"workload": f"hybrid_switch adaptation step (step + update_ema), {args.width}x{args.height}, "
                                    f"bs={args.batch} per GPU, {branch} branch, DeepLabV2-ResNet50 ProDA head, "
                                    f"random-init weights", "global_batch": world * args.batch,
-                       "parallelism": f"dp{world}", "branch": branch,
+                       "parallelism": f"dp{world}", "branch": branch, "conv_mode": conv_mode_note(),
                        "conv_tflop_per_step_per_gpu": tflop_step, "final_loss": round(loss, 5)},
             "roofline": roof, "cpu_baseline": cpu,
         }
