@@ -166,6 +166,13 @@ int onda_upsample_bwd(const float* dout_nchw, float* dlogits, int ldl, int B, in
 int onda_upsample_argmax(const float* logits, int ldl, uint8_t* cls, int B, int h, int w, int K, int H, int W,
                          onda_stream_t s);
 
+/* the whole evaluation tail of da_model.evaluate (adaptation_model.py:143-158): upsample ->
+ * argmax -> confusion matrix hist[K*K] += (row = ground truth u8[B,H,W] in [0,K), column =
+ * prediction), replacing the per-image .cpu().numpy() + np.bincount of func.py:77-79.  hist is
+ * accumulated (zero it first); cls (optional) also receives the class map. */
+int onda_upsample_argmax_hist(const float* logits, int ldl, const uint8_t* labels, int64_t* hist, uint8_t* cls, int B,
+                              int h, int w, int K, int H, int W, onda_stream_t s);
+
 /* ---- per-pixel softmax statistics --------------------------------------------------------
  * probs (optional, rows of stride ldp) = softmax(logits row); argmax (optional int32);
  * result[0] = mean over pixels of the max probability (the "prior ..." / "model" monitor

@@ -193,8 +193,9 @@ __device__ __forceinline__ Lerp lerp_index(int dst, float scale, int in_size) {
 
 template <bool ARGMAX>
 __global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__ logits, int ldl,
-                                                       float* __restrict__ out, uint8_t* __restrict__ cls, int B, int h,
-                                                       int w, int K, int H, int W, float sy, float sx) {
+                                                       float* __restrict__ out, uint8_t* __restrict__ cls,
+                                                       const uint8_t* __restrict__ gt, unsigned long long* __restrict__ hist,
+                                                       int B, int h, int w, int K, int H, int W, float sy, float sx) {
   const size_t total = (size_t)B * H * W;
   for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
     const int X = (int)(e % W);
@@ -218,7 +219,13 @@ __global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__
         out[(((size_t)b * K + k) * H + Y) * W + X] = v;
       }
     }
-    if (ARGMAX) cls[e] = (uint8_t)arg;
+    if (ARGMAX) {
+      if (cls) cls[e] = (uint8_t)arg;
+      if (hist) {  // fast_hist (func.py:77-79): rows = ground truth in [0,K), columns = prediction
+        const int g = gt[e];
+        if (g < K) atomicAdd(&hist[g * K + arg], 1ull);  // integer atomics: order-independent result
+      }
+    }
   }
 }
 
@@ -323,7 +330,8 @@ int onda_upsample_fwd(const float* logits, int ldl, float* out, int B, int h, in
                       onda_stream_t s) {
   ONDA_REQUIRE(logits && out && K <= ldl);
   hipLaunchKernelGGL((upsample_kernel<false>), dim3(ew_grid((size_t)B * H * W)), dim3(256), 0, ONDA_STREAM(s), logits,
-                     ldl, out, (uint8_t*)nullptr, B, h, w, K, H, W, ac_scale(h, H), ac_scale(w, W));
+                     ldl, out, (uint8_t*)nullptr, (const uint8_t*)nullptr, (unsigned long long*)nullptr, B, h, w, K, H, W,
+                     ac_scale(h, H), ac_scale(w, W));
   return ONDA_LAUNCH_RESULT();
 }
 
@@ -331,7 +339,17 @@ int onda_upsample_argmax(const float* logits, int ldl, uint8_t* cls, int B, int 
                          onda_stream_t s) {
   ONDA_REQUIRE(logits && cls && K <= ldl && K <= 255);
   hipLaunchKernelGGL((upsample_kernel<true>), dim3(ew_grid((size_t)B * H * W)), dim3(256), 0, ONDA_STREAM(s), logits,
-                     ldl, (float*)nullptr, cls, B, h, w, K, H, W, ac_scale(h, H), ac_scale(w, W));
+                     ldl, (float*)nullptr, cls, (const uint8_t*)nullptr, (unsigned long long*)nullptr, B, h, w, K, H, W,
+                     ac_scale(h, H), ac_scale(w, W));
+  return ONDA_LAUNCH_RESULT();
+}
+
+int onda_upsample_argmax_hist(const float* logits, int ldl, const uint8_t* labels, int64_t* hist, uint8_t* cls, int B,
+                              int h, int w, int K, int H, int W, onda_stream_t s) {
+  ONDA_REQUIRE(logits && labels && hist && K <= ldl && K <= 255);
+  hipLaunchKernelGGL((upsample_kernel<true>), dim3(ew_grid((size_t)B * H * W)), dim3(256), 0, ONDA_STREAM(s), logits,
+                     ldl, (float*)nullptr, cls, labels, reinterpret_cast<unsigned long long*>(hist), B, h, w, K, H, W,
+                     ac_scale(h, H), ac_scale(w, W));
   return ONDA_LAUNCH_RESULT();
 }
 

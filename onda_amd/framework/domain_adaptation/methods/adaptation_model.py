@@ -17,7 +17,7 @@ from torch import nn
 from onda_amd import ops
 from onda_amd.config import unset
 from onda_amd.optim import ReplaySGD
-from onda_amd.framework.utils.func import fast_hist, lr_poly, per_class_iu
+from onda_amd.framework.utils.func import lr_poly, per_class_iu
 
 
 def switch_batch_statistics(model, setting):
@@ -114,17 +114,16 @@ class da_model:
         function_dict = {"model": lambda x: self.model(x["image"].to(self.device))[1]["out"]}
         function_dict.update(additional_func)
         self.models_eval()
-        counters = {key: 0 for key in function_dict}
-        size = self.interp.size
+        n = self.cfg.NUM_CLASSES
+        # the confusion matrices live on the GPU; one read-back per evaluation instead of a class
+        # map per image (the fused kernel upsamples, takes the argmax and bins against the labels)
+        counters = {key: torch.zeros(n, n, dtype=torch.int64, device=self.device) for key in function_dict}
         with torch.no_grad():
             for batch in validation_loader:
                 for key, func in function_dict.items():
-                    cls = ops.upsample_argmax(func(batch), size).cpu().numpy()
-                    for item_pred, label in zip(cls, batch["label"]):
-                        counters[key] += fast_hist(label.numpy().flatten(), item_pred.flatten().astype(np.int64),
-                                                   self.cfg.NUM_CLASSES)
+                    ops.upsample_argmax_hist(func(batch), batch["label"], counters[key], n)
         self.models_default_config()
-        return {key: per_class_iu(count) for key, count in counters.items()}
+        return {key: per_class_iu(count.cpu().numpy()) for key, count in counters.items()}
 
     def evaluate_all(self, validation_loaders):
         validation_log = {}

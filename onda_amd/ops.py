@@ -601,6 +601,17 @@ def upsample_argmax(out, size):
     return cls
 
 
+def upsample_argmax_hist(out, labels, hist, num_classes):
+    """Evaluation tail on the GPU: hist[K,K] (int64, accumulated) += confusion matrix of the
+    upsampled argmax of `out` against `labels` u8[B,H,W] (values >= K are ignored)."""
+    rows, ld, _, K = logits_rows(out)
+    B, _, h, w = out.shape
+    labels = labels.to(device=out.device, dtype=torch.uint8).contiguous()
+    H, W = labels.shape[1:]
+    call("onda_upsample_argmax_hist", _p(rows), ld, _p(labels), _p(hist), None, B, h, w, num_classes, H, W, _stream())
+    return hist
+
+
 # ------------------------------------------------------------------------------- multi-tensor
 def _table(entries, struct):
     arr = (struct * len(entries))(*entries)

@@ -228,3 +228,72 @@ def test_full_step_golden(golden, tmp_path, tag, head_scale):
             assert (num / den) ** 0.5 <= (0.02 if s == 0 else 0.6), (s, (num / den) ** 0.5)
     finally:
         deeplabv2.drop_mask_fn = deeplabv2._default_drop_mask
+
+
+def test_evaluate_path_matches_oracle(tmp_path):
+    """da_model.evaluate: forward -> fused upsample/argmax/confusion-matrix on the GPU
+    against the oracle's interp -> softmax -> argmax -> np.bincount (BASELINE config 1 flow, small)."""
+    from onda_amd.config import hybrid_switch_cfg
+    from onda_amd.framework.domain_adaptation.methods.adaptation_model import evaluation
+    from onda_amd.framework.utils.func import fast_hist, per_class_iu
+    from onda_amd.synthetic import synth_batch, synth_tensor
+    from oracle import model as omodel
+    cfg, spec = hybrid_switch_cfg(128, 64, DEV, "NONE", batch_size=2)
+    m = build_model(1, 3.0)
+    ev = evaluation(m, cfg, spec)
+    loader = [synth_batch(2, 64, 128, seed=300 + i) for i in range(3)]
+    got = ev.evaluate_all({"val": loader})
+    sd = {k: synth_tensor(k, torch.empty(shape, dtype=dt), 1, 3.0).to(dt) for k, shape, dt in omodel.state_spec()}
+    hist = 0
+    with torch.no_grad():
+        for b in loader:
+            _, o = omodel.forward(b["image"], sd, omodel.BNMode(False))
+            _, amap = omodel.upsample_argmax(o["out"], (64, 128))
+            for pred, lab in zip(amap, b["label"]):
+                hist = hist + fast_hist(lab.numpy().flatten().astype(np.int64), pred.numpy().flatten(), 19)
+    ref = per_class_iu(hist)
+    assert got["Val mIoU model of val"] == pytest.approx(np.nanmean(ref), rel=1e-6)
+    assert got["Val std IoU model of val"] == pytest.approx(np.nanstd(ref), rel=1e-6)
+    assert ev.model.training is False  # evaluation.models_default_config keeps eval mode
+
+
+def test_segmentation_step_config2(golden):
+    """BASELINE config 2 (segmentation.py:62-88): train-mode forward -> bilinear upsample to the
+    label resolution -> CE -> backward -> SGD step, against the oracle on the CPU."""
+    import torch.nn.functional as F
+    from onda_amd import ops
+    from onda_amd.framework.model import deeplabv2
+    from onda_amd.optim import ReplaySGD
+    from onda_amd.synthetic import synth_batch, synth_tensor
+    from oracle import losses, model as omodel
+    g = golden("g2_train_small")
+    mask = torch.from_numpy(g["drop_mask"])
+    b = synth_batch(2, 64, 128, seed=7)
+    m = build_model(1, 3.0).train()
+    opt = ReplaySGD(m.optim_parameters(2.5e-4), lr=2.5e-4, momentum=0.9, weight_decay=5e-4)
+    deeplabv2.drop_mask_fn = lambda B, C, p, dev: mask.to(dev)
+    try:
+        _, pred = m(b["image"].to(DEV))
+    finally:
+        deeplabv2.drop_mask_fn = deeplabv2._default_drop_mask
+    up = ops.UpsampleFn.apply(pred["out"], (64, 128))
+    loss = ops.seg_losses(up, b["label"].to(DEV), 1.0, 0.0, 0.0)[0]
+    loss.backward()
+    # oracle
+    sd = {k: synth_tensor(k, torch.empty(shape, dtype=dt), 1, 3.0).to(dt) for k, shape, dt in omodel.state_spec()}
+    names = ["layer6.head.1.weight", "layer6.bottleneck.2.weight", "layer6.bottleneck.2.bias", "layer6.bottleneck.1.bias"]
+    for k in names:
+        sd[k].requires_grad_(True)
+    _, o = omodel.forward(b["image"], sd, omodel.BNMode(True, True, 0.1), mask)
+    ref_up = F.interpolate(o["out"], size=(64, 128), mode="bilinear", align_corners=True)
+    ref_loss = losses.ce_hard(ref_up, b["label"])
+    grads = torch.autograd.grad(ref_loss, [sd[k] for k in names])
+    assert loss.item() == pytest.approx(ref_loss.item(), rel=1e-4)
+    assert (up.detach().cpu() - ref_up.detach()).abs().max() <= 1e-3 * ref_up.abs().max()
+    params = dict(m.named_parameters())
+    for k, gr in zip(names, grads):
+        assert (params[k].grad.cpu() - gr).abs().max() <= 5e-3 * gr.abs().max(), k
+    before = params["layer6.head.1.weight"].detach().clone()
+    opt.step()
+    moved = (params["layer6.head.1.weight"].detach() - before).abs().max().item()
+    assert moved > 0 and all(torch.isfinite(p).all() for p in m.parameters())
