@@ -36,6 +36,11 @@ def init_from_env(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rk = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # test hooks: several ranks on ONE GPU over gloo exercise the whole multi-rank step logic on a
+    # single-GPU box (ONDA_DIST_BACKEND=gloo ONDA_FORCE_DEVICE=0); production leaves both unset
+    if "ONDA_FORCE_DEVICE" in os.environ:
+        local = int(os.environ["ONDA_FORCE_DEVICE"])
+    backend = backend or os.environ.get("ONDA_DIST_BACKEND")
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")

@@ -261,6 +261,14 @@ class online_proDA(da_model):
         """teacher = keep*teacher + (1-keep)*student for all 217 parameters, buffers copied
         (reference :407-416), as one multi-tensor launch."""
         keep = self.cfg_spec.EMA_UPDATE
+        if odist.is_on():
+            # BatchNorm normalises with rank-local batch statistics (like the bs=4 reference on each
+            # GPU); the RUNNING statistics are averaged over ranks here so that replicas -- and the
+            # teacher / dynamic copies taken from them -- stay identical
+            bufs = [b for b in self.model.buffers() if b.dtype == torch.float32]
+            flat = torch.cat([b.reshape(-1) for b in bufs])
+            odist.all_reduce_mean(flat)
+            torch._foreach_copy_(bufs, [v.view_as(b) for v, b in zip(flat.split([b.numel() for b in bufs]), bufs)])
         items = [(k, q, keep, 1.0 - keep) for q, k in zip(self.model.parameters(), self.ema_model.parameters())]
         ints_q, ints_k = [], []
         for bq, bk in zip(self.model.buffers(), self.ema_model.buffers()):
