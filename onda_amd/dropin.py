@@ -10,6 +10,7 @@ _MODULES = [
     "framework.domain_adaptation", "framework.domain_adaptation.methods",
     "framework.domain_adaptation.methods.adaptation_model", "framework.domain_adaptation.methods.prototype_handler",
     "framework.domain_adaptation.methods.prototypes", "framework.domain_adaptation.methods.prototypes_hybrid_switch",
+    "framework.domain_adaptation.methods.prototypes_hswitch", "framework.domain_adaptation.methods.prototypes_vswitch",
 ]
 
 

@@ -140,17 +140,37 @@ class online_proDA(da_model):
         conf, probs, am = ops.softmax_stats(pred["out"], want_probs=True, want_argmax=(key == "prior EMA"))
         return pred, probs, conf, am
 
+    def _rank_mean(self, *confs):
+        """Device scalars -> Python floats with ONE read-back; averaged over ranks first so that
+        every rank's monitor (and therefore every switch decision) sees the same numbers."""
+        return odist.all_reduce_mean(torch.stack(list(confs))).tolist()
+
+    def _teacher_and_static(self, batch):
+        """The part every prototype method shares: EMA-teacher pass (train mode), optional static
+        pass, their mean max-probabilities into the monitor.  Returns (image, teacher output, prior
+        so far, teacher argmax)."""
+        image = self._device_image(batch)
+        pred_ema, prior_ema, conf_ema, cls_ema = self._prior_of(self.ema_model, image, "prior EMA")
+        prior = self.cfg_spec.EMA_LAMBDA * prior_ema
+        if self.cfg_spec.STATIC_LAMBDA > 0:
+            _, prior_static, conf_static, _ = self._prior_of(self.static_model, image, "prior static")
+            vals = self._rank_mean(conf_ema, conf_static)
+            self.intensity_ma.add({"prior EMA": vals[0]})
+            self.intensity_ma.add({"prior static": vals[1]})
+            prior += self.cfg_spec.STATIC_LAMBDA * prior_static
+        else:
+            self.intensity_ma.add({"prior EMA": self._rank_mean(conf_ema)[0]})
+        return image, pred_ema, prior, cls_ema
+
+    def _dynamic_prior(self, image):
+        _, prior_dynamic, conf_dyn, _ = self._prior_of(self.dynamic_model, image, "prior dynamic")
+        self.intensity_ma.add({"prior dynamic": self._rank_mean(conf_dyn)[0]})
+        return prior_dynamic
+
     def prototype_predictions(self, batch):
         """Teacher / static / dynamic priors and prototype pseudo-labels (reference :208-273)."""
         with torch.no_grad():
-            image = self._device_image(batch)
-            pred_ema, prior_ema, conf_ema, cls_ema = self._prior_of(self.ema_model, image, "prior EMA")
-            self.intensity_ma.add({"prior EMA": conf_ema})
-            prior = self.cfg_spec.EMA_LAMBDA * prior_ema
-            if self.cfg_spec.STATIC_LAMBDA > 0:
-                _, prior_static, conf_static, _ = self._prior_of(self.static_model, image, "prior static")
-                self.intensity_ma.add({"prior static": conf_static})
-                prior += self.cfg_spec.STATIC_LAMBDA * prior_static
+            image, pred_ema, prior, cls_ema = self._teacher_and_static(batch)
             calculate_dyn, replace_dyn = True, False
             thr = self.cfg_spec.SWITCH_PRIOR_THRESH
             thr = 0 if unset(thr) else thr
@@ -159,8 +179,7 @@ class online_proDA(da_model):
             elif thr > 0:
                 calculate_dyn = False
             if self.cfg_spec.DYNAMIC_LAMBDA > 0 and calculate_dyn:
-                _, prior_dynamic, conf_dyn, _ = self._prior_of(self.dynamic_model, image, "prior dynamic")
-                self.intensity_ma.add({"prior dynamic": conf_dyn})
+                prior_dynamic = self._dynamic_prior(image)
                 prior = self.cfg_spec.DYNAMIC_LAMBDA * prior_dynamic if replace_dyn else \
                     prior + self.cfg_spec.DYNAMIC_LAMBDA * prior_dynamic
         return self._labels_from(pred_ema, prior, cls_ema)

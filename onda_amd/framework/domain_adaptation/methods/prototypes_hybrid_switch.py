@@ -2,7 +2,6 @@
 ``model_select`` (:5-34) and ``hybrid_proDA`` (:37-109), the hybrid static/dynamic switch."""
 import torch
 
-from onda_amd import dist as odist
 from onda_amd.config import unset
 from onda_amd.framework.domain_adaptation.methods.prototypes import online_proDA
 
@@ -46,31 +45,16 @@ class hybrid_proDA(online_proDA):
         """Priors with the switch: the static prior is used unless the switch is in its dynamic
         state, in which case the dynamic model's prior REPLACES it (reference :45-101)."""
         with torch.no_grad():
-            image = self._device_image(batch)
             if "label" not in batch:
                 batch["label"] = 0
-            pred_ema, prior_ema, conf_ema, cls_ema = self._prior_of(self.ema_model, image, "prior EMA")
-            prior = self.cfg_spec.EMA_LAMBDA * prior_ema
-            confs = [conf_ema]
-            prior_static = None
-            if self.cfg_spec.STATIC_LAMBDA > 0:
-                _, prior_static, conf_static, _ = self._prior_of(self.static_model, image, "prior static")
-                confs.append(conf_static)
-            # the only read-back the switch needs; summed over ranks so that all take one branch
-            vals = odist.all_reduce_mean(torch.stack(confs)).tolist()
-            self.intensity_ma.add({"prior EMA": vals[0]})
-            if prior_static is not None:
-                self.intensity_ma.add({"prior static": vals[1]})
-                prior += self.cfg_spec.STATIC_LAMBDA * prior_static
+            image, pred_ema, prior, cls_ema = self._teacher_and_static(batch)
             if not unset(self.cfg_spec.EXP_PR_STATIC) and self.cfg_spec.EXP_PR_STATIC:
                 static_conf = self.intensity_ma.exp("prior static")
             else:
                 static_conf = self.intensity_ma.avg("prior static")
             self.model_select.evaluate(static_conf, self.intensity_ma.dev_avg("prior static"))
             if self.model_select.current == model_select.dynamic and self.cfg_spec.DYNAMIC_LAMBDA > 0:
-                _, prior_dynamic, conf_dyn, _ = self._prior_of(self.dynamic_model, image, "prior dynamic")
-                self.intensity_ma.add({"prior dynamic": conf_dyn})
-                prior = self.cfg_spec.DYNAMIC_LAMBDA * prior_dynamic
+                prior = self.cfg_spec.DYNAMIC_LAMBDA * self._dynamic_prior(image)
         return self._labels_from(pred_ema, prior, cls_ema)
 
     def models_eval(self):

@@ -36,7 +36,14 @@ def _is_trainable(name, t):
 
 
 class OracleAdapter:
-    def __init__(self, sd, proto_state, cfg=None, first_step="torch2"):
+    """method: "hybrid" (prototypes_hybrid_switch.py:45-101, the BASELINE path), "online"
+    (prototypes.py:208-273, used by static_model.yml / dynamic_model.yml), "hswitch"
+    (prototypes_hswitch.py:27-84, confidence switch with soft transition) or "vswitch"
+    (prototypes_vswitch.py:20-89, confidence-derivative switch).  They differ only in how the
+    static / dynamic priors are mixed; fixtures G7 (hybrid) and G8 (the others) pin them."""
+
+    def __init__(self, sd, proto_state, cfg=None, first_step="torch2", method="hybrid"):
+        self.method = method
         self.cfg = dict(DEFAULTS, **(cfg or {}))
         self.student = {k: v.clone() for k, v in sd.items()}
         self.ema = deepcopy(self.student)
@@ -63,32 +70,65 @@ class OracleAdapter:
         for k, g in zip(names, gs):
             grads[k] = g if k not in grads else grads[k] + g
 
+    def _dynamic_prior(self, image):
+        dy = model.forward(image, self.dynamic, model.BNMode(False))[1]
+        p_dy = dy["out"].softmax(1)
+        self.stats.add({"prior dynamic": p_dy.max(1)[0].mean().item()})
+        return p_dy
+
     @torch.no_grad()
     def teacher_labels(self, image, mask):
         c = self.cfg
         ema = model.forward(image, self.ema, model.BNMode(True, True, 0.1), mask)[1]
         prior_ema = ema["out"].softmax(1)
-        self.stats.add({"prior EMA": prior_ema.max(1)[0].mean()})
+        self.stats.add({"prior EMA": prior_ema.max(1)[0].mean().item()})
         prior = c["EMA_LAMBDA"] * prior_ema
         if c["STATIC_LAMBDA"] > 0:
             st = model.forward(image, self.static, model.BNMode(False))[1]
             p_st = st["out"].softmax(1)
             self.stats.add({"prior static": p_st.max(1)[0].mean().item()})
             prior = prior + c["STATIC_LAMBDA"] * p_st
-        self.switch.evaluate(self.stats.avg("prior static"), self.stats.dev_avg("prior static"))
-        if self.switch.current == self.switch.DYNAMIC and c["DYNAMIC_LAMBDA"] > 0:
-            dy = model.forward(image, self.dynamic, model.BNMode(False))[1]
-            p_dy = dy["out"].softmax(1)
-            self.stats.add({"prior dynamic": p_dy.max(1)[0].mean()})
-            prior = c["DYNAMIC_LAMBDA"] * p_dy
-        self.stats.add({"prior": prior.max(1)[0].mean()})
+        thr = c.get("SWITCH_PRIOR_THRESH", 0)
+        if self.method == "hybrid":
+            self.switch.evaluate(self.stats.avg("prior static"), self.stats.dev_avg("prior static"))
+            if self.switch.current == self.switch.DYNAMIC and c["DYNAMIC_LAMBDA"] > 0:
+                prior = c["DYNAMIC_LAMBDA"] * self._dynamic_prior(image)
+        elif self.method == "online":
+            calculate, replace = True, False
+            if thr > 0 and self.stats.avg("prior static") < thr:
+                replace = True
+            elif thr > 0:
+                calculate = False
+            if c["DYNAMIC_LAMBDA"] > 0 and calculate:
+                p_dy = c["DYNAMIC_LAMBDA"] * self._dynamic_prior(image)
+                prior = p_dy if replace else prior + p_dy
+        elif self.method == "hswitch":
+            if c.get("SOFT_TRANS", True):
+                share = max(min(self.stats.avg("prior static") * (25.0 / 3) - (41.0 / 6), 1), 0)
+            else:
+                share = int(self.stats.avg("prior static") > thr)
+            self.stats.add({"percentage_static": share})
+            prior = prior * share
+            if c["DYNAMIC_LAMBDA"] > 0 and share < 1:
+                prior = prior + (1 - share) * c["DYNAMIC_LAMBDA"] * self._dynamic_prior(image)
+        elif self.method == "vswitch":
+            dev = self.stats.dev_avg("prior static")
+            if dev > thr:
+                self.switch.current = self.switch.STATIC
+            elif dev < -thr:
+                self.switch.current = self.switch.DYNAMIC
+            if self.switch.current == self.switch.DYNAMIC and c["DYNAMIC_LAMBDA"] > 0:
+                prior = c["DYNAMIC_LAMBDA"] * self._dynamic_prior(image)
+        else:
+            raise ValueError(self.method)
+        self.stats.add({"prior": prior.max(1)[0].mean().item()})
         labels, soft, conf = prototypes.assign(ema["feat"], prior, self.proto, self.tau,
                                                c["PSEUDO_THRESH"], c["DISTANCE_MEASURE"])
-        self.stats.add({"prototypes": conf})
+        self.stats.add({"prototypes": conf.item()})
         if self.stats.avg("prototypes") > c["CONF_REG_THRESH"]:
             self.tau += 0.001
             self.stats.add({"tau": self.tau})
-        self.stats.add({"pseudolabel confidence": soft.max(1)[0].mean()})
+        self.stats.add({"pseudolabel confidence": soft.max(1)[0].mean().item()})
         return ema, labels, soft
 
     @torch.no_grad()
@@ -122,7 +162,7 @@ class OracleAdapter:
         # target batch
         pred = self._student_forward(batch_trg["image"], True, masks[1])
         out_t = pred["out"]
-        self.stats.add({"model": out_t.detach().softmax(1).max(1)[0].mean()})
+        self.stats.add({"model": out_t.detach().softmax(1).max(1)[0].mean().item()})
         ema, labels, soft = self.teacher_labels(batch_trg["image"], masks[2])
         self.proto = prototypes.ema_update(self.proto, ema["feat"], ema["out"], c["MA_LAMBDA"])
         b, k, h, w = out_t.shape

@@ -317,7 +317,55 @@ def g7():
             print(tag, "branch", res["branch0"], res["branch1"], json.loads(str(res["log1_json"]))["pseudolabel_pixel_num"])
 
 
+# ------------------------------------------------------------------------------------- G8
+def g8():
+    """The other prototype methods of the reference (same kernels, different prior mixing):
+    PROTO_ONLINE with static_model.yml / dynamic_model.yml settings, PROTO_ONLINE_HSWITCH
+    (confidence_switch.yml) and PROTO_ONLINE_VSWITCH (confidence_der_switch.yml); two steps each."""
+    from framework.domain_adaptation.methods.prototypes import online_proDA
+    from framework.domain_adaptation.methods.prototypes_hswitch import hswitch_proDA
+    from framework.domain_adaptation.methods.prototypes_vswitch import vswitch_proDA
+    variants = {
+        "online_static": (online_proDA, dict(SWITCH_PRIOR_THRESH=1, STATIC_LAMBDA=1, DYNAMIC_LAMBDA=0), 40.0),
+        "online_dynamic": (online_proDA, dict(SWITCH_PRIOR_THRESH=0, STATIC_LAMBDA=0, DYNAMIC_LAMBDA=1), 40.0),
+        "hswitch": (hswitch_proDA, dict(SWITCH_PRIOR_THRESH=0.86, SOFT_TRANS=True), 9.0),
+        "vswitch": (vswitch_proDA, dict(SWITCH_PRIOR_THRESH=0.0002, DEV_THRESH=0.0002), 40.0),
+    }
+    import warnings
+    for tag, (cls, over, head_scale) in variants.items():
+        with tempfile.TemporaryDirectory() as tmp:
+            cfg, spec = make_cfg(tmp)
+            for k in ("GRAY_AREA",):
+                spec.pop(k, None)
+            for k, v in over.items():
+                spec[k] = v
+            model = ref_model(1, head_scale)
+            da = cls(model, cfg, spec)
+            src = [synth_batch(2, 64, 128, seed=100 + i) for i in range(2)]
+            trg = [synth_batch(2, 64, 128, seed=200 + i) for i in range(2)]
+            torch.manual_seed(123)
+            da.update_dynamic()
+            switch_batch_statistics(da.model, False)
+            da.calculate_prototypes(src)
+            switch_batch_statistics(da.model, True)
+            da.optimizer.zero_grad()
+            res = {}
+            for s in range(2):
+                da.adjust_learning_rate(s, 6)
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    log = da.step([src[s]], trg[s])
+                da.update_ema()
+                lg = tolog(log)
+                res[f"log{s}_json"] = np.array(json.dumps({k: v for k, v in lg.items() if np.isscalar(v)}))
+                res[f"soft{s}"] = trg[s]["stored_predictions"].to(torch.float32)
+                res[f"proto{s + 1}"] = da.prototypes.prototypes.clone()
+            save(f"g8_{tag}", **res)
+            print(tag, json.loads(str(res["log1_json"]))["pseudolabel_pixel_num"],
+                  {k: round(v, 4) for k, v in json.loads(str(res["log0_json"])).items() if "prior" in k or "percentage" in k})
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8"]
     for w in which:
         globals()[w]()

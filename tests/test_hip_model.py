@@ -297,3 +297,54 @@ def test_segmentation_step_config2(golden):
     opt.step()
     moved = (params["layer6.head.1.weight"].detach() - before).abs().max().item()
     assert moved > 0 and all(torch.isfinite(p).all() for p in m.parameters())
+
+
+G8 = {"online_static": ("PROTO_ONLINE", dict(SWITCH_PRIOR_THRESH=1, STATIC_LAMBDA=1, DYNAMIC_LAMBDA=0), 40.0),
+      "online_dynamic": ("PROTO_ONLINE", dict(SWITCH_PRIOR_THRESH=0, STATIC_LAMBDA=0, DYNAMIC_LAMBDA=1), 40.0),
+      "hswitch": ("PROTO_ONLINE_HSWITCH", dict(SWITCH_PRIOR_THRESH=0.86, SOFT_TRANS=True), 9.0),
+      "vswitch": ("PROTO_ONLINE_VSWITCH", dict(SWITCH_PRIOR_THRESH=0.0002, DEV_THRESH=0.0002), 40.0)}
+
+
+@pytest.mark.parametrize("tag", list(G8))
+def test_other_prototype_methods_golden(golden, tmp_path, tag):
+    """PROTO_ONLINE (static_model.yml / dynamic_model.yml), HSWITCH and VSWITCH: two steps each
+    against the reference's log dict, soft maps and prototypes (fixture G8)."""
+    from onda_amd.config import hybrid_switch_cfg
+    from onda_amd.framework.handlers import get_adapt_method, get_model
+    from onda_amd.framework.model import deeplabv2
+    from onda_amd.framework.domain_adaptation.methods.adaptation_model import switch_batch_statistics
+    from onda_amd.synthetic import fill_state_dict, synth_batch
+    from oracle import model as omodel
+    name, over, head_scale = G8[tag]
+    g = golden("g8_" + tag)
+    cfg, spec = hybrid_switch_cfg(128, 64, DEV, str(tmp_path), batch_size=2)
+    cfg.METHOD.ADAPTATION.NAME = name
+    spec.pop("GRAY_AREA", None)
+    for k, v in over.items():
+        spec[k] = v
+    model = get_model(cfg, 19)
+    fill_state_dict(model, 1, head_scale)
+    da = get_adapt_method(cfg)(model, cfg, spec)
+    src = [synth_batch(2, 64, 128, seed=100 + i) for i in range(2)]
+    trg = [synth_batch(2, 64, 128, seed=200 + i) for i in range(2)]
+    torch.manual_seed(123)
+    masks = iter([omodel.draw_drop_mask(2) for _ in range(8)])
+    deeplabv2.drop_mask_fn = lambda B, C, p, dev: next(masks).to(dev)
+    try:
+        da.update_dynamic()
+        switch_batch_statistics(da.model, False)
+        da.calculate_prototypes(src, save=False)
+        switch_batch_statistics(da.model, True)
+        da.optimizer.zero_grad()
+        for s in range(2):
+            da.adjust_learning_rate(s, 6)
+            log = da.step([src[s]], trg[s])
+            da.update_ema()
+            assert (trg[s]["stored_predictions"].cpu() - torch.from_numpy(g[f"soft{s}"])).abs().max() < 2e-3
+            for k, v in json.loads(str(g[f"log{s}_json"])).items():
+                mine = log[k]
+                mine = mine.item() if isinstance(mine, torch.Tensor) else float(mine)
+                assert mine == pytest.approx(v, rel=5e-3, abs=1e-5), (s, k)
+            np.testing.assert_allclose(da.prototypes.prototypes.cpu().numpy(), g[f"proto{s + 1}"], rtol=1e-3, atol=1e-4)
+    finally:
+        deeplabv2.drop_mask_fn = deeplabv2._default_drop_mask

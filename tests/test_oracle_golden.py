@@ -182,3 +182,36 @@ def test_g7_full_step(golden, tag, head_scale):
                 row = dg[names.index(who + k)]
                 mine = digest(v.float(), 64)
                 assert np.abs(mine[2:] - row[2:]).max() <= 1e-3 * max(np.abs(row[2:]).max(), 1e-6) + 1e-6, (s, who + k)
+
+
+G8 = {"online_static": ("online", dict(SWITCH_PRIOR_THRESH=1, STATIC_LAMBDA=1, DYNAMIC_LAMBDA=0), 40.0),
+      "online_dynamic": ("online", dict(SWITCH_PRIOR_THRESH=0, STATIC_LAMBDA=0, DYNAMIC_LAMBDA=1), 40.0),
+      "hswitch": ("hswitch", dict(SWITCH_PRIOR_THRESH=0.86, SOFT_TRANS=True), 9.0),
+      "vswitch": ("vswitch", dict(SWITCH_PRIOR_THRESH=0.0002, DEV_THRESH=0.0002), 40.0)}
+
+
+@pytest.mark.parametrize("tag", list(G8))
+def test_g8_other_prototype_methods(golden, tag):
+    """static_model.yml / dynamic_model.yml (PROTO_ONLINE), confidence_switch.yml (HSWITCH) and
+    confidence_der_switch.yml (VSWITCH): two steps each against the reference's log and soft maps."""
+    method, over, head_scale = G8[tag]
+    g = golden("g8_" + tag)
+    sd = oracle_sd(1, head_scale)
+    src = [synth_batch(2, 64, 128, seed=100 + i) for i in range(2)]
+    trg = [synth_batch(2, 64, 128, seed=200 + i) for i in range(2)]
+    torch.manual_seed(123)
+    ad = OracleAdapter(sd, (torch.zeros(19, 256), torch.zeros(19, 256), torch.zeros(19)), cfg=over, method=method)
+    ad.refresh_dynamic()
+    ad.proto = ad.initial_prototypes(src)
+    for s in range(2):
+        masks = tuple(model.draw_drop_mask(2) for _ in range(3))
+        log = ad.step(src[s], trg[s], masks)
+        ad.update_ema()
+        ref = json.loads(str(g[f"log{s}_json"]))
+        ref_soft = torch.from_numpy(g[f"soft{s}"])
+        assert (ad.last["soft"].reshape(2, 9, 17, 19).permute(0, 3, 1, 2) - ref_soft).abs().max() < 2e-3
+        for k, v in ref.items():
+            mine = log[k]
+            mine = mine.item() if isinstance(mine, torch.Tensor) else float(mine)
+            assert mine == pytest.approx(v, rel=5e-3, abs=1e-5), (s, k)
+        np.testing.assert_allclose(ad.proto[0].numpy(), g[f"proto{s + 1}"], rtol=1e-3, atol=1e-4)
