@@ -78,14 +78,15 @@ int onda_conv2d_fwd_bf3(const float* x, const void* w3, float* y, const float* s
  * sums of dy[m][n] * x[pix(m,tap)][c]  (autograd of F.conv2d w.r.t. weight).  Then
  * onda_wgrad_reduce sums the slabs in a fixed order (deterministic) into the OIHW
  * gradient dw[Cout_real][Cin_real][kh][kw] (flat_k: stem layout where the packed K index is
- * tap*Cin_real + c). */
+ * tap*Cin_real + c); accumulate != 0 adds into dw (gradient accumulation over the source and
+ * target backward passes of one step without a separate add pass). */
 int onda_conv2d_wgrad(const float* x, const float* dy, float* slabs, int lddy, int splitk,
                       const OndaConv* c, onda_stream_t s);
 /* the same slabs from the split-bf16 evaluation (csrc/conv_bf3.hip) */
 int onda_conv2d_wgrad_bf3(const float* x, const float* dy, float* slabs, int lddy, int splitk,
                           const OndaConv* c, onda_stream_t s);
 int onda_wgrad_reduce(const float* slabs, float* dw, int splitk, int Cout, int taps, int Cin,
-                      int Cout_real, int Cin_real, int flat_k, onda_stream_t s);
+                      int Cout_real, int Cin_real, int flat_k, int accumulate, onda_stream_t s);
 
 /* OIHW -> kernel layouts.  fwd: dst[n][tap*Cin_real + c] rows of length Kp (zero padded),
  * Cout_pad rows.  dgrad: dst[c][taps-1-tap][n] with rows of Cout_pad, for stride-1 convs

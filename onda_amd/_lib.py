@@ -36,7 +36,7 @@ SIGNATURES = {
     "onda_conv2d_fwd_bf3": (I, [P, P, P, P, P, P, P, P, POINTER(OndaConv), P]),
     "onda_conv2d_wgrad": (I, [P, P, P, I, I, POINTER(OndaConv), P]),
     "onda_conv2d_wgrad_bf3": (I, [P, P, P, I, I, POINTER(OndaConv), P]),
-    "onda_wgrad_reduce": (I, [P, P, I, I, I, I, I, I, I, P]),
+    "onda_wgrad_reduce": (I, [P, P, I, I, I, I, I, I, I, I, P]),
     "onda_pack_weight_fwd": (I, [P, P, I, I, I, I, I, P]),
     "onda_pack_weight_dgrad": (I, [P, P, I, I, I, I, P]),
     "onda_stem_im2col": (I, [P, P, I, I, I, I, I, I, P]),

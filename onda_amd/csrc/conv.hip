@@ -408,7 +408,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK a) {
 }
 
 __global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw, int splitk, int Cout,
-                                    int taps, int Cin, int Cout_real, int Cin_real, int flat_k) {
+                                    int taps, int Cin, int Cout_real, int Cin_real, int flat_k, int accumulate) {
   const size_t total = (size_t)Cout * taps * Cin;
   const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= total) return;
@@ -421,9 +421,13 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, float* __re
   if (n >= Cout_real) return;
   if (flat_k > 0) {  // stem: packed K index = tap7*Cin_real + c3, OIHW = [n][c3][tap7]
     const int tap7 = cc / Cin_real, c3 = cc - tap7 * Cin_real;
-    if (tap7 < flat_k) dw[((size_t)n * Cin_real + c3) * flat_k + tap7] = s;
+    if (tap7 < flat_k) {
+      float* d = dw + ((size_t)n * Cin_real + c3) * flat_k + tap7;
+      *d = accumulate ? *d + s : s;
+    }
   } else if (cc < Cin_real) {
-    dw[((size_t)n * Cin_real + cc) * taps + tap] = s;
+    float* d = dw + ((size_t)n * Cin_real + cc) * taps + tap;
+    *d = accumulate ? *d + s : s;
   }
 }
 
@@ -602,11 +606,11 @@ int onda_conv2d_wgrad(const float* x, const float* dy, float* slabs, int lddy, i
 }
 
 int onda_wgrad_reduce(const float* slabs, float* dw, int splitk, int Cout, int taps, int Cin, int Cout_real,
-                      int Cin_real, int flat_k, onda_stream_t s) {
+                      int Cin_real, int flat_k, int accumulate, onda_stream_t s) {
   ONDA_REQUIRE(slabs && dw && splitk >= 1);
   const size_t total = (size_t)Cout * taps * Cin;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ONDA_STREAM(s), slabs,
-                     dw, splitk, Cout, taps, Cin, Cout_real, Cin_real, flat_k);
+                     dw, splitk, Cout, taps, Cin, Cout_real, Cin_real, flat_k, accumulate);
   return ONDA_LAUNCH_RESULT();
 }
 

@@ -195,8 +195,9 @@ def _wgrad_splitk(M, cout, cin, taps):
     return best
 
 
-def conv_wgrad(x, dy, k, stride, dil, pad, cout_real, cin_real, flat_k=0):
-    """Weight gradient in OIHW.  x NHWC input of the conv, dy NHWC output gradient."""
+def conv_wgrad(x, dy, k, stride, dil, pad, cout_real, cin_real, flat_k=0, into=None):
+    """Weight gradient in OIHW.  x NHWC input of the conv, dy NHWC output gradient.  With `into`
+    (an existing contiguous gradient tensor) the result is ADDED to it and None is returned."""
     B, Hi, Wi, Cin = x.shape
     _, Ho, Wo, Co = dy.shape
     taps = k * k
@@ -208,12 +209,24 @@ def conv_wgrad(x, dy, k, stride, dil, pad, cout_real, cin_real, flat_k=0):
     _launch("conv_wgrad%s_kernel<%s>" % ("_bf3" if bf3 else "", "128,128" if (Co > 64 and Cin > 64) else "64,64"),
             2.0 * M * Co * taps * Cin, "onda_conv2d_wgrad_bf3" if bf3 else "onda_conv2d_wgrad", _p(x), _p(dy), _p(slabs), nhwc_ld(dy), sk, byref(d), _stream(),
             tag=("wgrad", M, Co, Cin, k, stride, dil, sk))
+    if into is not None:
+        call("onda_wgrad_reduce", _p(slabs), _p(into), sk, Co, taps, Cin, cout_real, cin_real, flat_k, 1, _stream())
+        return None
     if flat_k:
         dw = torch.empty(cout_real, cin_real, 7, 7, device=x.device, dtype=torch.float32)
     else:
         dw = torch.empty(cout_real, cin_real, k, k, device=x.device, dtype=torch.float32)
-    call("onda_wgrad_reduce", _p(slabs), _p(dw), sk, Co, taps, Cin, cout_real, cin_real, flat_k, _stream())
+    call("onda_wgrad_reduce", _p(slabs), _p(dw), sk, Co, taps, Cin, cout_real, cin_real, flat_k, 0, _stream())
     return dw
+
+
+def _accumulate_target(weight):
+    """The parameter's existing .grad if the weight gradient can be added to it in place (second
+    backward of a step): saves the separate accumulation pass autograd would run."""
+    g = weight.grad
+    if g is not None and g.is_contiguous() and g.dtype == torch.float32 and g.shape == weight.shape:
+        return g
+    return None
 
 
 def colsum(x, y=None, alpha=1.0, per_image=False):
@@ -265,6 +278,7 @@ class Conv2dFn(torch.autograd.Function):
         wp = cache.get_fwd(weight, cout_pad)
         y, stats, _tiles = conv_forward(x, wp, k, stride, dil, pad, co, shift=_pad_vec(bias, co), want_stats=want_stats)
         ctx.save_for_backward(x, weight)
+        ctx.weight_param = weight  # the Parameter itself: its .grad is the accumulation target
         ctx.cache, ctx.geom, ctx.has_bias = cache, (k, stride, dil, pad, cout, cin, cout_pad), bias is not None
         if want_stats:
             ctx.mark_non_differentiable(stats)
@@ -280,7 +294,7 @@ class Conv2dFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = conv_dgrad(dy, ctx.cache.get_dgrad(weight, cout_pad), k, stride, dil, pad, cin, x.shape[1:3])
         if ctx.needs_input_grad[1]:
-            dw = conv_wgrad(x, dy, k, stride, dil, pad, cout, cin)
+            dw = conv_wgrad(x, dy, k, stride, dil, pad, cout, cin, into=_accumulate_target(ctx.weight_param))
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = colsum(dy)[:cout]
         return dx, dw, db, None, None, None, None, None, None
@@ -308,7 +322,7 @@ class StemConvFn(torch.autograd.Function):
         wp = cache.get_fwd(weight, None, STEM_K)
         y, stats, _ = conv_forward(col, wp, 1, 1, 1, 0, weight.shape[0], want_stats=want_stats)
         ctx.save_for_backward(col)  # dropped again by autograd when no graph is being recorded
-        ctx.cout = weight.shape[0]
+        ctx.cout, ctx.weight = weight.shape[0], weight
         if want_stats:
             ctx.mark_non_differentiable(stats)
             return y, stats
@@ -317,7 +331,7 @@ class StemConvFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy, _dstats):
         (col,) = ctx.saved_tensors
-        dw = conv_wgrad(col, as_nhwc(dy), 1, 1, 1, 0, ctx.cout, 3, flat_k=49)
+        dw = conv_wgrad(col, as_nhwc(dy), 1, 1, 1, 0, ctx.cout, 3, flat_k=49, into=_accumulate_target(ctx.weight))
         return None, dw, None, None
 
 
