@@ -12,6 +12,8 @@
 // VALU on their way into LDS.  LDS holds the three limb planes of both operand tiles
 // ((128+128) rows x 32 k x 3 limbs, rows padded to 80 B: conflict-free ds_read_b128), single
 // stage with register prefetch, 61.4 KB -> two workgroups per CU.
+#include <cstdlib>
+
 #include "conv_common.h"
 
 namespace {
@@ -220,6 +222,194 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_bf3_kernel(const ConvK a, uns
       continue;
     }
     __syncthreads();  // all waves are past their last LDS read before the statistics reuse it
+    conv_epilogue<BM, BN, TM, TN, WAVES_M>(a, acc, reinterpret_cast<float*>(lds), tile_m, m0, n0, wm, wn, li, lh);
+  }
+}
+
+// ---- forward / data gradient, weight limbs by LDS-DMA ------------------------------------------------
+// Same contraction as conv_fwd_bf3_kernel, but the pre-split weight tile never passes through
+// VGPRs: each wave issues `buffer_load_dwordx4 ... lds` (1 KiB per instruction, lane l -> LDS base
+// + 16 l) into a double-buffered, UNPADDED [3][BN][64 B] image one K-step ahead.  The image is
+// lane-linear, so the bank-conflict fix is an XOR on the SOURCE side: LDS slot (row, c') holds
+// data chunk c' ^ ((row >> 2) & 3), and the fragment read applies the same involution (16 rows of
+// a ds_read_b128 lane group then hit 16 distinct 16-byte bank slots).  The VGPR -> LDS store path
+// (the slow side of the LDS) carries only the activation limbs.  79.9 KB LDS, 2 workgroups / CU.
+template <int BM, int BN, bool SK>
+__global__ __launch_bounds__(256, 2) void conv_fwd_bf3_dma_kernel(const ConvK a, unsigned limb_stride,
+                                                                   unsigned x_bytes, unsigned w_bytes) {
+  constexpr int WAVES_M = 2, WAVES_N = 2;
+  constexpr int TM = BM / (32 * WAVES_M), TN = BN / (32 * WAVES_N);
+  constexpr int AL = BM / 32;
+  constexpr int PLANE_A = BM * ROWB;       // activation limb plane, rows padded to 80 B
+  constexpr int PLANE_B = BN * 64;         // weight limb plane, 64-byte rows, source-swizzled
+  constexpr int A_BYTES = 3 * PLANE_A, B_STAGE = 3 * PLANE_B;
+  constexpr int CHUNKS = BN / 16;          // 1-KiB DMA pieces per limb plane
+  constexpr int DPW = 3 * CHUNKS / 4;      // DMA instructions per wave per K-step
+  __shared__ __attribute__((aligned(16))) unsigned char lds[A_BYTES + 2 * B_STAGE];
+
+  const OndaConv& c = a.c;
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+
+  const int nblk = gridDim.x, bid = blockIdx.x;
+  const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
+  const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  const int KT = a.taps * a.kcper;
+  const int tiles_all = a.tilesM * a.tilesN;
+  const int tiles_dp = SK ? a.tiles_dp : tiles_all;
+  const long long U = (long long)(tiles_all - tiles_dp) * KT;
+  long long u = SK ? swz * U / nblk : 0;
+  const long long u_begin = u;
+  const long long u_end = SK ? (swz + 1) * U / nblk : 0;
+  int dp_tile = swz;
+  const int ccol = (t & 7) * 4, rbase = t >> 3;
+  const int wstride = a.taps * c.Cin;
+  const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, x_bytes), rw = make_rsrc(a.w, w_bytes);
+
+  while (dp_tile < tiles_dp || u < u_end) {
+    const bool dp = dp_tile < tiles_dp;
+    const int tile = dp ? dp_tile : tiles_dp + (int)(u / KT);
+    const int k_begin = dp ? 0 : (int)(u - (long long)(tile - tiles_dp) * KT);
+    const int k_end = dp ? KT : (int)min((long long)KT, k_begin + (u_end - u));
+    const int tile_n = tile % a.tilesN, tile_m = tile / a.tilesN;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    int hi0[AL], wi0[AL], bH[AL];
+#pragma unroll
+    for (int i = 0; i < AL; ++i) {
+      const int m = m0 + rbase + 32 * i;
+      const bool vm = m < a.M;
+      const int mm = vm ? m : 0;
+      const int wo = mm % c.Wo, tq = mm / c.Wo;
+      const int ho = tq % c.Ho, b = tq / c.Ho;
+      hi0[i] = vm ? ho * c.stride - c.pad : -(1 << 28);
+      wi0[i] = wo * c.stride - c.pad;
+      bH[i] = b * c.Hi;
+    }
+    // this wave's DMA pieces: piece p = wave*DPW + d -> limb p / CHUNKS, 1-KiB chunk p % CHUNKS;
+    // lane -> LDS slot (row = chunk*16 + lane/4, c' = lane & 3) <- data chunk c' ^ ((row>>2)&3)
+    unsigned dofs[DPW];
+#pragma unroll
+    for (int d = 0; d < DPW; ++d) {
+      const int p = wave * DPW + d;
+      const int l = p / CHUNKS, j = p % CHUNKS;
+      const int row = j * 16 + (lane >> 2), cq = (lane & 3) ^ ((row >> 2) & 3);
+      const int n = n0 + row;
+      dofs[d] = n < c.Cout ? (l * limb_stride + (unsigned)n * wstride) * 2u + cq * 16u : OOB;
+    }
+
+    unsigned aofs[AL];
+    f32x4 ar[AL];
+    int tap = k_begin / a.kcper, c0 = (k_begin - tap * a.kcper) * BK;
+    auto set_tap = [&](int tp) {
+      const int rr = tp / c.kw, ss = tp - rr * c.kw;
+#pragma unroll
+      for (int i = 0; i < AL; ++i) {
+        const int hi = hi0[i] + rr * c.dil, wi = wi0[i] + ss * c.dil;
+        const bool ok = (unsigned)hi < (unsigned)c.Hi && (unsigned)wi < (unsigned)c.Wi;
+        aofs[i] = ok ? (unsigned)(((bH[i] + hi) * c.Wi + wi) * c.ldx + ccol) * 4u : OOB;
+      }
+    };
+    auto gload_a = [&]() {
+      const int sa = c0 * 4;
+#pragma unroll
+      for (int i = 0; i < AL; ++i)
+        ar[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, aofs[i], sa, 0));
+    };
+    auto dma_b = [&](int stage) {
+      const int sw = (tap * c.Cin + c0) * 2;
+#pragma unroll
+      for (int d = 0; d < DPW; ++d) {
+        const int p = wave * DPW + d;
+        const int l = p / CHUNKS, j = p % CHUNKS;
+        unsigned char* dst = lds + A_BYTES + stage * B_STAGE + l * PLANE_B + j * 1024;
+#if defined(__HIP_DEVICE_COMPILE__)  // (the host pass drops the whole kernel stub if it sees this cast in a lambda)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)dst, 16, dofs[d], sw, 0, 0);
+#else
+        (void)dst;
+        (void)sw;
+#endif
+      }
+    };
+    auto sstore_a = [&]() {
+#pragma unroll
+      for (int i = 0; i < AL; ++i) {
+        u32x2 l1, l2, l3;
+        split3(ar[i], l1, l2, l3);
+        const int off = (rbase + 32 * i) * ROWB + ccol * 2;
+        *reinterpret_cast<u32x2*>(lds + 0 * PLANE_A + off) = l1;
+        *reinterpret_cast<u32x2*>(lds + 1 * PLANE_A + off) = l2;
+        *reinterpret_cast<u32x2*>(lds + 2 * PLANE_A + off) = l3;
+      }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    __syncthreads();  // the previous segment's readers are done with every LDS region
+    set_tap(tap);
+    gload_a();
+    dma_b(0);
+    int cur = 0;
+    for (int kt = k_begin; kt < k_end; ++kt) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's A rows and weight DMA have landed
+      __syncthreads();                                   // ... and everybody else's; A image is free
+      sstore_a();
+      __syncthreads();
+      if (kt + 1 < k_end) {
+        c0 += BK;
+        if (c0 == c.Cin) {
+          c0 = 0;
+          ++tap;
+          set_tap(tap);
+        }
+        gload_a();
+        dma_b(cur ^ 1);  // the stage read one step ago; all waves are past that compute
+      }
+      const unsigned char* Ab = lds + (wm * TM * 32 + li) * ROWB + lh * 16;
+      const unsigned char* Bst = lds + A_BYTES + cur * B_STAGE;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        // A limbs stay in registers; B limbs stream 3 -> 2 -> 1 (smallest products first)
+        bf16x8 af[TM][3];
+#pragma unroll
+        for (int l = 0; l < 3; ++l)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+            af[i][l] = *reinterpret_cast<const bf16x8*>(Ab + l * PLANE_A + i * 32 * ROWB + s * 32);
+#pragma unroll
+        for (int l = 2; l >= 0; --l) {
+          bf16x8 bf[TN];
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const int row = wn * TN * 32 + j * 32 + li;
+            bf[j] = *reinterpret_cast<const bf16x8*>(Bst + l * PLANE_B + row * 64 + (((2 * s + lh) ^ ((row >> 2) & 3)) << 4));
+          }
+#pragma unroll
+          for (int la = 2 - l; la >= 0; --la)  // a_{la+1} * b_{l+1} with la + l <= 2
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+              for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][la], bf[j], acc[i][j], 0, 0, 0);
+        }
+      }
+      cur ^= 1;
+    }
+
+    if (dp) dp_tile += nblk; else u += k_end - k_begin;
+    if (SK && (k_begin != 0 || k_end != KT)) {
+      float* slot = a.ws + ((size_t)swz * 2 + (u - (k_end - k_begin) == u_begin ? 0 : 1)) * (BM * BN);
+      conv_store_partial<BN, TM, TN>(slot, acc, wm, wn, li, lh);
+      continue;
+    }
+    __syncthreads();
     conv_epilogue<BM, BN, TM, TN, WAVES_M>(a, acc, reinterpret_cast<float*>(lds), tile_m, m0, n0, wm, wn, li, lh);
   }
 }
@@ -453,6 +643,22 @@ int onda_conv2d_fwd_bf3(const float* x, const void* w3, float* y, const float* s
     }
   }
   hipStream_t st = ONDA_STREAM(s);
+  // ONDA_BF3_DMA=0 selects the older variant that stages the weight limbs through VGPRs
+  static const int use_dma = [] { const char* e = getenv("ONDA_BF3_DMA"); return e ? atoi(e) : 1; }();
+  if (use_dma) {
+    if (balanced) {
+      if (wide)
+        hipLaunchKernelGGL((conv_fwd_bf3_dma_kernel<128, 128, true>), dim3(G), dim3(256), 0, st, k, limb_stride, x_bytes, w_bytes);
+      else
+        hipLaunchKernelGGL((conv_fwd_bf3_dma_kernel<128, 64, true>), dim3(G), dim3(256), 0, st, k, limb_stride, x_bytes, w_bytes);
+      return conv_launch_fixup(k, G, wide, st);
+    }
+    if (wide)
+      hipLaunchKernelGGL((conv_fwd_bf3_dma_kernel<128, 128, false>), dim3(tiles), dim3(256), 0, st, k, limb_stride, x_bytes, w_bytes);
+    else
+      hipLaunchKernelGGL((conv_fwd_bf3_dma_kernel<128, 64, false>), dim3(tiles), dim3(256), 0, st, k, limb_stride, x_bytes, w_bytes);
+    return ONDA_LAUNCH_RESULT();
+  }
   if (balanced) {
     if (wide)
       hipLaunchKernelGGL((conv_fwd_bf3_kernel<128, 128, true>), dim3(G), dim3(256), 0, st, k, limb_stride, x_bytes, w_bytes);
