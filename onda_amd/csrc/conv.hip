@@ -167,10 +167,10 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvK a) {
   if (SK && (k_begin != 0 || k_end != KT)) {
     // partial tile: raw accumulators to this block's slot (0 = its first segment, 1 = its last)
     float* slot = a.ws + ((size_t)swz * 2 + (u - (k_end - k_begin) == u_begin ? 0 : 1)) * (BM * BN);
-    conv_store_partial<BN, TM, TN>(slot, acc, wm, wn, li, lh);
+    conv_store_partial<BN, TM, TN>(slot, acc, wm, wn, lane);
     continue;
   }
-  conv_epilogue<BM, BN, TM, TN, WAVES_M>(a, acc, lds, tile_m, m0, n0, wm, wn, li, lh);
+  conv_epilogue<BM, BN, TM, TN, WAVES_M>(a, acc, lds, tile_m, m0, n0, wm, wn, lane);
   }  // tile / segment loop
 }
 

@@ -218,11 +218,11 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_bf3_kernel(const ConvK a, uns
     if (dp) dp_tile += nblk; else u += k_end - k_begin;
     if (SK && (k_begin != 0 || k_end != KT)) {
       float* slot = a.ws + ((size_t)swz * 2 + (u - (k_end - k_begin) == u_begin ? 0 : 1)) * (BM * BN);
-      conv_store_partial<BN, TM, TN>(slot, acc, wm, wn, li, lh);
+      conv_store_partial<BN, TM, TN>(slot, acc, wm, wn, lane);
       continue;
     }
     __syncthreads();  // all waves are past their last LDS read before the statistics reuse it
-    conv_epilogue<BM, BN, TM, TN, WAVES_M>(a, acc, reinterpret_cast<float*>(lds), tile_m, m0, n0, wm, wn, li, lh);
+    conv_epilogue<BM, BN, TM, TN, WAVES_M>(a, acc, reinterpret_cast<float*>(lds), tile_m, m0, n0, wm, wn, lane);
   }
 }
 
@@ -406,11 +406,209 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_bf3_dma_kernel(const ConvK a,
     if (dp) dp_tile += nblk; else u += k_end - k_begin;
     if (SK && (k_begin != 0 || k_end != KT)) {
       float* slot = a.ws + ((size_t)swz * 2 + (u - (k_end - k_begin) == u_begin ? 0 : 1)) * (BM * BN);
-      conv_store_partial<BN, TM, TN>(slot, acc, wm, wn, li, lh);
+      conv_store_partial<BN, TM, TN>(slot, acc, wm, wn, lane);
       continue;
     }
     __syncthreads();
-    conv_epilogue<BM, BN, TM, TN, WAVES_M>(a, acc, reinterpret_cast<float*>(lds), tile_m, m0, n0, wm, wn, li, lh);
+    conv_epilogue<BM, BN, TM, TN, WAVES_M>(a, acc, reinterpret_cast<float*>(lds), tile_m, m0, n0, wm, wn, lane);
+  }
+}
+
+// ---- forward / data gradient on v_mfma_f32_16x16x32_bf16 ---------------------------------------------
+// The DMA kernel above re-tiled for the 16x16x32 MFMA shape (same 64 x 64 output per wave, same
+// LDS bytes and MFMA cycles per K-step; the chip holds a higher clock on this shape under load,
+// MI355X_MICROARCH.md "DVFS give-back" item 7).  One MFMA spans the whole BK = 32 step, lane l
+// reads row l & 15, 16-byte chunk l >> 4.  Both images are unpadded 64-byte rows with the chunk
+// index XOR-ed by swz_row(row), which makes every ds_read_b128 lane group
+// ({0-3, 12-15} chunk c with {4-11} chunk c + 1, and vice versa) hit 16 distinct 16-byte slots.
+// 73.7 KB LDS, 2 workgroups / CU.
+// (the (row >> 1) & 1 term additionally spreads the 8 consecutive rows of a ds_write_b128 lane group
+// of the weight-gradient staging over all 8 slots of the 128-byte store line)
+__device__ __forceinline__ int swz_row(int row) {
+  const int q = (row >> 2) & 3;
+  return q ^ ((q & 1) << 1) ^ ((row >> 1) & 1);
+}
+
+// (original DMA-kernel notes) the pre-split weight tile never passes through
+// VGPRs: each wave issues `buffer_load_dwordx4 ... lds` (1 KiB per instruction, lane l -> LDS base
+// + 16 l) into a double-buffered, UNPADDED [3][BN][64 B] image one K-step ahead.  The image is
+// lane-linear, so the bank-conflict fix is an XOR on the SOURCE side: LDS slot (row, c') holds
+// data chunk c' ^ ((row >> 2) & 3), and the fragment read applies the same involution (16 rows of
+// a ds_read_b128 lane group then hit 16 distinct 16-byte bank slots).  The VGPR -> LDS store path
+// (the slow side of the LDS) carries only the activation limbs.  79.9 KB LDS, 2 workgroups / CU.
+template <int BM, int BN, bool SK>
+__global__ __launch_bounds__(256, 2) void conv_fwd_bf3_m16_kernel(const ConvK a, unsigned limb_stride,
+                                                                   unsigned x_bytes, unsigned w_bytes) {
+  constexpr int WAVES_M = 2, WAVES_N = 2;
+  constexpr int MF = 16;
+  constexpr int TM = BM / (MF * WAVES_M), TN = BN / (MF * WAVES_N);
+  constexpr int AL = BM / 32;
+  constexpr int PLANE_A = BM * 64;         // activation limb plane, 64-byte rows, swizzled
+  constexpr int PLANE_B = BN * 64;         // weight limb plane, 64-byte rows, source-swizzled
+  constexpr int A_BYTES = 3 * PLANE_A, B_STAGE = 3 * PLANE_B;
+  constexpr int CHUNKS = BN / 16;          // 1-KiB DMA pieces per limb plane
+  constexpr int DPW = 3 * CHUNKS / 4;      // DMA instructions per wave per K-step
+  __shared__ __attribute__((aligned(16))) unsigned char lds[A_BYTES + 2 * B_STAGE];
+
+  const OndaConv& c = a.c;
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+
+  const int nblk = gridDim.x, bid = blockIdx.x;
+  const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
+  const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  const int KT = a.taps * a.kcper;
+  const int tiles_all = a.tilesM * a.tilesN;
+  const int tiles_dp = SK ? a.tiles_dp : tiles_all;
+  const long long U = (long long)(tiles_all - tiles_dp) * KT;
+  long long u = SK ? swz * U / nblk : 0;
+  const long long u_begin = u;
+  const long long u_end = SK ? (swz + 1) * U / nblk : 0;
+  int dp_tile = swz;
+  const int ccol = (t & 7) * 4, rbase = t >> 3;
+  const int wstride = a.taps * c.Cin;
+  const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, x_bytes), rw = make_rsrc(a.w, w_bytes);
+
+  while (dp_tile < tiles_dp || u < u_end) {
+    const bool dp = dp_tile < tiles_dp;
+    const int tile = dp ? dp_tile : tiles_dp + (int)(u / KT);
+    const int k_begin = dp ? 0 : (int)(u - (long long)(tile - tiles_dp) * KT);
+    const int k_end = dp ? KT : (int)min((long long)KT, k_begin + (u_end - u));
+    const int tile_n = tile % a.tilesN, tile_m = tile / a.tilesN;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    int hi0[AL], wi0[AL], bH[AL];
+#pragma unroll
+    for (int i = 0; i < AL; ++i) {
+      const int m = m0 + rbase + 32 * i;
+      const bool vm = m < a.M;
+      const int mm = vm ? m : 0;
+      const int wo = mm % c.Wo, tq = mm / c.Wo;
+      const int ho = tq % c.Ho, b = tq / c.Ho;
+      hi0[i] = vm ? ho * c.stride - c.pad : -(1 << 28);
+      wi0[i] = wo * c.stride - c.pad;
+      bH[i] = b * c.Hi;
+    }
+    // this wave's DMA pieces: piece p = wave*DPW + d -> limb p / CHUNKS, 1-KiB chunk p % CHUNKS;
+    // lane -> LDS slot (row = chunk*16 + lane/4, c' = lane & 3) <- data chunk c' ^ ((row>>2)&3)
+    unsigned dofs[DPW];
+#pragma unroll
+    for (int d = 0; d < DPW; ++d) {
+      const int p = wave * DPW + d;
+      const int l = p / CHUNKS, j = p % CHUNKS;
+      const int row = j * 16 + (lane >> 2), cq = (lane & 3) ^ swz_row(row);
+      const int n = n0 + row;
+      dofs[d] = n < c.Cout ? (l * limb_stride + (unsigned)n * wstride) * 2u + cq * 16u : OOB;
+    }
+
+    unsigned aofs[AL];
+    f32x4 ar[AL];
+    int tap = k_begin / a.kcper, c0 = (k_begin - tap * a.kcper) * BK;
+    auto set_tap = [&](int tp) {
+      const int rr = tp / c.kw, ss = tp - rr * c.kw;
+#pragma unroll
+      for (int i = 0; i < AL; ++i) {
+        const int hi = hi0[i] + rr * c.dil, wi = wi0[i] + ss * c.dil;
+        const bool ok = (unsigned)hi < (unsigned)c.Hi && (unsigned)wi < (unsigned)c.Wi;
+        aofs[i] = ok ? (unsigned)(((bH[i] + hi) * c.Wi + wi) * c.ldx + ccol) * 4u : OOB;
+      }
+    };
+    auto gload_a = [&]() {
+      const int sa = c0 * 4;
+#pragma unroll
+      for (int i = 0; i < AL; ++i)
+        ar[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, aofs[i], sa, 0));
+    };
+    auto dma_b = [&](int stage) {
+      const int sw = (tap * c.Cin + c0) * 2;
+#pragma unroll
+      for (int d = 0; d < DPW; ++d) {
+        const int p = wave * DPW + d;
+        const int l = p / CHUNKS, j = p % CHUNKS;
+        unsigned char* dst = lds + A_BYTES + stage * B_STAGE + l * PLANE_B + j * 1024;
+#if defined(__HIP_DEVICE_COMPILE__)  // (the host pass drops the whole kernel stub if it sees this cast in a lambda)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)dst, 16, dofs[d], sw, 0, 0);
+#else
+        (void)dst;
+        (void)sw;
+#endif
+      }
+    };
+    auto sstore_a = [&]() {
+#pragma unroll
+      for (int i = 0; i < AL; ++i) {
+        u32x2 l1, l2, l3;
+        split3(ar[i], l1, l2, l3);
+        const int row = rbase + 32 * i;
+        const int off = row * 64 + ((((t & 7) >> 1) ^ swz_row(row)) << 4) + (t & 1) * 8;
+        *reinterpret_cast<u32x2*>(lds + 0 * PLANE_A + off) = l1;
+        *reinterpret_cast<u32x2*>(lds + 1 * PLANE_A + off) = l2;
+        *reinterpret_cast<u32x2*>(lds + 2 * PLANE_A + off) = l3;
+      }
+    };
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
+
+    __syncthreads();  // the previous segment's readers are done with every LDS region
+    set_tap(tap);
+    gload_a();
+    dma_b(0);
+    int cur = 0;
+    for (int kt = k_begin; kt < k_end; ++kt) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's A rows and weight DMA have landed
+      __syncthreads();                                   // ... and everybody else's; A image is free
+      sstore_a();
+      __syncthreads();
+      if (kt + 1 < k_end) {
+        c0 += BK;
+        if (c0 == c.Cin) {
+          c0 = 0;
+          ++tap;
+          set_tap(tap);
+        }
+        gload_a();
+        dma_b(cur ^ 1);  // the stage read one step ago; all waves are past that compute
+      }
+      // lane l: row l & 15 of each 16-row block, data chunk l >> 4 (swizzle is the same for every block)
+      const int frag = (lane & 15) * 64 + (((lane >> 4) ^ swz_row(lane & 15)) << 4);
+      const unsigned char* Ab = lds + wm * TM * MF * 64 + frag;
+      const unsigned char* Bb = lds + A_BYTES + cur * B_STAGE + wn * TN * MF * 64 + frag;
+      // A limbs stay in registers; B limbs stream 3 -> 2 -> 1 (smallest products first)
+      bf16x8 af[TM][3];
+#pragma unroll
+      for (int l = 0; l < 3; ++l)
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[i][l] = *reinterpret_cast<const bf16x8*>(Ab + l * PLANE_A + i * MF * 64);
+#pragma unroll
+      for (int l = 2; l >= 0; --l) {
+        bf16x8 bf[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const bf16x8*>(Bb + l * PLANE_B + j * MF * 64);
+#pragma unroll
+        for (int la = 2 - l; la >= 0; --la)  // a_{la+1} * b_{l+1} with la + l <= 2
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][la], bf[j], acc[i][j], 0, 0, 0);
+      }
+      cur ^= 1;
+    }
+
+    if (dp) dp_tile += nblk; else u += k_end - k_begin;
+    if (SK && (k_begin != 0 || k_end != KT)) {
+      float* slot = a.ws + ((size_t)swz * 2 + (u - (k_end - k_begin) == u_begin ? 0 : 1)) * (BM * BN);
+      conv_store_partial<BN, TM, TN, MF>(slot, acc, wm, wn, lane);
+      continue;
+    }
+    __syncthreads();
+    conv_epilogue<BM, BN, TM, TN, WAVES_M, MF>(a, acc, reinterpret_cast<float*>(lds), tile_m, m0, n0, wm, wn, lane);
   }
 }
 
@@ -563,6 +761,175 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf3_kernel(const WgradK a, 
   }
 }
 
+// LDS image of the 16x16x32 weight-gradient kernel: 64-byte rows; inside each 16-row block the
+// row index is transposed as a 4 x 4 matrix and the 16-byte chunk index is XOR-ed with row bits
+// {0,1} and {3,4}.  Conflict-free for the ds_read_b128 fragment read (lane l: row l & 15, chunk
+// l >> 4) AND for both ds_write_b128 staging patterns (8 lanes on rows 4l + j, or on 8
+// consecutive rows): SQ_LDS_BANK_CONFLICT 0.32 -> 0 of the LDS-active cycles.
+__device__ __forceinline__ int wg_slot(int row, int chunk) {
+  const int phys = (row & ~15) | ((row & 3) << 2) | ((row >> 2) & 3);
+  return phys * 64 + ((chunk ^ (row & 3) ^ ((row >> 3) & 3)) << 4);
+}
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_bf3_m16_kernel(const WgradK a, unsigned x_bytes, unsigned dy_bytes) {
+  constexpr int WAVES_N = 2;
+  constexpr int MF = 16;
+  constexpr int TM = BM / (2 * MF), TN = BN / (2 * MF);
+  constexpr int ROWS = BM + BN;
+  constexpr int PLANE = ROWS * 64;  // 64-byte rows, placed by wg_slot()
+  constexpr int CPT = (BM > BN ? BM : BN) / 32;  // channel columns per staging thread
+  static_assert(BM == BN, "one staging half per operand");
+  __shared__ __attribute__((aligned(16))) unsigned char lds[3 * PLANE];
+  __shared__ unsigned pofs[32];
+
+  const OndaConv& c = a.c;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+
+  int bid = blockIdx.x;
+  const int tile_c = bid % a.tilesC;
+  bid /= a.tilesC;
+  const int tap = bid % a.taps;
+  bid /= a.taps;
+  const int tile_n = bid % a.tilesN;
+  const int ks = bid / a.tilesN;
+  const int n0 = tile_n * BM, c0 = tile_c * BN;
+  const int mbeg = ks * a.mchunk;
+  const int mend = min(a.M, mbeg + a.mchunk);
+  const int KT = mend > mbeg ? (mend - mbeg + BK - 1) / BK : 0;
+  const int rr = tap / c.kw, ss = tap - rr * c.kw;
+  const int dh = rr * c.dil - c.pad, dw = ss * c.dil - c.pad;
+
+  // staging role of this thread
+  // the role is wave-uniform; readfirstlane tells the compiler so (descriptor and scalar offset stay
+  // in SGPRs instead of a per-lane "waterfall" loop around every buffer load)
+  const bool is_x = __builtin_amdgcn_readfirstlane(t >> 7) != 0;
+  const int kgroup = (t >> 5) & 3;  // 8 pixels kgroup*8 .. +7
+  const __amdgpu_buffer_rsrc_t rs = is_x ? make_rsrc(a.x, x_bytes) : make_rsrc(a.dy, dy_bytes);
+  const int chmax = is_x ? c.Cin : c.Cout;
+
+  // byte offset (OOB = zero row) of pixel m of the X operand for this tap
+  auto pixel_offset = [&](int m) -> unsigned {
+    if (m >= mend) return OOB;
+    const int wo = m % c.Wo, tq = m / c.Wo;
+    const int ho = tq % c.Ho, b = tq / c.Ho;
+    const int hi = ho * c.stride + dh, wi = wo * c.stride + dw;
+    if ((unsigned)hi >= (unsigned)c.Hi || (unsigned)wi >= (unsigned)c.Wi) return OOB;
+    return (unsigned)(((b * c.Hi + hi) * c.Wi + wi) * c.ldx) * 4u;
+  };
+  // row (bytes, OOB past the chunk) of pixel slot q = kgroup*8 + p of K-step mb
+  auto row_offset = [&](int mb, int q) -> unsigned {
+    return is_x ? pofs[q] : (mb + q < mend ? (unsigned)(q * a.lddy) * 4u : OOB);
+  };
+
+  // WIDE: a thread owns 4 consecutive channels x 8 pixels, fetched as one 16-byte load per pixel
+  // (32 lanes = 512 contiguous bytes of a pixel row); the 4 x 8 register block is read out
+  // column-wise, so the transposition is free.  Otherwise (64-wide tiles): 2 channel columns of
+  // scalar loads as in conv_wgrad_bf3_kernel.
+  constexpr bool WIDE = BM == 128;
+  constexpr int NV = WIDE ? 8 : CPT * 2;
+  f32x4 v[NV];
+  const int cl = t & 31;
+  const int chb = (is_x ? c0 : n0) + (WIDE ? 4 * cl : cl);
+  unsigned chofs[WIDE ? 1 : CPT];
+  if constexpr (WIDE) {
+    chofs[0] = chb < chmax ? (unsigned)chb * 4u : CH_OOB;
+  } else {
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) chofs[j] = chb + 32 * j < chmax ? (unsigned)(chb + 32 * j) * 4u : CH_OOB;
+  }
+  auto gload = [&](int mb) {
+    const int so = is_x ? 0 : mb * a.lddy * 4;  // dY: the scalar part mb*lddy rides in the soffset
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      const unsigned row = row_offset(mb, kgroup * 8 + p);
+      if constexpr (WIDE) {
+        v[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, row + chofs[0], so, 0));
+      } else {
+#pragma unroll
+        for (int j = 0; j < CPT; ++j)
+          v[2 * j + (p >> 2)][p & 3] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, row + chofs[j], so, 0));
+      }
+    }
+  };
+  auto sstore = [&]() {
+#pragma unroll
+    for (int j = 0; j < (WIDE ? 4 : CPT); ++j) {
+      u32x2 a1, a2, a3, b1, b2, b3;
+      if constexpr (WIDE) {
+        split3(f32x4{v[0][j], v[1][j], v[2][j], v[3][j]}, a1, a2, a3);
+        split3(f32x4{v[4][j], v[5][j], v[6][j], v[7][j]}, b1, b2, b3);
+      } else {
+        split3(v[2 * j], a1, a2, a3);
+        split3(v[2 * j + 1], b1, b2, b3);
+      }
+      const int row = (is_x ? BM : 0) + (WIDE ? 4 * cl + j : cl + 32 * j);
+      unsigned char* dst = lds + wg_slot(row, kgroup);
+      *reinterpret_cast<u32x4*>(dst + 0 * PLANE) = u32x4{a1[0], a1[1], b1[0], b1[1]};
+      *reinterpret_cast<u32x4*>(dst + 1 * PLANE) = u32x4{a2[0], a2[1], b2[0], b2[1]};
+      *reinterpret_cast<u32x4*>(dst + 2 * PLANE) = u32x4{a3[0], a3[1], b3[0], b3[1]};
+    }
+  };
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
+
+  if (KT > 0) {
+    if (t < 32) pofs[t] = pixel_offset(mbeg + t);
+    __syncthreads();
+    gload(mbeg);
+  }
+  for (int kt = 0; kt < KT; ++kt) {
+    __syncthreads();  // LDS image and pofs are free
+    sstore();
+    if (t < 32 && kt + 1 < KT) pofs[t] = pixel_offset(mbeg + (kt + 1) * BK + t);
+    __syncthreads();
+    if (kt + 1 < KT) gload(mbeg + (kt + 1) * BK);
+    // odd 16-row blocks (row bit 4) flip chunk bit 1: byte offset ^ 32
+    const int frag = wg_slot(lane & 15, lane >> 4);
+    const unsigned char* Ab = lds + wm * TM * MF * 64;
+    const unsigned char* Bb = lds + (BM + wn * TN * MF) * 64;
+    bf16x8 af[TM][3];
+#pragma unroll
+    for (int l = 0; l < 3; ++l)
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i][l] = *reinterpret_cast<const bf16x8*>(Ab + l * PLANE + i * MF * 64 + (frag ^ ((i & 1) << 5)));
+#pragma unroll
+    for (int l = 2; l >= 0; --l) {
+      bf16x8 bf[TN];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const bf16x8*>(Bb + l * PLANE + j * MF * 64 + (frag ^ ((j & 1) << 5)));
+#pragma unroll
+      for (int la = 2 - l; la >= 0; --la)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][la], bf[j], acc[i][j], 0, 0, 0);
+    }
+  }
+
+#pragma unroll
+  for (int jn = 0; jn < TN; ++jn) {
+    const int cc = c0 + (wn * TN + jn) * MF + (lane & 15);
+    if (cc >= c.Cin) continue;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int n = n0 + (wm * TM + i) * MF + 4 * (lane >> 4) + e;
+        if (n >= c.Cout) continue;
+        a.slabs[(((size_t)ks * c.Cout + n) * a.taps + tap) * c.Cin + cc] = acc[i][jn][e];
+      }
+  }
+}
+
 // OIHW fp32 -> limb planes dst[3][rows_pad][Kp] bf16.  dgrad = 0: row n, k = tap*Cin + c.
 // dgrad = 1: row c, k = tap'*Cout_pad + n with the taps flipped (data-gradient operand).
 __global__ void pack_bf3_kernel(const float* __restrict__ w, __bf16* __restrict__ dst, int Cout, int Cin, int taps,
@@ -644,7 +1011,21 @@ int onda_conv2d_fwd_bf3(const float* x, const void* w3, float* y, const float* s
   }
   hipStream_t st = ONDA_STREAM(s);
   // ONDA_BF3_DMA=0 selects the older variant that stages the weight limbs through VGPRs
-  static const int use_dma = [] { const char* e = getenv("ONDA_BF3_DMA"); return e ? atoi(e) : 1; }();
+  static const int use_dma = [] { const char* e = getenv("ONDA_BF3_DMA"); return e ? atoi(e) : 2; }();
+  if (use_dma == 2) {
+    if (balanced) {
+      if (wide)
+        hipLaunchKernelGGL((conv_fwd_bf3_m16_kernel<128, 128, true>), dim3(G), dim3(256), 0, st, k, limb_stride, x_bytes, w_bytes);
+      else
+        hipLaunchKernelGGL((conv_fwd_bf3_m16_kernel<128, 64, true>), dim3(G), dim3(256), 0, st, k, limb_stride, x_bytes, w_bytes);
+      return conv_launch_fixup(k, G, wide, st);
+    }
+    if (wide)
+      hipLaunchKernelGGL((conv_fwd_bf3_m16_kernel<128, 128, false>), dim3(tiles), dim3(256), 0, st, k, limb_stride, x_bytes, w_bytes);
+    else
+      hipLaunchKernelGGL((conv_fwd_bf3_m16_kernel<128, 64, false>), dim3(tiles), dim3(256), 0, st, k, limb_stride, x_bytes, w_bytes);
+    return ONDA_LAUNCH_RESULT();
+  }
   if (use_dma) {
     if (balanced) {
       if (wide)
@@ -687,6 +1068,23 @@ int onda_conv2d_wgrad_bf3(const float* x, const float* dy, float* slabs, int ldd
   k.splitk = splitk;
   k.mchunk = (int)(((M + splitk - 1) / splitk + 31) / 32 * 32);
   k.taps = c->kh * c->kw;
+  static const int wg16 = [] { const char* e = getenv("ONDA_BF3_WG16"); return e ? atoi(e) : 1; }();
+  if (wg16) {
+    if (c->Cout > 64 && c->Cin > 64) {
+      // 16-byte loads along the channel axis of both operands
+      if (!ONDA_ALIGNED16(x) || !ONDA_ALIGNED16(dy) || (c->ldx & 3) || (lddy & 3)) return ONDA_EALIGN;
+      k.tilesN = (c->Cout + 127) / 128;
+      k.tilesC = (c->Cin + 127) / 128;
+      hipLaunchKernelGGL((conv_wgrad_bf3_m16_kernel<128, 128>), dim3(k.tilesN * k.tilesC * k.taps * splitk), dim3(256), 0,
+                         ONDA_STREAM(s), k, x_bytes, dy_bytes);
+    } else {
+      k.tilesN = (c->Cout + 63) / 64;
+      k.tilesC = (c->Cin + 63) / 64;
+      hipLaunchKernelGGL((conv_wgrad_bf3_m16_kernel<64, 64>), dim3(k.tilesN * k.tilesC * k.taps * splitk), dim3(256), 0,
+                         ONDA_STREAM(s), k, x_bytes, dy_bytes);
+    }
+    return ONDA_LAUNCH_RESULT();
+  }
   if (c->Cout > 64 && c->Cin > 64) {
     k.tilesN = (c->Cout + 127) / 128;
     k.tilesC = (c->Cin + 127) / 128;

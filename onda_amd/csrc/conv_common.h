@@ -1,6 +1,6 @@
 // Shared between the fp32 and the split-bf16 convolution kernels: argument block, the
 // stream-K partial-tile store and the common epilogue (statistics, scale/shift, residual, ReLU,
-// slice / scatter store) for a 4-wave workgroup of 32x32 MFMA accumulator tiles.
+// slice / scatter store) for a 4-wave workgroup of 32x32 or 16x16 MFMA accumulator tiles.
 #pragma once
 #include "common.h"
 
@@ -28,25 +28,46 @@ struct WgradK {
 
 constexpr int BK = 32;
 
+// Accumulator fragment of one MF x MF MFMA tile: which (row, column) of the tile register e of a
+// lane holds (32x32x* and 16x16x* MFMA result layouts).
+template <int MF>
+struct AccTile;
+template <>
+struct AccTile<32> {
+  using T = f32x16;
+  static constexpr int E = 16;
+  static __device__ __forceinline__ int row(int e, int lane) { return (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5); }
+  static __device__ __forceinline__ int col(int lane) { return lane & 31; }
+};
+template <>
+struct AccTile<16> {
+  using T = f32x4;
+  static constexpr int E = 4;
+  static __device__ __forceinline__ int row(int e, int lane) { return 4 * (lane >> 4) + e; }
+  static __device__ __forceinline__ int col(int lane) { return lane & 15; }
+};
+
 // raw accumulators of a partial (stream-K) tile -> slot[BM][BN]
-template <int BN, int TM, int TN>
-__device__ __forceinline__ void conv_store_partial(float* slot, const f32x16 (&acc)[TM][TN], int wm, int wn, int li,
-                                                   int lh) {
+template <int BN, int TM, int TN, int MF = 32>
+__device__ __forceinline__ void conv_store_partial(float* slot, const typename AccTile<MF>::T (&acc)[TM][TN], int wm,
+                                                   int wn, int lane) {
+  using L = AccTile<MF>;
 #pragma unroll
   for (int jn = 0; jn < TN; ++jn)
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int row = wm * TM * 32 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-        slot[row * BN + wn * TN * 32 + jn * 32 + li] = acc[i][jn][e];
+      for (int e = 0; e < L::E; ++e) {
+        const int row = (wm * TM + i) * MF + L::row(e, lane);
+        slot[row * BN + (wn * TN + jn) * MF + L::col(lane)] = acc[i][jn][e];
       }
 }
 
 // `red`: >= WAVES_M*BN*2 floats of LDS that no wave is still reading.
-template <int BM, int BN, int TM, int TN, int WAVES_M>
-__device__ __forceinline__ void conv_epilogue(const ConvK& a, const f32x16 (&acc)[TM][TN], float* red, int tile_m,
-                                              int m0, int n0, int wm, int wn, int li, int lh) {
+template <int BM, int BN, int TM, int TN, int WAVES_M, int MF = 32>
+__device__ __forceinline__ void conv_epilogue(const ConvK& a, const typename AccTile<MF>::T (&acc)[TM][TN],
+                                              float* red, int tile_m, int m0, int n0, int wm, int wn, int lane) {
+  using L = AccTile<MF>;
   const OndaConv& c = a.c;
   const int t = threadIdx.x;
   if (a.stats != nullptr) {
@@ -56,15 +77,18 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& a, const f32x16 (&acc
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
+        for (int e = 0; e < L::E; ++e) {
           const float v = acc[i][jn][e];
           s1 += v;
           s2 += v * v;
         }
-      s1 += __shfl_xor(s1, 32, 64);
-      s2 += __shfl_xor(s2, 32, 64);
-      if (lh == 0) {
-        const int col = wn * TN * 32 + jn * 32 + li;
+#pragma unroll
+      for (int sh = MF; sh < 64; sh <<= 1) {  // lanes holding other rows of the same column
+        s1 += __shfl_xor(s1, sh, 64);
+        s2 += __shfl_xor(s2, sh, 64);
+      }
+      if (lane < MF) {
+        const int col = (wn * TN + jn) * MF + lane;
         red[(wm * BN + col) * 2 + 0] = s1;
         red[(wm * BN + col) * 2 + 1] = s2;
       }
@@ -85,16 +109,15 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& a, const f32x16 (&acc
   const bool plain = (c.out_os == 1 && c.Hf == c.Ho && c.Wf == c.Wo);
 #pragma unroll
   for (int jn = 0; jn < TN; ++jn) {
-    const int n = n0 + wn * TN * 32 + jn * 32 + li;
+    const int n = n0 + (wn * TN + jn) * MF + L::col(lane);
     if (n >= c.Cout) continue;
     const float sc = a.scale ? a.scale[n] : 1.f;
     const float sh = a.shift ? a.shift[n] : 0.f;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int row = (e & 3) + 8 * (e >> 2) + 4 * lh;
-        const int m = m0 + wm * TM * 32 + i * 32 + row;
+      for (int e = 0; e < L::E; ++e) {
+        const int m = m0 + (wm * TM + i) * MF + L::row(e, lane);
         if (m >= a.M) continue;
         float v = acc[i][jn][e] * sc + sh;
         if (a.res) v += a.res[(size_t)m * c.ldr + n];
