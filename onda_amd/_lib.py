@@ -8,7 +8,7 @@ import os
 from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int64, c_void_p
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libonda_hip.so")
+LIB_PATH = os.environ.get("ONDA_LIB_PATH") or os.path.join(HERE, "libonda_hip.so")  # override: diagnostic builds
 
 P = c_void_p  # device pointers travel as integers (tensor.data_ptr())
 I, L, F = c_int, c_int64, c_float

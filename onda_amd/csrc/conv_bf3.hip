@@ -13,6 +13,7 @@
 // ((128+128) rows x 32 k x 3 limbs, rows padded to 80 B: conflict-free ds_read_b128), single
 // stage with register prefetch, 61.4 KB -> two workgroups per CU.
 #include <cstdlib>
+#include <utility>
 
 #include "conv_common.h"
 
@@ -59,6 +60,47 @@ constexpr unsigned CH_OOB = 0x7FFFF000u;  // second addend: row + channel never 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
 }
+
+// LDS-DMA issued as inline assembly.  Through the builtin the compiler tracks the LDS destination
+// and, as every image lives in one __shared__ array, puts an s_waitcnt vmcnt in front of later
+// ds_reads that "may alias" it -- which also waits for the row requests that were issued behind
+// the DMA on purpose.  The kernels below order DMA completion themselves (vmcnt + barrier).
+// lds_addr: byte address in LDS (M0); lane l writes lds_addr + 16 l.
+#pragma clang diagnostic ignored "-Winline-asm"  // m0 is "reserved": nothing else here depends on it
+__device__ __forceinline__ u32x4 raw_rsrc(const void* base, unsigned bytes) {
+  const unsigned long long p = (unsigned long long)base;
+  return u32x4{(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)p),
+               (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(p >> 32) & 0xFFFFu)),
+               (unsigned)__builtin_amdgcn_readfirstlane((int)bytes), 0x00020000u};
+}
+__device__ __forceinline__ void dma16(u32x4 rsrc, unsigned lds_addr, unsigned voff, unsigned soff) {
+  asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff)
+               : "memory", "m0");
+}
+__device__ __forceinline__ unsigned lds_address(const void* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return (unsigned)(size_t)(__attribute__((address_space(3))) const unsigned char*)p;
+#else
+  return 0;
+#endif
+}
+
+// 16-byte buffer load as inline assembly + the wait that makes its result usable.  The compiler
+// does not count asm memory operations, so the kernel that uses these places every vmcnt itself
+// (wait_rows ties the registers to the wait: nothing may read them earlier).
+__device__ __forceinline__ f32x4 bload16(u32x4 rsrc, unsigned voff, unsigned soff) {
+  f32x4 v;
+  asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=&v"(v) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+  return v;
+}
+template <int N>
+__device__ __forceinline__ void wait_rows(f32x4 (&r)[4]) {
+  asm volatile("s_waitcnt vmcnt(%4)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]) : "n"(N) : "memory");
+}
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it would
+// wait for the global loads / LDS-DMA a wave has just put in flight for a LATER step.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 template <int BM, int BN, bool SK>
 __global__ __launch_bounds__(256, 2) void conv_fwd_bf3_kernel(const ConvK a, unsigned limb_stride, unsigned x_bytes,
@@ -555,16 +597,29 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_bf3_m16_kernel(const ConvK a,
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
 
+#ifdef ONDA_BF3_STAMP  // diagnostic build only (tools/stamp_bf3.py): per-phase shader cycles of each wave
+    long long st[6] = {0, 0, 0, 0, 0, 0};
+    long long st0 = __builtin_amdgcn_s_memtime();
+    const long long clk0 = st0, rt0 = wall_clock64();
+#define STAMP(i) { const long long st1 = __builtin_amdgcn_s_memtime(); st[i] += st1 - st0; st0 = st1; }
+#else
+#define STAMP(i)
+#endif
     __syncthreads();  // the previous segment's readers are done with every LDS region
     set_tap(tap);
     gload_a();
     dma_b(0);
     int cur = 0;
+    STAMP(5)
     for (int kt = k_begin; kt < k_end; ++kt) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's A rows and weight DMA have landed
+      STAMP(0)
       __syncthreads();                                   // ... and everybody else's; A image is free
+      STAMP(1)
       sstore_a();
+      STAMP(2)
       __syncthreads();
+      STAMP(3)
       if (kt + 1 < k_end) {
         c0 += BK;
         if (c0 == c.Cin) {
@@ -575,6 +630,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_bf3_m16_kernel(const ConvK a,
         gload_a();
         dma_b(cur ^ 1);  // the stage read one step ago; all waves are past that compute
       }
+      STAMP(4)
       // lane l: row l & 15 of each 16-row block, data chunk l >> 4 (swizzle is the same for every block)
       const int frag = (lane & 15) * 64 + (((lane >> 4) ^ swz_row(lane & 15)) << 4);
       const unsigned char* Ab = lds + wm * TM * MF * 64 + frag;
@@ -599,7 +655,16 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_bf3_m16_kernel(const ConvK a,
               acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][la], bf[j], acc[i][j], 0, 0, 0);
       }
       cur ^= 1;
+      STAMP(5)
     }
+#ifdef ONDA_BF3_STAMP
+    if (lane == 0 && swz < 256)
+      for (int i = 0; i < 6; ++i) a.ws[(swz * 4 + wave) * 8 + i] = (float)st[i];
+    if (lane == 0 && swz < 256) {  // shader clock = d(memtime) / d(memrealtime) x 100 MHz
+      a.ws[(swz * 4 + wave) * 8 + 6] = (float)(__builtin_amdgcn_s_memtime() - clk0);
+      a.ws[(swz * 4 + wave) * 8 + 7] = (float)(wall_clock64() - rt0);
+    }
+#endif
 
     if (dp) dp_tile += nblk; else u += k_end - k_begin;
     if (SK && (k_begin != 0 || k_end != KT)) {
@@ -609,6 +674,555 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_bf3_m16_kernel(const ConvK a,
     }
     __syncthreads();
     conv_epilogue<BM, BN, TM, TN, WAVES_M, MF>(a, acc, reinterpret_cast<float*>(lds), tile_m, m0, n0, wm, wn, lane);
+  }
+}
+
+// ---- forward / data gradient, 16x16x32, hand-scheduled K-step --------------------------------------
+// What the measurements said about conv_fwd_bf3_m16_kernel: per K-step a wave spends ~45 % of its
+// time outside its MFMA phase (tools/stamp_bf3.py: limb split + LDS stores ~700 cycles, load / DMA
+// issue ~770, barriers ~400, of ~4000), and the other workgroup's wave on the same SIMD cannot use
+// that time for VALU work: beside a wave that streams MFMAs back to back, another wave's VALU gets
+// no issue slots at all (tools/micro/valu_vs_mfma.hip: 80 v_fma take 200 cycles alone, 1750 beside
+// a 1555-cycle MFMA stream).  Fillers only overlap MFMAs of their OWN wave (a 16x16x32 MFMA holds
+// the vector issue 8 of its 16 cycles).  So this kernel puts everything except the LDS stores of
+// the activation limbs inside the MFMA stream of the wave itself, at fixed slots:
+//   * rows are requested TWO K-steps ahead; their split (88 VALU) runs one K-step ahead, one small
+//     piece behind every second MFMA, into 24 parked VGPRs; the serial section between the two
+//     barriers is 12 ds_write_b64;
+//   * the weight DMA of the next step is issued behind the first MFMAs of the block, each row
+//     request right after the split freed its registers;
+//   * fragment reads are double-buffered by hand (two A-limb and two B-limb register sets; the
+//     limb-product order a1b3, a1b2, a2b2, a2b1, a3b1, a1b1 changes one operand per group).
+// __builtin_amdgcn_sched_barrier(0) after every MFMA slot pins that order; loads and DMA are inline
+// assembly so that every s_waitcnt vmcnt is placed here (oldest-first accounting in the comments).
+template <int BM, int BN, bool SK>
+__global__ __launch_bounds__(256, 2) void conv_fwd_bf3_p16_kernel(const ConvK a, unsigned limb_stride,
+                                                                   unsigned x_bytes, unsigned w_bytes) {
+  constexpr int WAVES_M = 2, WAVES_N = 2;
+  constexpr int MF = 16;
+  constexpr int TM = BM / (MF * WAVES_M), TN = BN / (MF * WAVES_N);
+  constexpr int AL = BM / 32;
+  static_assert(AL == 4 && TM == 4, "the slot schedule below is written for 128-row tiles");
+  constexpr int PLANE_A = BM * 64;         // activation limb plane, 64-byte rows, swizzled
+  constexpr int PLANE_B = BN * 64;         // weight limb plane, 64-byte rows, source-swizzled
+  constexpr int A_BYTES = 3 * PLANE_A, B_STAGE = 3 * PLANE_B;
+  constexpr int CHUNKS = BN / 16;          // 1-KiB DMA pieces per limb plane
+  constexpr int DPW = 3 * CHUNKS / 4;      // DMA instructions per wave per K-step
+  constexpr int B_OFF = A_BYTES;
+  // slot schedule (slot = one MFMA): GS MFMAs per limb-product group
+  constexpr int GS = TM * TN, NS = 6 * GS;
+  constexpr int DMA0 = 1, DMA_STEP = GS / 4;            // weight DMA piece d behind slot DMA0 + d*DMA_STEP
+  constexpr int SP0 = DMA0 + DPW * DMA_STEP, SP_STEP = TN / 2;  // split piece m behind slot SP0 + m*SP_STEP
+  static_assert(SP0 + 31 * SP_STEP < NS, "split pieces fit the block");
+  __shared__ __attribute__((aligned(16))) unsigned char lds[A_BYTES + 2 * B_STAGE];
+
+  const OndaConv& c = a.c;
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+
+  const int nblk = gridDim.x, bid = blockIdx.x;
+  const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
+  const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  const int KT = a.taps * a.kcper;
+  const int tiles_all = a.tilesM * a.tilesN;
+  const int tiles_dp = SK ? a.tiles_dp : tiles_all;
+  const long long U = (long long)(tiles_all - tiles_dp) * KT;
+  long long u = SK ? swz * U / nblk : 0;
+  const long long u_begin = u;
+  const long long u_end = SK ? (swz + 1) * U / nblk : 0;
+  int dp_tile = swz;
+  const int ccol = (t & 7) * 4, rbase = t >> 3;
+  const int wstride = a.taps * c.Cin;
+  const u32x4 rx = raw_rsrc(a.x, x_bytes), rw = raw_rsrc(a.w, w_bytes);
+  const unsigned lds_base = lds_address(lds);
+  // lane l: row l & 15 of each 16-row block, data chunk l >> 4 (swizzle is the same for every block)
+  const int frag = (lane & 15) * 64 + (((lane >> 4) ^ swz_row(lane & 15)) << 4);
+  const unsigned char* const Ab = lds + wm * TM * MF * 64 + frag;
+
+  while (dp_tile < tiles_dp || u < u_end) {
+    const bool dp = dp_tile < tiles_dp;
+    const int tile = dp ? dp_tile : tiles_dp + (int)(u / KT);
+    const int k_begin = dp ? 0 : (int)(u - (long long)(tile - tiles_dp) * KT);
+    const int k_end = dp ? KT : (int)min((long long)KT, k_begin + (u_end - u));
+    const int tile_n = tile % a.tilesN, tile_m = tile / a.tilesN;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    int hi0[AL], wi0[AL], bH[AL];
+#pragma unroll
+    for (int i = 0; i < AL; ++i) {
+      const int m = m0 + rbase + 32 * i;
+      const bool vm = m < a.M;
+      const int mm = vm ? m : 0;
+      const int wo = mm % c.Wo, tq = mm / c.Wo;
+      const int ho = tq % c.Ho, b = tq / c.Ho;
+      hi0[i] = vm ? ho * c.stride - c.pad : -(1 << 28);
+      wi0[i] = wo * c.stride - c.pad;
+      bH[i] = b * c.Hi;
+    }
+    // this wave's DMA pieces: piece p = wave*DPW + d -> limb p / CHUNKS, 1-KiB chunk p % CHUNKS;
+    // lane -> LDS slot (row = chunk*16 + lane/4, c' = lane & 3) <- data chunk c' ^ swz_row(row)
+    unsigned dofs[DPW];
+#pragma unroll
+    for (int d = 0; d < DPW; ++d) {
+      const int p = wave * DPW + d;
+      const int l = p / CHUNKS, j = p % CHUNKS;
+      const int row = j * 16 + (lane >> 2), cq = (lane & 3) ^ swz_row(row);
+      const int n = n0 + row;
+      dofs[d] = n < c.Cout ? (l * limb_stride + (unsigned)n * wstride) * 2u + cq * 16u : OOB;
+    }
+
+    unsigned aofs[AL];
+    f32x4 ar[AL];        // activation rows in flight (requested one K-step before they are split)
+    u32x2 lim[AL][3];    // limbs of the next K-step's rows, stored to LDS between the two barriers
+    // two cursors over (tap, channel block): A = next row request, B = next weight DMA
+    int tapA = k_begin / a.kcper, cA = (k_begin - tapA * a.kcper) * BK;
+    int tapB = tapA, cB = cA;
+    int soffA = cA * 4, soffB = (tapB * c.Cin + cB) * 2;
+    auto set_tap = [&](int tp) {
+      const int rr = tp / c.kw, ss = tp - rr * c.kw;
+#pragma unroll
+      for (int i = 0; i < AL; ++i) {
+        const int hi = hi0[i] + rr * c.dil, wi = wi0[i] + ss * c.dil;
+        const bool ok = (unsigned)hi < (unsigned)c.Hi && (unsigned)wi < (unsigned)c.Wi;
+        aofs[i] = ok ? (unsigned)(((bH[i] + hi) * c.Wi + wi) * c.ldx + ccol) * 4u : OOB;
+      }
+    };
+    auto advance_a = [&](bool live) {  // move the row cursor; past the segment every row is OOB (zeros)
+      if (!live) {
+#pragma unroll
+        for (int i = 0; i < AL; ++i) aofs[i] = OOB;
+        return;
+      }
+      cA += BK;
+      if (cA == c.Cin) {
+        cA = 0;
+        ++tapA;
+        set_tap(tapA);
+      }
+      soffA = cA * 4;
+    };
+    auto swrite_a = [&]() {
+#pragma unroll
+      for (int i = 0; i < AL; ++i) {
+        const int row = rbase + 32 * i;
+        const int off = row * 64 + ((((t & 7) >> 1) ^ swz_row(row)) << 4) + (t & 1) * 8;
+#pragma unroll
+        for (int l = 0; l < 3; ++l) *reinterpret_cast<u32x2*>(lds + l * PLANE_A + off) = lim[i][l];
+      }
+    };
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
+
+    __syncthreads();  // the previous segment's readers are done with every LDS region (and vmcnt is 0)
+    set_tap(tapA);
+#pragma unroll
+    for (int i = 0; i < AL; ++i) ar[i] = bload16(rx, aofs[i], soffA);
+#pragma unroll
+    for (int d = 0; d < DPW; ++d) {
+      const int p = wave * DPW + d;
+      dma16(rw, lds_base + B_OFF + (p / CHUNKS) * PLANE_B + (p % CHUNKS) * 1024, dofs[d], soffB);
+    }
+    wait_rows<0>(ar);
+#pragma unroll
+    for (int i = 0; i < AL; ++i) split3(ar[i], lim[i][0], lim[i][1], lim[i][2]);
+    advance_a(k_begin + 1 < k_end);
+#pragma unroll
+    for (int i = 0; i < AL; ++i) ar[i] = bload16(rx, aofs[i], soffA);
+    int cur = 0;
+#ifdef ONDA_BF3_STAMP  // diagnostic build only (tools/stamp_bf3.py)
+    long long st[6] = {0, 0, 0, 0, 0, 0};
+    long long st0 = __builtin_amdgcn_s_memtime();
+    const long long clk0 = st0, rt0 = wall_clock64();
+#endif
+    for (int kt = k_begin; kt < k_end; ++kt) {
+      // in flight, oldest first: this step's weight DMA (none at kt = k_begin), the rows of step kt+1
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AL) : "memory");
+      STAMP(0)
+      lds_barrier();  // everybody's DMA has landed, and the A image is free
+      STAMP(1)
+      swrite_a();
+      STAMP(2)
+      lds_barrier();
+      STAMP(3)
+      // cursors of what this block puts in flight: weights of step kt+1, rows of step kt+2
+      // (past the segment: zero rows, and a weight stage nobody reads)
+      cB += BK;
+      if (cB == c.Cin) {
+        cB = 0;
+        ++tapB;
+      }
+      soffB = (tapB * c.Cin + cB) * 2;
+      const unsigned dst_stage = lds_base + B_OFF + (cur ^ 1) * B_STAGE;
+      const bool more = kt + 1 < k_end;
+      advance_a(kt + 2 < k_end);
+
+      const unsigned char* const Bb = lds + A_BYTES + cur * B_STAGE + wn * TN * MF * 64 + frag;
+      bf16x8 A0[TM], A1[TM], B0[TN], B1[TN];
+      float r0[8], r1[8];  // split state of the 8 value pairs of this thread's rows
+#pragma unroll
+      for (int i = 0; i < TM; ++i) A0[i] = *reinterpret_cast<const bf16x8*>(Ab + 0 * PLANE_A + i * MF * 64);  // a1
+#pragma unroll
+      for (int j = 0; j < TN; ++j) B0[j] = *reinterpret_cast<const bf16x8*>(Bb + 2 * PLANE_B + j * MF * 64);  // b3
+      __builtin_amdgcn_sched_barrier(0);
+
+      auto slot = [&](auto ic) {
+        constexpr int S = decltype(ic)::value;
+        constexpr int g = S / GS, i = (S % GS) / TN, j = S % TN;
+        // operands of group g: (a1,b3) (a1,b2) (a2,b2) (a2,b1) (a3,b1) (a1,b1)
+        const bf16x8& av = (g == 0 || g == 1 || g == 4) ? A0[i] : A1[i];
+        const bf16x8& bv = (g == 1 || g == 2) ? B1[j] : B0[j];
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, acc[i][j], 0, 0, 0);
+        // fragment reads for the NEXT group, into the register set that just went dead
+        if constexpr (S % GS == 0) {
+          if constexpr (g == 0) {
+#pragma unroll
+            for (int jj = 0; jj < TN; ++jj) B1[jj] = *reinterpret_cast<const bf16x8*>(Bb + 1 * PLANE_B + jj * MF * 64);  // b2
+          } else if constexpr (g == 1) {
+#pragma unroll
+            for (int ii = 0; ii < TM; ++ii) A1[ii] = *reinterpret_cast<const bf16x8*>(Ab + 1 * PLANE_A + ii * MF * 64);  // a2
+          } else if constexpr (g == 2) {
+#pragma unroll
+            for (int jj = 0; jj < TN; ++jj) B0[jj] = *reinterpret_cast<const bf16x8*>(Bb + 0 * PLANE_B + jj * MF * 64);  // b1
+          } else if constexpr (g == 3) {
+#pragma unroll
+            for (int ii = 0; ii < TM; ++ii) A0[ii] = *reinterpret_cast<const bf16x8*>(Ab + 2 * PLANE_A + ii * MF * 64);  // a3
+          } else if constexpr (g == 4) {
+#pragma unroll
+            for (int ii = 0; ii < TM; ++ii) A1[ii] = *reinterpret_cast<const bf16x8*>(Ab + 0 * PLANE_A + ii * MF * 64);  // a1
+          }
+        }
+        // weight DMA of step kt+1
+        if constexpr (S >= DMA0 && S < DMA0 + DPW * DMA_STEP && (S - DMA0) % DMA_STEP == 0) {
+          constexpr int d = (S - DMA0) / DMA_STEP;
+          const int p = wave * DPW + d;
+          dma16(rw, dst_stage + (p / CHUNKS) * PLANE_B + (p % CHUNKS) * 1024, more ? dofs[d] : OOB, soffB);
+        }
+        // split of the rows of step kt+1: piece m = pair (m / 4) stage (m % 4); pair n = row n / 2, half n % 2
+        if constexpr (S >= SP0 && S < SP0 + 32 * SP_STEP && (S - SP0) % SP_STEP == 0) {
+          constexpr int m = (S - SP0) / SP_STEP, n = m / 4, st = m % 4, row = n / 2, h = n % 2;
+          if constexpr (m == 0) wait_rows<DPW>(ar);  // older than the DPW weight pieces issued above
+          if constexpr (st == 0) {
+            lim[row][0][h] = cvt2(ar[row][2 * h], ar[row][2 * h + 1]);
+          } else if constexpr (st == 1) {
+            r0[n] = ar[row][2 * h] - __builtin_bit_cast(float, lim[row][0][h] << 16);
+            r1[n] = ar[row][2 * h + 1] - __builtin_bit_cast(float, lim[row][0][h] & 0xFFFF0000u);
+            lim[row][1][h] = cvt2(r0[n], r1[n]);
+          } else if constexpr (st == 2) {
+            r0[n] -= __builtin_bit_cast(float, lim[row][1][h] << 16);
+            r1[n] -= __builtin_bit_cast(float, lim[row][1][h] & 0xFFFF0000u);
+          } else {
+            lim[row][2][h] = cvt2(r0[n], r1[n]);
+            if constexpr (h == 1) ar[row] = bload16(rx, aofs[row], soffA);  // row is free: request step kt+2
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      [&]<int... S>(std::integer_sequence<int, S...>) { (slot(std::integral_constant<int, S>{}), ...); }
+      (std::make_integer_sequence<int, NS>{});
+      cur ^= 1;
+      STAMP(5)
+    }
+#ifdef ONDA_BF3_STAMP
+    if (lane == 0 && swz < 256) {
+      for (int i = 0; i < 6; ++i) a.ws[(swz * 4 + wave) * 8 + i] = (float)st[i];
+      a.ws[(swz * 4 + wave) * 8 + 6] = (float)(__builtin_amdgcn_s_memtime() - clk0);
+      a.ws[(swz * 4 + wave) * 8 + 7] = (float)(wall_clock64() - rt0);
+    }
+#endif
+    // drain the (zero-filled) requests issued past the segment before their registers are reused
+    wait_rows<0>(ar);
+
+    if (dp) dp_tile += nblk; else u += k_end - k_begin;
+    if (SK && (k_begin != 0 || k_end != KT)) {
+      float* slot_ws = a.ws + ((size_t)swz * 2 + (u - (k_end - k_begin) == u_begin ? 0 : 1)) * (BM * BN);
+      conv_store_partial<BN, TM, TN, MF>(slot_ws, acc, wm, wn, lane);
+      continue;
+    }
+    __syncthreads();
+    conv_epilogue<BM, BN, TM, TN, WAVES_M, MF>(a, acc, reinterpret_cast<float*>(lds), tile_m, m0, n0, wm, wn, lane);
+  }
+}
+
+// ---- forward / data gradient, 8-wave ping-pong, hand-scheduled ------------------------------------
+// The hand-scheduled K-step of conv_fwd_bf3_p16_kernel in a 512-thread workgroup that owns a
+// 256 x 128 tile, ONE workgroup per CU.  Stamps of the 4-wave kernels show the other limit: a
+// weight stage requested one K-step ahead arrives ~3300 cycles later (vmcnt wait of ~2300 cycles
+// at the top of every K-step), longer than a K-step.  Here:
+//   * two 4-wave groups P (rows 0-127) and Q (rows 128-255); waves w and w+4 share a SIMD and run
+//     half a K-step apart (one s_barrier per half step), so while one group stores its limbs and
+//     waits at the barriers the other group's MFMA block owns the pipe;
+//   * THREE weight stages shared by both groups, filled two K-steps ahead (each wave 3 DMA pieces
+//     per K-step: half the DMA and weight traffic per MFMA of the 128 x 128 kernels);
+//   * rows requested two K-steps ahead, split inside the MFMA block of the step before use.
+// LDS: 2 x 24.5 KB activation images + 3 x 24.5 KB weight stages = 122.5 KB.
+template <bool SK>
+__global__ __launch_bounds__(512) void conv_fwd_bf3_pp_kernel(const ConvK a, unsigned limb_stride, unsigned x_bytes,
+                                                              unsigned w_bytes) {
+  constexpr int BM = 256, GM = 128, BN = 128;  // workgroup tile, rows per wave group
+  constexpr int MF = 16, WAVES_M = 2, WAVES_N = 2;
+  constexpr int TM = GM / (MF * WAVES_M), TN = BN / (MF * WAVES_N);
+  constexpr int AL = GM / 32;
+  constexpr int PLANE_A = GM * 64, A_GROUP = 3 * PLANE_A;
+  constexpr int PLANE_B = BN * 64, B_STAGE = 3 * PLANE_B;
+  constexpr int CHUNKS = BN / 16;      // 1-KiB DMA pieces per limb plane
+  constexpr int DPW = 3 * CHUNKS / 8;  // DMA instructions per wave per K-step
+  constexpr int B_OFF = 2 * A_GROUP;
+  constexpr int GS = TM * TN, NS = 6 * GS;
+  constexpr int SP0 = 4;  // split micro-op e (11 per value pair, 88 per thread) rides behind MFMA slot SP0 + e
+  static_assert(SP0 + 88 <= NS, "split micro-ops fit the block");
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * A_GROUP + 3 * B_STAGE];
+
+  const OndaConv& c = a.c;
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int grp = wave >> 2, wq = wave & 3, tl = t & 255;
+  const int wm = wq / WAVES_N, wn = wq % WAVES_N;
+  unsigned char* const Aimg = lds + grp * A_GROUP;
+
+  const int nblk = gridDim.x, bid = blockIdx.x;
+  const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
+  const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  const int KT = a.taps * a.kcper;
+  const int tiles_all = a.tilesM * a.tilesN;
+  const int tiles_dp = SK ? a.tiles_dp : tiles_all;
+  const long long U = (long long)(tiles_all - tiles_dp) * KT;
+  long long u = SK ? swz * U / nblk : 0;
+  const long long u_begin = u;
+  const long long u_end = SK ? (swz + 1) * U / nblk : 0;
+  int dp_tile = swz;
+  const int ccol = (tl & 7) * 4, rbase = tl >> 3;
+  const int wstride = a.taps * c.Cin;
+  const u32x4 rx = raw_rsrc(a.x, x_bytes), rw = raw_rsrc(a.w, w_bytes);
+  const unsigned lds_base = lds_address(lds);
+  // lane l: row l & 15 of each 16-row block, data chunk l >> 4 (swizzle is the same for every block)
+  const int frag = (lane & 15) * 64 + (((lane >> 4) ^ swz_row(lane & 15)) << 4);
+  const unsigned char* const Ab = Aimg + wm * TM * MF * 64 + frag;
+
+  while (dp_tile < tiles_dp || u < u_end) {
+    const bool dp = dp_tile < tiles_dp;
+    const int tile = dp ? dp_tile : tiles_dp + (int)(u / KT);
+    const int k_begin = dp ? 0 : (int)(u - (long long)(tile - tiles_dp) * KT);
+    const int k_end = dp ? KT : (int)min((long long)KT, k_begin + (u_end - u));
+    const int tile_n = tile % a.tilesN, tile_m = tile / a.tilesN;
+    const int m0 = tile_m * BM + grp * GM, n0 = tile_n * BN;  // this group's rows
+
+    int hi0[AL], wi0[AL], bH[AL];
+#pragma unroll
+    for (int i = 0; i < AL; ++i) {
+      const int m = m0 + rbase + 32 * i;
+      const bool vm = m < a.M;
+      const int mm = vm ? m : 0;
+      const int wo = mm % c.Wo, tq = mm / c.Wo;
+      const int ho = tq % c.Ho, b = tq / c.Ho;
+      hi0[i] = vm ? ho * c.stride - c.pad : -(1 << 28);
+      wi0[i] = wo * c.stride - c.pad;
+      bH[i] = b * c.Hi;
+    }
+    // this wave's DMA pieces: piece p = wave*DPW + d -> limb p / CHUNKS, 1-KiB chunk p % CHUNKS;
+    // lane -> LDS slot (row = chunk*16 + lane/4, c' = lane & 3) <- data chunk c' ^ swz_row(row)
+    unsigned dofs[DPW], ddst[DPW];
+#pragma unroll
+    for (int d = 0; d < DPW; ++d) {
+      const int p = wave * DPW + d;
+      const int l = p / CHUNKS, j = p % CHUNKS;
+      const int row = j * 16 + (lane >> 2), cq = (lane & 3) ^ swz_row(row);
+      const int n = n0 + row;
+      dofs[d] = n < c.Cout ? (l * limb_stride + (unsigned)n * wstride) * 2u + cq * 16u : OOB;
+      ddst[d] = lds_base + B_OFF + l * PLANE_B + j * 1024;
+    }
+
+    unsigned aofs[AL];
+    f32x4 ar[AL];        // activation rows in flight (requested one K-step before they are split)
+    u32x2 lim[AL][3];    // limbs of the next K-step's rows, stored to LDS between the two barriers
+    // two cursors over (tap, channel block): A = next row request, B = next weight DMA
+    int tapA = k_begin / a.kcper, cA = (k_begin - tapA * a.kcper) * BK;
+    int tapB = tapA, cB = cA;
+    int soffA = cA * 4, soffB = (tapB * c.Cin + cB) * 2;
+    auto set_tap = [&](int tp) {
+      const int rr = tp / c.kw, ss = tp - rr * c.kw;
+#pragma unroll
+      for (int i = 0; i < AL; ++i) {
+        const int hi = hi0[i] + rr * c.dil, wi = wi0[i] + ss * c.dil;
+        const bool ok = (unsigned)hi < (unsigned)c.Hi && (unsigned)wi < (unsigned)c.Wi;
+        aofs[i] = ok ? (unsigned)(((bH[i] + hi) * c.Wi + wi) * c.ldx + ccol) * 4u : OOB;
+      }
+    };
+    auto advance_a = [&](bool live) {  // move the row cursor; past the segment every row is OOB (zeros)
+      if (!live) {
+#pragma unroll
+        for (int i = 0; i < AL; ++i) aofs[i] = OOB;
+        return;
+      }
+      cA += BK;
+      if (cA == c.Cin) {
+        cA = 0;
+        ++tapA;
+        set_tap(tapA);
+      }
+      soffA = cA * 4;
+    };
+    auto advance_b = [&]() {
+      cB += BK;
+      if (cB == c.Cin) {
+        cB = 0;
+        ++tapB;
+      }
+      soffB = (tapB * c.Cin + cB) * 2;
+    };
+    auto swrite_a = [&]() {
+#pragma unroll
+      for (int i = 0; i < AL; ++i) {
+        const int row = rbase + 32 * i;
+        const int off = row * 64 + ((((tl & 7) >> 1) ^ swz_row(row)) << 4) + (tl & 1) * 8;
+#pragma unroll
+        for (int l = 0; l < 3; ++l) *reinterpret_cast<u32x2*>(Aimg + l * PLANE_A + off) = lim[i][l];
+      }
+    };
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
+
+    // ---- fill: weight stages of the first two steps, rows of the first step into the images
+    __syncthreads();  // the previous segment's readers are done with every LDS region (and vmcnt is 0)
+    set_tap(tapA);
+#pragma unroll
+    for (int i = 0; i < AL; ++i) ar[i] = bload16(rx, aofs[i], soffA);
+#pragma unroll
+    for (int d = 0; d < DPW; ++d) dma16(rw, ddst[d], dofs[d], soffB);
+    advance_b();
+#pragma unroll
+    for (int d = 0; d < DPW; ++d) dma16(rw, ddst[d] + B_STAGE, k_begin + 1 < k_end ? dofs[d] : OOB, soffB);
+    wait_rows<0>(ar);
+#pragma unroll
+    for (int i = 0; i < AL; ++i) split3(ar[i], lim[i][0], lim[i][1], lim[i][2]);
+    swrite_a();
+    advance_a(k_begin + 1 < k_end);
+#pragma unroll
+    for (int i = 0; i < AL; ++i) ar[i] = bload16(rx, aofs[i], soffA);
+    lds_barrier();
+    if (grp == 1) lds_barrier();  // Q runs half a K-step behind P
+
+    int stage = 0;  // weight stage of step kt; steps kt+1, kt+2 use the next two (mod 3)
+#ifdef ONDA_BF3_STAMP  // diagnostic build only (tools/stamp_bf3.py)
+    long long st[6] = {0, 0, 0, 0, 0, 0};
+    long long st0 = __builtin_amdgcn_s_memtime();
+    const long long clk0 = st0, rt0 = wall_clock64();
+#endif
+    for (int kt = k_begin; kt < k_end; ++kt) {
+      // cursors of what this block puts in flight: weights of step kt+2, rows of step kt+2
+      // (past the segment: zero rows, and a weight stage nobody reads)
+      advance_b();
+      const int st2 = stage >= 1 ? stage - 1 : 2;  // (stage + 2) % 3
+      const unsigned dst_off = st2 * B_STAGE;
+      const bool more2 = kt + 2 < k_end;
+      advance_a(more2);  // offsets of the row requests inside the block
+      // split below: rows of step kt+1 (in flight since the previous block); request: rows of step kt+2
+      const unsigned char* const Bb = lds + B_OFF + stage * B_STAGE + wn * TN * MF * 64 + frag;
+      bf16x8 A0[TM], A1[TM], B0[TN], B1[TN];
+      float r0, r1, f0, f1;  // split state of the value pair in flight
+#pragma unroll
+      for (int i = 0; i < TM; ++i) A0[i] = *reinterpret_cast<const bf16x8*>(Ab + 0 * PLANE_A + i * MF * 64);  // a1
+#pragma unroll
+      for (int j = 0; j < TN; ++j) B0[j] = *reinterpret_cast<const bf16x8*>(Bb + 2 * PLANE_B + j * MF * 64);  // b3
+      __builtin_amdgcn_sched_barrier(0);
+
+      auto slot = [&](auto ic) {
+        constexpr int S = decltype(ic)::value;
+        constexpr int g = S / GS, i = (S % GS) / TN, j = S % TN;
+        // operands of group g: (a1,b3) (a1,b2) (a2,b2) (a2,b1) (a3,b1) (a1,b1)
+        const bf16x8& av = (g == 0 || g == 1 || g == 4) ? A0[i] : A1[i];
+        const bf16x8& bv = (g == 1 || g == 2) ? B1[j] : B0[j];
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, acc[i][j], 0, 0, 0);
+        // fragment reads for the NEXT group, into the register set that just went dead
+        if constexpr (S % GS == 0) {
+          if constexpr (g == 0) {
+#pragma unroll
+            for (int jj = 0; jj < TN; ++jj) B1[jj] = *reinterpret_cast<const bf16x8*>(Bb + 1 * PLANE_B + jj * MF * 64);  // b2
+          } else if constexpr (g == 1) {
+#pragma unroll
+            for (int ii = 0; ii < TM; ++ii) A1[ii] = *reinterpret_cast<const bf16x8*>(Ab + 1 * PLANE_A + ii * MF * 64);  // a2
+          } else if constexpr (g == 2) {
+#pragma unroll
+            for (int jj = 0; jj < TN; ++jj) B0[jj] = *reinterpret_cast<const bf16x8*>(Bb + 0 * PLANE_B + jj * MF * 64);  // b1
+          } else if constexpr (g == 3) {
+#pragma unroll
+            for (int ii = 0; ii < TM; ++ii) A0[ii] = *reinterpret_cast<const bf16x8*>(Ab + 2 * PLANE_A + ii * MF * 64);  // a3
+          } else if constexpr (g == 4) {
+#pragma unroll
+            for (int ii = 0; ii < TM; ++ii) A1[ii] = *reinterpret_cast<const bf16x8*>(Ab + 0 * PLANE_A + ii * MF * 64);  // a1
+          }
+        }
+        // weight DMA of step kt+2
+        // split of the rows of step kt+1, one VALU micro-op per MFMA gap (a 16x16x32 MFMA leaves 8 of
+        // its 16 cycles of vector issue free; three or more VALU behind one MFMA delay the next one):
+        // pair n = row n / 2, half n % 2; x -> p = bf16(x), r = x - p, q = bf16(r), s = r - q, bf16(s)
+        if constexpr (S >= SP0 && S < SP0 + 88) {
+          constexpr int e = S - SP0, n = e / 11, op = e % 11, row = n / 2, h = n % 2;
+          if constexpr (e == 0) wait_rows<DPW>(ar);  // requested in the previous block; older than the last DMA
+          if constexpr (op == 0) lim[row][0][h] = cvt2(ar[row][2 * h], ar[row][2 * h + 1]);
+          else if constexpr (op == 1) f0 = __builtin_bit_cast(float, lim[row][0][h] << 16);
+          else if constexpr (op == 2) f1 = __builtin_bit_cast(float, lim[row][0][h] & 0xFFFF0000u);
+          else if constexpr (op == 3) r0 = ar[row][2 * h] - f0;
+          else if constexpr (op == 4) r1 = ar[row][2 * h + 1] - f1;
+          else if constexpr (op == 5) lim[row][1][h] = cvt2(r0, r1);
+          else if constexpr (op == 6) f0 = __builtin_bit_cast(float, lim[row][1][h] << 16);
+          else if constexpr (op == 7) f1 = __builtin_bit_cast(float, lim[row][1][h] & 0xFFFF0000u);
+          else if constexpr (op == 8) r0 -= f0;
+          else if constexpr (op == 9) r1 -= f1;
+          else {
+            lim[row][2][h] = cvt2(r0, r1);
+            if constexpr (h == 1) ar[row] = bload16(rx, aofs[row], soffA);  // row is free: request step kt+2
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      [&]<int... S>(std::integer_sequence<int, S...>) { (slot(std::integral_constant<int, S>{}), ...); }
+      (std::make_integer_sequence<int, NS>{});
+      // in flight, oldest first: weights kt+1 (issued after the previous block), rows kt+2 (this block):
+      // the weights must have landed before the barrier the other group's next block waits on
+      STAMP(0)
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AL) : "memory");
+      STAMP(1)
+      lds_barrier();
+      STAMP(2)
+      swrite_a();  // limbs of step kt+1; this group's block kt is done with the image
+      // weight DMA of step kt+2, while the other group's block owns the vector issue (VMEM and LDS
+      // instructions of this wave still get their slots; VALU would not)
+#pragma unroll
+      for (int d = 0; d < DPW; ++d) dma16(rw, ddst[d] + dst_off, more2 ? dofs[d] : OOB, soffB);
+      STAMP(3)
+      lds_barrier();
+      STAMP(4)
+      stage = stage == 2 ? 0 : stage + 1;
+    }
+#ifdef ONDA_BF3_STAMP
+    if (lane == 0 && swz < 128) {
+      for (int i = 0; i < 6; ++i) a.ws[(swz * 8 + wave) * 8 + i] = (float)st[i];
+      a.ws[(swz * 8 + wave) * 8 + 6] = (float)(__builtin_amdgcn_s_memtime() - clk0);
+      a.ws[(swz * 8 + wave) * 8 + 7] = (float)(wall_clock64() - rt0);
+    }
+#endif
+    if (grp == 0) lds_barrier();  // P waits for Q's last block
+    // drain the (zero-filled) requests issued past the segment before their registers are reused
+    wait_rows<0>(ar);
+
+    if (dp) dp_tile += nblk; else u += k_end - k_begin;
+    if (SK && (k_begin != 0 || k_end != KT)) {
+      float* slot_ws = a.ws + ((size_t)swz * 2 + (u - (k_end - k_begin) == u_begin ? 0 : 1)) * (BM * BN) + grp * (GM * BN);
+      conv_store_partial<BN, TM, TN, MF>(slot_ws, acc, wm, wn, lane);
+      continue;
+    }
+    conv_epilogue<GM, BN, TM, TN, WAVES_M, MF>(a, acc, reinterpret_cast<float*>(Aimg), tile_m * 2 + grp, m0, n0, wm, wn, lane, tl);
   }
 }
 
@@ -1012,6 +1626,44 @@ int onda_conv2d_fwd_bf3(const float* x, const void* w3, float* y, const float* s
   hipStream_t st = ONDA_STREAM(s);
   // ONDA_BF3_DMA=0 selects the older variant that stages the weight limbs through VGPRs
   static const int use_dma = [] { const char* e = getenv("ONDA_BF3_DMA"); return e ? atoi(e) : 2; }();
+  if (use_dma == 4 && wide) {
+    // 256 x 128 tiles, one 512-thread workgroup per CU
+    const int G2 = G / 2;
+    k.tilesM = (k.M + 255) / 256;
+    const int tiles2 = k.tilesM * k.tilesN, rem2 = tiles2 % G2;
+    k.tiles_dp = tiles2 - rem2;
+    const double tile_us = 2.0 * 256.0 * 128.0 * k.taps * c->Cin / 0.6e6;  // one tile on one CU, ~150 TF/s chip
+    const double fix2_us = 8.0 + (G2 + 2.0 * rem2) * 0.06;
+    bool bal2 = ws != nullptr && rem2 != 0 && KT >= 4 && tile_us * (1.0 - (double)rem2 / G2) > fix2_us;
+    if (const int force = conv_sched_override()) {
+      if (force == 1 || ws == nullptr) {
+        bal2 = false;
+      } else {
+        bal2 = true;
+        if (force == 3) k.tiles_dp = 0;
+      }
+    }
+    if (bal2) {
+      hipLaunchKernelGGL((conv_fwd_bf3_pp_kernel<true>), dim3(G2), dim3(512), 0, st, k, limb_stride, x_bytes, w_bytes);
+      return conv_launch_fixup(k, G2, true, st, 256);
+    }
+    hipLaunchKernelGGL((conv_fwd_bf3_pp_kernel<false>), dim3(tiles2), dim3(512), 0, st, k, limb_stride, x_bytes, w_bytes);
+    return ONDA_LAUNCH_RESULT();
+  }
+  if (use_dma == 3) {
+    if (balanced) {
+      if (wide)
+        hipLaunchKernelGGL((conv_fwd_bf3_p16_kernel<128, 128, true>), dim3(G), dim3(256), 0, st, k, limb_stride, x_bytes, w_bytes);
+      else
+        hipLaunchKernelGGL((conv_fwd_bf3_p16_kernel<128, 64, true>), dim3(G), dim3(256), 0, st, k, limb_stride, x_bytes, w_bytes);
+      return conv_launch_fixup(k, G, wide, st);
+    }
+    if (wide)
+      hipLaunchKernelGGL((conv_fwd_bf3_p16_kernel<128, 128, false>), dim3(tiles), dim3(256), 0, st, k, limb_stride, x_bytes, w_bytes);
+    else
+      hipLaunchKernelGGL((conv_fwd_bf3_p16_kernel<128, 64, false>), dim3(tiles), dim3(256), 0, st, k, limb_stride, x_bytes, w_bytes);
+    return ONDA_LAUNCH_RESULT();
+  }
   if (use_dma == 2) {
     if (balanced) {
       if (wide)
