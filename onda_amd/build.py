@@ -12,9 +12,6 @@ CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libonda_hip.so")
 SOURCES = ["conv.hip", "conv_bf3.hip", "norm.hip", "pointwise.hip", "loss_proto.hip"]
-# per-file flags.  conv_bf3: the SLP vectorizer turns the pairs of fp32 subtractions of the limb split
-# into v_pk_add_f32, which costs ~25 cycles apiece beside MFMAs (MI355X_MICROARCH.md, filler prices)
-EXTRA_FLAGS = {"conv_bf3.hip": ["-fno-slp-vectorize"]}
 
 
 def _stale(target, deps):
@@ -32,7 +29,7 @@ def build(force=False, verbose=True):
         path = os.path.join(CSRC, src)
         obj = os.path.join(CSRC, src.replace(".hip", ".o"))
         if force or _stale(obj, [path] + headers):
-            cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-I" + INCLUDE] + EXTRA_FLAGS.get(src, []) + ["-c", path, "-o", obj]
+            cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-I" + INCLUDE, "-c", path, "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)

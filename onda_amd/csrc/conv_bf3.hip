@@ -2,18 +2,30 @@
 // the exact sum of three bf16 limbs, x = x1 + x2 + x3 (8 + 8 + 8 mantissa bits), and the product
 // a*b is evaluated as the six limb products whose weight is >= 2^-16,
 //     a1*b1 + (a1*b2 + a2*b1) + (a1*b3 + a2*b2 + a3*b1),
-// each exact in fp32 and accumulated in fp32 by v_mfma_f32_32x32x16_bf16.  What is dropped
+// each exact in fp32 and accumulated in fp32 by v_mfma_f32_16x16x32_bf16.  What is dropped
 // (a2*b3 + a3*b2 + a3*b3 and the limb-3 rounding) is <= ~2^-23 |a||b| per product -- the size of
 // an fp32 rounding error -- while the bf16 pipe runs 16x the fp32-MFMA rate, i.e. 16/6 = 2.7x per
 // fp32-equivalent FLOP.  bf16 keeps fp32's exponent range, so no scaling is involved.
 //
-// Same implicit-GEMM geometry, stream-K schedule and epilogue as conv.hip.  Weights arrive
-// pre-split ([3][rows][tap*Cin] bf16, onda_pack_weight_*_bf3); activations are split by the
-// VALU on their way into LDS.  LDS holds the three limb planes of both operand tiles
-// ((128+128) rows x 32 k x 3 limbs, rows padded to 80 B: conflict-free ds_read_b128), single
-// stage with register prefetch, 61.4 KB -> two workgroups per CU.
-#include <cstdlib>
-#include <utility>
+// Same implicit-GEMM geometry, hybrid stream-K schedule and epilogue as conv.hip.  Weights arrive
+// pre-split ([3][rows][tap*Cin] bf16, onda_pack_weight_*_bf3) and reach LDS by LDS-DMA;
+// activations are split by the VALU on their way into LDS.  MFMA shape: 16x16x32 rather than
+// 32x32x16 -- same output tile per wave, same LDS bytes and MFMA cycles per K-step, but the chip
+// holds a higher clock on it under load (MI355X_MICROARCH.md "DVFS give-back" item 7): +8-15 %.
+//
+// What was measured on the way (DESIGN.md section 6 has the numbers; tools/stamp_bf3.py,
+// tools/micro/valu_vs_mfma.hip and tools/sq_summary.py reproduce them):
+//   * SQ_VALU_MFMA_BUSY_CYCLES: the MFMA pipe is busy ~55 % of the forward kernel, ~45 % of the
+//     weight-gradient kernel; in-kernel clock 2.15-2.3 GHz, so the rest is idle pipe, not DVFS;
+//   * beside a wave that streams MFMAs another wave of the same SIMD gets NO VALU issue slots
+//     (80 v_fma: 200 cycles alone, 1750 beside a 1555-cycle MFMA stream), so the second workgroup
+//     of a CU hides barriers and memory waits, never the limb split;
+//   * a weight stage requested one K-step ahead lands ~3300 cycles later (longer than a K-step);
+//   * v_pk_add_f32 (what the SLP vectorizer makes of the split's subtractions) costs ~25 cycles
+//     apiece between MFMAs of the same wave.
+// A hand-scheduled K-step (split inside the wave's own MFMA stream) and an 8-wave 256 x 128
+// ping-pong kernel with three weight stages built on those findings reached +3 % on the large
+// shapes and lost 10-20 % on the small ones; they are in the history (commit 918e473), not here.
 
 #include "conv_common.h"
 
@@ -22,8 +34,6 @@ namespace {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-constexpr int ROWB = 80;  // bytes per LDS row: 32 bf16 + 16 B pad
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -61,426 +71,29 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, un
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
 }
 
-// LDS-DMA issued as inline assembly.  Through the builtin the compiler tracks the LDS destination
-// and, as every image lives in one __shared__ array, puts an s_waitcnt vmcnt in front of later
-// ds_reads that "may alias" it -- which also waits for the row requests that were issued behind
-// the DMA on purpose.  The kernels below order DMA completion themselves (vmcnt + barrier).
-// lds_addr: byte address in LDS (M0); lane l writes lds_addr + 16 l.
-#pragma clang diagnostic ignored "-Winline-asm"  // m0 is "reserved": nothing else here depends on it
-__device__ __forceinline__ u32x4 raw_rsrc(const void* base, unsigned bytes) {
-  const unsigned long long p = (unsigned long long)base;
-  return u32x4{(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)p),
-               (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(p >> 32) & 0xFFFFu)),
-               (unsigned)__builtin_amdgcn_readfirstlane((int)bytes), 0x00020000u};
-}
-__device__ __forceinline__ void dma16(u32x4 rsrc, unsigned lds_addr, unsigned voff, unsigned soff) {
-  asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff)
-               : "memory", "m0");
-}
-__device__ __forceinline__ unsigned lds_address(const void* p) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  return (unsigned)(size_t)(__attribute__((address_space(3))) const unsigned char*)p;
-#else
-  return 0;
-#endif
-}
-
-// 16-byte buffer load as inline assembly + the wait that makes its result usable.  The compiler
-// does not count asm memory operations, so the kernel that uses these places every vmcnt itself
-// (wait_rows ties the registers to the wait: nothing may read them earlier).
-__device__ __forceinline__ f32x4 bload16(u32x4 rsrc, unsigned voff, unsigned soff) {
-  f32x4 v;
-  asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=&v"(v) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
-  return v;
-}
-template <int N>
-__device__ __forceinline__ void wait_rows(f32x4 (&r)[4]) {
-  asm volatile("s_waitcnt vmcnt(%4)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]) : "n"(N) : "memory");
-}
-
-// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it would
-// wait for the global loads / LDS-DMA a wave has just put in flight for a LATER step.
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-template <int BM, int BN, bool SK>
-__global__ __launch_bounds__(256, 2) void conv_fwd_bf3_kernel(const ConvK a, unsigned limb_stride, unsigned x_bytes,
-                                                               unsigned w_bytes) {
-  constexpr int WAVES_M = 2, WAVES_N = 2;
-  constexpr int TM = BM / (32 * WAVES_M), TN = BN / (32 * WAVES_N);
-  constexpr int AL = BM / 32;          // float4 loads per thread for the A tile
-  constexpr int BL = BN / 64;          // 16-byte loads per thread per limb for the B tile
-  constexpr int PLANE = (BM + BN) * ROWB;  // bytes of one limb plane (A rows then B rows)
-  __shared__ __attribute__((aligned(16))) unsigned char lds[3 * PLANE];
-
-  const OndaConv& c = a.c;
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int li = lane & 31, lh = lane >> 5;
-  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-
-  const int nblk = gridDim.x, bid = blockIdx.x;
-  const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
-  const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  const int KT = a.taps * a.kcper;
-  // SK: a.tiles_dp tiles (whole rounds of the grid) are processed one per workgroup, all starting
-  // at k = 0 together -- workgroups of an XCD then stream the SAME weight slices at the same time,
-  // which is what keeps them in its L2.  Only the remaining (< gridDim.x) tiles are cut into
-  // equal unit ranges over all workgroups.
-  const int tiles_all = a.tilesM * a.tilesN;
-  const int tiles_dp = SK ? a.tiles_dp : tiles_all;
-  const long long U = (long long)(tiles_all - tiles_dp) * KT;  // units of the stream-K remainder
-  long long u = SK ? swz * U / nblk : 0;
-  const long long u_begin = u;
-  const long long u_end = SK ? (swz + 1) * U / nblk : 0;
-  int dp_tile = swz;  // next data-parallel tile of this workgroup
-  const int ccol = (t & 7) * 4, rbase = t >> 3;  // A: 4 floats at k=ccol of rows rbase+32u
-  const int brow = t >> 2, bk = (t & 3) * 8;     // B: 8 bf16 at k=bk of rows brow+64v
-  const int wstride = a.taps * c.Cin;
-  const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, x_bytes), rw = make_rsrc(a.w, w_bytes);
-
-  while (dp_tile < tiles_dp || u < u_end) {
-    const bool dp = dp_tile < tiles_dp;
-    const int tile = dp ? dp_tile : tiles_dp + (int)(u / KT);
-    const int k_begin = dp ? 0 : (int)(u - (long long)(tile - tiles_dp) * KT);
-    const int k_end = dp ? KT : (int)min((long long)KT, k_begin + (u_end - u));
-    const int tile_n = tile % a.tilesN, tile_m = tile / a.tilesN;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
-
-    int hi0[AL], wi0[AL], bH[AL];
-#pragma unroll
-    for (int i = 0; i < AL; ++i) {
-      const int m = m0 + rbase + 32 * i;
-      const bool vm = m < a.M;
-      const int mm = vm ? m : 0;
-      const int wo = mm % c.Wo, tq = mm / c.Wo;
-      const int ho = tq % c.Ho, b = tq / c.Ho;
-      hi0[i] = vm ? ho * c.stride - c.pad : -(1 << 28);
-      wi0[i] = wo * c.stride - c.pad;
-      bH[i] = b * c.Hi;
-    }
-    unsigned wofs[3][BL];  // byte offsets into the limb planes, OOB for rows past Cout
-#pragma unroll
-    for (int v = 0; v < BL; ++v) {
-      const int n = n0 + brow + 64 * v;
-#pragma unroll
-      for (int l = 0; l < 3; ++l)
-        wofs[l][v] = n < c.Cout ? (l * limb_stride + (unsigned)n * wstride + bk) * 2u : OOB;
-    }
-
-    unsigned aofs[AL];  // byte offsets of this thread's rows for the current tap, OOB = zero row
-    f32x4 ar[AL];
-    u32x4 br[3][BL];
-    int tap = k_begin / a.kcper, c0 = (k_begin - tap * a.kcper) * BK;
-    auto set_tap = [&](int tp) {
-      const int rr = tp / c.kw, ss = tp - rr * c.kw;
-#pragma unroll
-      for (int i = 0; i < AL; ++i) {
-        const int hi = hi0[i] + rr * c.dil, wi = wi0[i] + ss * c.dil;
-        const bool ok = (unsigned)hi < (unsigned)c.Hi && (unsigned)wi < (unsigned)c.Wi;
-        aofs[i] = ok ? (unsigned)(((bH[i] + hi) * c.Wi + wi) * c.ldx + ccol) * 4u : OOB;
-      }
-    };
-    auto gload = [&]() {
-      const int sa = c0 * 4, sw = (tap * c.Cin + c0) * 2;  // scalar (wave-uniform) byte offsets
-#pragma unroll
-      for (int i = 0; i < AL; ++i)
-        ar[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, aofs[i], sa, 0));
-#pragma unroll
-      for (int l = 0; l < 3; ++l)
-#pragma unroll
-        for (int v = 0; v < BL; ++v) br[l][v] = __builtin_amdgcn_raw_buffer_load_b128(rw, wofs[l][v], sw, 0);
-    };
-    auto sstore = [&]() {
-#pragma unroll
-      for (int i = 0; i < AL; ++i) {
-        u32x2 l1, l2, l3;
-        split3(ar[i], l1, l2, l3);
-        const int off = (rbase + 32 * i) * ROWB + ccol * 2;
-        *reinterpret_cast<u32x2*>(lds + 0 * PLANE + off) = l1;
-        *reinterpret_cast<u32x2*>(lds + 1 * PLANE + off) = l2;
-        *reinterpret_cast<u32x2*>(lds + 2 * PLANE + off) = l3;
-      }
-#pragma unroll
-      for (int l = 0; l < 3; ++l)
-#pragma unroll
-        for (int v = 0; v < BL; ++v)
-          *reinterpret_cast<u32x4*>(lds + l * PLANE + (BM + brow + 64 * v) * ROWB + bk * 2) = br[l][v];
-    };
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-    set_tap(tap);
-    gload();
-    for (int kt = k_begin; kt < k_end; ++kt) {
-      __syncthreads();  // LDS free: the previous K-step's (or tile's) reads are done
-      sstore();
-      __syncthreads();
-      if (kt + 1 < k_end) {  // next tile's loads fly while this one is multiplied
-        c0 += BK;
-        if (c0 == c.Cin) {
-          c0 = 0;
-          ++tap;
-          set_tap(tap);
-        }
-        gload();
-      }
-      const unsigned char* Ab = lds + (wm * TM * 32 + li) * ROWB + lh * 16;
-      const unsigned char* Bb = lds + (BM + wn * TN * 32 + li) * ROWB + lh * 16;
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        // A limbs stay in registers; B limbs stream 3 -> 2 -> 1 (smallest products first)
-        bf16x8 af[TM][3];
-#pragma unroll
-        for (int l = 0; l < 3; ++l)
-#pragma unroll
-          for (int i = 0; i < TM; ++i)
-            af[i][l] = *reinterpret_cast<const bf16x8*>(Ab + l * PLANE + i * 32 * ROWB + s * 32);
-#pragma unroll
-        for (int l = 2; l >= 0; --l) {
-          bf16x8 bf[TN];
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-            bf[j] = *reinterpret_cast<const bf16x8*>(Bb + l * PLANE + j * 32 * ROWB + s * 32);
-#pragma unroll
-          for (int la = 2 - l; la >= 0; --la)  // a_{la+1} * b_{l+1} with la + l <= 2
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-              for (int j = 0; j < TN; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][la], bf[j], acc[i][j], 0, 0, 0);
-        }
-      }
-    }
-
-    if (dp) dp_tile += nblk; else u += k_end - k_begin;
-    if (SK && (k_begin != 0 || k_end != KT)) {
-      float* slot = a.ws + ((size_t)swz * 2 + (u - (k_end - k_begin) == u_begin ? 0 : 1)) * (BM * BN);
-      conv_store_partial<BN, TM, TN>(slot, acc, wm, wn, lane);
-      continue;
-    }
-    __syncthreads();  // all waves are past their last LDS read before the statistics reuse it
-    conv_epilogue<BM, BN, TM, TN, WAVES_M>(a, acc, reinterpret_cast<float*>(lds), tile_m, m0, n0, wm, wn, lane);
-  }
-}
-
-// ---- forward / data gradient, weight limbs by LDS-DMA ------------------------------------------------
-// Same contraction as conv_fwd_bf3_kernel, but the pre-split weight tile never passes through
-// VGPRs: each wave issues `buffer_load_dwordx4 ... lds` (1 KiB per instruction, lane l -> LDS base
-// + 16 l) into a double-buffered, UNPADDED [3][BN][64 B] image one K-step ahead.  The image is
-// lane-linear, so the bank-conflict fix is an XOR on the SOURCE side: LDS slot (row, c') holds
-// data chunk c' ^ ((row >> 2) & 3), and the fragment read applies the same involution (16 rows of
-// a ds_read_b128 lane group then hit 16 distinct 16-byte bank slots).  The VGPR -> LDS store path
-// (the slow side of the LDS) carries only the activation limbs.  79.9 KB LDS, 2 workgroups / CU.
-template <int BM, int BN, bool SK>
-__global__ __launch_bounds__(256, 2) void conv_fwd_bf3_dma_kernel(const ConvK a, unsigned limb_stride,
-                                                                   unsigned x_bytes, unsigned w_bytes) {
-  constexpr int WAVES_M = 2, WAVES_N = 2;
-  constexpr int TM = BM / (32 * WAVES_M), TN = BN / (32 * WAVES_N);
-  constexpr int AL = BM / 32;
-  constexpr int PLANE_A = BM * ROWB;       // activation limb plane, rows padded to 80 B
-  constexpr int PLANE_B = BN * 64;         // weight limb plane, 64-byte rows, source-swizzled
-  constexpr int A_BYTES = 3 * PLANE_A, B_STAGE = 3 * PLANE_B;
-  constexpr int CHUNKS = BN / 16;          // 1-KiB DMA pieces per limb plane
-  constexpr int DPW = 3 * CHUNKS / 4;      // DMA instructions per wave per K-step
-  __shared__ __attribute__((aligned(16))) unsigned char lds[A_BYTES + 2 * B_STAGE];
-
-  const OndaConv& c = a.c;
-  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int li = lane & 31, lh = lane >> 5;
-  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-
-  const int nblk = gridDim.x, bid = blockIdx.x;
-  const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
-  const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  const int KT = a.taps * a.kcper;
-  const int tiles_all = a.tilesM * a.tilesN;
-  const int tiles_dp = SK ? a.tiles_dp : tiles_all;
-  const long long U = (long long)(tiles_all - tiles_dp) * KT;
-  long long u = SK ? swz * U / nblk : 0;
-  const long long u_begin = u;
-  const long long u_end = SK ? (swz + 1) * U / nblk : 0;
-  int dp_tile = swz;
-  const int ccol = (t & 7) * 4, rbase = t >> 3;
-  const int wstride = a.taps * c.Cin;
-  const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, x_bytes), rw = make_rsrc(a.w, w_bytes);
-
-  while (dp_tile < tiles_dp || u < u_end) {
-    const bool dp = dp_tile < tiles_dp;
-    const int tile = dp ? dp_tile : tiles_dp + (int)(u / KT);
-    const int k_begin = dp ? 0 : (int)(u - (long long)(tile - tiles_dp) * KT);
-    const int k_end = dp ? KT : (int)min((long long)KT, k_begin + (u_end - u));
-    const int tile_n = tile % a.tilesN, tile_m = tile / a.tilesN;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
-
-    int hi0[AL], wi0[AL], bH[AL];
-#pragma unroll
-    for (int i = 0; i < AL; ++i) {
-      const int m = m0 + rbase + 32 * i;
-      const bool vm = m < a.M;
-      const int mm = vm ? m : 0;
-      const int wo = mm % c.Wo, tq = mm / c.Wo;
-      const int ho = tq % c.Ho, b = tq / c.Ho;
-      hi0[i] = vm ? ho * c.stride - c.pad : -(1 << 28);
-      wi0[i] = wo * c.stride - c.pad;
-      bH[i] = b * c.Hi;
-    }
-    // this wave's DMA pieces: piece p = wave*DPW + d -> limb p / CHUNKS, 1-KiB chunk p % CHUNKS;
-    // lane -> LDS slot (row = chunk*16 + lane/4, c' = lane & 3) <- data chunk c' ^ ((row>>2)&3)
-    unsigned dofs[DPW];
-#pragma unroll
-    for (int d = 0; d < DPW; ++d) {
-      const int p = wave * DPW + d;
-      const int l = p / CHUNKS, j = p % CHUNKS;
-      const int row = j * 16 + (lane >> 2), cq = (lane & 3) ^ ((row >> 2) & 3);
-      const int n = n0 + row;
-      dofs[d] = n < c.Cout ? (l * limb_stride + (unsigned)n * wstride) * 2u + cq * 16u : OOB;
-    }
-
-    unsigned aofs[AL];
-    f32x4 ar[AL];
-    int tap = k_begin / a.kcper, c0 = (k_begin - tap * a.kcper) * BK;
-    auto set_tap = [&](int tp) {
-      const int rr = tp / c.kw, ss = tp - rr * c.kw;
-#pragma unroll
-      for (int i = 0; i < AL; ++i) {
-        const int hi = hi0[i] + rr * c.dil, wi = wi0[i] + ss * c.dil;
-        const bool ok = (unsigned)hi < (unsigned)c.Hi && (unsigned)wi < (unsigned)c.Wi;
-        aofs[i] = ok ? (unsigned)(((bH[i] + hi) * c.Wi + wi) * c.ldx + ccol) * 4u : OOB;
-      }
-    };
-    auto gload_a = [&]() {
-      const int sa = c0 * 4;
-#pragma unroll
-      for (int i = 0; i < AL; ++i)
-        ar[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, aofs[i], sa, 0));
-    };
-    auto dma_b = [&](int stage) {
-      const int sw = (tap * c.Cin + c0) * 2;
-#pragma unroll
-      for (int d = 0; d < DPW; ++d) {
-        const int p = wave * DPW + d;
-        const int l = p / CHUNKS, j = p % CHUNKS;
-        unsigned char* dst = lds + A_BYTES + stage * B_STAGE + l * PLANE_B + j * 1024;
-#if defined(__HIP_DEVICE_COMPILE__)  // (the host pass drops the whole kernel stub if it sees this cast in a lambda)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)dst, 16, dofs[d], sw, 0, 0);
-#else
-        (void)dst;
-        (void)sw;
-#endif
-      }
-    };
-    auto sstore_a = [&]() {
-#pragma unroll
-      for (int i = 0; i < AL; ++i) {
-        u32x2 l1, l2, l3;
-        split3(ar[i], l1, l2, l3);
-        const int off = (rbase + 32 * i) * ROWB + ccol * 2;
-        *reinterpret_cast<u32x2*>(lds + 0 * PLANE_A + off) = l1;
-        *reinterpret_cast<u32x2*>(lds + 1 * PLANE_A + off) = l2;
-        *reinterpret_cast<u32x2*>(lds + 2 * PLANE_A + off) = l3;
-      }
-    };
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-    __syncthreads();  // the previous segment's readers are done with every LDS region
-    set_tap(tap);
-    gload_a();
-    dma_b(0);
-    int cur = 0;
-    for (int kt = k_begin; kt < k_end; ++kt) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's A rows and weight DMA have landed
-      __syncthreads();                                   // ... and everybody else's; A image is free
-      sstore_a();
-      __syncthreads();
-      if (kt + 1 < k_end) {
-        c0 += BK;
-        if (c0 == c.Cin) {
-          c0 = 0;
-          ++tap;
-          set_tap(tap);
-        }
-        gload_a();
-        dma_b(cur ^ 1);  // the stage read one step ago; all waves are past that compute
-      }
-      const unsigned char* Ab = lds + (wm * TM * 32 + li) * ROWB + lh * 16;
-      const unsigned char* Bst = lds + A_BYTES + cur * B_STAGE;
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        // A limbs stay in registers; B limbs stream 3 -> 2 -> 1 (smallest products first)
-        bf16x8 af[TM][3];
-#pragma unroll
-        for (int l = 0; l < 3; ++l)
-#pragma unroll
-          for (int i = 0; i < TM; ++i)
-            af[i][l] = *reinterpret_cast<const bf16x8*>(Ab + l * PLANE_A + i * 32 * ROWB + s * 32);
-#pragma unroll
-        for (int l = 2; l >= 0; --l) {
-          bf16x8 bf[TN];
-#pragma unroll
-          for (int j = 0; j < TN; ++j) {
-            const int row = wn * TN * 32 + j * 32 + li;
-            bf[j] = *reinterpret_cast<const bf16x8*>(Bst + l * PLANE_B + row * 64 + (((2 * s + lh) ^ ((row >> 2) & 3)) << 4));
-          }
-#pragma unroll
-          for (int la = 2 - l; la >= 0; --la)  // a_{la+1} * b_{l+1} with la + l <= 2
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-              for (int j = 0; j < TN; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][la], bf[j], acc[i][j], 0, 0, 0);
-        }
-      }
-      cur ^= 1;
-    }
-
-    if (dp) dp_tile += nblk; else u += k_end - k_begin;
-    if (SK && (k_begin != 0 || k_end != KT)) {
-      float* slot = a.ws + ((size_t)swz * 2 + (u - (k_end - k_begin) == u_begin ? 0 : 1)) * (BM * BN);
-      conv_store_partial<BN, TM, TN>(slot, acc, wm, wn, lane);
-      continue;
-    }
-    __syncthreads();
-    conv_epilogue<BM, BN, TM, TN, WAVES_M>(a, acc, reinterpret_cast<float*>(lds), tile_m, m0, n0, wm, wn, lane);
-  }
-}
-
-// ---- forward / data gradient on v_mfma_f32_16x16x32_bf16 ---------------------------------------------
-// The DMA kernel above re-tiled for the 16x16x32 MFMA shape (same 64 x 64 output per wave, same
-// LDS bytes and MFMA cycles per K-step; the chip holds a higher clock on this shape under load,
-// MI355X_MICROARCH.md "DVFS give-back" item 7).  One MFMA spans the whole BK = 32 step, lane l
-// reads row l & 15, 16-byte chunk l >> 4.  Both images are unpadded 64-byte rows with the chunk
-// index XOR-ed by swz_row(row), which makes every ds_read_b128 lane group
-// ({0-3, 12-15} chunk c with {4-11} chunk c + 1, and vice versa) hit 16 distinct 16-byte slots.
+// ---- forward / data gradient ----------------------------------------------------------------------
+// 128 x BN tile, 4 waves of 64 x (BN/2), BK = 32: one v_mfma_f32_16x16x32_bf16 spans the whole
+// K-step; lane l reads row l & 15, 16-byte chunk l >> 4 of a 16-row fragment block.
+//   * weights: the pre-split tile never passes through VGPRs.  Each wave issues
+//     `buffer_load_dwordx4 ... lds` (1 KiB per instruction, lane l -> LDS base + 16 l) into a
+//     double-buffered, unpadded [3][BN][64 B] image one K-step ahead;
+//   * activations: 16-byte buffer loads one K-step ahead into registers, split into limbs by the
+//     VALU and stored ([3][128][64 B], single stage) between the two barriers of a K-step -- the
+//     VGPR -> LDS store path, the slow side of the LDS, carries only these;
+//   * both images are lane-linear 64-byte rows, so the bank-conflict fix is an XOR: LDS slot
+//     (row, c') holds data chunk c' ^ swz_row(row) (applied on the SOURCE side of the DMA, on the
+//     store address of the activation limbs, and again by the fragment read).  Every
+//     ds_read_b128 lane group ({0-3, 12-15} chunk c with {4-11} chunk c + 1, and vice versa)
+//     then hits 16 distinct 16-byte slots: SQ_LDS_BANK_CONFLICT = 0.
 // 73.7 KB LDS, 2 workgroups / CU.
-// (the (row >> 1) & 1 term additionally spreads the 8 consecutive rows of a ds_write_b128 lane group
-// of the weight-gradient staging over all 8 slots of the 128-byte store line)
 __device__ __forceinline__ int swz_row(int row) {
   const int q = (row >> 2) & 3;
   return q ^ ((q & 1) << 1) ^ ((row >> 1) & 1);
 }
 
-// (original DMA-kernel notes) the pre-split weight tile never passes through
-// VGPRs: each wave issues `buffer_load_dwordx4 ... lds` (1 KiB per instruction, lane l -> LDS base
-// + 16 l) into a double-buffered, UNPADDED [3][BN][64 B] image one K-step ahead.  The image is
-// lane-linear, so the bank-conflict fix is an XOR on the SOURCE side: LDS slot (row, c') holds
-// data chunk c' ^ ((row >> 2) & 3), and the fragment read applies the same involution (16 rows of
-// a ds_read_b128 lane group then hit 16 distinct 16-byte bank slots).  The VGPR -> LDS store path
-// (the slow side of the LDS) carries only the activation limbs.  79.9 KB LDS, 2 workgroups / CU.
 template <int BM, int BN, bool SK>
-__global__ __launch_bounds__(256, 2) void conv_fwd_bf3_m16_kernel(const ConvK a, unsigned limb_stride,
-                                                                   unsigned x_bytes, unsigned w_bytes) {
+__global__ __launch_bounds__(256, 2) void conv_fwd_bf3_kernel(const ConvK a, unsigned limb_stride, unsigned x_bytes,
+                                                              unsigned w_bytes) {
   constexpr int WAVES_M = 2, WAVES_N = 2;
   constexpr int MF = 16;
   constexpr int TM = BM / (MF * WAVES_M), TN = BN / (MF * WAVES_N);
@@ -532,7 +145,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_bf3_m16_kernel(const ConvK a,
       bH[i] = b * c.Hi;
     }
     // this wave's DMA pieces: piece p = wave*DPW + d -> limb p / CHUNKS, 1-KiB chunk p % CHUNKS;
-    // lane -> LDS slot (row = chunk*16 + lane/4, c' = lane & 3) <- data chunk c' ^ ((row>>2)&3)
+    // lane -> LDS slot (row = chunk*16 + lane/4, c' = lane & 3) <- data chunk c' ^ swz_row(row)
     unsigned dofs[DPW];
 #pragma unroll
     for (int d = 0; d < DPW; ++d) {
@@ -677,703 +290,13 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_bf3_m16_kernel(const ConvK a,
   }
 }
 
-// ---- forward / data gradient, 16x16x32, hand-scheduled K-step --------------------------------------
-// What the measurements said about conv_fwd_bf3_m16_kernel: per K-step a wave spends ~45 % of its
-// time outside its MFMA phase (tools/stamp_bf3.py: limb split + LDS stores ~700 cycles, load / DMA
-// issue ~770, barriers ~400, of ~4000), and the other workgroup's wave on the same SIMD cannot use
-// that time for VALU work: beside a wave that streams MFMAs back to back, another wave's VALU gets
-// no issue slots at all (tools/micro/valu_vs_mfma.hip: 80 v_fma take 200 cycles alone, 1750 beside
-// a 1555-cycle MFMA stream).  Fillers only overlap MFMAs of their OWN wave (a 16x16x32 MFMA holds
-// the vector issue 8 of its 16 cycles).  So this kernel puts everything except the LDS stores of
-// the activation limbs inside the MFMA stream of the wave itself, at fixed slots:
-//   * rows are requested TWO K-steps ahead; their split (88 VALU) runs one K-step ahead, one small
-//     piece behind every second MFMA, into 24 parked VGPRs; the serial section between the two
-//     barriers is 12 ds_write_b64;
-//   * the weight DMA of the next step is issued behind the first MFMAs of the block, each row
-//     request right after the split freed its registers;
-//   * fragment reads are double-buffered by hand (two A-limb and two B-limb register sets; the
-//     limb-product order a1b3, a1b2, a2b2, a2b1, a3b1, a1b1 changes one operand per group).
-// __builtin_amdgcn_sched_barrier(0) after every MFMA slot pins that order; loads and DMA are inline
-// assembly so that every s_waitcnt vmcnt is placed here (oldest-first accounting in the comments).
-template <int BM, int BN, bool SK>
-__global__ __launch_bounds__(256, 2) void conv_fwd_bf3_p16_kernel(const ConvK a, unsigned limb_stride,
-                                                                   unsigned x_bytes, unsigned w_bytes) {
-  constexpr int WAVES_M = 2, WAVES_N = 2;
-  constexpr int MF = 16;
-  constexpr int TM = BM / (MF * WAVES_M), TN = BN / (MF * WAVES_N);
-  constexpr int AL = BM / 32;
-  static_assert(AL == 4 && TM == 4, "the slot schedule below is written for 128-row tiles");
-  constexpr int PLANE_A = BM * 64;         // activation limb plane, 64-byte rows, swizzled
-  constexpr int PLANE_B = BN * 64;         // weight limb plane, 64-byte rows, source-swizzled
-  constexpr int A_BYTES = 3 * PLANE_A, B_STAGE = 3 * PLANE_B;
-  constexpr int CHUNKS = BN / 16;          // 1-KiB DMA pieces per limb plane
-  constexpr int DPW = 3 * CHUNKS / 4;      // DMA instructions per wave per K-step
-  constexpr int B_OFF = A_BYTES;
-  // slot schedule (slot = one MFMA): GS MFMAs per limb-product group
-  constexpr int GS = TM * TN, NS = 6 * GS;
-  constexpr int DMA0 = 1, DMA_STEP = GS / 4;            // weight DMA piece d behind slot DMA0 + d*DMA_STEP
-  constexpr int SP0 = DMA0 + DPW * DMA_STEP, SP_STEP = TN / 2;  // split piece m behind slot SP0 + m*SP_STEP
-  static_assert(SP0 + 31 * SP_STEP < NS, "split pieces fit the block");
-  __shared__ __attribute__((aligned(16))) unsigned char lds[A_BYTES + 2 * B_STAGE];
-
-  const OndaConv& c = a.c;
-  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-
-  const int nblk = gridDim.x, bid = blockIdx.x;
-  const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
-  const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  const int KT = a.taps * a.kcper;
-  const int tiles_all = a.tilesM * a.tilesN;
-  const int tiles_dp = SK ? a.tiles_dp : tiles_all;
-  const long long U = (long long)(tiles_all - tiles_dp) * KT;
-  long long u = SK ? swz * U / nblk : 0;
-  const long long u_begin = u;
-  const long long u_end = SK ? (swz + 1) * U / nblk : 0;
-  int dp_tile = swz;
-  const int ccol = (t & 7) * 4, rbase = t >> 3;
-  const int wstride = a.taps * c.Cin;
-  const u32x4 rx = raw_rsrc(a.x, x_bytes), rw = raw_rsrc(a.w, w_bytes);
-  const unsigned lds_base = lds_address(lds);
-  // lane l: row l & 15 of each 16-row block, data chunk l >> 4 (swizzle is the same for every block)
-  const int frag = (lane & 15) * 64 + (((lane >> 4) ^ swz_row(lane & 15)) << 4);
-  const unsigned char* const Ab = lds + wm * TM * MF * 64 + frag;
-
-  while (dp_tile < tiles_dp || u < u_end) {
-    const bool dp = dp_tile < tiles_dp;
-    const int tile = dp ? dp_tile : tiles_dp + (int)(u / KT);
-    const int k_begin = dp ? 0 : (int)(u - (long long)(tile - tiles_dp) * KT);
-    const int k_end = dp ? KT : (int)min((long long)KT, k_begin + (u_end - u));
-    const int tile_n = tile % a.tilesN, tile_m = tile / a.tilesN;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
-
-    int hi0[AL], wi0[AL], bH[AL];
-#pragma unroll
-    for (int i = 0; i < AL; ++i) {
-      const int m = m0 + rbase + 32 * i;
-      const bool vm = m < a.M;
-      const int mm = vm ? m : 0;
-      const int wo = mm % c.Wo, tq = mm / c.Wo;
-      const int ho = tq % c.Ho, b = tq / c.Ho;
-      hi0[i] = vm ? ho * c.stride - c.pad : -(1 << 28);
-      wi0[i] = wo * c.stride - c.pad;
-      bH[i] = b * c.Hi;
-    }
-    // this wave's DMA pieces: piece p = wave*DPW + d -> limb p / CHUNKS, 1-KiB chunk p % CHUNKS;
-    // lane -> LDS slot (row = chunk*16 + lane/4, c' = lane & 3) <- data chunk c' ^ swz_row(row)
-    unsigned dofs[DPW];
-#pragma unroll
-    for (int d = 0; d < DPW; ++d) {
-      const int p = wave * DPW + d;
-      const int l = p / CHUNKS, j = p % CHUNKS;
-      const int row = j * 16 + (lane >> 2), cq = (lane & 3) ^ swz_row(row);
-      const int n = n0 + row;
-      dofs[d] = n < c.Cout ? (l * limb_stride + (unsigned)n * wstride) * 2u + cq * 16u : OOB;
-    }
-
-    unsigned aofs[AL];
-    f32x4 ar[AL];        // activation rows in flight (requested one K-step before they are split)
-    u32x2 lim[AL][3];    // limbs of the next K-step's rows, stored to LDS between the two barriers
-    // two cursors over (tap, channel block): A = next row request, B = next weight DMA
-    int tapA = k_begin / a.kcper, cA = (k_begin - tapA * a.kcper) * BK;
-    int tapB = tapA, cB = cA;
-    int soffA = cA * 4, soffB = (tapB * c.Cin + cB) * 2;
-    auto set_tap = [&](int tp) {
-      const int rr = tp / c.kw, ss = tp - rr * c.kw;
-#pragma unroll
-      for (int i = 0; i < AL; ++i) {
-        const int hi = hi0[i] + rr * c.dil, wi = wi0[i] + ss * c.dil;
-        const bool ok = (unsigned)hi < (unsigned)c.Hi && (unsigned)wi < (unsigned)c.Wi;
-        aofs[i] = ok ? (unsigned)(((bH[i] + hi) * c.Wi + wi) * c.ldx + ccol) * 4u : OOB;
-      }
-    };
-    auto advance_a = [&](bool live) {  // move the row cursor; past the segment every row is OOB (zeros)
-      if (!live) {
-#pragma unroll
-        for (int i = 0; i < AL; ++i) aofs[i] = OOB;
-        return;
-      }
-      cA += BK;
-      if (cA == c.Cin) {
-        cA = 0;
-        ++tapA;
-        set_tap(tapA);
-      }
-      soffA = cA * 4;
-    };
-    auto swrite_a = [&]() {
-#pragma unroll
-      for (int i = 0; i < AL; ++i) {
-        const int row = rbase + 32 * i;
-        const int off = row * 64 + ((((t & 7) >> 1) ^ swz_row(row)) << 4) + (t & 1) * 8;
-#pragma unroll
-        for (int l = 0; l < 3; ++l) *reinterpret_cast<u32x2*>(lds + l * PLANE_A + off) = lim[i][l];
-      }
-    };
-
-    f32x4 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
-
-    __syncthreads();  // the previous segment's readers are done with every LDS region (and vmcnt is 0)
-    set_tap(tapA);
-#pragma unroll
-    for (int i = 0; i < AL; ++i) ar[i] = bload16(rx, aofs[i], soffA);
-#pragma unroll
-    for (int d = 0; d < DPW; ++d) {
-      const int p = wave * DPW + d;
-      dma16(rw, lds_base + B_OFF + (p / CHUNKS) * PLANE_B + (p % CHUNKS) * 1024, dofs[d], soffB);
-    }
-    wait_rows<0>(ar);
-#pragma unroll
-    for (int i = 0; i < AL; ++i) split3(ar[i], lim[i][0], lim[i][1], lim[i][2]);
-    advance_a(k_begin + 1 < k_end);
-#pragma unroll
-    for (int i = 0; i < AL; ++i) ar[i] = bload16(rx, aofs[i], soffA);
-    int cur = 0;
-#ifdef ONDA_BF3_STAMP  // diagnostic build only (tools/stamp_bf3.py)
-    long long st[6] = {0, 0, 0, 0, 0, 0};
-    long long st0 = __builtin_amdgcn_s_memtime();
-    const long long clk0 = st0, rt0 = wall_clock64();
-#endif
-    for (int kt = k_begin; kt < k_end; ++kt) {
-      // in flight, oldest first: this step's weight DMA (none at kt = k_begin), the rows of step kt+1
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AL) : "memory");
-      STAMP(0)
-      lds_barrier();  // everybody's DMA has landed, and the A image is free
-      STAMP(1)
-      swrite_a();
-      STAMP(2)
-      lds_barrier();
-      STAMP(3)
-      // cursors of what this block puts in flight: weights of step kt+1, rows of step kt+2
-      // (past the segment: zero rows, and a weight stage nobody reads)
-      cB += BK;
-      if (cB == c.Cin) {
-        cB = 0;
-        ++tapB;
-      }
-      soffB = (tapB * c.Cin + cB) * 2;
-      const unsigned dst_stage = lds_base + B_OFF + (cur ^ 1) * B_STAGE;
-      const bool more = kt + 1 < k_end;
-      advance_a(kt + 2 < k_end);
-
-      const unsigned char* const Bb = lds + A_BYTES + cur * B_STAGE + wn * TN * MF * 64 + frag;
-      bf16x8 A0[TM], A1[TM], B0[TN], B1[TN];
-      float r0[8], r1[8];  // split state of the 8 value pairs of this thread's rows
-#pragma unroll
-      for (int i = 0; i < TM; ++i) A0[i] = *reinterpret_cast<const bf16x8*>(Ab + 0 * PLANE_A + i * MF * 64);  // a1
-#pragma unroll
-      for (int j = 0; j < TN; ++j) B0[j] = *reinterpret_cast<const bf16x8*>(Bb + 2 * PLANE_B + j * MF * 64);  // b3
-      __builtin_amdgcn_sched_barrier(0);
-
-      auto slot = [&](auto ic) {
-        constexpr int S = decltype(ic)::value;
-        constexpr int g = S / GS, i = (S % GS) / TN, j = S % TN;
-        // operands of group g: (a1,b3) (a1,b2) (a2,b2) (a2,b1) (a3,b1) (a1,b1)
-        const bf16x8& av = (g == 0 || g == 1 || g == 4) ? A0[i] : A1[i];
-        const bf16x8& bv = (g == 1 || g == 2) ? B1[j] : B0[j];
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, acc[i][j], 0, 0, 0);
-        // fragment reads for the NEXT group, into the register set that just went dead
-        if constexpr (S % GS == 0) {
-          if constexpr (g == 0) {
-#pragma unroll
-            for (int jj = 0; jj < TN; ++jj) B1[jj] = *reinterpret_cast<const bf16x8*>(Bb + 1 * PLANE_B + jj * MF * 64);  // b2
-          } else if constexpr (g == 1) {
-#pragma unroll
-            for (int ii = 0; ii < TM; ++ii) A1[ii] = *reinterpret_cast<const bf16x8*>(Ab + 1 * PLANE_A + ii * MF * 64);  // a2
-          } else if constexpr (g == 2) {
-#pragma unroll
-            for (int jj = 0; jj < TN; ++jj) B0[jj] = *reinterpret_cast<const bf16x8*>(Bb + 0 * PLANE_B + jj * MF * 64);  // b1
-          } else if constexpr (g == 3) {
-#pragma unroll
-            for (int ii = 0; ii < TM; ++ii) A0[ii] = *reinterpret_cast<const bf16x8*>(Ab + 2 * PLANE_A + ii * MF * 64);  // a3
-          } else if constexpr (g == 4) {
-#pragma unroll
-            for (int ii = 0; ii < TM; ++ii) A1[ii] = *reinterpret_cast<const bf16x8*>(Ab + 0 * PLANE_A + ii * MF * 64);  // a1
-          }
-        }
-        // weight DMA of step kt+1
-        if constexpr (S >= DMA0 && S < DMA0 + DPW * DMA_STEP && (S - DMA0) % DMA_STEP == 0) {
-          constexpr int d = (S - DMA0) / DMA_STEP;
-          const int p = wave * DPW + d;
-          dma16(rw, dst_stage + (p / CHUNKS) * PLANE_B + (p % CHUNKS) * 1024, more ? dofs[d] : OOB, soffB);
-        }
-        // split of the rows of step kt+1: piece m = pair (m / 4) stage (m % 4); pair n = row n / 2, half n % 2
-        if constexpr (S >= SP0 && S < SP0 + 32 * SP_STEP && (S - SP0) % SP_STEP == 0) {
-          constexpr int m = (S - SP0) / SP_STEP, n = m / 4, st = m % 4, row = n / 2, h = n % 2;
-          if constexpr (m == 0) wait_rows<DPW>(ar);  // older than the DPW weight pieces issued above
-          if constexpr (st == 0) {
-            lim[row][0][h] = cvt2(ar[row][2 * h], ar[row][2 * h + 1]);
-          } else if constexpr (st == 1) {
-            r0[n] = ar[row][2 * h] - __builtin_bit_cast(float, lim[row][0][h] << 16);
-            r1[n] = ar[row][2 * h + 1] - __builtin_bit_cast(float, lim[row][0][h] & 0xFFFF0000u);
-            lim[row][1][h] = cvt2(r0[n], r1[n]);
-          } else if constexpr (st == 2) {
-            r0[n] -= __builtin_bit_cast(float, lim[row][1][h] << 16);
-            r1[n] -= __builtin_bit_cast(float, lim[row][1][h] & 0xFFFF0000u);
-          } else {
-            lim[row][2][h] = cvt2(r0[n], r1[n]);
-            if constexpr (h == 1) ar[row] = bload16(rx, aofs[row], soffA);  // row is free: request step kt+2
-          }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      };
-      [&]<int... S>(std::integer_sequence<int, S...>) { (slot(std::integral_constant<int, S>{}), ...); }
-      (std::make_integer_sequence<int, NS>{});
-      cur ^= 1;
-      STAMP(5)
-    }
-#ifdef ONDA_BF3_STAMP
-    if (lane == 0 && swz < 256) {
-      for (int i = 0; i < 6; ++i) a.ws[(swz * 4 + wave) * 8 + i] = (float)st[i];
-      a.ws[(swz * 4 + wave) * 8 + 6] = (float)(__builtin_amdgcn_s_memtime() - clk0);
-      a.ws[(swz * 4 + wave) * 8 + 7] = (float)(wall_clock64() - rt0);
-    }
-#endif
-    // drain the (zero-filled) requests issued past the segment before their registers are reused
-    wait_rows<0>(ar);
-
-    if (dp) dp_tile += nblk; else u += k_end - k_begin;
-    if (SK && (k_begin != 0 || k_end != KT)) {
-      float* slot_ws = a.ws + ((size_t)swz * 2 + (u - (k_end - k_begin) == u_begin ? 0 : 1)) * (BM * BN);
-      conv_store_partial<BN, TM, TN, MF>(slot_ws, acc, wm, wn, lane);
-      continue;
-    }
-    __syncthreads();
-    conv_epilogue<BM, BN, TM, TN, WAVES_M, MF>(a, acc, reinterpret_cast<float*>(lds), tile_m, m0, n0, wm, wn, lane);
-  }
-}
-
-// ---- forward / data gradient, 8-wave ping-pong, hand-scheduled ------------------------------------
-// The hand-scheduled K-step of conv_fwd_bf3_p16_kernel in a 512-thread workgroup that owns a
-// 256 x 128 tile, ONE workgroup per CU.  Stamps of the 4-wave kernels show the other limit: a
-// weight stage requested one K-step ahead arrives ~3300 cycles later (vmcnt wait of ~2300 cycles
-// at the top of every K-step), longer than a K-step.  Here:
-//   * two 4-wave groups P (rows 0-127) and Q (rows 128-255); waves w and w+4 share a SIMD and run
-//     half a K-step apart (one s_barrier per half step), so while one group stores its limbs and
-//     waits at the barriers the other group's MFMA block owns the pipe;
-//   * THREE weight stages shared by both groups, filled two K-steps ahead (each wave 3 DMA pieces
-//     per K-step: half the DMA and weight traffic per MFMA of the 128 x 128 kernels);
-//   * rows requested two K-steps ahead, split inside the MFMA block of the step before use.
-// LDS: 2 x 24.5 KB activation images + 3 x 24.5 KB weight stages = 122.5 KB.
-template <bool SK>
-__global__ __launch_bounds__(512) void conv_fwd_bf3_pp_kernel(const ConvK a, unsigned limb_stride, unsigned x_bytes,
-                                                              unsigned w_bytes) {
-  constexpr int BM = 256, GM = 128, BN = 128;  // workgroup tile, rows per wave group
-  constexpr int MF = 16, WAVES_M = 2, WAVES_N = 2;
-  constexpr int TM = GM / (MF * WAVES_M), TN = BN / (MF * WAVES_N);
-  constexpr int AL = GM / 32;
-  constexpr int PLANE_A = GM * 64, A_GROUP = 3 * PLANE_A;
-  constexpr int PLANE_B = BN * 64, B_STAGE = 3 * PLANE_B;
-  constexpr int CHUNKS = BN / 16;      // 1-KiB DMA pieces per limb plane
-  constexpr int DPW = 3 * CHUNKS / 8;  // DMA instructions per wave per K-step
-  constexpr int B_OFF = 2 * A_GROUP;
-  constexpr int GS = TM * TN, NS = 6 * GS;
-  constexpr int SP0 = 4;  // split micro-op e (11 per value pair, 88 per thread) rides behind MFMA slot SP0 + e
-  static_assert(SP0 + 88 <= NS, "split micro-ops fit the block");
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * A_GROUP + 3 * B_STAGE];
-
-  const OndaConv& c = a.c;
-  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int grp = wave >> 2, wq = wave & 3, tl = t & 255;
-  const int wm = wq / WAVES_N, wn = wq % WAVES_N;
-  unsigned char* const Aimg = lds + grp * A_GROUP;
-
-  const int nblk = gridDim.x, bid = blockIdx.x;
-  const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
-  const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  const int KT = a.taps * a.kcper;
-  const int tiles_all = a.tilesM * a.tilesN;
-  const int tiles_dp = SK ? a.tiles_dp : tiles_all;
-  const long long U = (long long)(tiles_all - tiles_dp) * KT;
-  long long u = SK ? swz * U / nblk : 0;
-  const long long u_begin = u;
-  const long long u_end = SK ? (swz + 1) * U / nblk : 0;
-  int dp_tile = swz;
-  const int ccol = (tl & 7) * 4, rbase = tl >> 3;
-  const int wstride = a.taps * c.Cin;
-  const u32x4 rx = raw_rsrc(a.x, x_bytes), rw = raw_rsrc(a.w, w_bytes);
-  const unsigned lds_base = lds_address(lds);
-  // lane l: row l & 15 of each 16-row block, data chunk l >> 4 (swizzle is the same for every block)
-  const int frag = (lane & 15) * 64 + (((lane >> 4) ^ swz_row(lane & 15)) << 4);
-  const unsigned char* const Ab = Aimg + wm * TM * MF * 64 + frag;
-
-  while (dp_tile < tiles_dp || u < u_end) {
-    const bool dp = dp_tile < tiles_dp;
-    const int tile = dp ? dp_tile : tiles_dp + (int)(u / KT);
-    const int k_begin = dp ? 0 : (int)(u - (long long)(tile - tiles_dp) * KT);
-    const int k_end = dp ? KT : (int)min((long long)KT, k_begin + (u_end - u));
-    const int tile_n = tile % a.tilesN, tile_m = tile / a.tilesN;
-    const int m0 = tile_m * BM + grp * GM, n0 = tile_n * BN;  // this group's rows
-
-    int hi0[AL], wi0[AL], bH[AL];
-#pragma unroll
-    for (int i = 0; i < AL; ++i) {
-      const int m = m0 + rbase + 32 * i;
-      const bool vm = m < a.M;
-      const int mm = vm ? m : 0;
-      const int wo = mm % c.Wo, tq = mm / c.Wo;
-      const int ho = tq % c.Ho, b = tq / c.Ho;
-      hi0[i] = vm ? ho * c.stride - c.pad : -(1 << 28);
-      wi0[i] = wo * c.stride - c.pad;
-      bH[i] = b * c.Hi;
-    }
-    // this wave's DMA pieces: piece p = wave*DPW + d -> limb p / CHUNKS, 1-KiB chunk p % CHUNKS;
-    // lane -> LDS slot (row = chunk*16 + lane/4, c' = lane & 3) <- data chunk c' ^ swz_row(row)
-    unsigned dofs[DPW], ddst[DPW];
-#pragma unroll
-    for (int d = 0; d < DPW; ++d) {
-      const int p = wave * DPW + d;
-      const int l = p / CHUNKS, j = p % CHUNKS;
-      const int row = j * 16 + (lane >> 2), cq = (lane & 3) ^ swz_row(row);
-      const int n = n0 + row;
-      dofs[d] = n < c.Cout ? (l * limb_stride + (unsigned)n * wstride) * 2u + cq * 16u : OOB;
-      ddst[d] = lds_base + B_OFF + l * PLANE_B + j * 1024;
-    }
-
-    unsigned aofs[AL];
-    f32x4 ar[AL];        // activation rows in flight (requested one K-step before they are split)
-    u32x2 lim[AL][3];    // limbs of the next K-step's rows, stored to LDS between the two barriers
-    // two cursors over (tap, channel block): A = next row request, B = next weight DMA
-    int tapA = k_begin / a.kcper, cA = (k_begin - tapA * a.kcper) * BK;
-    int tapB = tapA, cB = cA;
-    int soffA = cA * 4, soffB = (tapB * c.Cin + cB) * 2;
-    auto set_tap = [&](int tp) {
-      const int rr = tp / c.kw, ss = tp - rr * c.kw;
-#pragma unroll
-      for (int i = 0; i < AL; ++i) {
-        const int hi = hi0[i] + rr * c.dil, wi = wi0[i] + ss * c.dil;
-        const bool ok = (unsigned)hi < (unsigned)c.Hi && (unsigned)wi < (unsigned)c.Wi;
-        aofs[i] = ok ? (unsigned)(((bH[i] + hi) * c.Wi + wi) * c.ldx + ccol) * 4u : OOB;
-      }
-    };
-    auto advance_a = [&](bool live) {  // move the row cursor; past the segment every row is OOB (zeros)
-      if (!live) {
-#pragma unroll
-        for (int i = 0; i < AL; ++i) aofs[i] = OOB;
-        return;
-      }
-      cA += BK;
-      if (cA == c.Cin) {
-        cA = 0;
-        ++tapA;
-        set_tap(tapA);
-      }
-      soffA = cA * 4;
-    };
-    auto advance_b = [&]() {
-      cB += BK;
-      if (cB == c.Cin) {
-        cB = 0;
-        ++tapB;
-      }
-      soffB = (tapB * c.Cin + cB) * 2;
-    };
-    auto swrite_a = [&]() {
-#pragma unroll
-      for (int i = 0; i < AL; ++i) {
-        const int row = rbase + 32 * i;
-        const int off = row * 64 + ((((tl & 7) >> 1) ^ swz_row(row)) << 4) + (tl & 1) * 8;
-#pragma unroll
-        for (int l = 0; l < 3; ++l) *reinterpret_cast<u32x2*>(Aimg + l * PLANE_A + off) = lim[i][l];
-      }
-    };
-
-    f32x4 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
-
-    // ---- fill: weight stages of the first two steps, rows of the first step into the images
-    __syncthreads();  // the previous segment's readers are done with every LDS region (and vmcnt is 0)
-    set_tap(tapA);
-#pragma unroll
-    for (int i = 0; i < AL; ++i) ar[i] = bload16(rx, aofs[i], soffA);
-#pragma unroll
-    for (int d = 0; d < DPW; ++d) dma16(rw, ddst[d], dofs[d], soffB);
-    advance_b();
-#pragma unroll
-    for (int d = 0; d < DPW; ++d) dma16(rw, ddst[d] + B_STAGE, k_begin + 1 < k_end ? dofs[d] : OOB, soffB);
-    wait_rows<0>(ar);
-#pragma unroll
-    for (int i = 0; i < AL; ++i) split3(ar[i], lim[i][0], lim[i][1], lim[i][2]);
-    swrite_a();
-    advance_a(k_begin + 1 < k_end);
-#pragma unroll
-    for (int i = 0; i < AL; ++i) ar[i] = bload16(rx, aofs[i], soffA);
-    lds_barrier();
-    if (grp == 1) lds_barrier();  // Q runs half a K-step behind P
-
-    int stage = 0;  // weight stage of step kt; steps kt+1, kt+2 use the next two (mod 3)
-#ifdef ONDA_BF3_STAMP  // diagnostic build only (tools/stamp_bf3.py)
-    long long st[6] = {0, 0, 0, 0, 0, 0};
-    long long st0 = __builtin_amdgcn_s_memtime();
-    const long long clk0 = st0, rt0 = wall_clock64();
-#endif
-    for (int kt = k_begin; kt < k_end; ++kt) {
-      // cursors of what this block puts in flight: weights of step kt+2, rows of step kt+2
-      // (past the segment: zero rows, and a weight stage nobody reads)
-      advance_b();
-      const int st2 = stage >= 1 ? stage - 1 : 2;  // (stage + 2) % 3
-      const unsigned dst_off = st2 * B_STAGE;
-      const bool more2 = kt + 2 < k_end;
-      advance_a(more2);  // offsets of the row requests inside the block
-      // split below: rows of step kt+1 (in flight since the previous block); request: rows of step kt+2
-      const unsigned char* const Bb = lds + B_OFF + stage * B_STAGE + wn * TN * MF * 64 + frag;
-      bf16x8 A0[TM], A1[TM], B0[TN], B1[TN];
-      float r0, r1, f0, f1;  // split state of the value pair in flight
-#pragma unroll
-      for (int i = 0; i < TM; ++i) A0[i] = *reinterpret_cast<const bf16x8*>(Ab + 0 * PLANE_A + i * MF * 64);  // a1
-#pragma unroll
-      for (int j = 0; j < TN; ++j) B0[j] = *reinterpret_cast<const bf16x8*>(Bb + 2 * PLANE_B + j * MF * 64);  // b3
-      __builtin_amdgcn_sched_barrier(0);
-
-      auto slot = [&](auto ic) {
-        constexpr int S = decltype(ic)::value;
-        constexpr int g = S / GS, i = (S % GS) / TN, j = S % TN;
-        // operands of group g: (a1,b3) (a1,b2) (a2,b2) (a2,b1) (a3,b1) (a1,b1)
-        const bf16x8& av = (g == 0 || g == 1 || g == 4) ? A0[i] : A1[i];
-        const bf16x8& bv = (g == 1 || g == 2) ? B1[j] : B0[j];
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, acc[i][j], 0, 0, 0);
-        // fragment reads for the NEXT group, into the register set that just went dead
-        if constexpr (S % GS == 0) {
-          if constexpr (g == 0) {
-#pragma unroll
-            for (int jj = 0; jj < TN; ++jj) B1[jj] = *reinterpret_cast<const bf16x8*>(Bb + 1 * PLANE_B + jj * MF * 64);  // b2
-          } else if constexpr (g == 1) {
-#pragma unroll
-            for (int ii = 0; ii < TM; ++ii) A1[ii] = *reinterpret_cast<const bf16x8*>(Ab + 1 * PLANE_A + ii * MF * 64);  // a2
-          } else if constexpr (g == 2) {
-#pragma unroll
-            for (int jj = 0; jj < TN; ++jj) B0[jj] = *reinterpret_cast<const bf16x8*>(Bb + 0 * PLANE_B + jj * MF * 64);  // b1
-          } else if constexpr (g == 3) {
-#pragma unroll
-            for (int ii = 0; ii < TM; ++ii) A0[ii] = *reinterpret_cast<const bf16x8*>(Ab + 2 * PLANE_A + ii * MF * 64);  // a3
-          } else if constexpr (g == 4) {
-#pragma unroll
-            for (int ii = 0; ii < TM; ++ii) A1[ii] = *reinterpret_cast<const bf16x8*>(Ab + 0 * PLANE_A + ii * MF * 64);  // a1
-          }
-        }
-        // weight DMA of step kt+2
-        // split of the rows of step kt+1, one VALU micro-op per MFMA gap (a 16x16x32 MFMA leaves 8 of
-        // its 16 cycles of vector issue free; three or more VALU behind one MFMA delay the next one):
-        // pair n = row n / 2, half n % 2; x -> p = bf16(x), r = x - p, q = bf16(r), s = r - q, bf16(s)
-        if constexpr (S >= SP0 && S < SP0 + 88) {
-          constexpr int e = S - SP0, n = e / 11, op = e % 11, row = n / 2, h = n % 2;
-          if constexpr (e == 0) wait_rows<DPW>(ar);  // requested in the previous block; older than the last DMA
-          if constexpr (op == 0) lim[row][0][h] = cvt2(ar[row][2 * h], ar[row][2 * h + 1]);
-          else if constexpr (op == 1) f0 = __builtin_bit_cast(float, lim[row][0][h] << 16);
-          else if constexpr (op == 2) f1 = __builtin_bit_cast(float, lim[row][0][h] & 0xFFFF0000u);
-          else if constexpr (op == 3) r0 = ar[row][2 * h] - f0;
-          else if constexpr (op == 4) r1 = ar[row][2 * h + 1] - f1;
-          else if constexpr (op == 5) lim[row][1][h] = cvt2(r0, r1);
-          else if constexpr (op == 6) f0 = __builtin_bit_cast(float, lim[row][1][h] << 16);
-          else if constexpr (op == 7) f1 = __builtin_bit_cast(float, lim[row][1][h] & 0xFFFF0000u);
-          else if constexpr (op == 8) r0 -= f0;
-          else if constexpr (op == 9) r1 -= f1;
-          else {
-            lim[row][2][h] = cvt2(r0, r1);
-            if constexpr (h == 1) ar[row] = bload16(rx, aofs[row], soffA);  // row is free: request step kt+2
-          }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      };
-      [&]<int... S>(std::integer_sequence<int, S...>) { (slot(std::integral_constant<int, S>{}), ...); }
-      (std::make_integer_sequence<int, NS>{});
-      // in flight, oldest first: weights kt+1 (issued after the previous block), rows kt+2 (this block):
-      // the weights must have landed before the barrier the other group's next block waits on
-      STAMP(0)
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AL) : "memory");
-      STAMP(1)
-      lds_barrier();
-      STAMP(2)
-      swrite_a();  // limbs of step kt+1; this group's block kt is done with the image
-      // weight DMA of step kt+2, while the other group's block owns the vector issue (VMEM and LDS
-      // instructions of this wave still get their slots; VALU would not)
-#pragma unroll
-      for (int d = 0; d < DPW; ++d) dma16(rw, ddst[d] + dst_off, more2 ? dofs[d] : OOB, soffB);
-      STAMP(3)
-      lds_barrier();
-      STAMP(4)
-      stage = stage == 2 ? 0 : stage + 1;
-    }
-#ifdef ONDA_BF3_STAMP
-    if (lane == 0 && swz < 128) {
-      for (int i = 0; i < 6; ++i) a.ws[(swz * 8 + wave) * 8 + i] = (float)st[i];
-      a.ws[(swz * 8 + wave) * 8 + 6] = (float)(__builtin_amdgcn_s_memtime() - clk0);
-      a.ws[(swz * 8 + wave) * 8 + 7] = (float)(wall_clock64() - rt0);
-    }
-#endif
-    if (grp == 0) lds_barrier();  // P waits for Q's last block
-    // drain the (zero-filled) requests issued past the segment before their registers are reused
-    wait_rows<0>(ar);
-
-    if (dp) dp_tile += nblk; else u += k_end - k_begin;
-    if (SK && (k_begin != 0 || k_end != KT)) {
-      float* slot_ws = a.ws + ((size_t)swz * 2 + (u - (k_end - k_begin) == u_begin ? 0 : 1)) * (BM * BN) + grp * (GM * BN);
-      conv_store_partial<BN, TM, TN, MF>(slot_ws, acc, wm, wn, lane);
-      continue;
-    }
-    conv_epilogue<GM, BN, TM, TN, WAVES_M, MF>(a, acc, reinterpret_cast<float*>(Aimg), tile_m * 2 + grp, m0, n0, wm, wn, lane, tl);
-  }
-}
-
 // ---- weight gradient on the bf16 pipe ------------------------------------------------------------
 // dW[n][tap][c] = sum_m dY[m][n] * X[pix(m,tap)][c]: both operands have the contraction index
 // (the pixel m) as their SLOW axis in memory, while an MFMA fragment wants 8 consecutive k per
-// lane.  The transposition happens in registers on the way into LDS: a thread owns 8 consecutive
-// pixels of ONE channel column (lanes run over consecutive channels, so every scalar load
-// instruction reads 128 contiguous bytes of one pixel row), splits the 8 values into limbs and
-// writes each limb's 8 bf16 as one ds_write_b128 into the [channel row][k] image (consecutive
-// lanes -> consecutive rows of 80 B: conflict-free).  Threads 0-127 stage dY, 128-255 stage X.
+// lane.  The transposition happens in registers on the way into LDS (see WIDE below): a thread
+// splits 8 consecutive pixels of a channel into limbs and writes each limb's 8 bf16 as one
+// ds_write_b128 into the [channel row][k] image.  Threads 0-127 stage dY, 128-255 stage X.
 // The consumer side is the forward kernel's: [row][k] limb planes, six limb products.
-template <int BM, int BN>
-__global__ __launch_bounds__(256, 2) void conv_wgrad_bf3_kernel(const WgradK a, unsigned x_bytes, unsigned dy_bytes) {
-  constexpr int WAVES_N = 2;
-  constexpr int TM = BM / 64, TN = BN / 64;
-  constexpr int ROWS = BM + BN;
-  constexpr int PLANE = ROWS * ROWB;
-  constexpr int CPT = (BM > BN ? BM : BN) / 32;  // channel columns per staging thread
-  static_assert(BM == BN, "one staging half per operand");
-  __shared__ __attribute__((aligned(16))) unsigned char lds[3 * PLANE];
-  __shared__ unsigned pofs[32];
-
-  const OndaConv& c = a.c;
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int li = lane & 31, lh = lane >> 5;
-  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-
-  int bid = blockIdx.x;
-  const int tile_c = bid % a.tilesC;
-  bid /= a.tilesC;
-  const int tap = bid % a.taps;
-  bid /= a.taps;
-  const int tile_n = bid % a.tilesN;
-  const int ks = bid / a.tilesN;
-  const int n0 = tile_n * BM, c0 = tile_c * BN;
-  const int mbeg = ks * a.mchunk;
-  const int mend = min(a.M, mbeg + a.mchunk);
-  const int KT = mend > mbeg ? (mend - mbeg + BK - 1) / BK : 0;
-  const int rr = tap / c.kw, ss = tap - rr * c.kw;
-  const int dh = rr * c.dil - c.pad, dw = ss * c.dil - c.pad;
-
-  // staging role of this thread
-  // the role is wave-uniform; readfirstlane tells the compiler so (descriptor and scalar offset stay
-  // in SGPRs instead of a per-lane "waterfall" loop around every buffer load)
-  const bool is_x = __builtin_amdgcn_readfirstlane(t >> 7) != 0;
-  const int ch_lane = t & 31, kgroup = (t >> 5) & 3;  // 8 pixels kgroup*8 .. +7
-  const __amdgpu_buffer_rsrc_t rs = is_x ? make_rsrc(a.x, x_bytes) : make_rsrc(a.dy, dy_bytes);
-  const int ch0 = (is_x ? c0 : n0) + ch_lane;
-  const int chmax = is_x ? c.Cin : c.Cout;
-  unsigned chofs[CPT];  // byte offset of this thread's channel columns, OOB past the operand's width
-#pragma unroll
-  for (int j = 0; j < CPT; ++j) chofs[j] = ch0 + 32 * j < chmax ? (unsigned)(ch0 + 32 * j) * 4u : CH_OOB;
-
-  // byte offset (OOB = zero row) of pixel m of the X operand for this tap
-  auto pixel_offset = [&](int m) -> unsigned {
-    if (m >= mend) return OOB;
-    const int wo = m % c.Wo, tq = m / c.Wo;
-    const int ho = tq % c.Ho, b = tq / c.Ho;
-    const int hi = ho * c.stride + dh, wi = wo * c.stride + dw;
-    if ((unsigned)hi >= (unsigned)c.Hi || (unsigned)wi >= (unsigned)c.Wi) return OOB;
-    return (unsigned)(((b * c.Hi + hi) * c.Wi + wi) * c.ldx) * 4u;
-  };
-
-  float v[CPT][8];
-  auto gload = [&](int mb) {
-#pragma unroll
-    for (int p = 0; p < 8; ++p) {
-      const int m = mb + kgroup * 8 + p;
-      // X: gathered row from the table; dY: row m itself (scalar part mb*lddy rides in the soffset)
-      const unsigned row = is_x ? pofs[kgroup * 8 + p] : (m < mend ? (unsigned)((kgroup * 8 + p) * a.lddy) * 4u : OOB);
-      const int so = is_x ? 0 : mb * a.lddy * 4;
-#pragma unroll
-      for (int j = 0; j < CPT; ++j)
-        v[j][p] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, row + chofs[j], so, 0));
-    }
-  };
-  auto sstore = [&]() {
-#pragma unroll
-    for (int j = 0; j < CPT; ++j) {
-      u32x2 a1, a2, a3, b1, b2, b3;
-      split3(f32x4{v[j][0], v[j][1], v[j][2], v[j][3]}, a1, a2, a3);
-      split3(f32x4{v[j][4], v[j][5], v[j][6], v[j][7]}, b1, b2, b3);
-      unsigned char* dst = lds + ((is_x ? BM : 0) + ch_lane + 32 * j) * ROWB + kgroup * 16;
-      *reinterpret_cast<u32x4*>(dst + 0 * PLANE) = u32x4{a1[0], a1[1], b1[0], b1[1]};
-      *reinterpret_cast<u32x4*>(dst + 1 * PLANE) = u32x4{a2[0], a2[1], b2[0], b2[1]};
-      *reinterpret_cast<u32x4*>(dst + 2 * PLANE) = u32x4{a3[0], a3[1], b3[0], b3[1]};
-    }
-  };
-
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-  if (KT > 0) {
-    if (t < 32) pofs[t] = pixel_offset(mbeg + t);
-    __syncthreads();
-    gload(mbeg);
-  }
-  for (int kt = 0; kt < KT; ++kt) {
-    __syncthreads();  // LDS image and pofs are free
-    sstore();
-    if (t < 32 && kt + 1 < KT) pofs[t] = pixel_offset(mbeg + (kt + 1) * BK + t);
-    __syncthreads();
-    if (kt + 1 < KT) gload(mbeg + (kt + 1) * BK);
-    const unsigned char* Ab = lds + (wm * TM * 32 + li) * ROWB + lh * 16;
-    const unsigned char* Bb = lds + (BM + wn * TN * 32 + li) * ROWB + lh * 16;
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      bf16x8 af[TM][3];
-#pragma unroll
-      for (int l = 0; l < 3; ++l)
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-          af[i][l] = *reinterpret_cast<const bf16x8*>(Ab + l * PLANE + i * 32 * ROWB + s * 32);
-#pragma unroll
-      for (int l = 2; l >= 0; --l) {
-        bf16x8 bf[TN];
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          bf[j] = *reinterpret_cast<const bf16x8*>(Bb + l * PLANE + j * 32 * ROWB + s * 32);
-#pragma unroll
-        for (int la = 2 - l; la >= 0; --la)
-#pragma unroll
-          for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][la], bf[j], acc[i][j], 0, 0, 0);
-      }
-    }
-  }
-
-#pragma unroll
-  for (int jn = 0; jn < TN; ++jn) {
-    const int cc = c0 + wn * TN * 32 + jn * 32 + li;
-    if (cc >= c.Cin) continue;
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int row = (e & 3) + 8 * (e >> 2) + 4 * lh;
-        const int n = n0 + wm * TM * 32 + i * 32 + row;
-        if (n >= c.Cout) continue;
-        a.slabs[(((size_t)ks * c.Cout + n) * a.taps + tap) * c.Cin + cc] = acc[i][jn][e];
-      }
-  }
-}
 
 // LDS image of the 16x16x32 weight-gradient kernel: 64-byte rows; inside each 16-row block the
 // row index is transposed as a 4 x 4 matrix and the 16-byte chunk index is XOR-ed with row bits
@@ -1386,7 +309,7 @@ __device__ __forceinline__ int wg_slot(int row, int chunk) {
 }
 
 template <int BM, int BN>
-__global__ __launch_bounds__(256, 2) void conv_wgrad_bf3_m16_kernel(const WgradK a, unsigned x_bytes, unsigned dy_bytes) {
+__global__ __launch_bounds__(256, 2) void conv_wgrad_bf3_kernel(const WgradK a, unsigned x_bytes, unsigned dy_bytes) {
   constexpr int WAVES_N = 2;
   constexpr int MF = 16;
   constexpr int TM = BM / (2 * MF), TN = BN / (2 * MF);
@@ -1624,74 +547,6 @@ int onda_conv2d_fwd_bf3(const float* x, const void* w3, float* y, const float* s
     }
   }
   hipStream_t st = ONDA_STREAM(s);
-  // ONDA_BF3_DMA=0 selects the older variant that stages the weight limbs through VGPRs
-  static const int use_dma = [] { const char* e = getenv("ONDA_BF3_DMA"); return e ? atoi(e) : 2; }();
-  if (use_dma == 4 && wide) {
-    // 256 x 128 tiles, one 512-thread workgroup per CU
-    const int G2 = G / 2;
-    k.tilesM = (k.M + 255) / 256;
-    const int tiles2 = k.tilesM * k.tilesN, rem2 = tiles2 % G2;
-    k.tiles_dp = tiles2 - rem2;
-    const double tile_us = 2.0 * 256.0 * 128.0 * k.taps * c->Cin / 0.6e6;  // one tile on one CU, ~150 TF/s chip
-    const double fix2_us = 8.0 + (G2 + 2.0 * rem2) * 0.06;
-    bool bal2 = ws != nullptr && rem2 != 0 && KT >= 4 && tile_us * (1.0 - (double)rem2 / G2) > fix2_us;
-    if (const int force = conv_sched_override()) {
-      if (force == 1 || ws == nullptr) {
-        bal2 = false;
-      } else {
-        bal2 = true;
-        if (force == 3) k.tiles_dp = 0;
-      }
-    }
-    if (bal2) {
-      hipLaunchKernelGGL((conv_fwd_bf3_pp_kernel<true>), dim3(G2), dim3(512), 0, st, k, limb_stride, x_bytes, w_bytes);
-      return conv_launch_fixup(k, G2, true, st, 256);
-    }
-    hipLaunchKernelGGL((conv_fwd_bf3_pp_kernel<false>), dim3(tiles2), dim3(512), 0, st, k, limb_stride, x_bytes, w_bytes);
-    return ONDA_LAUNCH_RESULT();
-  }
-  if (use_dma == 3) {
-    if (balanced) {
-      if (wide)
-        hipLaunchKernelGGL((conv_fwd_bf3_p16_kernel<128, 128, true>), dim3(G), dim3(256), 0, st, k, limb_stride, x_bytes, w_bytes);
-      else
-        hipLaunchKernelGGL((conv_fwd_bf3_p16_kernel<128, 64, true>), dim3(G), dim3(256), 0, st, k, limb_stride, x_bytes, w_bytes);
-      return conv_launch_fixup(k, G, wide, st);
-    }
-    if (wide)
-      hipLaunchKernelGGL((conv_fwd_bf3_p16_kernel<128, 128, false>), dim3(tiles), dim3(256), 0, st, k, limb_stride, x_bytes, w_bytes);
-    else
-      hipLaunchKernelGGL((conv_fwd_bf3_p16_kernel<128, 64, false>), dim3(tiles), dim3(256), 0, st, k, limb_stride, x_bytes, w_bytes);
-    return ONDA_LAUNCH_RESULT();
-  }
-  if (use_dma == 2) {
-    if (balanced) {
-      if (wide)
-        hipLaunchKernelGGL((conv_fwd_bf3_m16_kernel<128, 128, true>), dim3(G), dim3(256), 0, st, k, limb_stride, x_bytes, w_bytes);
-      else
-        hipLaunchKernelGGL((conv_fwd_bf3_m16_kernel<128, 64, true>), dim3(G), dim3(256), 0, st, k, limb_stride, x_bytes, w_bytes);
-      return conv_launch_fixup(k, G, wide, st);
-    }
-    if (wide)
-      hipLaunchKernelGGL((conv_fwd_bf3_m16_kernel<128, 128, false>), dim3(tiles), dim3(256), 0, st, k, limb_stride, x_bytes, w_bytes);
-    else
-      hipLaunchKernelGGL((conv_fwd_bf3_m16_kernel<128, 64, false>), dim3(tiles), dim3(256), 0, st, k, limb_stride, x_bytes, w_bytes);
-    return ONDA_LAUNCH_RESULT();
-  }
-  if (use_dma) {
-    if (balanced) {
-      if (wide)
-        hipLaunchKernelGGL((conv_fwd_bf3_dma_kernel<128, 128, true>), dim3(G), dim3(256), 0, st, k, limb_stride, x_bytes, w_bytes);
-      else
-        hipLaunchKernelGGL((conv_fwd_bf3_dma_kernel<128, 64, true>), dim3(G), dim3(256), 0, st, k, limb_stride, x_bytes, w_bytes);
-      return conv_launch_fixup(k, G, wide, st);
-    }
-    if (wide)
-      hipLaunchKernelGGL((conv_fwd_bf3_dma_kernel<128, 128, false>), dim3(tiles), dim3(256), 0, st, k, limb_stride, x_bytes, w_bytes);
-    else
-      hipLaunchKernelGGL((conv_fwd_bf3_dma_kernel<128, 64, false>), dim3(tiles), dim3(256), 0, st, k, limb_stride, x_bytes, w_bytes);
-    return ONDA_LAUNCH_RESULT();
-  }
   if (balanced) {
     if (wide)
       hipLaunchKernelGGL((conv_fwd_bf3_kernel<128, 128, true>), dim3(G), dim3(256), 0, st, k, limb_stride, x_bytes, w_bytes);
@@ -1720,24 +575,9 @@ int onda_conv2d_wgrad_bf3(const float* x, const float* dy, float* slabs, int ldd
   k.splitk = splitk;
   k.mchunk = (int)(((M + splitk - 1) / splitk + 31) / 32 * 32);
   k.taps = c->kh * c->kw;
-  static const int wg16 = [] { const char* e = getenv("ONDA_BF3_WG16"); return e ? atoi(e) : 1; }();
-  if (wg16) {
-    if (c->Cout > 64 && c->Cin > 64) {
-      // 16-byte loads along the channel axis of both operands
-      if (!ONDA_ALIGNED16(x) || !ONDA_ALIGNED16(dy) || (c->ldx & 3) || (lddy & 3)) return ONDA_EALIGN;
-      k.tilesN = (c->Cout + 127) / 128;
-      k.tilesC = (c->Cin + 127) / 128;
-      hipLaunchKernelGGL((conv_wgrad_bf3_m16_kernel<128, 128>), dim3(k.tilesN * k.tilesC * k.taps * splitk), dim3(256), 0,
-                         ONDA_STREAM(s), k, x_bytes, dy_bytes);
-    } else {
-      k.tilesN = (c->Cout + 63) / 64;
-      k.tilesC = (c->Cin + 63) / 64;
-      hipLaunchKernelGGL((conv_wgrad_bf3_m16_kernel<64, 64>), dim3(k.tilesN * k.tilesC * k.taps * splitk), dim3(256), 0,
-                         ONDA_STREAM(s), k, x_bytes, dy_bytes);
-    }
-    return ONDA_LAUNCH_RESULT();
-  }
   if (c->Cout > 64 && c->Cin > 64) {
+    // 16-byte loads along the channel axis of both operands
+    if (!ONDA_ALIGNED16(x) || !ONDA_ALIGNED16(dy) || (c->ldx & 3) || (lddy & 3)) return ONDA_EALIGN;
     k.tilesN = (c->Cout + 127) / 128;
     k.tilesC = (c->Cin + 127) / 128;
     hipLaunchKernelGGL((conv_wgrad_bf3_kernel<128, 128>), dim3(k.tilesN * k.tilesC * k.taps * splitk), dim3(256), 0,
@@ -1752,3 +592,4 @@ int onda_conv2d_wgrad_bf3(const float* x, const float* dy, float* slabs, int ldd
 }
 
 }  // extern "C"
+

@@ -66,11 +66,10 @@ __device__ __forceinline__ void conv_store_partial(float* slot, const typename A
 // `red`: >= WAVES_M*BN*2 floats of LDS that no wave is still reading.
 template <int BM, int BN, int TM, int TN, int WAVES_M, int MF = 32>
 __device__ __forceinline__ void conv_epilogue(const ConvK& a, const typename AccTile<MF>::T (&acc)[TM][TN],
-                                              float* red, int tile_m, int m0, int n0, int wm, int wn, int lane,
-                                              int t = threadIdx.x) {
-  // t: thread index inside the 256-thread group that owns this BM-row tile (tile_m counts BM-row blocks)
+                                              float* red, int tile_m, int m0, int n0, int wm, int wn, int lane) {
   using L = AccTile<MF>;
   const OndaConv& c = a.c;
+  const int t = threadIdx.x;
   if (a.stats != nullptr) {
 #pragma unroll
     for (int jn = 0; jn < TN; ++jn) {
@@ -95,7 +94,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& a, const typename Acc
       }
     }
     __syncthreads();
-    if (t < BN && n0 + t < c.Cout && m0 < a.M) {
+    if (t < BN && n0 + t < c.Cout) {
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
       for (int w_ = 0; w_ < WAVES_M; ++w_) {
@@ -136,6 +135,6 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& a, const typename Acc
 }
 
 // conv.hip: sums stream-K partial tiles and runs the epilogue for split tiles
-int conv_launch_fixup(const ConvK& k, int G, bool wide, hipStream_t st, int BM = 128);
+int conv_launch_fixup(const ConvK& k, int G, bool wide, hipStream_t st);
 int conv_resident_workgroups();
 int conv_sched_override();  // debugging aid: environment variable ONDA_CONV_SCHED (0 / unset = automatic)

@@ -1,23 +1,25 @@
 """Diagnostic: per-phase shader cycles of the bf16x3 forward kernel (in-kernel s_memtime stamps).
 
-Builds conv_bf3.hip with -DONDA_BF3_STAMP into tools/_stamp/libonda_hip.so (never the product
-library), runs one conv shape one tile per workgroup (ONDA_CONV_SCHED=1) and prints the median
-cycles per K-step each wave spends in: vmcnt wait | barrier 1 | split+store A | barrier 2 |
-issue next loads | fragment reads + MFMA issue.
+Builds the kernels with -DONDA_BF3_STAMP into tools/_stamp/libonda_hip.so (never the product
+library), runs conv shapes one tile per workgroup (ONDA_CONV_SCHED=1) and prints the median cycles
+per K-step each wave spends in: vmcnt wait | barrier 1 | split + store A | barrier 2 | issue of
+the next loads / DMA | fragment reads + MFMA issue, plus the in-kernel shader clock
+(d s_memtime / d wall_clock64 x 100 MHz).  Stamps cost ~10 % and MFMAs may slide across them, so
+read the split between "vmcnt" and "reads+mfma" with that in mind.
 
     python tools/stamp_bf3.py build      (in the build container)
-    python tools/stamp_bf3.py            (on the GPU box)
+    REPS=400 python tools/stamp_bf3.py   (on the GPU box)
 """
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-OUT = os.path.join(ROOT, "tools", os.environ.get("STAMP_DIR", "_stamp"))
+OUT = os.path.join(ROOT, "tools", "_stamp")
 LIB = os.path.join(OUT, "libonda_hip.so")
 if len(sys.argv) > 1 and sys.argv[1] == "build":
     os.makedirs(OUT, exist_ok=True)
     objs = []
     for src in ["conv.hip", "conv_bf3.hip", "norm.hip", "pointwise.hip", "loss_proto.hip"]:
         obj = os.path.join(OUT, src.replace(".hip", ".o"))
-        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-DONDA_BF3_STAMP", "-fno-slp-vectorize"] + sys.argv[2:] + [
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-DONDA_BF3_STAMP",
                                "-I" + os.path.join(ROOT, "include"), "-c", os.path.join(ROOT, "onda_amd", "csrc", src), "-o", obj])
         objs.append(obj)
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
@@ -27,6 +29,7 @@ os.environ["ONDA_CONV_SCHED"] = "1"
 sys.path.insert(0, ROOT)
 import torch
 from onda_amd import ops
+NAMES = ["vmcnt", "barrier1", "split+store", "barrier2", "issue loads", "reads+mfma"]
 for (B, H, W, Cin, Cout, k, dil) in [(4, 65, 129, 512, 512, 3, 4), (4, 65, 129, 2048, 512, 1, 1), (4, 65, 129, 256, 1024, 1, 1)]:
     x = torch.randn(B, H, W, Cin, device="cuda")
     w = torch.randn(Cout, Cin, k, k, device="cuda") / (Cin * k * k) ** 0.5
@@ -36,23 +39,9 @@ for (B, H, W, Cin, Cout, k, dil) in [(4, 65, 129, 512, 512, 3, 4), (4, 65, 129, 
         ops.conv_forward(x, wp, k, 1, dil, pad, Cout)
     torch.cuda.synchronize()
     KT = k * k * Cin // 32
-    if os.environ.get("ONDA_BF3_DMA") == "4":  # 8-wave ping-pong kernel: per group (P = waves 0-3, Q = 4-7)
-        ws = ops._conv_ws(x.device)[:128 * 8 * 8].view(128, 8, 8).double().cpu()
-        for g, nm in ((0, "P"), (1, "Q")):
-            names = ["block (mfma + fillers)", "vmcnt", "barrier 1", "limb stores", "barrier 2", "-"]
-            med = ws[:, 4 * g:4 * g + 4].reshape(-1, 8).median(dim=0).values[:6] / KT
-            print(f"Cin={Cin} Cout={Cout} k={k} group {nm}: cycles per K-step per wave: " +
-                  "  ".join(f"{n} {v:.0f}" for n, v in zip(names, med.tolist())) + f"  | total {med.sum():.0f}")
-        w = ws.view(-1, 8)
-        ok = w[:, 7] > 0
-        print(f"    in-kernel shader clock: {(w[ok, 6] / w[ok, 7]).median().item() * 0.1:.2f} GHz")
-        continue
-    ws = ops._conv_ws(x.device)[:256 * 4 * 8].view(256, 4, 8).double().cpu()
-    med = ws.view(-1, 8).median(dim=0).values[:6] / KT
-    names = ["vmcnt", "barrier1", "split+store", "barrier2", "issue loads", "reads+mfma"]
-    print(f"Cin={Cin} Cout={Cout} k={k}: K-steps {KT}; cycles per K-step per wave: " +
-          "  ".join(f"{n} {v:.0f}" for n, v in zip(names, med.tolist())) + f"  | total {med.sum():.0f}")
-    w = ws.view(-1, 8)
-    ok = w[:, 7] > 0
-    print(f"    in-kernel shader clock: {(w[ok, 6] / w[ok, 7]).median().item() * 0.1:.2f} GHz  ({int(ok.sum())} waves; "
-          f"cycles {w[ok, 6].median().item():.0f}, 100 MHz ticks {w[ok, 7].median().item():.0f})")
+    w8 = ops._conv_ws(x.device)[:256 * 4 * 8].view(-1, 8).double().cpu()
+    med = w8.median(dim=0).values[:6] / KT
+    ok = w8[:, 7] > 0
+    print(f"Cin={Cin} Cout={Cout} k={k}: {KT} K-steps; cycles per K-step per wave: " +
+          "  ".join(f"{n} {v:.0f}" for n, v in zip(NAMES, med.tolist())) + f"  | total {med.sum():.0f}"
+          f"  | shader clock {(w8[ok, 6] / w8[ok, 7]).median().item() * 0.1:.2f} GHz")
