@@ -74,17 +74,6 @@ int onda_pack_weight_bf3(const float* w_oihw, void* dst, int Cout, int Cin, int 
 int onda_conv2d_fwd_bf3(const float* x, const void* w3, float* y, const float* scale, const float* shift,
                         const float* residual, float* stats, float* ws, const OndaConv* c, onda_stream_t s);
 
-/* Limb planes of an activation tensor: fp32 x[rows][ld] (C valid channels, C % 8 == 0) ->
- * dst[3][rows][C] bf16 with x = dst[0] + dst[1] + dst[2] exactly (round to nearest at each level). */
-int onda_split_bf3(const float* x, void* dst, int64_t rows, int C, int ld, onda_stream_t s);
-
-/* onda_conv2d_fwd_bf3 on activations that were split beforehand by onda_split_bf3
- * (xl = [3][B*Hi*Wi][Cin] bf16; c->ldx is ignored, rows are dense).  Cout > 64.  Both operands reach
- * LDS by LDS-DMA; 256 x 128 tiles, one 512-thread workgroup per CU.  Same epilogue, workspace and
- * results (bit-identical limb products; the summation order inside a K-step is the MFMA's). */
-int onda_conv2d_fwd_bf3l(const void* xl, const void* w3, float* y, const float* scale, const float* shift,
-                         const float* residual, float* stats, float* ws, const OndaConv* c, onda_stream_t s);
-
 /* Weight gradient, split over `splitk` pixel ranges: slabs[ks][Cout][kh*kw][Cin] partial
  * sums of dy[m][n] * x[pix(m,tap)][c]  (autograd of F.conv2d w.r.t. weight).  Then
  * onda_wgrad_reduce sums the slabs in a fixed order (deterministic) into the OIHW

@@ -34,8 +34,6 @@ SIGNATURES = {
     "onda_conv2d_fwd": (I, [P, P, P, P, P, P, P, P, POINTER(OndaConv), P]),
     "onda_pack_weight_bf3": (I, [P, P, I, I, I, I, I, I, I, P]),
     "onda_conv2d_fwd_bf3": (I, [P, P, P, P, P, P, P, P, POINTER(OndaConv), P]),
-    "onda_split_bf3": (I, [P, P, L, I, I, P]),
-    "onda_conv2d_fwd_bf3l": (I, [P, P, P, P, P, P, P, P, POINTER(OndaConv), P]),
     "onda_conv2d_wgrad": (I, [P, P, P, I, I, POINTER(OndaConv), P]),
     "onda_conv2d_wgrad_bf3": (I, [P, P, P, I, I, POINTER(OndaConv), P]),
     "onda_wgrad_reduce": (I, [P, P, I, I, I, I, I, I, I, I, P]),

@@ -210,6 +210,7 @@ template <int BM, int BN>
 __global__ __launch_bounds__(256) void conv_fixup_kernel(const ConvK a, int G, const float* __restrict__ sums) {
   constexpr int C4 = BN / 4;        // float4 columns of a tile row
   constexpr int RG = 256 / C4;      // row groups covered by the workgroup at once
+  constexpr int RPT = BM / RG;      // rows per thread
   __shared__ f32x4 red[2][256];
   const OndaConv& c = a.c;
   const int KT = a.taps * a.kcper;
@@ -239,55 +240,50 @@ __global__ __launch_bounds__(256) void conv_fixup_kernel(const ConvK a, int G, c
   }
   __syncthreads();
 
-  // batch-statistic partials are kept per 128-row block (onda_conv_tiles_m), whatever the tile height
-  for (int h = 0; h < BM / 128; ++h) {
-    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 2
-    for (int i = 0; i < 128 / RG; ++i) {
-      const int row = h * 128 + rg + RG * i;
-      const int eo = row * BN + col;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (sums != nullptr) {
-        v = *reinterpret_cast<const f32x4*>(sums + (size_t)blockIdx.x * (BM * BN) + eo);
-      } else {
+  for (int i = 0; i < RPT; ++i) {
+    const int row = rg + RG * i;
+    const int eo = row * BN + col;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (sums != nullptr) {
+      v = *reinterpret_cast<const f32x4*>(sums + (size_t)blockIdx.x * (BM * BN) + eo);
+    } else {
 #pragma unroll 4
-        for (int p = 0; p < npieces; ++p) {
-          const int pc = piece[p];
-          if (pc >= 0) v += *reinterpret_cast<const f32x4*>(a.ws + (size_t)pc * (BM * BN) + eo);
-        }
+      for (int p = 0; p < npieces; ++p) {
+        const int pc = piece[p];
+        if (pc >= 0) v += *reinterpret_cast<const f32x4*>(a.ws + (size_t)pc * (BM * BN) + eo);
       }
-      s1 += v;
-      s2 += v * v;
-      const int m = m0 + row;
-      if (m >= a.M || !vn) continue;
-      f32x4 o = v * sc + sh;
-      if (a.res) o += *reinterpret_cast<const f32x4*>(a.res + (size_t)m * c.ldr + n);
-      if (c.relu) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = fmaxf(o[j], 0.f);
-      }
-      size_t orow = m;
-      if (!plain) {
-        const int wo = m % c.Wo, tq = m / c.Wo;
-        const int ho = tq % c.Ho, b = tq / c.Ho;
-        orow = ((size_t)b * c.Hf + (size_t)ho * c.out_os) * c.Wf + (size_t)wo * c.out_os;
-      }
-      *reinterpret_cast<f32x4*>(a.y + orow * c.ldy + n) = o;
     }
-    if (a.stats != nullptr) {
-      if (h > 0) __syncthreads();  // the previous block's readers are done with `red`
-      red[0][t] = s1;
-      red[1][t] = s2;
-      __syncthreads();
-      if (rg == 0 && vn && m0 + h * 128 < a.M) {
-        for (int g = 1; g < RG; ++g) {
-          s1 += red[0][g * C4 + t];
-          s2 += red[1][g * C4 + t];
-        }
-        const size_t srow = (size_t)tile_m * (BM / 128) + h;
-        *reinterpret_cast<f32x4*>(a.stats + (srow * 2 + 0) * c.Cout + n) = s1;
-        *reinterpret_cast<f32x4*>(a.stats + (srow * 2 + 1) * c.Cout + n) = s2;
+    s1 += v;
+    s2 += v * v;
+    const int m = m0 + row;
+    if (m >= a.M || !vn) continue;
+    f32x4 o = v * sc + sh;
+    if (a.res) o += *reinterpret_cast<const f32x4*>(a.res + (size_t)m * c.ldr + n);
+    if (c.relu) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = fmaxf(o[j], 0.f);
+    }
+    size_t orow = m;
+    if (!plain) {
+      const int wo = m % c.Wo, tq = m / c.Wo;
+      const int ho = tq % c.Ho, b = tq / c.Ho;
+      orow = ((size_t)b * c.Hf + (size_t)ho * c.out_os) * c.Wf + (size_t)wo * c.out_os;
+    }
+    *reinterpret_cast<f32x4*>(a.y + orow * c.ldy + n) = o;
+  }
+  if (a.stats != nullptr) {
+    red[0][t] = s1;
+    red[1][t] = s2;
+    __syncthreads();
+    if (rg == 0 && vn) {
+      for (int g = 1; g < RG; ++g) {
+        s1 += red[0][g * C4 + t];
+        s2 += red[1][g * C4 + t];
       }
+      *reinterpret_cast<f32x4*>(a.stats + ((size_t)tile_m * 2 + 0) * c.Cout + n) = s1;
+      *reinterpret_cast<f32x4*>(a.stats + ((size_t)tile_m * 2 + 1) * c.Cout + n) = s2;
     }
   }
 }
@@ -493,15 +489,12 @@ int onda_conv_tiles_m(int M) { return (M + 127) / 128; }
 
 }  // extern "C"
 
-int conv_launch_fixup(const ConvK& k, int G, bool wide, hipStream_t st, int BM) {
+int conv_launch_fixup(const ConvK& k, int G, bool wide, hipStream_t st) {
   const int tiles = k.tilesM * k.tilesN - k.tiles_dp;
   if (tiles <= 0) return ONDA_LAUNCH_RESULT();
   // few tiles cut into many pieces: sum the pieces with a wide launch first
-  float* sums = (tiles * 4 < G) ? k.ws + (size_t)G * 2 * BM * 128 : nullptr;
-  if (BM == 256) {  // the 8-wave ping-pong kernel's 256 x 128 tiles
-    if (sums) hipLaunchKernelGGL((conv_piece_sum_kernel<256, 128>), dim3(tiles, 256 * 128 / 1024), dim3(256), 0, st, k, G, sums);
-    hipLaunchKernelGGL((conv_fixup_kernel<256, 128>), dim3(tiles), dim3(256), 0, st, k, G, sums);
-  } else if (wide) {
+  float* sums = (tiles * 4 < G) ? k.ws + (size_t)G * 2 * 128 * 128 : nullptr;
+  if (wide) {
     if (sums) hipLaunchKernelGGL((conv_piece_sum_kernel<128, 128>), dim3(tiles, 128 * 128 / 1024), dim3(256), 0, st, k, G, sums);
     hipLaunchKernelGGL((conv_fixup_kernel<128, 128>), dim3(tiles), dim3(256), 0, st, k, G, sums);
   } else {

@@ -290,208 +290,6 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_bf3_kernel(const ConvK a, uns
   }
 }
 
-// ---- forward / data gradient on PRE-SPLIT activations ---------------------------------------------
-// The measurements in the header say where conv_fwd_bf3_kernel loses the pipe: the limb split (VALU)
-// cannot overlap another wave's MFMAs, its LDS stores sit between two barriers, and one K-step of
-// prefetch does not cover the fetch latency.  Here the activations arrive already split
-// (split_bf3_kernel: [3][pixels][C] bf16, written once per tensor and reused by every conv that
-// reads it), so BOTH operands go global -> LDS by LDS-DMA and the K-step is: wait, ONE barrier,
-// issue the next step's DMA, fragment reads + 96 MFMAs per wave.  No VALU, no LDS stores, no
-// staging registers.  512 threads own a 256 x 128 tile (8 waves of 64 x 64, 2 per SIMD), one
-// workgroup per CU; two stages of (3 x 256 + 3 x 128) rows x 64 B = 147 KB LDS.
-// The DMA is inline assembly: through the builtin the compiler tracks the LDS destination and may
-// put an s_waitcnt vmcnt(0) in front of ds_reads that "may alias" the stage just requested.
-__device__ __forceinline__ u32x4 raw_rsrc(const void* base, unsigned bytes) {
-  const unsigned long long p = (unsigned long long)base;
-  return u32x4{(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)p),
-               (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(p >> 32) & 0xFFFFu)),
-               (unsigned)__builtin_amdgcn_readfirstlane((int)bytes), 0x00020000u};
-}
-#pragma clang diagnostic ignored "-Winline-asm"  // m0 is "reserved": nothing else in this kernel depends on it
-// lds_addr: byte address in LDS (M0); lane l writes 16 bytes at lds_addr + 16 l
-__device__ __forceinline__ void dma16(u32x4 rsrc, unsigned lds_addr, unsigned voff, unsigned soff) {
-  asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff)
-               : "memory", "m0");
-}
-__device__ __forceinline__ unsigned lds_address(const void* p) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  return (unsigned)(size_t)(__attribute__((address_space(3))) const unsigned char*)p;
-#else
-  return 0;
-#endif
-}
-// barrier that orders LDS traffic only (__syncthreads() would also drain vmcnt)
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-// fp32 [rows][ld] (C valid channels) -> limb planes dst[3][rows][C] bf16; 8 elements per thread
-__global__ __launch_bounds__(256) void split_bf3_kernel(const float* __restrict__ x, unsigned short* __restrict__ dst,
-                                                        long long rows, int C, int ld) {
-  const int c8 = C >> 3;
-  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= rows * c8) return;
-  const long long row = e / c8;
-  const int ch = (int)(e - row * c8) * 8;
-  const f32x4 v0 = *reinterpret_cast<const f32x4*>(x + row * ld + ch);
-  const f32x4 v1 = *reinterpret_cast<const f32x4*>(x + row * ld + ch + 4);
-  u32x2 a1, a2, a3, b1, b2, b3;
-  split3(v0, a1, a2, a3);
-  split3(v1, b1, b2, b3);
-  const size_t plane = (size_t)rows * C, o = (size_t)row * C + ch;
-  *reinterpret_cast<u32x4*>(dst + o) = u32x4{a1[0], a1[1], b1[0], b1[1]};
-  *reinterpret_cast<u32x4*>(dst + plane + o) = u32x4{a2[0], a2[1], b2[0], b2[1]};
-  *reinterpret_cast<u32x4*>(dst + 2 * plane + o) = u32x4{a3[0], a3[1], b3[0], b3[1]};
-}
-
-template <bool SK>
-__global__ __launch_bounds__(512) void conv_fwd_bf3l_kernel(const ConvK a, unsigned wlimb_stride, unsigned xplane_bytes,
-                                                            unsigned w_bytes) {
-  constexpr int BM = 256, BN = 128, MF = 16;
-  constexpr int WAVES_M = 4, WAVES_N = 2;
-  constexpr int TM = BM / (MF * WAVES_M), TN = BN / (MF * WAVES_N);  // 4 x 4 MFMA tiles per wave
-  constexpr int PLANE_A = BM * 64, PLANE_B = BN * 64;                // limb planes of a stage, 64-byte rows
-  constexpr int STAGE = 3 * (PLANE_A + PLANE_B), B_OFF = 3 * PLANE_A;
-  constexpr int RPW = BM / (16 * 8);  // 16-row DMA chunks of the activation tile per wave: 2
-  constexpr int WPW = 3 * (BN / 16) / 8;  // weight DMA pieces per wave: 3
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE];
-
-  const OndaConv& c = a.c;
-  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-
-  const int nblk = gridDim.x, bid = blockIdx.x;
-  const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
-  const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  const int KT = a.taps * a.kcper;
-  const int tiles_all = a.tilesM * a.tilesN;
-  const int tiles_dp = SK ? a.tiles_dp : tiles_all;
-  const long long U = (long long)(tiles_all - tiles_dp) * KT;
-  long long u = SK ? swz * U / nblk : 0;
-  const long long u_begin = u;
-  const long long u_end = SK ? (swz + 1) * U / nblk : 0;
-  int dp_tile = swz;
-  const int wstride = a.taps * c.Cin;
-  // the range check covers voffset + soffset (the limb plane rides in the soffset): all three planes
-  const u32x4 rx = raw_rsrc(a.x, 3 * xplane_bytes), rw = raw_rsrc(a.w, w_bytes);
-  const unsigned lds_base = lds_address(lds);
-  // lane l: row l & 15 of each 16-row block, data chunk l >> 4 (swizzle is the same for every block)
-  const int frag = (lane & 15) * 64 + (((lane >> 4) ^ swz_row(lane & 15)) << 4);
-  // DMA lane: row lane / 4 of a 16-row chunk, LDS slot c' = lane & 3 <- data chunk c' ^ swz_row(row)
-  const int drow = lane >> 2, dchunk = ((lane & 3) ^ swz_row(drow)) * 16;
-
-  while (dp_tile < tiles_dp || u < u_end) {
-    const bool dp = dp_tile < tiles_dp;
-    const int tile = dp ? dp_tile : tiles_dp + (int)(u / KT);
-    const int k_begin = dp ? 0 : (int)(u - (long long)(tile - tiles_dp) * KT);
-    const int k_end = dp ? KT : (int)min((long long)KT, k_begin + (u_end - u));
-    const int tile_n = tile % a.tilesN, tile_m = tile / a.tilesN;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
-
-    // this wave's share of a stage: activation row chunks 2*wave, 2*wave+1 (all three limbs) and three
-    // of the 24 weight pieces
-    int hi0[RPW], wi0[RPW], bH[RPW];
-#pragma unroll
-    for (int i = 0; i < RPW; ++i) {
-      const int m = m0 + (wave * RPW + i) * 16 + drow;
-      const bool vm = m < a.M;
-      const int mm = vm ? m : 0;
-      const int wo = mm % c.Wo, tq = mm / c.Wo;
-      const int ho = tq % c.Ho, b = tq / c.Ho;
-      hi0[i] = vm ? ho * c.stride - c.pad : -(1 << 28);
-      wi0[i] = wo * c.stride - c.pad;
-      bH[i] = b * c.Hi;
-    }
-    unsigned wofs[WPW], wdst[WPW];
-#pragma unroll
-    for (int d = 0; d < WPW; ++d) {
-      const int p = wave * WPW + d;
-      const int l = p / (BN / 16), j = p % (BN / 16);
-      const int n = n0 + j * 16 + drow;
-      wofs[d] = n < c.Cout ? (l * wlimb_stride + (unsigned)n * wstride) * 2u + dchunk : OOB;
-      wdst[d] = lds_base + B_OFF + l * PLANE_B + j * 1024;
-    }
-
-    unsigned aofs[RPW];
-    int tap = k_begin / a.kcper, c0 = (k_begin - tap * a.kcper) * BK;
-    auto set_tap = [&](int tp) {
-      const int rr = tp / c.kw, ss = tp - rr * c.kw;
-#pragma unroll
-      for (int i = 0; i < RPW; ++i) {
-        const int hi = hi0[i] + rr * c.dil, wi = wi0[i] + ss * c.dil;
-        const bool ok = (unsigned)hi < (unsigned)c.Hi && (unsigned)wi < (unsigned)c.Wi;
-        aofs[i] = ok ? (unsigned)(((bH[i] + hi) * c.Wi + wi) * c.Cin) * 2u + dchunk : OOB;
-      }
-    };
-    auto dma_stage = [&](int stage) {
-      const unsigned base = lds_base + stage * STAGE;
-#pragma unroll
-      for (int l = 0; l < 3; ++l)
-#pragma unroll
-        for (int i = 0; i < RPW; ++i)
-          dma16(rx, base + l * PLANE_A + (wave * RPW + i) * 1024, aofs[i], l * xplane_bytes + c0 * 2);
-      const int sw = (tap * c.Cin + c0) * 2;
-#pragma unroll
-      for (int d = 0; d < WPW; ++d) dma16(rw, wdst[d] + stage * STAGE, wofs[d], sw);
-    };
-
-    f32x4 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
-
-    __syncthreads();  // the previous segment's readers are done with every LDS region
-    set_tap(tap);
-    dma_stage(0);
-    int cur = 0;
-    for (int kt = k_begin; kt < k_end; ++kt) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of the stage have landed
-      lds_barrier();                                     // ... everybody's; the other stage is free
-      if (kt + 1 < k_end) {
-        c0 += BK;
-        if (c0 == c.Cin) {
-          c0 = 0;
-          ++tap;
-          set_tap(tap);
-        }
-        dma_stage(cur ^ 1);
-      }
-      const unsigned char* Ab = lds + cur * STAGE + wm * TM * MF * 64 + frag;
-      const unsigned char* Bb = lds + cur * STAGE + B_OFF + wn * TN * MF * 64 + frag;
-      // A limbs stay in registers; B limbs stream 3 -> 2 -> 1 (smallest products first)
-      bf16x8 af[TM][3];
-#pragma unroll
-      for (int l = 0; l < 3; ++l)
-#pragma unroll
-        for (int i = 0; i < TM; ++i) af[i][l] = *reinterpret_cast<const bf16x8*>(Ab + l * PLANE_A + i * MF * 64);
-#pragma unroll
-      for (int l = 2; l >= 0; --l) {
-        bf16x8 bf[TN];
-#pragma unroll
-        for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const bf16x8*>(Bb + l * PLANE_B + j * MF * 64);
-#pragma unroll
-        for (int la = 2 - l; la >= 0; --la)  // a_{la+1} * b_{l+1} with la + l <= 2
-#pragma unroll
-          for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][la], bf[j], acc[i][j], 0, 0, 0);
-      }
-      cur ^= 1;
-    }
-
-    if (dp) dp_tile += nblk; else u += k_end - k_begin;
-    if (SK && (k_begin != 0 || k_end != KT)) {
-      float* slot = a.ws + ((size_t)swz * 2 + (u - (k_end - k_begin) == u_begin ? 0 : 1)) * (BM * BN);
-      conv_store_partial<BN, TM, TN, MF>(slot, acc, wm, wn, lane);
-      continue;
-    }
-    __syncthreads();
-    conv_epilogue<BM, BN, TM, TN, WAVES_M, MF>(a, acc, reinterpret_cast<float*>(lds), tile_m, m0, n0, wm, wn, lane);
-  }
-}
-
 // ---- weight gradient on the bf16 pipe ------------------------------------------------------------
 // dW[n][tap][c] = sum_m dY[m][n] * X[pix(m,tap)][c]: both operands have the contraction index
 // (the pixel m) as their SLOW axis in memory, while an MFMA fragment wants 8 consecutive k per
@@ -760,65 +558,6 @@ int onda_conv2d_fwd_bf3(const float* x, const void* w3, float* y, const float* s
     hipLaunchKernelGGL((conv_fwd_bf3_kernel<128, 128, false>), dim3(tiles), dim3(256), 0, st, k, limb_stride, x_bytes, w_bytes);
   else
     hipLaunchKernelGGL((conv_fwd_bf3_kernel<128, 64, false>), dim3(tiles), dim3(256), 0, st, k, limb_stride, x_bytes, w_bytes);
-  return ONDA_LAUNCH_RESULT();
-}
-
-// Limb planes of an activation tensor for onda_conv2d_fwd_bf3l: dst[3][rows][C] bf16 (C % 8 == 0).
-int onda_split_bf3(const float* x, void* dst, int64_t rows, int C, int ld, onda_stream_t s) {
-  ONDA_REQUIRE(x && dst && rows > 0 && C > 0 && C % 8 == 0 && ld >= C && ld % 4 == 0);
-  if (!ONDA_ALIGNED16(x) || !ONDA_ALIGNED16(dst)) return ONDA_EALIGN;
-  const long long n = rows * (C / 8);
-  hipLaunchKernelGGL(split_bf3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ONDA_STREAM(s), x,
-                     static_cast<unsigned short*>(dst), (long long)rows, C, ld);
-  return ONDA_LAUNCH_RESULT();
-}
-
-// onda_conv2d_fwd_bf3 on pre-split activations xl = [3][B*Hi*Wi][Cin] bf16 (onda_split_bf3); Cout > 64.
-int onda_conv2d_fwd_bf3l(const void* xl, const void* w3, float* y, const float* scale, const float* shift,
-                         const float* residual, float* stats, float* ws, const OndaConv* c, onda_stream_t s) {
-  ONDA_REQUIRE(xl && w3 && y && c);
-  ONDA_REQUIRE(c->Cin > 0 && c->Cin % 32 == 0 && c->Cout > 64 && c->Cout % 4 == 0);
-  ONDA_REQUIRE(c->kh >= 1 && c->kw >= 1 && c->stride >= 1 && c->dil >= 1 && c->out_os >= 1);
-  if (!ONDA_ALIGNED16(xl) || !ONDA_ALIGNED16(w3)) return ONDA_EALIGN;
-  if (ws && (c->ldy % 4 != 0 || !ONDA_ALIGNED16(y) || (residual && (c->ldr % 4 != 0 || !ONDA_ALIGNED16(residual)))))
-    ws = nullptr;
-  ConvK k;
-  k.x = static_cast<const float*>(xl); k.w = w3; k.y = y; k.scale = scale; k.shift = shift; k.res = residual; k.stats = stats;
-  k.ws = ws;
-  k.c = *c;
-  const long long M = (long long)c->B * c->Ho * c->Wo;
-  ONDA_REQUIRE(M > 0 && M < (1ll << 31));
-  const long long xplane = (long long)c->B * c->Hi * c->Wi * c->Cin * 2;  // bytes of one limb plane
-  ONDA_REQUIRE(3 * xplane < 0x7FFFF000ll);                                // 32-bit byte offsets
-  k.M = (int)M;
-  k.taps = c->kh * c->kw;
-  k.kcper = c->Cin / 32;
-  k.tilesM = (k.M + 255) / 256;
-  k.tilesN = (c->Cout + 127) / 128;
-  const size_t limb_elems = (size_t)c->Cout * k.taps * c->Cin;  // planes are [Cout][taps*Cin]
-  ONDA_REQUIRE(limb_elems * 6 < (1ull << 31));
-  const int tiles = k.tilesM * k.tilesN, KT = k.taps * k.kcper, G = conv_resident_workgroups() / 2;  // one workgroup per CU
-  const int rem = tiles % G;
-  k.tiles_dp = tiles - rem;
-  const double t_tile_us = 2.0 * 256.0 * 128.0 * k.taps * c->Cin / 0.8e6;  // one tile on one CU, ~200 TF/s chip
-  const double fix_us = 8.0 + (G + 2.0 * rem) * 0.06;                        // partial tiles written + read
-  bool balanced = ws != nullptr && rem != 0 && KT >= 4 && t_tile_us * (1.0 - (double)rem / G) > fix_us;
-  if (const int force = conv_sched_override()) {
-    if (force == 1 || ws == nullptr) {
-      balanced = false;
-    } else {
-      balanced = true;
-      if (force == 3) k.tiles_dp = 0;
-    }
-  }
-  hipStream_t st = ONDA_STREAM(s);
-  if (balanced) {
-    hipLaunchKernelGGL((conv_fwd_bf3l_kernel<true>), dim3(G), dim3(512), 0, st, k, (unsigned)limb_elems, (unsigned)xplane,
-                       (unsigned)(limb_elems * 6));
-    return conv_launch_fixup(k, G, true, st, 256);
-  }
-  hipLaunchKernelGGL((conv_fwd_bf3l_kernel<false>), dim3(tiles), dim3(512), 0, st, k, (unsigned)limb_elems, (unsigned)xplane,
-                     (unsigned)(limb_elems * 6));
   return ONDA_LAUNCH_RESULT();
 }
 

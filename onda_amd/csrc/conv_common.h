@@ -1,6 +1,6 @@
 // Shared between the fp32 and the split-bf16 convolution kernels: argument block, the
 // stream-K partial-tile store and the common epilogue (statistics, scale/shift, residual, ReLU,
-// slice / scatter store) for a workgroup of 32x32 or 16x16 MFMA accumulator tiles (BM = 128 or 256).
+// slice / scatter store) for a 4-wave workgroup of 32x32 or 16x16 MFMA accumulator tiles.
 #pragma once
 #include "common.h"
 
@@ -66,11 +66,10 @@ __device__ __forceinline__ void conv_store_partial(float* slot, const typename A
 // `red`: >= WAVES_M*BN*2 floats of LDS that no wave is still reading.
 template <int BM, int BN, int TM, int TN, int WAVES_M, int MF = 32>
 __device__ __forceinline__ void conv_epilogue(const ConvK& a, const typename AccTile<MF>::T (&acc)[TM][TN],
-                                              float* red, int tile_m, int m0, int n0, int wm, int wn, int lane,
-                                              int t = threadIdx.x) {
-  // t: thread index inside the group of waves that owns this BM-row tile (tile_m counts BM-row blocks)
+                                              float* red, int tile_m, int m0, int n0, int wm, int wn, int lane) {
   using L = AccTile<MF>;
   const OndaConv& c = a.c;
+  const int t = threadIdx.x;
   if (a.stats != nullptr) {
 #pragma unroll
     for (int jn = 0; jn < TN; ++jn) {
@@ -95,18 +94,15 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& a, const typename Acc
       }
     }
     __syncthreads();
-    // batch-statistic partials are kept per 128-row block (onda_conv_tiles_m): a BM = 256 tile writes two
-    constexpr int SG = BM / 128, WPG = WAVES_M / SG;  // statistic groups, wave rows per group
-    const int sg = t / BN, col = t - sg * BN;
-    if (sg < SG && n0 + col < c.Cout && m0 + sg * 128 < a.M) {
+    if (t < BN && n0 + t < c.Cout) {
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-      for (int w_ = 0; w_ < WPG; ++w_) {
-        s1 += red[((sg * WPG + w_) * BN + col) * 2 + 0];
-        s2 += red[((sg * WPG + w_) * BN + col) * 2 + 1];
+      for (int w_ = 0; w_ < WAVES_M; ++w_) {
+        s1 += red[(w_ * BN + t) * 2 + 0];
+        s2 += red[(w_ * BN + t) * 2 + 1];
       }
-      a.stats[(((size_t)tile_m * SG + sg) * 2 + 0) * c.Cout + n0 + col] = s1;
-      a.stats[(((size_t)tile_m * SG + sg) * 2 + 1) * c.Cout + n0 + col] = s2;
+      a.stats[((size_t)tile_m * 2 + 0) * c.Cout + n0 + t] = s1;
+      a.stats[((size_t)tile_m * 2 + 1) * c.Cout + n0 + t] = s2;
     }
   }
 
@@ -139,6 +135,6 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& a, const typename Acc
 }
 
 // conv.hip: sums stream-K partial tiles and runs the epilogue for split tiles
-int conv_launch_fixup(const ConvK& k, int G, bool wide, hipStream_t st, int BM = 128);
+int conv_launch_fixup(const ConvK& k, int G, bool wide, hipStream_t st);
 int conv_resident_workgroups();
 int conv_sched_override();  // debugging aid: environment variable ONDA_CONV_SCHED (0 / unset = automatic)

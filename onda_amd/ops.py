@@ -130,30 +130,6 @@ def pack_weight_dgrad(weight, cout_pad=None):
     return dst
 
 
-PRESPLIT = os.environ.get("ONDA_BF3_PRESPLIT", "1") != "0"
-
-
-def split_limbs(x):
-    """Limb planes [3][B*H*W][C] bf16 of an NHWC fp32 activation (bf16x3 mode, conv_fwd_bf3l_kernel).
-    Kept on the tensor object, so every conv that reads the same activation (a block's conv1 and
-    its downsample, the five ASPP branches) shares one split pass."""
-    hit = getattr(x, "_onda_limbs", None)
-    if hit is not None and hit[0] == x._version:
-        return hit[1]
-    B, H, W, C = x.shape
-    xl = torch.empty(3, B * H * W, C, device=x.device, dtype=torch.bfloat16)
-    call("onda_split_bf3", _p(x), _p(xl), B * H * W, C, nhwc_ld(x), _stream())
-    try:
-        x._onda_limbs = (x._version, xl)
-    except AttributeError:
-        pass
-    return xl
-
-
-def _use_presplit(bf3, cout, cin):
-    return bf3 and PRESPLIT and cout > 64 and cin % 32 == 0
-
-
 def conv_forward(x, wp, k, stride, dil, pad, cout, out=None, scale=None, shift=None, residual=None, relu=False,
                  want_stats=False):
     """x NHWC view, wp packed [cout][k*k*Cin].  Returns (y, stats partials or None, tiles)."""
@@ -171,11 +147,6 @@ def conv_forward(x, wp, k, stride, dil, pad, cout, out=None, scale=None, shift=N
         stats = torch.empty(tiles, 2, cout, device=x.device, dtype=torch.float32)
     d = _desc(B, Hi, Wi, Cin, Ho, Wo, cout, k, stride, dil, pad, ldx, ldy, ldr, relu=relu)
     bf3 = wp.dtype == torch.bfloat16
-    if _use_presplit(bf3, cout, Cin):
-        _launch("conv_fwd_bf3l_kernel", 2.0 * B * Ho * Wo * cout * k * k * Cin, "onda_conv2d_fwd_bf3l", _p(split_limbs(x)),
-                _p(wp), _p(out), _p(scale), _p(shift), _p(residual), _p(stats), _p(_conv_ws(x.device)), byref(d), _stream(),
-                tag=("fwd", B * Ho * Wo, cout, Cin, k, stride, dil))
-        return out, stats, tiles
     _launch("conv_fwd%s_kernel<128,%d>" % ("_bf3" if bf3 else "", 128 if cout > 64 else 64),
             2.0 * B * Ho * Wo * cout * k * k * Cin, "onda_conv2d_fwd_bf3" if bf3 else "onda_conv2d_fwd", _p(x), _p(wp), _p(out), _p(scale), _p(shift), _p(residual), _p(stats),
             _p(_conv_ws(x.device)), byref(d), _stream(),
@@ -197,11 +168,6 @@ def conv_dgrad(dy, wpd, k, stride, dil, pad, cin, in_hw):
         dx = torch.zeros(B, Hi, Wi, cin, device=dy.device, dtype=torch.float32)
         d = _desc(B, Ho, Wo, Co, Ho, Wo, cin, 1, 1, 1, 0, ldy, cin, out_os=stride, Hf=Hi, Wf=Wi)
     bf3 = wpd.dtype == torch.bfloat16
-    if _use_presplit(bf3, cin, Co):
-        _launch("conv_fwd_bf3l_kernel", 2.0 * B * Ho * Wo * cin * k * k * Co, "onda_conv2d_fwd_bf3l", _p(split_limbs(dy)),
-                _p(wpd), _p(dx), None, None, None, None, _p(_conv_ws(dy.device)), byref(d), _stream(),
-                tag=("dgrad", B * Ho * Wo if stride != 1 else B * Hi * Wi, cin, Co, k, stride, dil))
-        return dx
     _launch("conv_fwd%s_kernel<128,%d>" % ("_bf3" if bf3 else "", 128 if cin > 64 else 64),
             2.0 * B * Ho * Wo * cin * k * k * Co, "onda_conv2d_fwd_bf3" if bf3 else "onda_conv2d_fwd", _p(dy), _p(wpd), _p(dx), None, None, None, None, _p(_conv_ws(dy.device)), byref(d),
             _stream(),
