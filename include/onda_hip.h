@@ -225,6 +225,24 @@ int onda_sgd_multi(const OndaSgdEntry* table, int n, float momentum, float weigh
 typedef struct OndaEmaEntry { float* k; const float* q; int64_t n; float keep; float blend; } OndaEmaEntry;
 int onda_ema_multi(const OndaEmaEntry* table, int n, int64_t max_n, onda_stream_t s);
 
+/* ---- input pipeline -----------------------------------------------------------
+ * Replaces the per-sample CPU work of framework/dataset/segmentation_db.py:56-99 (`__getitem__`,
+ * `_load_img` base_dataset.py:89-95, `preprocess` :98-99, `color_mapper` func.py:88-115) AFTER the
+ * PNG decode: Pillow's antialiased BICUBIC resize, RGB->BGR, ToTensor + Normalize, NEAREST label
+ * resizes + id map.  Tables come from the host (built in double precision as Pillow builds them);
+ * results are bit-identical to the reference's path (fixture G9).
+ *   bounds int32[n][2] = (first source index, tap count), kk int32[n][ksize] = 22-bit fixed-point taps. */
+/* horizontal pass: in u8[H][Win][3] -> out u8[H][Wout][3] */
+int onda_resample_h_u8(const unsigned char* in, unsigned char* out, int H, int Win, int Wout, const int* bounds,
+                       const int* kk, int ksize, onda_stream_t s);
+/* vertical pass + tensor transform: tmp u8[Hin][W][3] -> out f32[3][Hout][W];
+ * out[c] = ((v[flip ? 2-c : c] / 255) - mean3[c]) / std3[c] in fp32; mean3/std3 are HOST pointers */
+int onda_resample_v_norm(const unsigned char* tmp, float* out, int Hin, int W, int Hout, const int* bounds, const int* kk,
+                         int ksize, const float* mean3, const float* std3, int flip, onda_stream_t s);
+/* label path: out u8[Hout][Wout] = lut256[in[ytab[y]][xtab[x]]], in u8[Hin][Win] */
+int onda_resize_nearest_lut(const unsigned char* in, unsigned char* out, int Win, int Hout, int Wout, const int* xtab,
+                            const int* ytab, const unsigned char* lut256, onda_stream_t s);
+
 /* library identity, for the loader's sanity check */
 const char* onda_version(void);
 

@@ -72,6 +72,9 @@ SIGNATURES = {
     "onda_proto_append": (I, [P, P, P, P, P, I, I, P]),
     "onda_sgd_multi": (I, [P, I, F, F, L, P]),
     "onda_ema_multi": (I, [P, I, L, P]),
+    "onda_resample_h_u8": (I, [P, P, I, I, I, P, P, I, P]),
+    "onda_resample_v_norm": (I, [P, P, I, I, I, P, P, I, POINTER(c_float), POINTER(c_float), I, P]),
+    "onda_resize_nearest_lut": (I, [P, P, I, I, I, P, P, P, P]),
     "onda_version": (c_char_p, []),
 }
 

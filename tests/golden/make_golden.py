@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Generate the golden vectors (G1-G7) by IMPORTING the reference on CPU.
+"""Generate the golden vectors (G1-G9) by IMPORTING the reference on CPU.
 
 Run in the build container only (the reference does not exist on the GPU box):
 
@@ -365,7 +365,52 @@ def g8():
                   {k: round(v, 4) for k, v in json.loads(str(res["log0_json"])).items() if "prior" in k or "percentage" in k})
 
 
+def g9():
+    """Input pipeline: the reference's own `_load_img` (base_dataset.py:89-95, i.e. Pillow) on
+    PNG files written here, for the resize cases of segmentation_db.py:82-96; `color_mapper`
+    (func.py:88-115) for the id map.  The tensor transform is torchvision's (absent): stored as the
+    formula of its published source evaluated with torch ops (unpinned, see oracle/pipeline.py)."""
+    from PIL import Image
+    from framework.dataset.base_dataset import _load_img
+    from framework.utils.func import color_mapper
+    rng = np.random.default_rng(9)
+    res = {}
+    cases = [(64, 96, 48, 32), (50, 37, 23, 31), (48, 64, 100, 70), (128, 256, 128, 64), (77, 33, 77, 66)]
+    # the label table: Cityscapes ids 0..33 -> 19 train ids, 255 elsewhere (dataset json of the reference run)
+    ids = {i: 255 for i in range(34)}
+    for tid, i in enumerate([7, 8, 11, 12, 13, 17, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 31, 32, 33]):
+        ids[i] = tid
+    if not hasattr(np, "int"):
+        np.int = int  # func.py:107 uses the alias numpy removed
+    mapper = color_mapper(ids)
+    res["lut"] = np.asarray(mapper.color_map, np.int32)
+    mean, std = np.array([123.675, 116.28, 103.53]), np.array([58.395, 57.12, 57.375])  # hybrid_switch.yml:9-10
+    res["mean"], res["std"] = mean, std
+    with tempfile.TemporaryDirectory() as tmp:
+        for n, (h, w, W, H) in enumerate(cases):
+            # smooth + noise, so that the antialiased filter sees structure as well as extremes
+            yy, xx = np.mgrid[0:h, 0:w]
+            base = (127 + 120 * np.sin(xx / 7.0 + n)[..., None] * np.cos(yy / 5.0)[..., None] * np.array([1, .5, -1])).clip(0, 255)
+            img = (base + rng.integers(-40, 41, (h, w, 3))).clip(0, 255).astype(np.uint8)
+            img[:3, :5] = 255
+            img[-4:, -2:] = 0
+            lab = rng.integers(0, 34, (h, w), dtype=np.uint8)
+            fi, fl = os.path.join(tmp, f"i{n}.png"), os.path.join(tmp, f"l{n}.png")
+            Image.fromarray(img).save(fi)
+            Image.fromarray(lab).save(fl)
+            out = _load_img(fi, (W, H), Image.BICUBIC, rgb=True)
+            res[f"img{n}"], res[f"size{n}"], res[f"resized{n}"] = img, np.array([W, H]), out
+            t = torch.from_numpy(out[:, :, ::-1].copy().transpose(2, 0, 1)).contiguous().to(torch.float32).div(255)
+            m32, s32 = torch.as_tensor(mean / 255, dtype=torch.float32), torch.as_tensor(std / 255, dtype=torch.float32)
+            res[f"tensor{n}"] = t.sub_(m32[:, None, None]).div_(s32[:, None, None])
+            res[f"lab{n}"] = lab
+            res[f"label{n}"] = mapper(_load_img(fl, (W, H), Image.NEAREST, rgb=False)).astype(np.uint8)
+            res[f"label_res{n}"] = mapper(_load_img(fl, [int(x / 8 + 1) for x in (W, H)], Image.NEAREST, rgb=False)).astype(np.uint8)
+    res["ncases"] = np.array(len(cases))
+    save("g9_pipeline", **res)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9"]
     for w in which:
         globals()[w]()

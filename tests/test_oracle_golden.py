@@ -215,3 +215,16 @@ def test_g8_other_prototype_methods(golden, tag):
             mine = mine.item() if isinstance(mine, torch.Tensor) else float(mine)
             assert mine == pytest.approx(v, rel=5e-3, abs=1e-5), (s, k)
         np.testing.assert_allclose(ad.proto[0].numpy(), g[f"proto{s + 1}"], rtol=1e-3, atol=1e-4)
+
+
+def test_g9_input_pipeline(golden):
+    """oracle/pipeline.py (Pillow's resampling restated) against what the reference's _load_img produced."""
+    from oracle import pipeline
+    g = golden("g9_pipeline")
+    for n in range(int(g["ncases"])):
+        W, H = (int(v) for v in g[f"size{n}"])
+        assert np.array_equal(pipeline.resize_bicubic_u8(g[f"img{n}"], (W, H)), g[f"resized{n}"]), n
+        t = pipeline.preprocess_image(g[f"img{n}"], (W, H), g["mean"], g["std"])
+        assert np.array_equal(t, g[f"tensor{n}"]), n  # fp32 ops in the same order: bit-identical
+        full, res = pipeline.labels(g[f"lab{n}"], (W, H), g["lut"])
+        assert np.array_equal(full, g[f"label{n}"]) and np.array_equal(res, g[f"label_res{n}"]), n
