@@ -88,15 +88,20 @@ def one_step(da, src, trg, i, total):
     return log
 
 
-def measure_roofline(da, src, trg, args, steps_done):
+def measure_roofline(da, src, trg, args, steps_done, record=True):
     """Per-kernel-family time via events recorded around every conv launch on the launch
     stream (torch's current stream).  Reported for the dominant family: the 128x128-tile
-    MFMA implicit-GEMM kernel that runs all forward and data-gradient convolutions."""
+    MFMA implicit-GEMM kernel that runs all forward and data-gradient convolutions.
+    Every rank runs the two instrumented steps (they contain the step's collectives); only the
+    recording rank keeps events."""
     from onda_amd import ops
-    ops.PROFILE = []
+    if record:
+        ops.PROFILE = []
     one_step(da, src, trg, steps_done, steps_done + 2)
     one_step(da, src, trg, steps_done + 1, steps_done + 2)
     torch.cuda.synchronize()
+    if not record:
+        return None
     fam = {}
     for name, flops, e0, e1, _tag in ops.PROFILE:
         f = fam.setdefault(name, [0.0, 0.0, 0])
@@ -206,8 +211,8 @@ def main():
         dt = tmax.item()
         branch = "dynamic" if da.model_select.current == 1 else "static"
         roof = None
-        if rank == 0 and not args.no_roofline:
-            roof = measure_roofline(da, src, trg, args, total)
+        if not args.no_roofline:
+            roof = measure_roofline(da, src, trg, args, total, record=(rank == 0))
         loss = float(log["Total target loss"].detach())
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
