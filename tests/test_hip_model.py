@@ -348,3 +348,58 @@ def test_other_prototype_methods_golden(golden, tmp_path, tag):
             np.testing.assert_allclose(da.prototypes.prototypes.cpu().numpy(), g[f"proto{s + 1}"], rtol=1e-3, atol=1e-4)
     finally:
         deeplabv2.drop_mask_fn = deeplabv2._default_drop_mask
+
+
+@pytest.mark.parametrize("B,H,W", [(1, 75, 141), (3, 33, 65), (2, 97, 50)])
+def test_ragged_sizes_against_oracle(B, H, W):
+    """Sizes that are not multiples of the stride chain (odd grids, partial 128-row tiles, batch 1 / 3):
+    eval forward, the bilinear class map and one train-mode forward+backward against the CPU oracle."""
+    from onda_amd import ops
+    from onda_amd.synthetic import synth_tensor
+    from oracle import losses as olosses, model as omodel
+    m = build_model(5, 3.0)
+    sd = {k: synth_tensor(k, torch.empty(shape, dtype=dt), 5, 3.0).to(dt) for k, shape, dt in omodel.state_spec()}
+    gen = torch.Generator().manual_seed(B * 1000 + H)
+    x = torch.randn(B, 3, H, W, generator=gen)
+    # eval
+    m.eval()
+    with torch.no_grad():
+        _, o = m(x.to(DEV))
+        cls = ops.upsample_argmax(o["out"], (H, W))
+        _, ro = omodel.forward(x, sd, omodel.BNMode(False))
+        _, rcls = omodel.upsample_argmax(ro["out"], (H, W))
+    h, w = ro["out"].shape[2:]
+    assert o["out"].shape == (B, 19, h, w) and o["feat"].shape == (B, 256, h, w)
+    for key in ("feat", "out"):
+        ref = ro[key].numpy()
+        assert np.abs(o[key].cpu().numpy() - ref).max() <= 1e-4 * np.abs(ref).max(), key
+    diff = (cls.cpu() != rcls)
+    if diff.any():  # only numerical ties of the top two classes may differ
+        up = torch.nn.functional.interpolate(ro["out"], size=(H, W), mode="bilinear", align_corners=True)
+        top2 = up.topk(2, dim=1).values
+        margin = (top2[:, 0] - top2[:, 1])[diff]
+        assert diff.float().mean() < 1e-4 and margin.max() < 1e-4 * up.abs().max()
+    # train-mode forward + backward of CE on the low-resolution logits
+    m.train()
+    from onda_amd.framework.model import deeplabv2
+    mask = omodel.draw_drop_mask(B)
+    lab = torch.randint(0, 19, (B, h, w), generator=gen)
+    lab[:, 0, :] = 255
+    deeplabv2.drop_mask_fn = lambda nb, nc, p, dev: mask.to(dev)
+    try:
+        _, o = m(x.to(DEV))
+        loss = ops.seg_losses(o["out"], lab.to(DEV), 1.0, 0.0, 0.0)[0]
+        loss.backward()
+    finally:
+        deeplabv2.drop_mask_fn = deeplabv2._default_drop_mask
+    sdr = {k: v.clone().double().requires_grad_(v.is_floating_point() and "running" not in k) if v.is_floating_point() else v.clone()
+           for k, v in sd.items()}
+    _, ro = omodel.forward(x.double(), sdr, omodel.BNMode(True, False), mask.double())
+    rloss = olosses.ce_hard(ro["out"], lab)
+    rloss.backward()
+    assert abs(loss.item() - rloss.item()) <= 1e-4 * abs(rloss.item())
+    assert np.abs(o["out"].detach().cpu().numpy() - ro["out"].detach().numpy()).max() <= 1e-3 * ro["out"].abs().max().item()
+    for name in ("conv1.weight", "layer1.0.conv1.weight", "layer3.2.conv2.weight", "layer6.head.1.weight"):
+        g = dict(m.named_parameters())[name].grad.cpu().double()
+        r = sdr[name].grad
+        assert (g - r).norm() <= 2e-2 * r.norm() + 1e-12, name
