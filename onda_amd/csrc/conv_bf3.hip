@@ -210,12 +210,14 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_bf3_kernel(const ConvK a, uns
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
 
-#ifdef ONDA_BF3_STAMP  // diagnostic build only (tools/stamp_bf3.py): per-phase shader cycles of each wave
+#if defined(ONDA_BF3_STAMP) || defined(ONDA_BF3_CLOCK)  // diagnostic builds only (tools/stamp_bf3.py)
     long long st[6] = {0, 0, 0, 0, 0, 0};
     long long st0 = __builtin_amdgcn_s_memtime();
     const long long clk0 = st0, rt0 = wall_clock64();
+#endif
+#ifdef ONDA_BF3_STAMP  // per-phase shader cycles of each wave (perturbs the kernel by ~10 %)
 #define STAMP(i) { const long long st1 = __builtin_amdgcn_s_memtime(); st[i] += st1 - st0; st0 = st1; }
-#else
+#else  // ONDA_BF3_CLOCK: two stamps per tile, for the in-kernel clock of the unperturbed loop
 #define STAMP(i)
 #endif
     __syncthreads();  // the previous segment's readers are done with every LDS region
@@ -270,7 +272,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_bf3_kernel(const ConvK a, uns
       cur ^= 1;
       STAMP(5)
     }
-#ifdef ONDA_BF3_STAMP
+#if defined(ONDA_BF3_STAMP) || defined(ONDA_BF3_CLOCK)
     if (lane == 0 && swz < 256)
       for (int i = 0; i < 6; ++i) a.ws[(swz * 4 + wave) * 8 + i] = (float)st[i];
     if (lane == 0 && swz < 256) {  // shader clock = d(memtime) / d(memrealtime) x 100 MHz
