@@ -223,7 +223,7 @@ def main():
         if (args.height, args.width) != (512, 1024):
             tflop_step = None
         line = {
-            "metric": "adaptation-step images/sec (fwd+bwd+proto) 512x1024 bs=4",
+            "metric": f"adaptation-step images/sec (fwd+bwd+proto) {args.height}x{args.width} bs={args.batch}",
             "value": round(world * args.batch * args.steps / dt, 4), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
