@@ -320,7 +320,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf3_kernel(const WgradK a, 
   constexpr int CPT = (BM > BN ? BM : BN) / 32;  // channel columns per staging thread
   static_assert(BM == BN, "one staging half per operand");
   __shared__ __attribute__((aligned(16))) unsigned char lds[3 * PLANE];
-  __shared__ unsigned pofs[32];
+  __shared__ unsigned pofs[33];  // [32]: does any of the 32 pixels of the K-step see a real input pixel for this tap?
 
   const OndaConv& c = a.c;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -419,17 +419,33 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf3_kernel(const WgradK a, 
 #pragma unroll
       for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
 
+  // K-steps whose 32 pixels all fall into the padding for this tap (a dilated tap near the image
+  // border: 9-34 % of the ASPP weight-gradient work) contribute exact zeros and are skipped: no loads,
+  // no split, no MFMAs.  The flag rides with the offset table, so the test is uniform.
+  auto fill_offsets = [&](int mb) {
+    if (t < 32) {
+      const unsigned o = pixel_offset(mb + t);
+      pofs[t] = o;
+      const unsigned long long any = __ballot(o != OOB);
+      if (t == 0) pofs[32] = (any & 0xFFFFFFFFull) != 0;
+    }
+  };
+  bool live = false;  // the K-step held in registers has work
   if (KT > 0) {
-    if (t < 32) pofs[t] = pixel_offset(mbeg + t);
+    fill_offsets(mbeg);
     __syncthreads();
-    gload(mbeg);
+    live = pofs[32] != 0;
+    if (live) gload(mbeg);
   }
   for (int kt = 0; kt < KT; ++kt) {
     __syncthreads();  // LDS image and pofs are free
-    sstore();
-    if (t < 32 && kt + 1 < KT) pofs[t] = pixel_offset(mbeg + (kt + 1) * BK + t);
+    const bool cur = live;
+    if (cur) sstore();
+    if (kt + 1 < KT) fill_offsets(mbeg + (kt + 1) * BK);
     __syncthreads();
-    if (kt + 1 < KT) gload(mbeg + (kt + 1) * BK);
+    live = kt + 1 < KT && pofs[32] != 0;
+    if (live) gload(mbeg + (kt + 1) * BK);
+    if (!cur) continue;
     // odd 16-row blocks (row bit 4) flip chunk bit 1: byte offset ^ 32
     const int frag = wg_slot(lane & 15, lane >> 4);
     const unsigned char* Ab = lds + wm * TM * MF * 64;
