@@ -118,7 +118,12 @@ def measure_roofline(da, src, trg, args, steps_done, record=True):
             "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
             "launches_per_step": n // 2, "avg_launch_ms": round(secs / n * 1e3, 4),
             "avg_launch_gflop": round(flops / n / 1e9, 3), "families": detail}
-    if "bf3" in name:
+    if "h2" in name:
+        # three f16 MFMA products per fp32 product (two limbs per operand, per-tensor power-of-two scale)
+        roof["pipe"] = {"what": "f16 MFMA, 3 limb products per fp32 product, fp32 accumulate",
+                        "executed_tflops": round(3 * achieved, 1), "peak": BF16_MFMA_PEAK_TFLOPS,
+                        "frac": round(3 * achieved / BF16_MFMA_PEAK_TFLOPS, 4)}
+    elif "bf3" in name:
         # achieved/peak above are ALGORITHMIC fp32 flops against the fp32 matrix peak; the kernel
         # executes six bf16 MFMA products per fp32 product, so on the pipe it actually uses:
         roof["pipe"] = {"what": "bf16 MFMA, 6 limb products per fp32 product, fp32 accumulate",
@@ -177,6 +182,10 @@ def cpu_baseline(args):
 
 def conv_mode_note():
     from onda_amd import ops
+    if ops.CONV_MODE == "f16x2":
+        return ("f16x2: fp32 operands scaled by a per-tensor power of two and split into 2 f16 limbs, 3 limb products on "
+                "the f16 MFMA pipe, fp32 accumulation (3e-7 relative L2 against fp64, the accuracy of an fp32 FMA chain; "
+                "same parity tests as the exact-fp32 MFMA kernels)")
     if ops.CONV_MODE == "bf16x3":
         return ("bf16x3: fp32 operands split exactly into 3 bf16 limbs, 6 limb products on the bf16 MFMA pipe, "
                 "fp32 accumulation (2e-7 relative to the exact-fp32 MFMA kernels; same parity tests)")

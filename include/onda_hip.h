@@ -74,6 +74,26 @@ int onda_pack_weight_bf3(const float* w_oihw, void* dst, int Cout, int Cin, int 
 int onda_conv2d_fwd_bf3(const float* x, const void* w3, float* y, const float* scale, const float* shift,
                         const float* residual, float* stats, float* ws, const OndaConv* c, onda_stream_t s);
 
+/* ---- "f16x2": the same convolution with TWO f16 limbs per operand and a per-tensor power-of-two
+ * scale (csrc/conv_h2.hip): a1*b1 + a1*b2 + a2*b1 on v_mfma_f32_16x16x32_f16, half the MFMA work of the
+ * three-limb bf16 split at fp32-GEMM accuracy (3e-7 relative L2 against fp64). */
+/* scale2[0] = 2^e, scale2[1] = 2^-e with max|x| * 2^e in [2^13, 2^14) over x[rows][ld] (C valid channels,
+ * C % 4 == 0); ws: onda_absmax_ws_floats() floats.  Device-side only, no host round trip. */
+int64_t onda_absmax_ws_floats(void);
+int onda_absmax_scale(const float* x, int64_t rows, int C, int ld, float* ws, float* scale2, onda_stream_t s);
+/* OIHW fp32 weights -> dst[2][rows_pad][Kp] f16 limbs of w * scale2[0]; arguments as onda_pack_weight_bf3 */
+int onda_pack_weight_h2(const float* w_oihw, void* dst, int Cout, int Cin, int taps, int rows_pad, int Kp, int dgrad,
+                        int Cout_pad, const float* scale2, onda_stream_t s);
+/* onda_conv2d_fwd with the activations split in-kernel (xscale2 from onda_absmax_scale on x) and the
+ * weights pre-split (w2 / wscale2 from onda_pack_weight_h2); same epilogue, workspace and schedule */
+int onda_conv2d_fwd_h2(const float* x, const float* xscale2, const void* w2, const float* wscale2, float* y,
+                       const float* scale, const float* shift, const float* residual, float* stats, float* ws,
+                       const OndaConv* c, onda_stream_t s);
+
+/* onda_conv2d_wgrad slabs from the two-limb f16 evaluation; xscale2 / dyscale2 from onda_absmax_scale on x / dy */
+int onda_conv2d_wgrad_h2(const float* x, const float* xscale2, const float* dy, const float* dyscale2, float* slabs, int lddy,
+                         int splitk, const OndaConv* c, onda_stream_t s);
+
 /* Weight gradient, split over `splitk` pixel ranges: slabs[ks][Cout][kh*kw][Cin] partial
  * sums of dy[m][n] * x[pix(m,tap)][c]  (autograd of F.conv2d w.r.t. weight).  Then
  * onda_wgrad_reduce sums the slabs in a fixed order (deterministic) into the OIHW

@@ -34,6 +34,11 @@ SIGNATURES = {
     "onda_conv2d_fwd": (I, [P, P, P, P, P, P, P, P, POINTER(OndaConv), P]),
     "onda_pack_weight_bf3": (I, [P, P, I, I, I, I, I, I, I, P]),
     "onda_conv2d_fwd_bf3": (I, [P, P, P, P, P, P, P, P, POINTER(OndaConv), P]),
+    "onda_absmax_ws_floats": (L, []),
+    "onda_absmax_scale": (I, [P, L, I, I, P, P, P]),
+    "onda_pack_weight_h2": (I, [P, P, I, I, I, I, I, I, I, P, P]),
+    "onda_conv2d_fwd_h2": (I, [P, P, P, P, P, P, P, P, P, P, POINTER(OndaConv), P]),
+    "onda_conv2d_wgrad_h2": (I, [P, P, P, P, P, I, I, POINTER(OndaConv), P]),
     "onda_conv2d_wgrad": (I, [P, P, P, I, I, POINTER(OndaConv), P]),
     "onda_conv2d_wgrad_bf3": (I, [P, P, P, I, I, POINTER(OndaConv), P]),
     "onda_wgrad_reduce": (I, [P, P, I, I, I, I, I, I, I, I, P]),

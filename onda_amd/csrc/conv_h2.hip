@@ -1,0 +1,615 @@
+// fp32-accurate convolution on the f16 matrix pipe with TWO limbs ("f16x2"): half the MFMA work of the
+// three-limb bf16 split (conv_bf3.hip), which matters because that kernel is bound by a power-managed
+// clock, not by issue slots or operand delivery.
+//
+//   x * s = h1 + h2 + e,   h1 = f16(x * s), h2 = f16(x * s - h1),   |e| <= 2^-22 |x * s|  (or <= 2^-25 absolute)
+//
+// with s a power of two per TENSOR chosen so that the largest |x * s| lies in [2^13, 2^14): f16 has 11
+// significant bits but only 5 exponent bits, so unlike bf16 it needs the scale; a power of two keeps the
+// scaling exact, and a per-tensor factor comes out of the whole contraction (a per-pixel one would not:
+// an im2col row mixes pixels).  Elements more than 2^16 below the tensor maximum lose relative precision
+// but their absolute error stays below 2^-38 of the maximum -- invisible next to fp32's own accumulation
+// error.  The product is evaluated as a1*b1 + (a1*b2 + a2*b1), each exact in fp32 (11 x 11 bits),
+// accumulated in fp32 by v_mfma_f32_16x16x32_f16; what is dropped (a2*b2 and the representation error)
+// is ~2^-22 |a||b| per product.  Measured (numpy emulation and on the GPU): 3.1e-7 relative L2 against
+// fp64 where fp32 FMA chains give 3.1e-7 and the bf16x3 kernels 1.3-2.4e-7.
+//
+// Same geometry, LDS images (two limb planes instead of three: 48 KB), weight DMA, hybrid stream-K
+// schedule and epilogue as conv_fwd_bf3_kernel; the accumulators are multiplied by 1 / (sa * sb)
+// (exact) before the epilogue or the partial-tile store.  The scales live in device memory
+// ([scale, 1/scale], written by absmax_scale_kernel) -- no host round trip.
+#include "conv_common.h"
+
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// two floats -> two f16 (round to nearest even) in one dword
+__device__ __forceinline__ unsigned cvt2h(float lo, float hi) {
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{lo, hi}, f16x2));
+}
+__device__ __forceinline__ f32x2 unpack2h(unsigned p) {
+  return __builtin_convertvector(__builtin_bit_cast(f16x2, p), f32x2);
+}
+
+// float4 (already scaled) -> two limbs, each 4 f16 packed in 8 bytes
+__device__ __forceinline__ void split2(const f32x4 v, u32x2& l1, u32x2& l2) {
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const float x0 = v[2 * h], x1 = v[2 * h + 1];
+    const unsigned p = cvt2h(x0, x1);
+    const f32x2 f = unpack2h(p);
+    l1[h] = p;
+    l2[h] = cvt2h(x0 - f[0], x1 - f[1]);
+  }
+}
+
+constexpr unsigned OOB = 0x80000000u;     // every operand is < 2 GiB - 4 KiB (checked on the host)
+constexpr unsigned CH_OOB = 0x7FFFF000u;  // second addend: row + channel never wraps, stays out of range
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+// chunk swizzle of the 64-byte-row LDS images (see conv_bf3.hip)
+__device__ __forceinline__ int swz_row(int row) {
+  const int q = (row >> 2) & 3;
+  return q ^ ((q & 1) << 1) ^ ((row >> 1) & 1);
+}
+
+// ---- per-tensor scale --------------------------------------------------------------------------
+// stage 1: block maxima of |x| over [rows][ld] (C valid channels); stage 2: one block reduces them
+// (max is order-independent: deterministic) and writes out[0] = 2^e, out[1] = 2^-e with
+// max|x| * 2^e in [2^13, 2^14).  An all-zero (or non-finite) tensor gets e = 0.
+__global__ __launch_bounds__(256) void absmax_partial_kernel(const float* __restrict__ x, long long rows, int C, int ld,
+                                                             float* __restrict__ part) {
+  const int c4 = C >> 2;
+  const long long n = rows * c4;
+  float m = 0.f;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256) {
+    const long long row = e / c4;
+    const int ch = (int)(e - row * c4) * 4;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(x + row * ld + ch);
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+  }
+#pragma unroll
+  for (int sh = 32; sh > 0; sh >>= 1) m = fmaxf(m, __shfl_xor(m, sh, 64));
+  __shared__ float red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+__global__ __launch_bounds__(256) void absmax_final_kernel(const float* __restrict__ part, int n, float* __restrict__ out) {
+  float m = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) m = fmaxf(m, part[i]);
+#pragma unroll
+  for (int sh = 32; sh > 0; sh >>= 1) m = fmaxf(m, __shfl_xor(m, sh, 64));
+  __shared__ float red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    int e = 0;
+    if (m > 0.f && m < 3.0e38f) {
+      int ex;
+      frexpf(m, &ex);  // m = f * 2^ex, f in [0.5, 1)
+      e = 14 - ex;
+      e = e > 100 ? 100 : (e < -100 ? -100 : e);
+    }
+    out[0] = ldexpf(1.f, e);
+    out[1] = ldexpf(1.f, -e);
+  }
+}
+
+// OIHW fp32 -> limb planes dst[2][rows_pad][Kp] f16 of w * scale[0].  dgrad = 0: row n, k = tap*Cin + c.
+// dgrad = 1: row c, k = tap'*Cout_pad + n with the taps flipped (data-gradient operand).
+__global__ void pack_h2_kernel(const float* __restrict__ w, _Float16* __restrict__ dst, int Cout, int Cin, int taps,
+                               int rows_pad, int Kp, int dgrad, int Cout_pad, const float* __restrict__ scale) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t plane = (size_t)rows_pad * Kp;
+  if (e >= plane) return;
+  const int k = (int)(e % Kp), row = (int)(e / Kp);
+  float v = 0.f;
+  if (!dgrad) {
+    if (row < Cout && k < taps * Cin) {
+      const int tap = k / Cin, cc = k - tap * Cin;
+      v = w[((size_t)row * Cin + cc) * taps + tap];
+    }
+  } else {
+    const int tap = k / Cout_pad, n = k - tap * Cout_pad;
+    if (row < Cin && tap < taps && n < Cout) v = w[((size_t)n * Cin + row) * taps + (taps - 1 - tap)];
+  }
+  v *= scale[0];
+  const _Float16 a = (_Float16)v;
+  dst[e] = a;
+  dst[plane + e] = (_Float16)(v - (float)a);
+}
+
+// ---- forward / data gradient ----------------------------------------------------------------------
+template <int BM, int BN, bool SK>
+__global__ __launch_bounds__(256, 2) void conv_fwd_h2_kernel(const ConvK a, unsigned limb_stride, unsigned x_bytes, unsigned w_bytes,
+                                                             const float* __restrict__ xscale, const float* __restrict__ wscale) {
+  constexpr int WAVES_M = 2, WAVES_N = 2;
+  constexpr int MF = 16;
+  constexpr int TM = BM / (MF * WAVES_M), TN = BN / (MF * WAVES_N);
+  constexpr int AL = BM / 32;
+  constexpr int PLANE_A = BM * 64;         // activation limb plane, 64-byte rows, swizzled
+  constexpr int PLANE_B = BN * 64;         // weight limb plane, 64-byte rows, source-swizzled
+  constexpr int A_BYTES = 2 * PLANE_A, B_STAGE = 2 * PLANE_B;
+  constexpr int CHUNKS = BN / 16;          // 1-KiB DMA pieces per limb plane
+  constexpr int DPW = 2 * CHUNKS / 4;      // DMA instructions per wave per K-step
+  __shared__ __attribute__((aligned(16))) unsigned char lds[A_BYTES + 2 * B_STAGE];
+
+  const OndaConv& c = a.c;
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+
+  const int nblk = gridDim.x, bid = blockIdx.x;
+  const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
+  const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  const int KT = a.taps * a.kcper;
+  const int tiles_all = a.tilesM * a.tilesN;
+  const int tiles_dp = SK ? a.tiles_dp : tiles_all;
+  const long long U = (long long)(tiles_all - tiles_dp) * KT;
+  long long u = SK ? swz * U / nblk : 0;
+  const long long u_begin = u;
+  const long long u_end = SK ? (swz + 1) * U / nblk : 0;
+  int dp_tile = swz;
+  const int ccol = (t & 7) * 4, rbase = t >> 3;
+  const int wstride = a.taps * c.Cin;
+  const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, x_bytes), rw = make_rsrc(a.w, w_bytes);
+  const float sa = xscale[0];                 // power of two: x * sa has its largest magnitude in [2^13, 2^14)
+  const float unscale = xscale[1] * wscale[1];  // 1 / (sa * sb), exact
+
+  while (dp_tile < tiles_dp || u < u_end) {
+    const bool dp = dp_tile < tiles_dp;
+    const int tile = dp ? dp_tile : tiles_dp + (int)(u / KT);
+    const int k_begin = dp ? 0 : (int)(u - (long long)(tile - tiles_dp) * KT);
+    const int k_end = dp ? KT : (int)min((long long)KT, k_begin + (u_end - u));
+    const int tile_n = tile % a.tilesN, tile_m = tile / a.tilesN;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    int hi0[AL], wi0[AL], bH[AL];
+#pragma unroll
+    for (int i = 0; i < AL; ++i) {
+      const int m = m0 + rbase + 32 * i;
+      const bool vm = m < a.M;
+      const int mm = vm ? m : 0;
+      const int wo = mm % c.Wo, tq = mm / c.Wo;
+      const int ho = tq % c.Ho, b = tq / c.Ho;
+      hi0[i] = vm ? ho * c.stride - c.pad : -(1 << 28);
+      wi0[i] = wo * c.stride - c.pad;
+      bH[i] = b * c.Hi;
+    }
+    // this wave's DMA pieces: piece p = wave*DPW + d -> limb p / CHUNKS, 1-KiB chunk p % CHUNKS;
+    // lane -> LDS slot (row = chunk*16 + lane/4, c' = lane & 3) <- data chunk c' ^ swz_row(row)
+    unsigned dofs[DPW];
+#pragma unroll
+    for (int d = 0; d < DPW; ++d) {
+      const int p = wave * DPW + d;
+      const int l = p / CHUNKS, j = p % CHUNKS;
+      const int row = j * 16 + (lane >> 2), cq = (lane & 3) ^ swz_row(row);
+      const int n = n0 + row;
+      dofs[d] = n < c.Cout ? (l * limb_stride + (unsigned)n * wstride) * 2u + cq * 16u : OOB;
+    }
+
+    unsigned aofs[AL];
+    f32x4 ar[AL];
+    int tap = k_begin / a.kcper, c0 = (k_begin - tap * a.kcper) * BK;
+    auto set_tap = [&](int tp) {
+      const int rr = tp / c.kw, ss = tp - rr * c.kw;
+#pragma unroll
+      for (int i = 0; i < AL; ++i) {
+        const int hi = hi0[i] + rr * c.dil, wi = wi0[i] + ss * c.dil;
+        const bool ok = (unsigned)hi < (unsigned)c.Hi && (unsigned)wi < (unsigned)c.Wi;
+        aofs[i] = ok ? (unsigned)(((bH[i] + hi) * c.Wi + wi) * c.ldx + ccol) * 4u : OOB;
+      }
+    };
+    auto gload_a = [&]() {
+      const int sa = c0 * 4;
+#pragma unroll
+      for (int i = 0; i < AL; ++i)
+        ar[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, aofs[i], sa, 0));
+    };
+    auto dma_b = [&](int stage) {
+      const int sw = (tap * c.Cin + c0) * 2;
+#pragma unroll
+      for (int d = 0; d < DPW; ++d) {
+        const int p = wave * DPW + d;
+        const int l = p / CHUNKS, j = p % CHUNKS;
+        unsigned char* dst = lds + A_BYTES + stage * B_STAGE + l * PLANE_B + j * 1024;
+#if defined(__HIP_DEVICE_COMPILE__)  // (the host pass drops the whole kernel stub if it sees this cast in a lambda)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)dst, 16, dofs[d], sw, 0, 0);
+#else
+        (void)dst;
+        (void)sw;
+#endif
+      }
+    };
+    auto sstore_a = [&]() {
+#pragma unroll
+      for (int i = 0; i < AL; ++i) {
+        u32x2 l1, l2;
+        split2(ar[i] * sa, l1, l2);
+        const int row = rbase + 32 * i;
+        const int off = row * 64 + ((((t & 7) >> 1) ^ swz_row(row)) << 4) + (t & 1) * 8;
+        *reinterpret_cast<u32x2*>(lds + 0 * PLANE_A + off) = l1;
+        *reinterpret_cast<u32x2*>(lds + 1 * PLANE_A + off) = l2;
+      }
+    };
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
+
+    __syncthreads();  // the previous segment's readers are done with every LDS region
+    set_tap(tap);
+    gload_a();
+    dma_b(0);
+    int cur = 0;
+    for (int kt = k_begin; kt < k_end; ++kt) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's A rows and weight DMA have landed
+      __syncthreads();                                   // ... and everybody else's; A image is free
+      sstore_a();
+      __syncthreads();
+      if (kt + 1 < k_end) {
+        c0 += BK;
+        if (c0 == c.Cin) {
+          c0 = 0;
+          ++tap;
+          set_tap(tap);
+        }
+        gload_a();
+        dma_b(cur ^ 1);  // the stage read one step ago; all waves are past that compute
+      }
+      // lane l: row l & 15 of each 16-row block, data chunk l >> 4 (swizzle is the same for every block)
+      const int frag = (lane & 15) * 64 + (((lane >> 4) ^ swz_row(lane & 15)) << 4);
+      const unsigned char* Ab = lds + wm * TM * MF * 64 + frag;
+      const unsigned char* Bb = lds + A_BYTES + cur * B_STAGE + wn * TN * MF * 64 + frag;
+      // A limbs stay in registers; B limbs stream 2 -> 1 (smaller products first): a1*b2, a2*b1, a1*b1
+      f16x8 af[TM][2];
+#pragma unroll
+      for (int l = 0; l < 2; ++l)
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[i][l] = *reinterpret_cast<const f16x8*>(Ab + l * PLANE_A + i * MF * 64);
+#pragma unroll
+      for (int l = 1; l >= 0; --l) {
+        f16x8 bf[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f16x8*>(Bb + l * PLANE_B + j * MF * 64);
+#pragma unroll
+        for (int la = 1 - l; la >= 0; --la)  // a_{la+1} * b_{l+1} with la + l <= 1
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][la], bf[j], acc[i][j], 0, 0, 0);
+      }
+      cur ^= 1;
+    }
+
+    // back to the operands' own units (exact: a power of two) before anything reads the accumulators
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] *= unscale;
+    if (dp) dp_tile += nblk; else u += k_end - k_begin;
+    if (SK && (k_begin != 0 || k_end != KT)) {
+      float* slot = a.ws + ((size_t)swz * 2 + (u - (k_end - k_begin) == u_begin ? 0 : 1)) * (BM * BN);
+      conv_store_partial<BN, TM, TN, MF>(slot, acc, wm, wn, lane);
+      continue;
+    }
+    __syncthreads();
+    conv_epilogue<BM, BN, TM, TN, WAVES_M, MF>(a, acc, reinterpret_cast<float*>(lds), tile_m, m0, n0, wm, wn, lane);
+  }
+}
+
+
+// ---- weight gradient ------------------------------------------------------------------------------
+// conv_wgrad_bf3_kernel (conv_bf3.hip) with two f16 limbs per operand: the staging thread multiplies its
+// operand by that tensor's power-of-two scale before the split, the slabs are written in the operands' own
+// units (acc * 1 / (sx * sdy), exact).  LDS image: 64-byte rows; inside each 16-row block the
+// row index is transposed as a 4 x 4 matrix and the 16-byte chunk index is XOR-ed with row bits
+// {0,1} and {3,4}.  Conflict-free for the ds_read_b128 fragment read (lane l: row l & 15, chunk
+// l >> 4) AND for both ds_write_b128 staging patterns (8 lanes on rows 4l + j, or on 8
+// consecutive rows): SQ_LDS_BANK_CONFLICT 0.32 -> 0 of the LDS-active cycles.
+__device__ __forceinline__ int wg_slot(int row, int chunk) {
+  const int phys = (row & ~15) | ((row & 3) << 2) | ((row >> 2) & 3);
+  return phys * 64 + ((chunk ^ (row & 3) ^ ((row >> 3) & 3)) << 4);
+}
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_h2_kernel(const WgradK a, unsigned x_bytes, unsigned dy_bytes, const float* __restrict__ xscale,
+                                                              const float* __restrict__ dyscale) {
+  constexpr int WAVES_N = 2;
+  constexpr int MF = 16;
+  constexpr int TM = BM / (2 * MF), TN = BN / (2 * MF);
+  constexpr int ROWS = BM + BN;
+  constexpr int PLANE = ROWS * 64;  // 64-byte rows, placed by wg_slot()
+  constexpr int CPT = (BM > BN ? BM : BN) / 32;  // channel columns per staging thread
+  static_assert(BM == BN, "one staging half per operand");
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * PLANE];
+  __shared__ unsigned pofs[33];  // [32]: does any of the 32 pixels of the K-step see a real input pixel for this tap?
+
+  const OndaConv& c = a.c;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+
+  int bid = blockIdx.x;
+  const int tile_c = bid % a.tilesC;
+  bid /= a.tilesC;
+  const int tap = bid % a.taps;
+  bid /= a.taps;
+  const int tile_n = bid % a.tilesN;
+  const int ks = bid / a.tilesN;
+  const int n0 = tile_n * BM, c0 = tile_c * BN;
+  const int mbeg = ks * a.mchunk;
+  const int mend = min(a.M, mbeg + a.mchunk);
+  const int KT = mend > mbeg ? (mend - mbeg + BK - 1) / BK : 0;
+  const int rr = tap / c.kw, ss = tap - rr * c.kw;
+  const int dh = rr * c.dil - c.pad, dw = ss * c.dil - c.pad;
+
+  // staging role of this thread
+  // the role is wave-uniform; readfirstlane tells the compiler so (descriptor and scalar offset stay
+  // in SGPRs instead of a per-lane "waterfall" loop around every buffer load)
+  const bool is_x = __builtin_amdgcn_readfirstlane(t >> 7) != 0;
+  const float sop = is_x ? xscale[0] : dyscale[0];  // per-tensor power of two of this thread's operand
+  const float unscale = xscale[1] * dyscale[1];
+  const int kgroup = (t >> 5) & 3;  // 8 pixels kgroup*8 .. +7
+  const __amdgpu_buffer_rsrc_t rs = is_x ? make_rsrc(a.x, x_bytes) : make_rsrc(a.dy, dy_bytes);
+  const int chmax = is_x ? c.Cin : c.Cout;
+
+  // byte offset (OOB = zero row) of pixel m of the X operand for this tap
+  auto pixel_offset = [&](int m) -> unsigned {
+    if (m >= mend) return OOB;
+    const int wo = m % c.Wo, tq = m / c.Wo;
+    const int ho = tq % c.Ho, b = tq / c.Ho;
+    const int hi = ho * c.stride + dh, wi = wo * c.stride + dw;
+    if ((unsigned)hi >= (unsigned)c.Hi || (unsigned)wi >= (unsigned)c.Wi) return OOB;
+    return (unsigned)(((b * c.Hi + hi) * c.Wi + wi) * c.ldx) * 4u;
+  };
+  // row (bytes, OOB past the chunk) of pixel slot q = kgroup*8 + p of K-step mb
+  auto row_offset = [&](int mb, int q) -> unsigned {
+    return is_x ? pofs[q] : (mb + q < mend ? (unsigned)(q * a.lddy) * 4u : OOB);
+  };
+
+  // WIDE: a thread owns 4 consecutive channels x 8 pixels, fetched as one 16-byte load per pixel
+  // (32 lanes = 512 contiguous bytes of a pixel row); the 4 x 8 register block is read out
+  // column-wise, so the transposition is free.  Otherwise (64-wide tiles): 2 channel columns of
+  // scalar loads as in conv_wgrad_bf3_kernel.
+  constexpr bool WIDE = BM == 128;
+  constexpr int NV = WIDE ? 8 : CPT * 2;
+  f32x4 v[NV];
+  const int cl = t & 31;
+  const int chb = (is_x ? c0 : n0) + (WIDE ? 4 * cl : cl);
+  unsigned chofs[WIDE ? 1 : CPT];
+  if constexpr (WIDE) {
+    chofs[0] = chb < chmax ? (unsigned)chb * 4u : CH_OOB;
+  } else {
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) chofs[j] = chb + 32 * j < chmax ? (unsigned)(chb + 32 * j) * 4u : CH_OOB;
+  }
+  auto gload = [&](int mb) {
+    const int so = is_x ? 0 : mb * a.lddy * 4;  // dY: the scalar part mb*lddy rides in the soffset
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      const unsigned row = row_offset(mb, kgroup * 8 + p);
+      if constexpr (WIDE) {
+        v[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, row + chofs[0], so, 0));
+      } else {
+#pragma unroll
+        for (int j = 0; j < CPT; ++j)
+          v[2 * j + (p >> 2)][p & 3] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, row + chofs[j], so, 0));
+      }
+    }
+  };
+  auto sstore = [&]() {
+#pragma unroll
+    for (int j = 0; j < (WIDE ? 4 : CPT); ++j) {
+      u32x2 a1, a2, b1, b2;
+      if constexpr (WIDE) {
+        split2(f32x4{v[0][j], v[1][j], v[2][j], v[3][j]} * sop, a1, a2);
+        split2(f32x4{v[4][j], v[5][j], v[6][j], v[7][j]} * sop, b1, b2);
+      } else {
+        split2(v[2 * j] * sop, a1, a2);
+        split2(v[2 * j + 1] * sop, b1, b2);
+      }
+      const int row = (is_x ? BM : 0) + (WIDE ? 4 * cl + j : cl + 32 * j);
+      unsigned char* dst = lds + wg_slot(row, kgroup);
+      *reinterpret_cast<u32x4*>(dst + 0 * PLANE) = u32x4{a1[0], a1[1], b1[0], b1[1]};
+      *reinterpret_cast<u32x4*>(dst + 1 * PLANE) = u32x4{a2[0], a2[1], b2[0], b2[1]};
+    }
+  };
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
+
+  // K-steps whose 32 pixels all fall into the padding for this tap (a dilated tap near the image
+  // border: 9-34 % of the ASPP weight-gradient work) contribute exact zeros and are skipped: no loads,
+  // no split, no MFMAs.  The flag rides with the offset table, so the test is uniform.
+  auto fill_offsets = [&](int mb) {
+    if (t < 32) {
+      const unsigned o = pixel_offset(mb + t);
+      pofs[t] = o;
+      const unsigned long long any = __ballot(o != OOB);
+      if (t == 0) pofs[32] = (any & 0xFFFFFFFFull) != 0;
+    }
+  };
+  bool live = false;  // the K-step held in registers has work
+  if (KT > 0) {
+    fill_offsets(mbeg);
+    __syncthreads();
+    live = pofs[32] != 0;
+    if (live) gload(mbeg);
+  }
+  for (int kt = 0; kt < KT; ++kt) {
+    __syncthreads();  // LDS image and pofs are free
+    const bool cur = live;
+    if (cur) sstore();
+    if (kt + 1 < KT) fill_offsets(mbeg + (kt + 1) * BK);
+    __syncthreads();
+    live = kt + 1 < KT && pofs[32] != 0;
+    if (live) gload(mbeg + (kt + 1) * BK);
+    if (!cur) continue;
+    // odd 16-row blocks (row bit 4) flip chunk bit 1: byte offset ^ 32
+    const int frag = wg_slot(lane & 15, lane >> 4);
+    const unsigned char* Ab = lds + wm * TM * MF * 64;
+    const unsigned char* Bb = lds + (BM + wn * TN * MF) * 64;
+    f16x8 af[TM][2];
+#pragma unroll
+    for (int l = 0; l < 2; ++l)
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i][l] = *reinterpret_cast<const f16x8*>(Ab + l * PLANE + i * MF * 64 + (frag ^ ((i & 1) << 5)));
+#pragma unroll
+    for (int l = 1; l >= 0; --l) {
+      f16x8 bf[TN];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f16x8*>(Bb + l * PLANE + j * MF * 64 + (frag ^ ((j & 1) << 5)));
+#pragma unroll
+      for (int la = 1 - l; la >= 0; --la)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][la], bf[j], acc[i][j], 0, 0, 0);
+    }
+  }
+
+#pragma unroll
+  for (int jn = 0; jn < TN; ++jn) {
+    const int cc = c0 + (wn * TN + jn) * MF + (lane & 15);
+    if (cc >= c.Cin) continue;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int n = n0 + (wm * TM + i) * MF + 4 * (lane >> 4) + e;
+        if (n >= c.Cout) continue;
+        a.slabs[(((size_t)ks * c.Cout + n) * a.taps + tap) * c.Cin + cc] = acc[i][jn][e] * unscale;
+      }
+  }
+}
+
+
+}  // namespace
+
+extern "C" {
+
+int64_t onda_absmax_ws_floats(void) { return 1024; }
+
+int onda_absmax_scale(const float* x, int64_t rows, int C, int ld, float* ws, float* scale2, onda_stream_t s) {
+  ONDA_REQUIRE(x && ws && scale2 && rows > 0 && C > 0 && C % 4 == 0 && ld >= C && ld % 4 == 0);
+  if (!ONDA_ALIGNED16(x)) return ONDA_EALIGN;
+  const long long n = rows * (C / 4);
+  const int blocks = (int)(n / 256 / 8 + 1 > 1024 ? 1024 : n / 256 / 8 + 1);
+  hipLaunchKernelGGL(absmax_partial_kernel, dim3(blocks), dim3(256), 0, ONDA_STREAM(s), x, (long long)rows, C, ld, ws);
+  hipLaunchKernelGGL(absmax_final_kernel, dim3(1), dim3(256), 0, ONDA_STREAM(s), ws, blocks, scale2);
+  return ONDA_LAUNCH_RESULT();
+}
+
+int onda_pack_weight_h2(const float* w_oihw, void* dst, int Cout, int Cin, int taps, int rows_pad, int Kp, int dgrad,
+                        int Cout_pad, const float* scale2, onda_stream_t s) {
+  ONDA_REQUIRE(w_oihw && dst && scale2 && Cout > 0 && Cin > 0 && taps > 0 && rows_pad > 0 && Kp > 0);
+  const size_t plane = (size_t)rows_pad * Kp;
+  hipLaunchKernelGGL(pack_h2_kernel, dim3((unsigned)((plane + 255) / 256)), dim3(256), 0, ONDA_STREAM(s), w_oihw,
+                     static_cast<_Float16*>(dst), Cout, Cin, taps, rows_pad, Kp, dgrad, Cout_pad, scale2);
+  return ONDA_LAUNCH_RESULT();
+}
+
+int onda_conv2d_fwd_h2(const float* x, const float* xscale2, const void* w2, const float* wscale2, float* y,
+                       const float* scale, const float* shift, const float* residual, float* stats, float* ws,
+                       const OndaConv* c, onda_stream_t s) {
+  ONDA_REQUIRE(x && xscale2 && w2 && wscale2 && y && c);
+  ONDA_REQUIRE(c->Cin > 0 && c->Cin % 32 == 0 && c->Cout > 0 && c->Cout % 4 == 0 && c->ldx % 4 == 0 && c->ldx >= c->Cin);
+  ONDA_REQUIRE(c->kh >= 1 && c->kw >= 1 && c->stride >= 1 && c->dil >= 1 && c->out_os >= 1);
+  if (!ONDA_ALIGNED16(x) || !ONDA_ALIGNED16(w2)) return ONDA_EALIGN;
+  if (ws && (c->ldy % 4 != 0 || !ONDA_ALIGNED16(y) || (residual && (c->ldr % 4 != 0 || !ONDA_ALIGNED16(residual)))))
+    ws = nullptr;
+  ConvK k;
+  k.x = x; k.w = w2; k.y = y; k.scale = scale; k.shift = shift; k.res = residual; k.stats = stats; k.ws = ws;
+  k.c = *c;
+  const long long M = (long long)c->B * c->Ho * c->Wo;
+  ONDA_REQUIRE(M > 0 && M < (1ll << 31));
+  ONDA_REQUIRE((long long)c->B * c->Hi * c->Wi * c->ldx * 4 < 0x7FFFF000ll);  // 32-bit byte offsets
+  k.M = (int)M;
+  k.taps = c->kh * c->kw;
+  k.kcper = c->Cin / 32;
+  k.tilesM = (k.M + 127) / 128;
+  const bool wide = c->Cout > 64;
+  k.tilesN = wide ? (c->Cout + 127) / 128 : (c->Cout + 63) / 64;
+  const size_t limb_elems = (size_t)c->Cout * k.taps * c->Cin;  // planes are [Cout][taps*Cin]
+  ONDA_REQUIRE(limb_elems * 4 < (1ull << 31));
+  const unsigned limb_stride = (unsigned)limb_elems;
+  const unsigned x_bytes = (unsigned)((size_t)c->B * c->Hi * c->Wi * c->ldx * 4), w_bytes = (unsigned)(limb_elems * 4);
+  const int tiles = k.tilesM * k.tilesN, KT = k.taps * k.kcper, G = conv_resident_workgroups();
+  const int rem = tiles % G;
+  k.tiles_dp = tiles - rem;
+  const double t_tile_us = 2.0 * 128.0 * (wide ? 128.0 : 64.0) * k.taps * c->Cin / 0.5e6;  // one tile, half a CU, ~250 TF/s chip
+  const double fix_us = 8.0 + (G + 2.0 * rem) * (wide ? 0.03 : 0.015);  // partial tiles written + read
+  bool balanced = ws != nullptr && rem != 0 && KT >= 4 && t_tile_us * (1.0 - (double)rem / G) > fix_us;
+  if (const int force = conv_sched_override()) {  // ONDA_CONV_SCHED: 1 tile-per-workgroup, 2 hybrid, 3 pure stream-K
+    if (force == 1 || ws == nullptr) {
+      balanced = false;
+    } else {
+      balanced = true;
+      if (force == 3) k.tiles_dp = 0;
+    }
+  }
+  hipStream_t st = ONDA_STREAM(s);
+  if (balanced) {
+    if (wide)
+      hipLaunchKernelGGL((conv_fwd_h2_kernel<128, 128, true>), dim3(G), dim3(256), 0, st, k, limb_stride, x_bytes, w_bytes, xscale2, wscale2);
+    else
+      hipLaunchKernelGGL((conv_fwd_h2_kernel<128, 64, true>), dim3(G), dim3(256), 0, st, k, limb_stride, x_bytes, w_bytes, xscale2, wscale2);
+    return conv_launch_fixup(k, G, wide, st);
+  }
+  if (wide)
+    hipLaunchKernelGGL((conv_fwd_h2_kernel<128, 128, false>), dim3(tiles), dim3(256), 0, st, k, limb_stride, x_bytes, w_bytes, xscale2, wscale2);
+  else
+    hipLaunchKernelGGL((conv_fwd_h2_kernel<128, 64, false>), dim3(tiles), dim3(256), 0, st, k, limb_stride, x_bytes, w_bytes, xscale2, wscale2);
+  return ONDA_LAUNCH_RESULT();
+}
+
+int onda_conv2d_wgrad_h2(const float* x, const float* xscale2, const float* dy, const float* dyscale2, float* slabs, int lddy,
+                         int splitk, const OndaConv* c, onda_stream_t s) {
+  ONDA_REQUIRE(x && dy && xscale2 && dyscale2 && slabs && c && splitk >= 1);
+  const long long M = (long long)c->B * c->Ho * c->Wo;
+  ONDA_REQUIRE(M > 0 && M < (1ll << 31));
+  ONDA_REQUIRE((long long)c->B * c->Hi * c->Wi * c->ldx * 4 < 0x7FFFF000ll && M * lddy * 4 < 0x7FFFF000ll);
+  const unsigned x_bytes = (unsigned)((size_t)c->B * c->Hi * c->Wi * c->ldx * 4), dy_bytes = (unsigned)(M * lddy * 4);
+  WgradK k;
+  k.x = x; k.dy = dy; k.slabs = slabs; k.c = *c;
+  k.M = (int)M;
+  k.lddy = lddy;
+  k.splitk = splitk;
+  k.mchunk = (int)(((M + splitk - 1) / splitk + 31) / 32 * 32);
+  k.taps = c->kh * c->kw;
+  if (c->Cout > 64 && c->Cin > 64) {
+    // 16-byte loads along the channel axis of both operands
+    if (!ONDA_ALIGNED16(x) || !ONDA_ALIGNED16(dy) || (c->ldx & 3) || (lddy & 3)) return ONDA_EALIGN;
+    k.tilesN = (c->Cout + 127) / 128;
+    k.tilesC = (c->Cin + 127) / 128;
+    hipLaunchKernelGGL((conv_wgrad_h2_kernel<128, 128>), dim3(k.tilesN * k.tilesC * k.taps * splitk), dim3(256), 0,
+                       ONDA_STREAM(s), k, x_bytes, dy_bytes, xscale2, dyscale2);
+  } else {
+    k.tilesN = (c->Cout + 63) / 64;
+    k.tilesC = (c->Cin + 63) / 64;
+    hipLaunchKernelGGL((conv_wgrad_h2_kernel<64, 64>), dim3(k.tilesN * k.tilesC * k.taps * splitk), dim3(256), 0,
+                       ONDA_STREAM(s), k, x_bytes, dy_bytes, xscale2, dyscale2);
+  }
+  return ONDA_LAUNCH_RESULT();
+}
+
+}  // extern "C"

@@ -24,11 +24,13 @@ HEAD_PAD = 32  # the 19-class head is computed as a 32-wide GEMM (padded rows ar
 STEM_K = 160   # 7*7*3 = 147 patch values padded to a multiple of 32
 
 
-# How forward / data-gradient convolutions are evaluated:
-#   "bf16x3": fp32 operands split into three bf16 limbs, six products on the bf16 MFMA pipe with
-#             fp32 accumulation (fp32-level accuracy at 16/6 of the fp32-MFMA rate);
-#   "f32"   : v_mfma_f32_32x32x2_f32 (an exact fp32 fmaf chain).
-CONV_MODE = os.environ.get("ONDA_CONV_MODE", "bf16x3")
+# How the convolutions (forward, data gradient, weight gradient) are evaluated:
+#   "f16x2" : fp32 operands scaled by a per-tensor power of two and split into two f16 limbs, three
+#             products on the f16 MFMA pipe with fp32 accumulation (the accuracy of an fp32 FMA chain at
+#             16/3 of the fp32-MFMA rate; csrc/conv_h2.hip) -- the default;
+#   "bf16x3": three bf16 limbs, six products on the bf16 MFMA pipe (no scale needed; csrc/conv_bf3.hip);
+#   "f32"   : v_mfma_f32_32x32x2_f32 (an exact fp32 fmaf chain; csrc/conv.hip).
+CONV_MODE = os.environ.get("ONDA_CONV_MODE", "f16x2")
 
 # bench.py sets this to a list to collect (kernel family, algorithmic flops, start event, end event)
 # around every conv launch; the events are recorded on the launch stream (torch's current stream)
@@ -99,14 +101,62 @@ def _conv_ws(device):
     return ws
 
 
+class H2Weight:
+    """Packed weight of the "f16x2" mode: two f16 limb planes of w * 2^e and the device-side [2^e, 2^-e]."""
+    __slots__ = ("limbs", "scale")
+
+    def __init__(self, limbs, scale):
+        self.limbs, self.scale = limbs, scale
+
+
+def absmax_scale(t2d_rows, C, ld, like):
+    """[2^e, 2^-e] (device tensor) with max|x| * 2^e in [2^13, 2^14); computed on the device."""
+    dev = like.device
+    ws = _ABSMAX_WS.get(str(dev))
+    if ws is None:
+        ws = _ABSMAX_WS[str(dev)] = torch.empty(query("onda_absmax_ws_floats"), device=dev, dtype=torch.float32)
+    out = torch.empty(2, device=dev, dtype=torch.float32)
+    call("onda_absmax_scale", _p(like), t2d_rows, C, ld, _p(ws), _p(out), _stream())
+    return out
+
+
+_ABSMAX_WS = {}
+
+
+def activation_scale(x):
+    """Per-tensor scale of an NHWC fp32 activation, kept on the tensor object so that every conv
+    reading it shares one pass."""
+    hit = getattr(x, "_onda_scale", None)
+    if hit is not None and hit[0] == x._version:
+        return hit[1]
+    B, H, W, C = x.shape
+    sc = absmax_scale(B * H * W, C, nhwc_ld(x), x)
+    try:
+        x._onda_scale = (x._version, sc)
+    except AttributeError:
+        pass
+    return sc
+
+
+def _pack_h2(weight, rows_pad, kp, dgrad, cout_pad):
+    cout, cin, kh, kw = weight.shape
+    w = weight.detach().contiguous()
+    sc = absmax_scale(cout, cin * kh * kw, cin * kh * kw, w)
+    dst = torch.empty(2, rows_pad, kp, device=weight.device, dtype=torch.float16)
+    call("onda_pack_weight_h2", _p(w), _p(dst), cout, cin, kh * kw, rows_pad, kp, dgrad, cout_pad, _p(sc), _stream())
+    return H2Weight(dst, sc)
+
+
 def pack_weight_fwd(weight, cout_pad=None, kp=None):
     """OIHW -> [Cout_pad][tap*Cin + c] rows of length kp (zero padded); three bf16 limb planes
-    of the same matrix in "bf16x3" mode."""
+    of the same matrix in "bf16x3" mode, two scaled f16 planes in "f16x2" mode."""
     cout, cin, kh, kw = weight.shape
     taps = kh * kw
     cout_pad = cout_pad or cout
     kp = kp or taps * cin
-    if CONV_MODE == "bf16x3":
+    if CONV_MODE == "f16x2" and (cin * taps) % 4 == 0:
+        return _pack_h2(weight, cout_pad, kp, 0, cout_pad)
+    if CONV_MODE in ("bf16x3", "f16x2"):
         dst = torch.empty(3, cout_pad, kp, device=weight.device, dtype=torch.bfloat16)
         call("onda_pack_weight_bf3", _p(weight.detach().contiguous()), _p(dst), cout, cin, taps, cout_pad, kp, 0,
              cout_pad, _stream())
@@ -120,7 +170,9 @@ def pack_weight_dgrad(weight, cout_pad=None):
     """OIHW -> [Cin][taps (flipped)][Cout_pad]: the data gradient of a stride-1 conv is a conv of dy with this."""
     cout, cin, kh, kw = weight.shape
     cout_pad = cout_pad or cout
-    if CONV_MODE == "bf16x3":
+    if CONV_MODE == "f16x2" and (cin * kh * kw) % 4 == 0:
+        return _pack_h2(weight, cin, kh * kw * cout_pad, 1, cout_pad)
+    if CONV_MODE in ("bf16x3", "f16x2"):
         dst = torch.empty(3, cin, kh * kw * cout_pad, device=weight.device, dtype=torch.bfloat16)
         call("onda_pack_weight_bf3", _p(weight.detach().contiguous()), _p(dst), cout, cin, kh * kw, cin,
              kh * kw * cout_pad, 1, cout_pad, _stream())
@@ -146,6 +198,12 @@ def conv_forward(x, wp, k, stride, dil, pad, cout, out=None, scale=None, shift=N
         tiles = query("onda_conv_tiles_m", B * Ho * Wo)
         stats = torch.empty(tiles, 2, cout, device=x.device, dtype=torch.float32)
     d = _desc(B, Hi, Wi, Cin, Ho, Wo, cout, k, stride, dil, pad, ldx, ldy, ldr, relu=relu)
+    if isinstance(wp, H2Weight):
+        _launch("conv_fwd_h2_kernel<128,%d>" % (128 if cout > 64 else 64), 2.0 * B * Ho * Wo * cout * k * k * Cin,
+                "onda_conv2d_fwd_h2", _p(x), _p(activation_scale(x)), _p(wp.limbs), _p(wp.scale), _p(out), _p(scale), _p(shift),
+                _p(residual), _p(stats), _p(_conv_ws(x.device)), byref(d), _stream(),
+                tag=("fwd", B * Ho * Wo, cout, Cin, k, stride, dil))
+        return out, stats, tiles
     bf3 = wp.dtype == torch.bfloat16
     _launch("conv_fwd%s_kernel<128,%d>" % ("_bf3" if bf3 else "", 128 if cout > 64 else 64),
             2.0 * B * Ho * Wo * cout * k * k * Cin, "onda_conv2d_fwd_bf3" if bf3 else "onda_conv2d_fwd", _p(x), _p(wp), _p(out), _p(scale), _p(shift), _p(residual), _p(stats),
@@ -167,6 +225,12 @@ def conv_dgrad(dy, wpd, k, stride, dil, pad, cin, in_hw):
             raise RuntimeError("onda_amd: strided data gradient is implemented for 1x1 convs only")
         dx = torch.zeros(B, Hi, Wi, cin, device=dy.device, dtype=torch.float32)
         d = _desc(B, Ho, Wo, Co, Ho, Wo, cin, 1, 1, 1, 0, ldy, cin, out_os=stride, Hf=Hi, Wf=Wi)
+    if isinstance(wpd, H2Weight):
+        _launch("conv_fwd_h2_kernel<128,%d>" % (128 if cin > 64 else 64), 2.0 * B * Ho * Wo * cin * k * k * Co,
+                "onda_conv2d_fwd_h2", _p(dy), _p(activation_scale(dy)), _p(wpd.limbs), _p(wpd.scale), _p(dx), None, None, None,
+                None, _p(_conv_ws(dy.device)), byref(d), _stream(),
+                tag=("dgrad", B * Ho * Wo if stride != 1 else B * Hi * Wi, cin, Co, k, stride, dil))
+        return dx
     bf3 = wpd.dtype == torch.bfloat16
     _launch("conv_fwd%s_kernel<128,%d>" % ("_bf3" if bf3 else "", 128 if cin > 64 else 64),
             2.0 * B * Ho * Wo * cin * k * k * Co, "onda_conv2d_fwd_bf3" if bf3 else "onda_conv2d_fwd", _p(dy), _p(wpd), _p(dx), None, None, None, None, _p(_conv_ws(dy.device)), byref(d),
@@ -195,9 +259,10 @@ def _wgrad_splitk(M, cout, cin, taps):
     return best
 
 
-def conv_wgrad(x, dy, k, stride, dil, pad, cout_real, cin_real, flat_k=0, into=None):
+def conv_wgrad(x, dy, k, stride, dil, pad, cout_real, cin_real, flat_k=0, into=None, xscale=None):
     """Weight gradient in OIHW.  x NHWC input of the conv, dy NHWC output gradient.  With `into`
-    (an existing contiguous gradient tensor) the result is ADDED to it and None is returned."""
+    (an existing contiguous gradient tensor) the result is ADDED to it and None is returned.
+    xscale: the per-tensor scale of x when the forward pass already computed it ("f16x2" mode)."""
     B, Hi, Wi, Cin = x.shape
     _, Ho, Wo, Co = dy.shape
     taps = k * k
@@ -205,17 +270,31 @@ def conv_wgrad(x, dy, k, stride, dil, pad, cout_real, cin_real, flat_k=0, into=N
     sk = _wgrad_splitk(M, Co, Cin, taps)
     slabs = torch.empty(sk, Co, taps, Cin, device=x.device, dtype=torch.float32)
     d = _desc(B, Hi, Wi, Cin, Ho, Wo, Co, k, stride, dil, pad, nhwc_ld(x), Co)
-    bf3 = CONV_MODE == "bf16x3"
+    if CONV_MODE == "f16x2" and Cin % 4 == 0 and Co % 4 == 0:
+        xs = xscale if xscale is not None else activation_scale(x)
+        _launch("conv_wgrad_h2_kernel<%s>" % ("128,128" if (Co > 64 and Cin > 64) else "64,64"), 2.0 * M * Co * taps * Cin,
+                "onda_conv2d_wgrad_h2", _p(x), _p(xs), _p(dy), _p(activation_scale(dy)), _p(slabs), nhwc_ld(dy), sk, byref(d),
+                _stream(), tag=("wgrad", M, Co, Cin, k, stride, dil, sk))
+    else:
+        _wgrad_other(x, dy, slabs, sk, d, M, Co, taps, Cin, k, stride, dil)
+    return _wgrad_finish(slabs, into, sk, Co, taps, Cin, cout_real, cin_real, flat_k, k, x.device)
+
+
+def _wgrad_other(x, dy, slabs, sk, d, M, Co, taps, Cin, k, stride, dil):
+    bf3 = CONV_MODE in ("bf16x3", "f16x2")
     _launch("conv_wgrad%s_kernel<%s>" % ("_bf3" if bf3 else "", "128,128" if (Co > 64 and Cin > 64) else "64,64"),
             2.0 * M * Co * taps * Cin, "onda_conv2d_wgrad_bf3" if bf3 else "onda_conv2d_wgrad", _p(x), _p(dy), _p(slabs), nhwc_ld(dy), sk, byref(d), _stream(),
             tag=("wgrad", M, Co, Cin, k, stride, dil, sk))
+
+
+def _wgrad_finish(slabs, into, sk, Co, taps, Cin, cout_real, cin_real, flat_k, k, device):
     if into is not None:
         call("onda_wgrad_reduce", _p(slabs), _p(into), sk, Co, taps, Cin, cout_real, cin_real, flat_k, 1, _stream())
         return None
     if flat_k:
-        dw = torch.empty(cout_real, cin_real, 7, 7, device=x.device, dtype=torch.float32)
+        dw = torch.empty(cout_real, cin_real, 7, 7, device=device, dtype=torch.float32)
     else:
-        dw = torch.empty(cout_real, cin_real, k, k, device=x.device, dtype=torch.float32)
+        dw = torch.empty(cout_real, cin_real, k, k, device=device, dtype=torch.float32)
     call("onda_wgrad_reduce", _p(slabs), _p(dw), sk, Co, taps, Cin, cout_real, cin_real, flat_k, 0, _stream())
     return dw
 
@@ -278,6 +357,8 @@ class Conv2dFn(torch.autograd.Function):
         wp = cache.get_fwd(weight, cout_pad)
         y, stats, _tiles = conv_forward(x, wp, k, stride, dil, pad, co, shift=_pad_vec(bias, co), want_stats=want_stats)
         ctx.save_for_backward(x, weight)
+        hit = getattr(x, "_onda_scale", None)  # "f16x2": the input's scale, reused by the weight gradient
+        ctx.xscale = hit[1] if hit is not None and hit[0] == x._version else None
         ctx.weight_param = weight  # the Parameter itself: its .grad is the accumulation target
         ctx.cache, ctx.geom, ctx.has_bias = cache, (k, stride, dil, pad, cout, cin, cout_pad), bias is not None
         if want_stats:
@@ -294,7 +375,7 @@ class Conv2dFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = conv_dgrad(dy, ctx.cache.get_dgrad(weight, cout_pad), k, stride, dil, pad, cin, x.shape[1:3])
         if ctx.needs_input_grad[1]:
-            dw = conv_wgrad(x, dy, k, stride, dil, pad, cout, cin, into=_accumulate_target(ctx.weight_param))
+            dw = conv_wgrad(x, dy, k, stride, dil, pad, cout, cin, into=_accumulate_target(ctx.weight_param), xscale=ctx.xscale)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = colsum(dy)[:cout]
         return dx, dw, db, None, None, None, None, None, None

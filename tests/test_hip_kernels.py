@@ -44,7 +44,7 @@ CONV_CASES = [
 ]
 
 
-@pytest.fixture(params=["f32", "bf16x3"])
+@pytest.fixture(params=["f32", "bf16x3", "f16x2"])
 def conv_mode(request):
     from onda_amd import ops
     old, ops.CONV_MODE = ops.CONV_MODE, request.param

@@ -18,7 +18,7 @@ LIB = os.path.join(OUT, "libonda_hip.so")
 if len(sys.argv) > 1 and sys.argv[1] == "build":
     os.makedirs(OUT, exist_ok=True)
     objs = []
-    for src in ["conv.hip", "conv_bf3.hip", "norm.hip", "pointwise.hip", "loss_proto.hip", "pipeline.hip"]:
+    for src in ["conv.hip", "conv_bf3.hip", "conv_h2.hip", "norm.hip", "pointwise.hip", "loss_proto.hip", "pipeline.hip"]:
         obj = os.path.join(OUT, src.replace(".hip", ".o"))
         subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-DONDA_BF3_CLOCK" if "clock" in sys.argv[2:] else "-DONDA_BF3_STAMP",
                                "-I" + os.path.join(ROOT, "include"), "-c", os.path.join(ROOT, "onda_amd", "csrc", src), "-o", obj])
