@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_h2_kernel(const ConvK a, unsi
   const int wstride = a.taps * c.Cin;
   const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, x_bytes), rw = make_rsrc(a.w, w_bytes);
   const float sa = xscale[0];                 // power of two: x * sa has its largest magnitude in [2^13, 2^14)
-  const float unscale = xscale[1] * wscale[1];  // 1 / (sa * sb), exact
+  const float unscale_a = xscale[1], unscale_b = wscale[1];  // applied one after the other: their product may underflow
 
   while (dp_tile < tiles_dp || u < u_end) {
     const bool dp = dp_tile < tiles_dp;
@@ -295,11 +295,11 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_h2_kernel(const ConvK a, unsi
       cur ^= 1;
     }
 
-    // back to the operands' own units (exact: a power of two) before anything reads the accumulators
+    // back to the operands' own units (exact: powers of two) before anything reads the accumulators
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int j = 0; j < TN; ++j) acc[i][j] *= unscale;
+      for (int j = 0; j < TN; ++j) acc[i][j] = (acc[i][j] * unscale_a) * unscale_b;
     if (dp) dp_tile += nblk; else u += k_end - k_begin;
     if (SK && (k_begin != 0 || k_end != KT)) {
       float* slot = a.ws + ((size_t)swz * 2 + (u - (k_end - k_begin) == u_begin ? 0 : 1)) * (BM * BN);
@@ -361,7 +361,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_h2_kernel(const WgradK a, u
   // in SGPRs instead of a per-lane "waterfall" loop around every buffer load)
   const bool is_x = __builtin_amdgcn_readfirstlane(t >> 7) != 0;
   const float sop = is_x ? xscale[0] : dyscale[0];  // per-tensor power of two of this thread's operand
-  const float unscale = xscale[1] * dyscale[1];
+  const float unscale_a = xscale[1], unscale_b = dyscale[1];  // applied one after the other (no underflow of the product)
   const int kgroup = (t >> 5) & 3;  // 8 pixels kgroup*8 .. +7
   const __amdgpu_buffer_rsrc_t rs = is_x ? make_rsrc(a.x, x_bytes) : make_rsrc(a.dy, dy_bytes);
   const int chmax = is_x ? c.Cin : c.Cout;
@@ -497,7 +497,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_h2_kernel(const WgradK a, u
       for (int e = 0; e < 4; ++e) {
         const int n = n0 + (wm * TM + i) * MF + 4 * (lane >> 4) + e;
         if (n >= c.Cout) continue;
-        a.slabs[(((size_t)ks * c.Cout + n) * a.taps + tap) * c.Cin + cc] = acc[i][jn][e] * unscale;
+        a.slabs[(((size_t)ks * c.Cout + n) * a.taps + tap) * c.Cin + cc] = (acc[i][jn][e] * unscale_a) * unscale_b;
       }
   }
 }

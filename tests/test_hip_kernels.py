@@ -453,3 +453,84 @@ def test_bad_arguments_raise():
     x = torch.zeros(1, 4, 4, 48, device=DEV)  # Cin not a multiple of 32
     with pytest.raises(RuntimeError, match="ONDA_EINVAL"):
         ops.conv_forward(x, torch.zeros(32, 48, device=DEV), 1, 1, 1, 0, 32)
+
+
+# ------------------------------------------------------------------------------------------- f16x2 specifics
+def test_absmax_scale_kernel():
+    """[2^e, 2^-e] with max|x| * 2^e in [2^13, 2^14); zeros and channel slices handled; device-side only."""
+    from onda_amd import ops
+    g = torch.Generator().manual_seed(11)
+    for mag in (1e-30, 3e-7, 0.37, 1.0, 8191.9, 8192.0, 16384.0, 5e9, 1e30):
+        x = torch.randn(2, 5, 7, 64, generator=g)
+        x = x / x.abs().max() * mag
+        sc = ops.activation_scale(x.to(DEV)).cpu()
+        m = x.abs().max().item() * sc[0].item()
+        assert sc[0].item() * sc[1].item() == 1.0 and float(np.log2(sc[0].item())).is_integer()
+        assert (2.0 ** 13 <= m < 2.0 ** 14) or abs(np.log2(sc[0].item())) == 100, (mag, m)
+    assert ops.activation_scale(torch.zeros(1, 3, 3, 32, device=DEV)).cpu().tolist() == [1.0, 1.0]
+    buf = torch.randn(2, 4, 4, 96, generator=g).to(DEV)
+    buf[..., 64:] *= 1e6  # outside the slice: must not be seen
+    sl = buf[..., :64]
+    assert ops.activation_scale(sl).cpu()[0].item() == ops.activation_scale(sl.contiguous()).cpu()[0].item()
+
+
+@pytest.mark.parametrize("regime", ["wide-range", "tiny", "huge", "outlier", "mixed-sign-cancel"])
+def test_f16x2_accuracy_against_fp64(regime):
+    """The two-limb f16 evaluation against fp64, next to what a plain fp32 conv (torch CPU) achieves on the
+    same data: forward, data gradient and weight gradient stay within 2x of fp32's own error (and below
+    1e-6 relative L2) over dynamic ranges that a single f16 could not hold."""
+    from onda_amd import ops
+    old, ops.CONV_MODE = ops.CONV_MODE, "f16x2"
+    try:
+        g = torch.Generator().manual_seed(hash(regime) & 0xFFF)
+        B, C, K, H, W = 2, 128, 128, 17, 23
+        x = torch.randn(B, C, H, W, generator=g)
+        w = torch.randn(K, C, 3, 3, generator=g) * 0.03
+        if regime == "wide-range":
+            x = torch.relu(x) * torch.exp(torch.randn(x.shape, generator=g) * 3)
+        elif regime == "tiny":
+            x, w = x * 1e-20, w * 1e-12
+        elif regime == "huge":
+            x, w = x * 1e15, w * 1e10
+        elif regime == "outlier":
+            x[0, 0, 0, 0] = 4000.0
+        else:
+            x = x + 100.0
+            w = w - w.mean(dim=(1, 2, 3), keepdim=True)
+        gy = torch.randn(B, K, H, W, generator=g) * (1e-7 if regime == "tiny" else 1.0)
+        x64, w64 = x.double().requires_grad_(True), w.double().requires_grad_(True)
+        y64 = F.conv2d(x64, w64, None, 1, 2, 2)
+        y64.backward(gy.double())
+        x32, w32 = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+        y32 = F.conv2d(x32, w32, None, 1, 2, 2)
+        y32.backward(gy)
+        xd, wd = nhwc(x).to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
+        y, _ = ops.Conv2dFn.apply(xd, wd, None, ops._PackCache(), 1, 2, 2, False, None)
+        y.backward(nhwc(gy).to(DEV))
+
+        def rel(a, ref):
+            return ((a.double() - ref).norm() / ref.norm()).item()
+
+        for name, mine, f32, ref in (("fwd", nchw(y).detach().cpu(), y32.detach(), y64.detach()),
+                                     ("dgrad", nchw(xd.grad).cpu(), x32.grad, x64.grad),
+                                     ("wgrad", wd.grad.cpu(), w32.grad, w64.grad)):
+            e_mine, e_f32 = rel(mine, ref), rel(f32, ref)
+            assert e_mine <= max(2.0 * e_f32, 4e-7) and e_mine < 1e-6, (regime, name, e_mine, e_f32)
+    finally:
+        ops.CONV_MODE = old
+
+
+def test_f16x2_zero_and_nonfinite():
+    from onda_amd import ops
+    old, ops.CONV_MODE = ops.CONV_MODE, "f16x2"
+    try:
+        w = torch.randn(128, 64, 1, 1).to(DEV)
+        wp = ops.pack_weight_fwd(w)
+        z = ops.conv_forward(torch.zeros(1, 5, 5, 64, device=DEV), wp, 1, 1, 1, 0, 128)[0]
+        assert z.abs().max().item() == 0.0
+        x = torch.randn(1, 5, 5, 64, device=DEV)
+        x[0, 2, 2, 3] = float("nan")
+        y = ops.conv_forward(x, wp, 1, 1, 1, 0, 128)[0]
+        assert torch.isnan(y[0, 2, 2]).all() and not torch.isnan(y[0, 0, 0]).any()
+    finally:
+        ops.CONV_MODE = old
