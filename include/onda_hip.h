@@ -76,22 +76,26 @@ int onda_conv2d_fwd_bf3(const float* x, const void* w3, float* y, const float* s
 
 /* ---- "f16x2": the same convolution with TWO f16 limbs per operand and a per-tensor power-of-two
  * scale (csrc/conv_h2.hip): a1*b1 + a1*b2 + a2*b1 on v_mfma_f32_16x16x32_f16, half the MFMA work of the
- * three-limb bf16 split at fp32-GEMM accuracy (3e-7 relative L2 against fp64). */
-/* scale2[0] = 2^e, scale2[1] = 2^-e with max|x| * 2^e in [2^13, 2^14) over x[rows][ld] (C valid channels,
- * C % 4 == 0); ws: onda_absmax_ws_floats() floats.  Device-side only, no host round trip. */
-int64_t onda_absmax_ws_floats(void);
-int onda_absmax_scale(const float* x, int64_t rows, int C, int ld, float* ws, float* scale2, onda_stream_t s);
-/* OIHW fp32 weights -> dst[2][rows_pad][Kp] f16 limbs of w * scale2[0]; arguments as onda_pack_weight_bf3 */
+ * three-limb bf16 split at fp32-GEMM accuracy (3e-7 relative L2 against fp64).
+ * A tensor's scale travels as `amax`: ONDA_AMAX_FLOATS device floats whose maximum is max|x| (producers spread
+ * their atomicMax over ONDA_AMAX_SLOTS slots, one cache line apart); every consumer derives 2^e (max * 2^e in
+ * [2^13, 2^14)) from it in-kernel.  amax buffers must be ZERO before their producer runs; producers are
+ * onda_absmax below, or -- fused, no extra pass -- onda_bn_apply / onda_bn_bwd / onda_conv2d_fwd_h2 (their
+ * `amax` / `yamax` argument, may be NULL). */
+#define ONDA_AMAX_SLOTS 64     /* slots, one 128-byte line apart */
+#define ONDA_AMAX_FLOATS 2048  /* floats per amax buffer */
+int onda_absmax(const float* x, int64_t rows, int C, int ld, float* amax, onda_stream_t s);
+/* OIHW fp32 weights -> dst[2][rows_pad][Kp] f16 limbs of w * 2^e(amax); other arguments as onda_pack_weight_bf3 */
 int onda_pack_weight_h2(const float* w_oihw, void* dst, int Cout, int Cin, int taps, int rows_pad, int Kp, int dgrad,
-                        int Cout_pad, const float* scale2, onda_stream_t s);
-/* onda_conv2d_fwd with the activations split in-kernel (xscale2 from onda_absmax_scale on x) and the
- * weights pre-split (w2 / wscale2 from onda_pack_weight_h2); same epilogue, workspace and schedule */
-int onda_conv2d_fwd_h2(const float* x, const float* xscale2, const void* w2, const float* wscale2, float* y,
+                        int Cout_pad, const float* amax, onda_stream_t s);
+/* onda_conv2d_fwd with the activations split in-kernel (xamax = max|x|) and the weights pre-split (w2 / wamax
+ * from onda_pack_weight_h2); same epilogue, workspace and schedule.  yamax (optional, zeroed): max|y| */
+int onda_conv2d_fwd_h2(const float* x, const float* xamax, const void* w2, const float* wamax, float* y,
                        const float* scale, const float* shift, const float* residual, float* stats, float* ws,
-                       const OndaConv* c, onda_stream_t s);
+                       float* yamax, const OndaConv* c, onda_stream_t s);
 
-/* onda_conv2d_wgrad slabs from the two-limb f16 evaluation; xscale2 / dyscale2 from onda_absmax_scale on x / dy */
-int onda_conv2d_wgrad_h2(const float* x, const float* xscale2, const float* dy, const float* dyscale2, float* slabs, int lddy,
+/* onda_conv2d_wgrad slabs from the two-limb f16 evaluation; xamax / dyamax = max|x| / max|dy| */
+int onda_conv2d_wgrad_h2(const float* x, const float* xamax, const float* dy, const float* dyamax, float* slabs, int lddy,
                          int splitk, const OndaConv* c, onda_stream_t s);
 
 /* Weight gradient, split over `splitk` pixel ranges: slabs[ks][Cout][kh*kw][Cin] partial
@@ -132,7 +136,7 @@ int onda_bn_finalize(const float* partials, int tiles, int C, int64_t count, flo
 int onda_bn_stats(const float* x, int64_t M, int C, int ldx, float* partials, int* tiles_out, onda_stream_t s);
 /* out = [relu]( (x-mean)*invstd*gamma + beta [+ residual] ) */
 int onda_bn_apply(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
-                  const float* residual, float* out, int64_t M, int C, int relu, onda_stream_t s);
+                  const float* residual, float* out, int64_t M, int C, int relu, float* amax, onda_stream_t s);
 /* eval-mode fold: scale = gamma/sqrt(var+eps), shift = beta - mean*scale (for conv_fwd's epilogue) */
 int onda_bn_fold(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                  float eps, float* scale, float* shift, int C, onda_stream_t s);
@@ -141,7 +145,7 @@ int onda_bn_fold(const float* gamma, const float* beta, const float* running_mea
  * ws: float workspace of onda_bn_bwd_ws(M, C) floats. */
 int64_t onda_bn_bwd_ws(int64_t M, int C);
 int onda_bn_bwd(const float* dout, const float* out, const float* x, const float* mean, const float* invstd,
-                const float* gamma, float* dx, float* dres, float* ws, int64_t M, int C, int relu, onda_stream_t s);
+                const float* gamma, float* dx, float* dres, float* ws, int64_t M, int C, int relu, float* amax, onda_stream_t s);
 
 /* ---- GroupNorm(32 groups, eps 1e-5, trainable affine) [+ReLU] [* Dropout2d mask] -----------
  * deeplabv2.py:141,163,182 and :203,250 (feat is taken after the dropout). x[B][HW][C]

@@ -34,10 +34,9 @@ SIGNATURES = {
     "onda_conv2d_fwd": (I, [P, P, P, P, P, P, P, P, POINTER(OndaConv), P]),
     "onda_pack_weight_bf3": (I, [P, P, I, I, I, I, I, I, I, P]),
     "onda_conv2d_fwd_bf3": (I, [P, P, P, P, P, P, P, P, POINTER(OndaConv), P]),
-    "onda_absmax_ws_floats": (L, []),
-    "onda_absmax_scale": (I, [P, L, I, I, P, P, P]),
+    "onda_absmax": (I, [P, L, I, I, P, P]),
     "onda_pack_weight_h2": (I, [P, P, I, I, I, I, I, I, I, P, P]),
-    "onda_conv2d_fwd_h2": (I, [P, P, P, P, P, P, P, P, P, P, POINTER(OndaConv), P]),
+    "onda_conv2d_fwd_h2": (I, [P, P, P, P, P, P, P, P, P, P, P, POINTER(OndaConv), P]),
     "onda_conv2d_wgrad_h2": (I, [P, P, P, P, P, I, I, POINTER(OndaConv), P]),
     "onda_conv2d_wgrad": (I, [P, P, P, I, I, POINTER(OndaConv), P]),
     "onda_conv2d_wgrad_bf3": (I, [P, P, P, I, I, POINTER(OndaConv), P]),
@@ -47,10 +46,10 @@ SIGNATURES = {
     "onda_stem_im2col": (I, [P, P, I, I, I, I, I, I, P]),
     "onda_bn_finalize": (I, [P, I, I, L, F, P, P, P, P, P, F, P]),
     "onda_bn_stats": (I, [P, L, I, I, P, POINTER(c_int), P]),
-    "onda_bn_apply": (I, [P, P, P, P, P, P, P, L, I, I, P]),
+    "onda_bn_apply": (I, [P, P, P, P, P, P, P, L, I, I, P, P]),
     "onda_bn_fold": (I, [P, P, P, P, F, P, P, I, P]),
     "onda_bn_bwd_ws": (L, [L, I]),
-    "onda_bn_bwd": (I, [P, P, P, P, P, P, P, P, P, L, I, I, P]),
+    "onda_bn_bwd": (I, [P, P, P, P, P, P, P, P, P, L, I, I, P, P]),
     "onda_gn_ws": (L, [I, L, I]),
     "onda_gn_fwd": (I, [P, I, P, P, P, P, I, P, P, P, I, L, I, I, F, I, P]),
     "onda_gn_bwd": (I, [P, I, P, I, P, I, P, P, P, P, P, P, P, P, I, L, I, I, I, P]),

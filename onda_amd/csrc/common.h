@@ -33,6 +33,35 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// Running max|x| of a tensor for the "f16x2" convolutions.  The value lives in ONDA_AMAX_FLOATS device floats
+// (all zero before the producer runs), used as ONDA_AMAX_SLOTS slots one 128-byte line apart: L2 serialises
+// atomics per line, so the slots are what lets thousands of workgroups fold their maxima without queueing.
+// A producer does one atomicMax on the bit pattern (monotonic for non-negative floats) per workgroup
+// (amax_update_block) or per wave (amax_update); a consumer takes the maximum over the slots (amax_read).
+// max is order-independent: the result is deterministic.  Every lane / thread must call these.
+constexpr int AMAX_STRIDE = ONDA_AMAX_FLOATS / ONDA_AMAX_SLOTS;
+__device__ __forceinline__ void amax_update(float* amax, float m) {
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0 && m > 0.f)
+    atomicMax(reinterpret_cast<unsigned*>(amax) + ((blockIdx.x * 4 + (threadIdx.x >> 6)) & (ONDA_AMAX_SLOTS - 1)) * AMAX_STRIDE,
+              __float_as_uint(m));
+}
+// one atomic per 256-thread workgroup; `red`: 4 floats of LDS
+__device__ __forceinline__ void amax_update_block(float* amax, float m, float* red) {
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    if (m > 0.f)
+      atomicMax(reinterpret_cast<unsigned*>(amax) + (blockIdx.x & (ONDA_AMAX_SLOTS - 1)) * AMAX_STRIDE, __float_as_uint(m));
+  }
+}
+__device__ __forceinline__ float amax_read(const float* __restrict__ amax) {
+  static_assert(ONDA_AMAX_SLOTS == 64, "one slot per lane");
+  return wave_max(amax[(threadIdx.x & 63) * AMAX_STRIDE]);
+}
+
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -241,6 +241,7 @@ __global__ __launch_bounds__(256) void conv_fixup_kernel(const ConvK a, int G, c
   __syncthreads();
 
   f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+  float mx = 0.f;
 #pragma unroll 2
   for (int i = 0; i < RPT; ++i) {
     const int row = rg + RG * i;
@@ -272,7 +273,10 @@ __global__ __launch_bounds__(256) void conv_fixup_kernel(const ConvK a, int G, c
       orow = ((size_t)b * c.Hf + (size_t)ho * c.out_os) * c.Wf + (size_t)wo * c.out_os;
     }
     *reinterpret_cast<f32x4*>(a.y + orow * c.ldy + n) = o;
+    mx = fmaxf(fmaxf(mx, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
   }
+  __shared__ float amax_red[4];
+  if (a.amax != nullptr) amax_update_block(a.amax, mx, amax_red);
   if (a.stats != nullptr) {
     red[0][t] = s1;
     red[1][t] = s2;

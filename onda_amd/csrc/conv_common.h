@@ -16,6 +16,7 @@ struct ConvK {
   int M, tilesM, tilesN, taps, kcper;
   float* ws;     // stream-K partial tiles [grid][2][BM*BN]
   int tiles_dp;  // tiles done one-per-workgroup before the stream-K remainder (multiple of the grid)
+  float* amax = nullptr;  // optional: running max|y| of the stored output (amax_update, common.h)
 };
 
 struct WgradK {
@@ -63,7 +64,7 @@ __device__ __forceinline__ void conv_store_partial(float* slot, const typename A
       }
 }
 
-// `red`: >= WAVES_M*BN*2 floats of LDS that no wave is still reading.
+// `red`: >= WAVES_M*BN*2 + 2*WAVES_M floats of LDS that no wave is still reading.
 template <int BM, int BN, int TM, int TN, int WAVES_M, int MF = 32>
 __device__ __forceinline__ void conv_epilogue(const ConvK& a, const typename AccTile<MF>::T (&acc)[TM][TN],
                                               float* red, int tile_m, int m0, int n0, int wm, int wn, int lane) {
@@ -107,6 +108,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& a, const typename Acc
   }
 
   const bool plain = (c.out_os == 1 && c.Hf == c.Ho && c.Wf == c.Wo);
+  float mx = 0.f;
 #pragma unroll
   for (int jn = 0; jn < TN; ++jn) {
     const int n = n0 + (wn * TN + jn) * MF + L::col(lane);
@@ -129,7 +131,21 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& a, const typename Acc
           orow = ((size_t)b * c.Hf + (size_t)ho * c.out_os) * c.Wf + (size_t)wo * c.out_os;
         }
         a.y[orow * c.ldy + n] = v;
+        mx = fmaxf(mx, fabsf(v));
       }
+    }
+  }
+  if (a.amax != nullptr) {  // one atomic per tile: max over the workgroup's waves through LDS (past the statistics' scratch)
+    float* ar = red + WAVES_M * BN * 2;
+    mx = wave_max(mx);
+    if ((t & 63) == 0) ar[t >> 6] = mx;
+    __syncthreads();
+    if (t == 0) {
+      float m = ar[0];
+#pragma unroll
+      for (int w_ = 1; w_ < 2 * WAVES_M; ++w_) m = fmaxf(m, ar[w_]);
+      if (m > 0.f)
+        atomicMax(reinterpret_cast<unsigned*>(a.amax) + (blockIdx.x & (ONDA_AMAX_SLOTS - 1)) * AMAX_STRIDE, __float_as_uint(m));
     }
   }
 }

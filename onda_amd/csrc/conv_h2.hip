@@ -16,8 +16,8 @@
 //
 // Same geometry, LDS images (two limb planes instead of three: 48 KB), weight DMA, hybrid stream-K
 // schedule and epilogue as conv_fwd_bf3_kernel; the accumulators are multiplied by 1 / (sa * sb)
-// (exact) before the epilogue or the partial-tile store.  The scales live in device memory
-// ([scale, 1/scale], written by absmax_scale_kernel) -- no host round trip.
+// (exact) before the epilogue or the partial-tile store.  The scale of a tensor lives in device memory as
+// its max|x| (written by the kernel that produced the tensor, or by absmax_kernel) -- no host round trip.
 #include "conv_common.h"
 
 namespace {
@@ -60,11 +60,29 @@ __device__ __forceinline__ int swz_row(int row) {
 }
 
 // ---- per-tensor scale --------------------------------------------------------------------------
-// stage 1: block maxima of |x| over [rows][ld] (C valid channels); stage 2: one block reduces them
-// (max is order-independent: deterministic) and writes out[0] = 2^e, out[1] = 2^-e with
-// max|x| * 2^e in [2^13, 2^14).  An all-zero (or non-finite) tensor gets e = 0.
-__global__ __launch_bounds__(256) void absmax_partial_kernel(const float* __restrict__ x, long long rows, int C, int ld,
-                                                             float* __restrict__ part) {
+// A tensor's scale travels as its max|x| in ONDA_AMAX_FLOATS device floats (written by absmax_kernel below or,
+// fused, by the kernel that produced the tensor: BatchNorm apply / backward, the conv epilogue; common.h
+// amax_update / amax_read).  Every consumer derives s = 2^e, 1/s = 2^-e with amax * 2^e in [2^13, 2^14) from
+// it -- a few loads and scalar operations per wave, no finalisation kernel, no host round trip.  An all-zero
+// (or non-finite) tensor gets e = 0.
+struct Scale2 {
+  float s, inv;
+};
+__device__ __forceinline__ Scale2 scale_of(const float* __restrict__ amax) {
+  const float m = amax_read(amax);
+  int e = 0;
+  if (m > 0.f && m < 3.0e38f) {
+    int ex;
+    frexpf(m, &ex);  // m = f * 2^ex, f in [0.5, 1)
+    e = 14 - ex;
+    e = e > 100 ? 100 : (e < -100 ? -100 : e);
+  }
+  return Scale2{ldexpf(1.f, e), ldexpf(1.f, -e)};
+}
+
+// amax[ONDA_AMAX_FLOATS] (zero on entry): slot-wise max|x| over x[rows][ld] (C valid channels)
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, long long rows, int C, int ld,
+                                                     float* __restrict__ amax) {
   const int c4 = C >> 2;
   const long long n = rows * c4;
   float m = 0.f;
@@ -74,40 +92,14 @@ __global__ __launch_bounds__(256) void absmax_partial_kernel(const float* __rest
     const f32x4 v = *reinterpret_cast<const f32x4*>(x + row * ld + ch);
     m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
   }
-#pragma unroll
-  for (int sh = 32; sh > 0; sh >>= 1) m = fmaxf(m, __shfl_xor(m, sh, 64));
   __shared__ float red[4];
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
-  __syncthreads();
-  if (threadIdx.x == 0) part[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  amax_update_block(amax, m, red);
 }
 
-__global__ __launch_bounds__(256) void absmax_final_kernel(const float* __restrict__ part, int n, float* __restrict__ out) {
-  float m = 0.f;
-  for (int i = threadIdx.x; i < n; i += 256) m = fmaxf(m, part[i]);
-#pragma unroll
-  for (int sh = 32; sh > 0; sh >>= 1) m = fmaxf(m, __shfl_xor(m, sh, 64));
-  __shared__ float red[4];
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    int e = 0;
-    if (m > 0.f && m < 3.0e38f) {
-      int ex;
-      frexpf(m, &ex);  // m = f * 2^ex, f in [0.5, 1)
-      e = 14 - ex;
-      e = e > 100 ? 100 : (e < -100 ? -100 : e);
-    }
-    out[0] = ldexpf(1.f, e);
-    out[1] = ldexpf(1.f, -e);
-  }
-}
-
-// OIHW fp32 -> limb planes dst[2][rows_pad][Kp] f16 of w * scale[0].  dgrad = 0: row n, k = tap*Cin + c.
+// OIHW fp32 -> limb planes dst[2][rows_pad][Kp] f16 of w * 2^e (e from *amax).  dgrad = 0: row n, k = tap*Cin + c.
 // dgrad = 1: row c, k = tap'*Cout_pad + n with the taps flipped (data-gradient operand).
 __global__ void pack_h2_kernel(const float* __restrict__ w, _Float16* __restrict__ dst, int Cout, int Cin, int taps,
-                               int rows_pad, int Kp, int dgrad, int Cout_pad, const float* __restrict__ scale) {
+                               int rows_pad, int Kp, int dgrad, int Cout_pad, const float* __restrict__ amax) {
   const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t plane = (size_t)rows_pad * Kp;
   if (e >= plane) return;
@@ -122,7 +114,7 @@ __global__ void pack_h2_kernel(const float* __restrict__ w, _Float16* __restrict
     const int tap = k / Cout_pad, n = k - tap * Cout_pad;
     if (row < Cin && tap < taps && n < Cout) v = w[((size_t)n * Cin + row) * taps + (taps - 1 - tap)];
   }
-  v *= scale[0];
+  v *= scale_of(amax).s;
   const _Float16 a = (_Float16)v;
   dst[e] = a;
   dst[plane + e] = (_Float16)(v - (float)a);
@@ -131,7 +123,7 @@ __global__ void pack_h2_kernel(const float* __restrict__ w, _Float16* __restrict
 // ---- forward / data gradient ----------------------------------------------------------------------
 template <int BM, int BN, bool SK>
 __global__ __launch_bounds__(256, 2) void conv_fwd_h2_kernel(const ConvK a, unsigned limb_stride, unsigned x_bytes, unsigned w_bytes,
-                                                             const float* __restrict__ xscale, const float* __restrict__ wscale) {
+                                                             const float* __restrict__ xamax, const float* __restrict__ wamax) {
   constexpr int WAVES_M = 2, WAVES_N = 2;
   constexpr int MF = 16;
   constexpr int TM = BM / (MF * WAVES_M), TN = BN / (MF * WAVES_N);
@@ -161,8 +153,9 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_h2_kernel(const ConvK a, unsi
   const int ccol = (t & 7) * 4, rbase = t >> 3;
   const int wstride = a.taps * c.Cin;
   const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, x_bytes), rw = make_rsrc(a.w, w_bytes);
-  const float sa = xscale[0];                 // power of two: x * sa has its largest magnitude in [2^13, 2^14)
-  const float unscale_a = xscale[1], unscale_b = wscale[1];  // applied one after the other: their product may underflow
+  const Scale2 sx = scale_of(xamax), sw = scale_of(wamax);
+  const float sa = sx.s;                                 // power of two: x * sa has its largest magnitude in [2^13, 2^14)
+  const float unscale_a = sx.inv, unscale_b = sw.inv;  // applied one after the other: their product may underflow
 
   while (dp_tile < tiles_dp || u < u_end) {
     const bool dp = dp_tile < tiles_dp;
@@ -326,8 +319,8 @@ __device__ __forceinline__ int wg_slot(int row, int chunk) {
 }
 
 template <int BM, int BN>
-__global__ __launch_bounds__(256, 2) void conv_wgrad_h2_kernel(const WgradK a, unsigned x_bytes, unsigned dy_bytes, const float* __restrict__ xscale,
-                                                              const float* __restrict__ dyscale) {
+__global__ __launch_bounds__(256, 2) void conv_wgrad_h2_kernel(const WgradK a, unsigned x_bytes, unsigned dy_bytes, const float* __restrict__ xamax,
+                                                              const float* __restrict__ dyamax) {
   constexpr int WAVES_N = 2;
   constexpr int MF = 16;
   constexpr int TM = BM / (2 * MF), TN = BN / (2 * MF);
@@ -360,8 +353,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_h2_kernel(const WgradK a, u
   // the role is wave-uniform; readfirstlane tells the compiler so (descriptor and scalar offset stay
   // in SGPRs instead of a per-lane "waterfall" loop around every buffer load)
   const bool is_x = __builtin_amdgcn_readfirstlane(t >> 7) != 0;
-  const float sop = is_x ? xscale[0] : dyscale[0];  // per-tensor power of two of this thread's operand
-  const float unscale_a = xscale[1], unscale_b = dyscale[1];  // applied one after the other (no underflow of the product)
+  const Scale2 sx = scale_of(xamax), sd = scale_of(dyamax);
+  const float sop = is_x ? sx.s : sd.s;               // per-tensor power of two of this thread's operand
+  const float unscale_a = sx.inv, unscale_b = sd.inv;  // applied one after the other (no underflow of the product)
   const int kgroup = (t >> 5) & 3;  // 8 pixels kgroup*8 .. +7
   const __amdgpu_buffer_rsrc_t rs = is_x ? make_rsrc(a.x, x_bytes) : make_rsrc(a.dy, dy_bytes);
   const int chmax = is_x ? c.Cin : c.Cout;
@@ -507,31 +501,28 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_h2_kernel(const WgradK a, u
 
 extern "C" {
 
-int64_t onda_absmax_ws_floats(void) { return 1024; }
-
-int onda_absmax_scale(const float* x, int64_t rows, int C, int ld, float* ws, float* scale2, onda_stream_t s) {
-  ONDA_REQUIRE(x && ws && scale2 && rows > 0 && C > 0 && C % 4 == 0 && ld >= C && ld % 4 == 0);
+int onda_absmax(const float* x, int64_t rows, int C, int ld, float* amax, onda_stream_t s) {
+  ONDA_REQUIRE(x && amax && rows > 0 && C > 0 && C % 4 == 0 && ld >= C && ld % 4 == 0);
   if (!ONDA_ALIGNED16(x)) return ONDA_EALIGN;
   const long long n = rows * (C / 4);
   const int blocks = (int)(n / 256 / 8 + 1 > 1024 ? 1024 : n / 256 / 8 + 1);
-  hipLaunchKernelGGL(absmax_partial_kernel, dim3(blocks), dim3(256), 0, ONDA_STREAM(s), x, (long long)rows, C, ld, ws);
-  hipLaunchKernelGGL(absmax_final_kernel, dim3(1), dim3(256), 0, ONDA_STREAM(s), ws, blocks, scale2);
+  hipLaunchKernelGGL(absmax_kernel, dim3(blocks), dim3(256), 0, ONDA_STREAM(s), x, (long long)rows, C, ld, amax);
   return ONDA_LAUNCH_RESULT();
 }
 
 int onda_pack_weight_h2(const float* w_oihw, void* dst, int Cout, int Cin, int taps, int rows_pad, int Kp, int dgrad,
-                        int Cout_pad, const float* scale2, onda_stream_t s) {
-  ONDA_REQUIRE(w_oihw && dst && scale2 && Cout > 0 && Cin > 0 && taps > 0 && rows_pad > 0 && Kp > 0);
+                        int Cout_pad, const float* amax, onda_stream_t s) {
+  ONDA_REQUIRE(w_oihw && dst && amax && Cout > 0 && Cin > 0 && taps > 0 && rows_pad > 0 && Kp > 0);
   const size_t plane = (size_t)rows_pad * Kp;
   hipLaunchKernelGGL(pack_h2_kernel, dim3((unsigned)((plane + 255) / 256)), dim3(256), 0, ONDA_STREAM(s), w_oihw,
-                     static_cast<_Float16*>(dst), Cout, Cin, taps, rows_pad, Kp, dgrad, Cout_pad, scale2);
+                     static_cast<_Float16*>(dst), Cout, Cin, taps, rows_pad, Kp, dgrad, Cout_pad, amax);
   return ONDA_LAUNCH_RESULT();
 }
 
-int onda_conv2d_fwd_h2(const float* x, const float* xscale2, const void* w2, const float* wscale2, float* y,
+int onda_conv2d_fwd_h2(const float* x, const float* xamax, const void* w2, const float* wamax, float* y,
                        const float* scale, const float* shift, const float* residual, float* stats, float* ws,
-                       const OndaConv* c, onda_stream_t s) {
-  ONDA_REQUIRE(x && xscale2 && w2 && wscale2 && y && c);
+                       float* yamax, const OndaConv* c, onda_stream_t s) {
+  ONDA_REQUIRE(x && xamax && w2 && wamax && y && c);
   ONDA_REQUIRE(c->Cin > 0 && c->Cin % 32 == 0 && c->Cout > 0 && c->Cout % 4 == 0 && c->ldx % 4 == 0 && c->ldx >= c->Cin);
   ONDA_REQUIRE(c->kh >= 1 && c->kw >= 1 && c->stride >= 1 && c->dil >= 1 && c->out_os >= 1);
   if (!ONDA_ALIGNED16(x) || !ONDA_ALIGNED16(w2)) return ONDA_EALIGN;
@@ -539,6 +530,7 @@ int onda_conv2d_fwd_h2(const float* x, const float* xscale2, const void* w2, con
     ws = nullptr;
   ConvK k;
   k.x = x; k.w = w2; k.y = y; k.scale = scale; k.shift = shift; k.res = residual; k.stats = stats; k.ws = ws;
+  k.amax = yamax;
   k.c = *c;
   const long long M = (long long)c->B * c->Ho * c->Wo;
   ONDA_REQUIRE(M > 0 && M < (1ll << 31));
@@ -570,21 +562,21 @@ int onda_conv2d_fwd_h2(const float* x, const float* xscale2, const void* w2, con
   hipStream_t st = ONDA_STREAM(s);
   if (balanced) {
     if (wide)
-      hipLaunchKernelGGL((conv_fwd_h2_kernel<128, 128, true>), dim3(G), dim3(256), 0, st, k, limb_stride, x_bytes, w_bytes, xscale2, wscale2);
+      hipLaunchKernelGGL((conv_fwd_h2_kernel<128, 128, true>), dim3(G), dim3(256), 0, st, k, limb_stride, x_bytes, w_bytes, xamax, wamax);
     else
-      hipLaunchKernelGGL((conv_fwd_h2_kernel<128, 64, true>), dim3(G), dim3(256), 0, st, k, limb_stride, x_bytes, w_bytes, xscale2, wscale2);
+      hipLaunchKernelGGL((conv_fwd_h2_kernel<128, 64, true>), dim3(G), dim3(256), 0, st, k, limb_stride, x_bytes, w_bytes, xamax, wamax);
     return conv_launch_fixup(k, G, wide, st);
   }
   if (wide)
-    hipLaunchKernelGGL((conv_fwd_h2_kernel<128, 128, false>), dim3(tiles), dim3(256), 0, st, k, limb_stride, x_bytes, w_bytes, xscale2, wscale2);
+    hipLaunchKernelGGL((conv_fwd_h2_kernel<128, 128, false>), dim3(tiles), dim3(256), 0, st, k, limb_stride, x_bytes, w_bytes, xamax, wamax);
   else
-    hipLaunchKernelGGL((conv_fwd_h2_kernel<128, 64, false>), dim3(tiles), dim3(256), 0, st, k, limb_stride, x_bytes, w_bytes, xscale2, wscale2);
+    hipLaunchKernelGGL((conv_fwd_h2_kernel<128, 64, false>), dim3(tiles), dim3(256), 0, st, k, limb_stride, x_bytes, w_bytes, xamax, wamax);
   return ONDA_LAUNCH_RESULT();
 }
 
-int onda_conv2d_wgrad_h2(const float* x, const float* xscale2, const float* dy, const float* dyscale2, float* slabs, int lddy,
+int onda_conv2d_wgrad_h2(const float* x, const float* xamax, const float* dy, const float* dyamax, float* slabs, int lddy,
                          int splitk, const OndaConv* c, onda_stream_t s) {
-  ONDA_REQUIRE(x && dy && xscale2 && dyscale2 && slabs && c && splitk >= 1);
+  ONDA_REQUIRE(x && dy && xamax && dyamax && slabs && c && splitk >= 1);
   const long long M = (long long)c->B * c->Ho * c->Wo;
   ONDA_REQUIRE(M > 0 && M < (1ll << 31));
   ONDA_REQUIRE((long long)c->B * c->Hi * c->Wi * c->ldx * 4 < 0x7FFFF000ll && M * lddy * 4 < 0x7FFFF000ll);
@@ -602,12 +594,12 @@ int onda_conv2d_wgrad_h2(const float* x, const float* xscale2, const float* dy, 
     k.tilesN = (c->Cout + 127) / 128;
     k.tilesC = (c->Cin + 127) / 128;
     hipLaunchKernelGGL((conv_wgrad_h2_kernel<128, 128>), dim3(k.tilesN * k.tilesC * k.taps * splitk), dim3(256), 0,
-                       ONDA_STREAM(s), k, x_bytes, dy_bytes, xscale2, dyscale2);
+                       ONDA_STREAM(s), k, x_bytes, dy_bytes, xamax, dyamax);
   } else {
     k.tilesN = (c->Cout + 63) / 64;
     k.tilesC = (c->Cin + 63) / 64;
     hipLaunchKernelGGL((conv_wgrad_h2_kernel<64, 64>), dim3(k.tilesN * k.tilesC * k.taps * splitk), dim3(256), 0,
-                       ONDA_STREAM(s), k, x_bytes, dy_bytes, xscale2, dyscale2);
+                       ONDA_STREAM(s), k, x_bytes, dy_bytes, xamax, dyamax);
   }
   return ONDA_LAUNCH_RESULT();
 }

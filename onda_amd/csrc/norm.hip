@@ -177,8 +177,9 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
                                                        const float* __restrict__ invstd,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        const float* __restrict__ res, float* __restrict__ out,
-                                                       size_t total4, int C, int relu) {
+                                                       size_t total4, int C, int relu, float* __restrict__ amax) {
   const int c4 = C / 4;
+  float mx = 0.f;
   for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total4; e += (size_t)gridDim.x * blockDim.x) {
     const int col = (int)(e % c4) * 4;
     const f32x4 sc = LD4(invstd + col) * LD4(gamma + col);
@@ -189,7 +190,10 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
       for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
     }
     *reinterpret_cast<f32x4*>(out + e * 4) = v;
+    mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
   }
+  __shared__ float amax_red[4];
+  if (amax != nullptr) amax_update_block(amax, mx, amax_red);
 }
 
 __global__ void bn_fold_kernel(const float* gamma, const float* beta, const float* rmean, const float* rvar, float eps,
@@ -226,8 +230,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ invstd,
                                                            const float* __restrict__ gamma,
                                                            const float* __restrict__ sums, float* __restrict__ dx,
-                                                           size_t total4, int C, float inv_m, int relu) {
+                                                           size_t total4, int C, float inv_m, int relu,
+                                                           float* __restrict__ amax) {
   const int c4 = C / 4;
+  float mx = 0.f;
   for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total4; e += (size_t)gridDim.x * blockDim.x) {
     const int col = (int)(e % c4) * 4;
     f32x4 g = LD4(dout + e * 4);
@@ -240,7 +246,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     const f32x4 xh = (LD4(x + e * 4) - LD4(mean + col)) * is;
     const f32x4 v = LD4(gamma + col) * is * (g - LD4(sums + col) * inv_m - xh * (LD4(sums + C + col) * inv_m));
     *reinterpret_cast<f32x4*>(dx + e * 4) = v;
+    mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
   }
+  __shared__ float amax_red[4];
+  if (amax != nullptr) amax_update_block(amax, mx, amax_red);
 }
 
 // ---- GroupNorm --------------------------------------------------------------------------
@@ -409,11 +418,11 @@ int onda_bn_stats(const float* x, int64_t M, int C, int ldx, float* partials, in
 }
 
 int onda_bn_apply(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
-                  const float* residual, float* out, int64_t M, int C, int relu, onda_stream_t s) {
+                  const float* residual, float* out, int64_t M, int C, int relu, float* amax, onda_stream_t s) {
   ONDA_REQUIRE(x && mean && invstd && gamma && beta && out && C % 4 == 0);
   const size_t total4 = (size_t)M * C / 4;
   hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid(total4)), dim3(256), 0, ONDA_STREAM(s), x, mean, invstd, gamma, beta,
-                     residual, out, total4, C, relu);
+                     residual, out, total4, C, relu, amax);
   return ONDA_LAUNCH_RESULT();
 }
 
@@ -431,7 +440,8 @@ int64_t onda_bn_bwd_ws(int64_t M, int C) {
 }
 
 int onda_bn_bwd(const float* dout, const float* out, const float* x, const float* mean, const float* invstd,
-                const float* gamma, float* dx, float* dres, float* ws, int64_t M, int C, int relu, onda_stream_t s) {
+                const float* gamma, float* dx, float* dres, float* ws, int64_t M, int C, int relu, float* amax,
+                onda_stream_t s) {
   ONDA_REQUIRE(dout && x && mean && invstd && gamma && dx && ws && C % 4 == 0 && (!relu || out));
   const ColPlan p = col_plan(1, M, C);
   float* sums = ws + (size_t)p.chunks * 2 * C;
@@ -441,7 +451,7 @@ int onda_bn_bwd(const float* dout, const float* out, const float* x, const float
   hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3((C + 3) / 4), dim3(256), 0, ONDA_STREAM(s), ws, p.chunks, C, sums);
   const size_t total4 = (size_t)M * C / 4;
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(total4)), dim3(256), 0, ONDA_STREAM(s), dout, out, x, mean,
-                     invstd, gamma, sums, dx, total4, C, (float)(1.0 / (double)M), relu);
+                     invstd, gamma, sums, dx, total4, C, (float)(1.0 / (double)M), relu, amax);
   return ONDA_LAUNCH_RESULT();
 }
 

@@ -102,49 +102,68 @@ def _conv_ws(device):
 
 
 class H2Weight:
-    """Packed weight of the "f16x2" mode: two f16 limb planes of w * 2^e and the device-side [2^e, 2^-e]."""
-    __slots__ = ("limbs", "scale")
+    """Packed weight of the "f16x2" mode: two f16 limb planes of w * 2^e and the device float max|w| that
+    defines e (include/onda_hip.h, f16x2 section)."""
+    __slots__ = ("limbs", "amax")
 
-    def __init__(self, limbs, scale):
-        self.limbs, self.scale = limbs, scale
-
-
-def absmax_scale(t2d_rows, C, ld, like):
-    """[2^e, 2^-e] (device tensor) with max|x| * 2^e in [2^13, 2^14); computed on the device."""
-    dev = like.device
-    ws = _ABSMAX_WS.get(str(dev))
-    if ws is None:
-        ws = _ABSMAX_WS[str(dev)] = torch.empty(query("onda_absmax_ws_floats"), device=dev, dtype=torch.float32)
-    out = torch.empty(2, device=dev, dtype=torch.float32)
-    call("onda_absmax_scale", _p(like), t2d_rows, C, ld, _p(ws), _p(out), _stream())
-    return out
+    def __init__(self, limbs, amax):
+        self.limbs, self.amax = limbs, amax
 
 
-_ABSMAX_WS = {}
+_AMAX_POOL = {}
+
+
+AMAX_SLOTS = 2048  # ONDA_AMAX_FLOATS (include/onda_hip.h): 64 slots, one 128-byte line apart
+
+
+def amax_slot(device):
+    """Zeroed device floats for a tensor's running max|x| (slices of a zero-filled pool: one fill kernel per
+    2048 tensors instead of one per tensor; a slice is written by exactly one producer and never reused)."""
+    key = str(device)
+    pool = _AMAX_POOL.get(key)
+    if pool is None or pool[1] + AMAX_SLOTS > pool[0].numel():
+        pool = _AMAX_POOL[key] = [torch.zeros(2048 * AMAX_SLOTS, device=device, dtype=torch.float32), 0]
+    i = pool[1]
+    pool[1] = i + AMAX_SLOTS
+    return pool[0][i:i + AMAX_SLOTS]
+
+
+def tag_amax(t, slot):
+    """Remember that `slot` holds max|t| (valid while t is not modified in place)."""
+    try:
+        t._onda_scale = (t._version, slot)
+    except AttributeError:
+        pass
+    return t
+
+
+def known_amax(t):
+    hit = getattr(t, "_onda_scale", None)
+    return hit[1] if hit is not None and hit[0] == t._version else None
 
 
 def activation_scale(x):
-    """Per-tensor scale of an NHWC fp32 activation, kept on the tensor object so that every conv
-    reading it shares one pass."""
-    hit = getattr(x, "_onda_scale", None)
-    if hit is not None and hit[0] == x._version:
-        return hit[1]
+    """Device float max|x| of an NHWC fp32 activation ("f16x2" mode).  Usually the kernel that produced x
+    already left it behind (BatchNorm apply / backward, folded-BN conv epilogue: tag_amax); otherwise one
+    reduction pass, shared by every conv that reads the same tensor object."""
+    slot = known_amax(x)
+    if slot is not None:
+        return slot
     B, H, W, C = x.shape
-    sc = absmax_scale(B * H * W, C, nhwc_ld(x), x)
-    try:
-        x._onda_scale = (x._version, sc)
-    except AttributeError:
-        pass
-    return sc
+    slot = amax_slot(x.device)
+    call("onda_absmax", _p(x), B * H * W, C, nhwc_ld(x), _p(slot), _stream())
+    tag_amax(x, slot)
+    return slot
 
 
 def _pack_h2(weight, rows_pad, kp, dgrad, cout_pad):
     cout, cin, kh, kw = weight.shape
     w = weight.detach().contiguous()
-    sc = absmax_scale(cout, cin * kh * kw, cin * kh * kw, w)
+    slot = amax_slot(weight.device)
+    call("onda_absmax", _p(w), cout, cin * kh * kw, cin * kh * kw, _p(slot), _stream())
     dst = torch.empty(2, rows_pad, kp, device=weight.device, dtype=torch.float16)
-    call("onda_pack_weight_h2", _p(w), _p(dst), cout, cin, kh * kw, rows_pad, kp, dgrad, cout_pad, _p(sc), _stream())
-    return H2Weight(dst, sc)
+    call("onda_pack_weight_h2", _p(w), _p(dst), cout, cin, kh * kw, rows_pad, kp, dgrad, cout_pad, _p(slot), _stream())
+    return H2Weight(dst, slot)
 
 
 def pack_weight_fwd(weight, cout_pad=None, kp=None):
@@ -199,10 +218,14 @@ def conv_forward(x, wp, k, stride, dil, pad, cout, out=None, scale=None, shift=N
         stats = torch.empty(tiles, 2, cout, device=x.device, dtype=torch.float32)
     d = _desc(B, Hi, Wi, Cin, Ho, Wo, cout, k, stride, dil, pad, ldx, ldy, ldr, relu=relu)
     if isinstance(wp, H2Weight):
+        # a folded-BN (+ReLU) output is the next conv's input: let the epilogue leave its max|y| behind
+        yamax = amax_slot(x.device) if (scale is not None or relu) else None
         _launch("conv_fwd_h2_kernel<128,%d>" % (128 if cout > 64 else 64), 2.0 * B * Ho * Wo * cout * k * k * Cin,
-                "onda_conv2d_fwd_h2", _p(x), _p(activation_scale(x)), _p(wp.limbs), _p(wp.scale), _p(out), _p(scale), _p(shift),
-                _p(residual), _p(stats), _p(_conv_ws(x.device)), byref(d), _stream(),
+                "onda_conv2d_fwd_h2", _p(x), _p(activation_scale(x)), _p(wp.limbs), _p(wp.amax), _p(out), _p(scale), _p(shift),
+                _p(residual), _p(stats), _p(_conv_ws(x.device)), _p(yamax), byref(d), _stream(),
                 tag=("fwd", B * Ho * Wo, cout, Cin, k, stride, dil))
+        if yamax is not None:
+            tag_amax(out, yamax)
         return out, stats, tiles
     bf3 = wp.dtype == torch.bfloat16
     _launch("conv_fwd%s_kernel<128,%d>" % ("_bf3" if bf3 else "", 128 if cout > 64 else 64),
@@ -227,8 +250,8 @@ def conv_dgrad(dy, wpd, k, stride, dil, pad, cin, in_hw):
         d = _desc(B, Ho, Wo, Co, Ho, Wo, cin, 1, 1, 1, 0, ldy, cin, out_os=stride, Hf=Hi, Wf=Wi)
     if isinstance(wpd, H2Weight):
         _launch("conv_fwd_h2_kernel<128,%d>" % (128 if cin > 64 else 64), 2.0 * B * Ho * Wo * cin * k * k * Co,
-                "onda_conv2d_fwd_h2", _p(dy), _p(activation_scale(dy)), _p(wpd.limbs), _p(wpd.scale), _p(dx), None, None, None,
-                None, _p(_conv_ws(dy.device)), byref(d), _stream(),
+                "onda_conv2d_fwd_h2", _p(dy), _p(activation_scale(dy)), _p(wpd.limbs), _p(wpd.amax), _p(dx), None, None, None,
+                None, _p(_conv_ws(dy.device)), None, byref(d), _stream(),
                 tag=("dgrad", B * Ho * Wo if stride != 1 else B * Hi * Wi, cin, Co, k, stride, dil))
         return dx
     bf3 = wpd.dtype == torch.bfloat16
@@ -357,8 +380,7 @@ class Conv2dFn(torch.autograd.Function):
         wp = cache.get_fwd(weight, cout_pad)
         y, stats, _tiles = conv_forward(x, wp, k, stride, dil, pad, co, shift=_pad_vec(bias, co), want_stats=want_stats)
         ctx.save_for_backward(x, weight)
-        hit = getattr(x, "_onda_scale", None)  # "f16x2": the input's scale, reused by the weight gradient
-        ctx.xscale = hit[1] if hit is not None and hit[0] == x._version else None
+        ctx.xscale = known_amax(x)  # "f16x2": max|x| of the input, reused by the weight gradient
         ctx.weight_param = weight  # the Parameter itself: its .grad is the accumulation target
         ctx.cache, ctx.geom, ctx.has_bias = cache, (k, stride, dil, pad, cout, cin, cout_pad), bias is not None
         if want_stats:
@@ -447,8 +469,11 @@ class BNTrainFn(torch.autograd.Function):
         res = as_nhwc(residual) if residual is not None else None
         if res is not None and nhwc_ld(res) != C:
             res = res.contiguous()
+        amax = amax_slot(y.device) if CONV_MODE == "f16x2" else None  # the output feeds a conv: leave max|out| behind
         call("onda_bn_apply", _p(y), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(res), _p(out), M, C, int(relu),
-             _stream())
+             _p(amax), _stream())
+        if amax is not None:
+            tag_amax(out, amax)
         ctx.save_for_backward(y, out if relu else None, mean, invstd, gamma)
         ctx.relu, ctx.has_res = relu, residual is not None
         return out
@@ -461,12 +486,15 @@ class BNTrainFn(torch.autograd.Function):
         dout = dout.contiguous()
         ws = torch.empty(query("onda_bn_bwd_ws", M, C), device=y.device, dtype=torch.float32)
         dx = torch.empty_like(y)
+        amax = amax_slot(y.device) if CONV_MODE == "f16x2" else None
         need_res = ctx.has_res and ctx.needs_input_grad[4]
         dres = None
         if need_res:
             dres = torch.empty_like(y) if ctx.relu else dout
         call("onda_bn_bwd", _p(dout), _p(out), _p(y), _p(mean), _p(invstd), _p(gamma), _p(dx),
-             _p(dres) if (need_res and ctx.relu) else None, _p(ws), M, C, int(ctx.relu), _stream())
+             _p(dres) if (need_res and ctx.relu) else None, _p(ws), M, C, int(ctx.relu), _p(amax), _stream())
+        if amax is not None:
+            tag_amax(dx, amax)  # dx is the dy of the conv below: data gradient and weight gradient read it
         return dx, None, None, None, dres, None, None, None
 
 

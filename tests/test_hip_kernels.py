@@ -456,22 +456,54 @@ def test_bad_arguments_raise():
 
 
 # ------------------------------------------------------------------------------------------- f16x2 specifics
-def test_absmax_scale_kernel():
-    """[2^e, 2^-e] with max|x| * 2^e in [2^13, 2^14); zeros and channel slices handled; device-side only."""
+def test_amax_producers():
+    """max|x| as the f16x2 kernels see it: the standalone pass (channel slices, zeros) and the fused producers
+    (BatchNorm apply / backward, folded-BN conv epilogue incl. stream-K fix-up tiles) all leave exactly
+    tensor.abs().max() behind, on the device."""
     from onda_amd import ops
-    g = torch.Generator().manual_seed(11)
-    for mag in (1e-30, 3e-7, 0.37, 1.0, 8191.9, 8192.0, 16384.0, 5e9, 1e30):
-        x = torch.randn(2, 5, 7, 64, generator=g)
-        x = x / x.abs().max() * mag
-        sc = ops.activation_scale(x.to(DEV)).cpu()
-        m = x.abs().max().item() * sc[0].item()
-        assert sc[0].item() * sc[1].item() == 1.0 and float(np.log2(sc[0].item())).is_integer()
-        assert (2.0 ** 13 <= m < 2.0 ** 14) or abs(np.log2(sc[0].item())) == 100, (mag, m)
-    assert ops.activation_scale(torch.zeros(1, 3, 3, 32, device=DEV)).cpu().tolist() == [1.0, 1.0]
-    buf = torch.randn(2, 4, 4, 96, generator=g).to(DEV)
-    buf[..., 64:] *= 1e6  # outside the slice: must not be seen
-    sl = buf[..., :64]
-    assert ops.activation_scale(sl).cpu()[0].item() == ops.activation_scale(sl.contiguous()).cpu()[0].item()
+    old, ops.CONV_MODE = ops.CONV_MODE, "f16x2"
+    try:
+        g = torch.Generator().manual_seed(11)
+        for mag in (1e-30, 3e-7, 0.37, 8192.0, 1e30):
+            x = torch.randn(2, 5, 7, 64, generator=g)
+            x = (x / x.abs().max() * mag).to(DEV)
+            assert ops.activation_scale(x).max().item() == x.abs().max().item()
+        assert ops.activation_scale(torch.zeros(1, 3, 3, 32, device=DEV)).max().item() == 0.0
+        buf = torch.randn(2, 4, 4, 96, generator=g).to(DEV)
+        buf[..., 64:] *= 1e6  # outside the slice: must not be seen
+        sl = buf[..., :64]
+        assert ops.activation_scale(sl).max().item() == sl.abs().max().item()
+        # BatchNorm apply (+residual, ReLU) and its backward
+        y = torch.randn(2, 9, 17, 64, generator=g).to(DEV).requires_grad_(True)
+        stats = torch.stack([y.detach().sum((0, 1, 2)), (y.detach() ** 2).sum((0, 1, 2))])[None].contiguous()
+        res = torch.randn(2, 9, 17, 64, generator=g).to(DEV)
+        out = ops.BNTrainFn.apply(y, stats, torch.rand(64, device=DEV) + 0.5, torch.randn(64, device=DEV), res, True, None, 0.1)
+        assert ops.known_amax(out) is not None and ops.known_amax(out).max().item() == out.abs().max().item()
+        seen = {}
+
+        class Probe(torch.autograd.Function):
+            @staticmethod
+            def forward(ctx, t):
+                return t.view_as(t)
+
+            @staticmethod
+            def backward(ctx, gr):
+                seen["amax"], seen["true"] = ops.known_amax(gr), gr.abs().max().item()
+                return gr
+
+        y2 = torch.randn(2, 9, 17, 64, generator=g).to(DEV).requires_grad_(True)
+        out2 = ops.BNTrainFn.apply(Probe.apply(y2), stats, torch.rand(64, device=DEV) + 0.5, torch.randn(64, device=DEV), None, True,
+                                   None, 0.1)
+        out2.backward(torch.randn(out2.shape, generator=g).to(DEV))
+        assert seen["amax"] is not None and seen["amax"].max().item() == seen["true"]
+        # folded-BN conv epilogue, one tile per workgroup and stream-K (fix-up kernel) schedules
+        x = torch.randn(4, 33, 65, 128, generator=g).to(DEV)
+        wp = ops.pack_weight_fwd((torch.randn(256, 128, 3, 3, generator=g) / 34).to(DEV))
+        sc, sh = (torch.rand(256, generator=g) + 0.5).to(DEV), torch.randn(256, generator=g).to(DEV)
+        yy = ops.conv_forward(x, wp, 3, 1, 2, 2, 256, scale=sc, shift=sh, relu=True)[0]
+        assert ops.known_amax(yy).max().item() == yy.abs().max().item()
+    finally:
+        ops.CONV_MODE = old
 
 
 @pytest.mark.parametrize("regime", ["wide-range", "tiny", "huge", "outlier", "mixed-sign-cancel"])
