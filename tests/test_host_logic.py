@@ -146,3 +146,14 @@ def test_dropin_aliases_reference_names():
         for k in [k for k in sys.modules if k == "framework" or k.startswith("framework.")]:
             del sys.modules[k]
         sys.modules.update(saved)
+
+
+def test_amax_constants_match_header():
+    """ops.AMAX_SLOTS is the buffer size the kernels assume (ONDA_AMAX_FLOATS in include/onda_hip.h)."""
+    import os
+    import re
+    from onda_amd import ops
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "onda_hip.h")).read()
+    floats = int(re.search(r"#define ONDA_AMAX_FLOATS (\d+)", hdr).group(1))
+    slots = int(re.search(r"#define ONDA_AMAX_SLOTS (\d+)", hdr).group(1))
+    assert ops.AMAX_SLOTS == floats and floats % slots == 0 and (floats // slots) * 4 == 128 and slots == 64

@@ -11,6 +11,8 @@ SHAPES = [  # (B,H,W,Cin,Cout,k,dil)
 ]
 for (B, H, W, Cin, Cout, k, dil) in SHAPES:
     x = torch.randn(B, H, W, Cin, device="cuda")
+    if os.environ.get("ZERO"):  # all-zero activations: same instruction stream and bytes, less switching power
+        x.zero_()
     w = torch.randn(Cout, Cin, k, k, device="cuda") / (Cin * k * k) ** 0.5
     wp = ops.pack_weight_fwd(w)
     pad = dil * (k - 1) // 2
