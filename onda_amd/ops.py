@@ -159,8 +159,11 @@ def activation_scale(x):
 def _pack_h2(weight, rows_pad, kp, dgrad, cout_pad):
     cout, cin, kh, kw = weight.shape
     w = weight.detach().contiguous()
-    slot = amax_slot(weight.device)
-    call("onda_absmax", _p(w), cout, cin * kh * kw, cin * kh * kw, _p(slot), _stream())
+    slot = known_amax(weight)  # the forward and the data-gradient packing of one weight version share max|w|
+    if slot is None:
+        slot = amax_slot(weight.device)
+        call("onda_absmax", _p(w), cout, cin * kh * kw, cin * kh * kw, _p(slot), _stream())
+        tag_amax(weight, slot)
     dst = torch.empty(2, rows_pad, kp, device=weight.device, dtype=torch.float16)
     call("onda_pack_weight_h2", _p(w), _p(dst), cout, cin, kh * kw, rows_pad, kp, dgrad, cout_pad, _p(slot), _stream())
     return H2Weight(dst, slot)
