@@ -79,7 +79,7 @@ int onda_conv2d_fwd_bf3(const float* x, const void* w3, float* y, const float* s
  * three-limb bf16 split at fp32-GEMM accuracy (3e-7 relative L2 against fp64).
  * A tensor's scale travels as `amax`: ONDA_AMAX_FLOATS device floats whose maximum is max|x| (producers spread
  * their atomicMax over ONDA_AMAX_SLOTS slots, one cache line apart); every consumer derives 2^e (max * 2^e in
- * [2^13, 2^14)) from it in-kernel.  amax buffers must be ZERO before their producer runs; producers are
+ * [2^14, 2^15)) from it in-kernel.  amax buffers must be ZERO before their producer runs; producers are
  * onda_absmax below, or -- fused, no extra pass -- onda_bn_apply / onda_bn_bwd / onda_conv2d_fwd_h2 (their
  * `amax` / `yamax` argument, may be NULL). */
 #define ONDA_AMAX_SLOTS 64     /* slots, one 128-byte line apart */

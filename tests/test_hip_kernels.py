@@ -566,3 +566,28 @@ def test_f16x2_zero_and_nonfinite():
         assert torch.isnan(y[0, 2, 2]).all() and not torch.isnan(y[0, 0, 0]).any()
     finally:
         ops.CONV_MODE = old
+
+
+def test_f16x2_interpixel_range():
+    """The one place where two scaled f16 limbs differ from fp32: outputs that depend ONLY on elements far
+    below the tensor's maximum (here: half of the pixels scaled down, through a 1x1 conv).  Full accuracy down
+    to 2^-16 of the maximum, graceful (subnormal second limb, no flush) below; bf16x3 is scale-free."""
+    from onda_amd import ops
+    old = ops.CONV_MODE
+    try:
+        g = torch.Generator().manual_seed(1)
+        w = torch.randn(256, 256, 1, 1, generator=g) * 0.05
+        bounds = {"f16x2": {0: 4e-7, 12: 4e-7, 16: 6e-7, 20: 1e-5, 24: 2e-4}, "bf16x3": {0: 2e-7, 16: 2e-7, 24: 2e-7}}
+        for mode, table in bounds.items():
+            ops.CONV_MODE = mode
+            wp = ops.pack_weight_fwd(w.to(DEV))
+            for shift, bound in table.items():
+                x = torch.randn(1, 16, 64, 256, generator=g)
+                x[:, 8:] *= 2.0 ** -shift
+                y = ops.conv_forward(x.to(DEV), wp, 1, 1, 1, 0, 256)[0].cpu().double()
+                ref = torch.einsum("bhwc,kc->bhwk", x.double(), w[:, :, 0, 0].double())
+                for part in (slice(0, 8), slice(8, 16)):
+                    err = ((y[:, part] - ref[:, part]).norm() / ref[:, part].norm()).item()
+                    assert err <= bound, (mode, shift, part, err)
+    finally:
+        ops.CONV_MODE = old
