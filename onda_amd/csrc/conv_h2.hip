@@ -8,16 +8,18 @@
 // 65504): f16 has 11
 // significant bits but only 5 exponent bits, so unlike bf16 it needs the scale; a power of two keeps the
 // scaling exact, and a per-tensor factor comes out of the whole contraction (a per-pixel one would not:
-// an im2col row mixes pixels).  Elements more than 2^17 below the tensor maximum lose relative precision
-// (their second limb becomes an f16 subnormal; nothing is flushed) but their absolute error stays below 2^-39
-// of the maximum -- invisible next to fp32's own accumulation error in any output that also sees large
-// elements.  The one case that differs from fp32: an output that depends ONLY on elements far below the
-// tensor maximum (a pixel 2^20 smaller than the largest one, through a 1x1 conv) keeps ~17 significant bits
-// instead of 24 (measured: 2e-7 down to 2^-16 of the maximum, 1e-6 at 2^-18, 4e-6 at 2^-20, 1e-3 at 2^-28;
-// tests/test_hip_kernels.py::test_f16x2_interpixel_range).  "bf16x3" has no such dependence.  The product is evaluated as a1*b1 + (a1*b2 + a2*b1), each exact in fp32 (11 x 11 bits),
-// accumulated in fp32 by v_mfma_f32_16x16x32_f16; what is dropped (a2*b2 and the representation error)
-// is ~2^-22 |a||b| per product.  Measured (numpy emulation and on the GPU): 3.1e-7 relative L2 against
-// fp64 where fp32 FMA chains give 3.1e-7 and the bf16x3 kernels 1.3-2.4e-7.
+// an im2col row mixes pixels).  The second limb is stored times 2^11 (the residual of an f16 rounding is
+// <= 2^-11 of the first limb), so both limbs keep 11 significant bits for every element down to 2^-28 of the
+// tensor maximum; below that the limbs slide into f16 subnormals (nothing is flushed) and precision falls off
+// gradually.  Measured on outputs that depend ONLY on small elements (a pixel far below the largest one,
+// through a 1x1 conv; tests/test_hip_kernels.py::test_f16x2_interpixel_range): 1.3e-7 down to 2^-24 of the
+// maximum, 6e-7 at 2^-28, 1e-5 at 2^-32 -- 7-8 decades of per-element range at full accuracy, against fp32's
+// own 2^-126; "bf16x3" has no such dependence.
+// The product is evaluated as a1*b1 + (a1*b2 + a2*b1), each exact in fp32 (11 x 11 bits),
+// accumulated in fp32 by v_mfma_f32_16x16x32_f16 -- a1*b1 in one accumulator set, the two cross products
+// (2^11 too large) in a second one that is folded in with 2^-11 at the end; what is dropped (a2*b2 and the
+// representation error) is ~2^-22 |a||b| per product.  Measured on the GPU: 1.3-3e-7 relative L2 against
+// fp64, where fp32 FMA chains give 3e-7 and the bf16x3 kernels 0.7-2.4e-7.
 //
 // Same geometry, LDS images (two limb planes instead of three: 48 KB), weight DMA, hybrid stream-K
 // schedule and epilogue as conv_fwd_bf3_kernel; the accumulators are multiplied by 1 / (sa * sb)
@@ -41,6 +43,12 @@ __device__ __forceinline__ f32x2 unpack2h(unsigned p) {
   return __builtin_convertvector(__builtin_bit_cast(f16x2, p), f32x2);
 }
 
+// The second limb is stored times 2^11: the residual of an f16 rounding is <= 2^-11 of the first limb, so
+// h2 * 2^11 lives in the first limb's own exponent range instead of sliding into f16 subnormals for small
+// elements.  The cross products a1*b2' + a2'*b1 go to a second accumulator set that is folded in with 2^-11
+// at the end (exact scaling): full two-limb precision for every element down to 2^-28 of the tensor maximum.
+constexpr float LIMB2_SCALE = 2048.f, LIMB2_UNSCALE = 1.f / 2048.f;
+
 // float4 (already scaled) -> two limbs, each 4 f16 packed in 8 bytes
 __device__ __forceinline__ void split2(const f32x4 v, u32x2& l1, u32x2& l2) {
 #pragma unroll
@@ -49,7 +57,7 @@ __device__ __forceinline__ void split2(const f32x4 v, u32x2& l1, u32x2& l2) {
     const unsigned p = cvt2h(x0, x1);
     const f32x2 f = unpack2h(p);
     l1[h] = p;
-    l2[h] = cvt2h(x0 - f[0], x1 - f[1]);
+    l2[h] = cvt2h((x0 - f[0]) * LIMB2_SCALE, (x1 - f[1]) * LIMB2_SCALE);
   }
 }
 
@@ -122,7 +130,7 @@ __global__ void pack_h2_kernel(const float* __restrict__ w, _Float16* __restrict
   v *= scale_of(amax).s;
   const _Float16 a = (_Float16)v;
   dst[e] = a;
-  dst[plane + e] = (_Float16)(v - (float)a);
+  dst[plane + e] = (_Float16)((v - (float)a) * LIMB2_SCALE);
 }
 
 // ---- forward / data gradient ----------------------------------------------------------------------
@@ -239,13 +247,13 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_h2_kernel(const ConvK a, unsi
       }
     };
 
-    f32x4 acc[TM][TN];
+    f32x4 acc[TM][TN], accx[TM][TN];  // a1*b1, and the cross products (2^11 too large)
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
+        for (int e = 0; e < 4; ++e) acc[i][j][e] = accx[i][j][e] = 0.f;
 
     __syncthreads();  // the previous segment's readers are done with every LDS region
     set_tap(tap);
@@ -287,8 +295,12 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_h2_kernel(const ConvK a, unsi
 #pragma unroll
           for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][la], bf[j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < TN; ++j) {
+              if (la + l == 0)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][la], bf[j], acc[i][j], 0, 0, 0);
+              else
+                accx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][la], bf[j], accx[i][j], 0, 0, 0);
+            }
       }
       cur ^= 1;
     }
@@ -297,7 +309,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_h2_kernel(const ConvK a, unsi
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int j = 0; j < TN; ++j) acc[i][j] = (acc[i][j] * unscale_a) * unscale_b;
+      for (int j = 0; j < TN; ++j) acc[i][j] = ((acc[i][j] + accx[i][j] * LIMB2_UNSCALE) * unscale_a) * unscale_b;
     if (dp) dp_tile += nblk; else u += k_end - k_begin;
     if (SK && (k_begin != 0 || k_end != KT)) {
       float* slot = a.ws + ((size_t)swz * 2 + (u - (k_end - k_begin) == u_begin ? 0 : 1)) * (BM * BN);
@@ -427,13 +439,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_h2_kernel(const WgradK a, u
     }
   };
 
-  f32x4 acc[TM][TN];
+  f32x4 acc[TM][TN], accx[TM][TN];  // a1*b1, and the cross products (2^11 too large)
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
+      for (int e = 0; e < 4; ++e) acc[i][j][e] = accx[i][j][e] = 0.f;
 
   // K-steps whose 32 pixels all fall into the padding for this tap (a dilated tap near the image
   // border: 9-34 % of the ASPP weight-gradient work) contribute exact zeros and are skipped: no loads,
@@ -481,8 +493,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_h2_kernel(const WgradK a, u
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][la], bf[j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < TN; ++j) {
+            if (la + l == 0)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][la], bf[j], acc[i][j], 0, 0, 0);
+            else
+              accx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][la], bf[j], accx[i][j], 0, 0, 0);
+          }
     }
   }
 
@@ -496,7 +512,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_h2_kernel(const WgradK a, u
       for (int e = 0; e < 4; ++e) {
         const int n = n0 + (wm * TM + i) * MF + 4 * (lane >> 4) + e;
         if (n >= c.Cout) continue;
-        a.slabs[(((size_t)ks * c.Cout + n) * a.taps + tap) * c.Cin + cc] = (acc[i][jn][e] * unscale_a) * unscale_b;
+        a.slabs[(((size_t)ks * c.Cout + n) * a.taps + tap) * c.Cin + cc] = ((acc[i][jn][e] + accx[i][jn][e] * LIMB2_UNSCALE) * unscale_a) * unscale_b;
       }
   }
 }
