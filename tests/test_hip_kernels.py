@@ -591,3 +591,28 @@ def test_f16x2_interpixel_range():
                     assert err <= bound, (mode, shift, part, err)
     finally:
         ops.CONV_MODE = old
+
+
+def test_f16x2_bitwise_reproducible():
+    """Same inputs -> bit-identical conv outputs, gradients and fused max|x| on every run: the only atomics on
+    the path are order-independent maxima, every sum has a fixed order."""
+    from onda_amd import ops
+    old, ops.CONV_MODE = ops.CONV_MODE, "f16x2"
+    try:
+        g = torch.Generator().manual_seed(21)
+        x0 = torch.randn(4, 33, 65, 256, generator=g).to(DEV)
+        w0 = (torch.randn(256, 256, 3, 3, generator=g) / 48).to(DEV)
+        gy = torch.randn(4, 33, 65, 256, generator=g).to(DEV)
+        gamma, beta = torch.rand(256, device=DEV) + 0.5, torch.randn(256, device=DEV)
+        runs = []
+        for _ in range(3):
+            x, w = x0.clone().requires_grad_(True), w0.clone().requires_grad_(True)
+            y, stats = ops.Conv2dFn.apply(x, w, None, ops._PackCache(), 1, 2, 2, True, None)
+            out = ops.BNTrainFn.apply(y, stats, gamma, beta, None, True, None, 0.1)
+            out.backward(gy)
+            runs.append((out.detach().clone(), x.grad.clone(), w.grad.clone(), ops.known_amax(out).max().clone()))
+        for r in runs[1:]:
+            for a, b in zip(runs[0], r):
+                assert torch.equal(a, b)
+    finally:
+        ops.CONV_MODE = old
