@@ -180,6 +180,32 @@ def cpu_baseline(args):
                       f"branch={'dynamic' if ad.switch.current else 'static'}, {dt:.1f} s, torch CPU fp32, {cores} threads"}
 
 
+def conv_accuracy_probe(device):
+    """Evidence for the line's `dtype`: the conv path's error against fp64 on a sample (3x3 dilated conv,
+    forward + both gradients), next to the error of a plain fp32 conv (torch CPU) on the same data."""
+    import torch.nn.functional as F
+    from onda_amd import ops
+    g = torch.Generator().manual_seed(3)
+    x = torch.relu(torch.randn(2, 128, 17, 23, generator=g)) * torch.exp(torch.randn(2, 128, 17, 23, generator=g))
+    w = torch.randn(128, 128, 3, 3, generator=g) * 0.03
+    gy = torch.randn(2, 128, 17, 23, generator=g)
+    x64, w64 = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    F.conv2d(x64, w64, None, 1, 2, 2).backward(gy.double())
+    x32, w32 = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    F.conv2d(x32, w32, None, 1, 2, 2).backward(gy)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(device).requires_grad_(True)
+    wd = w.to(device).requires_grad_(True)
+    y, _ = ops.Conv2dFn.apply(xd, wd, None, ops._PackCache(), 1, 2, 2, False, None)
+    y.backward(gy.permute(0, 2, 3, 1).contiguous().to(device))
+
+    def rel(a, ref):
+        return float((a.double().cpu() - ref).norm() / ref.norm())
+
+    return {"dgrad_rel_l2_vs_fp64": rel(xd.grad.permute(0, 3, 1, 2), x64.grad), "wgrad_rel_l2_vs_fp64": rel(wd.grad, w64.grad),
+            "torch_cpu_fp32_dgrad_rel_l2_vs_fp64": rel(x32.grad, x64.grad),
+            "torch_cpu_fp32_wgrad_rel_l2_vs_fp64": rel(w32.grad, w64.grad)}
+
+
 def conv_mode_note():
     from onda_amd import ops
     if ops.CONV_MODE == "f16x2":
@@ -241,7 +267,8 @@ def main():
                                    f"bs={args.batch} per GPU, {branch} branch, DeepLabV2-ResNet50 ProDA head, "
                                    f"random-init weights", "global_batch": world * args.batch,
                        "parallelism": f"dp{world}", "branch": branch, "conv_mode": conv_mode_note(),
-                       "conv_tflop_per_step_per_gpu": tflop_step, "final_loss": round(loss, 5)},
+                       "conv_tflop_per_step_per_gpu": tflop_step, "final_loss": round(loss, 5),
+                       "conv_accuracy": conv_accuracy_probe(device)},
             "roofline": roof, "cpu_baseline": cpu,
         }
         if tflop_step:
