@@ -162,7 +162,7 @@ def _pack_h2(weight, rows_pad, kp, dgrad, cout_pad):
     slot = known_amax(weight)  # the forward and the data-gradient packing of one weight version share max|w|
     if slot is None:
         slot = amax_slot(weight.device)
-        call("onda_absmax", _p(w), cout, cin * kh * kw, cin * kh * kw, _p(slot), _stream())
+        call("onda_absmax", _p(w), 1, w.numel(), w.numel(), _p(slot), _stream())  # the whole tensor as one row
         tag_amax(weight, slot)
     dst = torch.empty(2, rows_pad, kp, device=weight.device, dtype=torch.float16)
     call("onda_pack_weight_h2", _p(w), _p(dst), cout, cin, kh * kw, rows_pad, kp, dgrad, cout_pad, _p(slot), _stream())
@@ -176,7 +176,7 @@ def pack_weight_fwd(weight, cout_pad=None, kp=None):
     taps = kh * kw
     cout_pad = cout_pad or cout
     kp = kp or taps * cin
-    if CONV_MODE == "f16x2" and (cin * taps) % 4 == 0:
+    if CONV_MODE == "f16x2" and weight.numel() % 4 == 0:
         return _pack_h2(weight, cout_pad, kp, 0, cout_pad)
     if CONV_MODE in ("bf16x3", "f16x2"):
         dst = torch.empty(3, cout_pad, kp, device=weight.device, dtype=torch.bfloat16)
@@ -192,7 +192,7 @@ def pack_weight_dgrad(weight, cout_pad=None):
     """OIHW -> [Cin][taps (flipped)][Cout_pad]: the data gradient of a stride-1 conv is a conv of dy with this."""
     cout, cin, kh, kw = weight.shape
     cout_pad = cout_pad or cout
-    if CONV_MODE == "f16x2" and (cin * kh * kw) % 4 == 0:
+    if CONV_MODE == "f16x2" and weight.numel() % 4 == 0:
         return _pack_h2(weight, cin, kh * kw * cout_pad, 1, cout_pad)
     if CONV_MODE in ("bf16x3", "f16x2"):
         dst = torch.empty(3, cin, kh * kw * cout_pad, device=weight.device, dtype=torch.bfloat16)
