@@ -114,21 +114,24 @@ def measure_roofline(da, src, trg, args, steps_done, record=True):
     achieved = flops / secs / 1e12
     detail = {k: {"launches": v[2], "ms_total": round(v[1] * 1e3, 3), "tflops": round(v[0] / v[1] / 1e12, 2)}
               for k, v in fam.items()}
-    roof = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
-            "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-            "launches_per_step": n // 2, "avg_launch_ms": round(secs / n * 1e3, 4),
-            "avg_launch_gflop": round(flops / n / 1e9, 3), "families": detail}
+    # The roofline of the kernel is the matrix pipe it executes on: `peak` = that pipe's dense peak divided by
+    # the MFMA products the evaluation spends per fp32 product (f16x2: 3, bf16x3: 6, f32: the fp32 MFMA itself),
+    # so `frac` = executed MFMA flops / pipe peak.  The comparison with the fp32 matrix peak (what a kernel
+    # that did not split its operands could reach at most) is reported next to it.
     if "h2" in name:
-        # three f16 MFMA products per fp32 product (two limbs per operand, per-tensor power-of-two scale)
-        roof["pipe"] = {"what": "f16 MFMA, 3 limb products per fp32 product, fp32 accumulate",
-                        "executed_tflops": round(3 * achieved, 1), "peak": BF16_MFMA_PEAK_TFLOPS,
-                        "frac": round(3 * achieved / BF16_MFMA_PEAK_TFLOPS, 4)}
+        products, what = 3, "f16 MFMA (v_mfma_f32_16x16x32_f16), 3 limb products per fp32 product, fp32 accumulate"
     elif "bf3" in name:
-        # achieved/peak above are ALGORITHMIC fp32 flops against the fp32 matrix peak; the kernel
-        # executes six bf16 MFMA products per fp32 product, so on the pipe it actually uses:
-        roof["pipe"] = {"what": "bf16 MFMA, 6 limb products per fp32 product, fp32 accumulate",
-                        "executed_tflops": round(6 * achieved, 1), "peak": BF16_MFMA_PEAK_TFLOPS,
-                        "frac": round(6 * achieved / BF16_MFMA_PEAK_TFLOPS, 4)}
+        products, what = 6, "bf16 MFMA (v_mfma_f32_16x16x32_bf16), 6 limb products per fp32 product, fp32 accumulate"
+    else:
+        products, what = 0, "fp32 MFMA (v_mfma_f32_32x32x2_f32)"
+    peak = BF16_MFMA_PEAK_TFLOPS / products if products else FP32_MFMA_PEAK_TFLOPS
+    roof = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": round(peak, 1),
+            "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
+            "launches_per_step": n // 2, "avg_launch_ms": round(secs / n * 1e3, 4),
+            "avg_launch_gflop": round(flops / n / 1e9, 3), "families": detail,
+            "pipe": {"what": what, "pipe_peak_tflops": BF16_MFMA_PEAK_TFLOPS if products else FP32_MFMA_PEAK_TFLOPS,
+                     "executed_tflops": round((products or 1) * achieved, 1)},
+            "vs_fp32_matrix_peak": {"peak": FP32_MFMA_PEAK_TFLOPS, "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4)}}
     roof.update(committed_traffic(name))
     return roof
 
