@@ -616,3 +616,31 @@ def test_f16x2_bitwise_reproducible():
                 assert torch.equal(a, b)
     finally:
         ops.CONV_MODE = old
+
+
+def test_f16x2_scale_equivariance_full_size():
+    """Size-independent property at the BASELINE layer size (33 540 pixels, 2048 -> 256 channels, dilated 3x3):
+    the per-tensor power-of-two scale makes the evaluation EXACTLY equivariant -- conv(2^a x, 2^b w) is
+    bit-for-bit 2^(a+b) conv(x, w), for forward, data gradient and weight gradient."""
+    from onda_amd import ops
+    old, ops.CONV_MODE = ops.CONV_MODE, "f16x2"
+    try:
+        g = torch.Generator(device=DEV).manual_seed(5)
+        x = torch.randn(4, 65, 129, 2048, device=DEV, generator=g)
+        w = torch.randn(256, 2048, 3, 3, device=DEV, generator=g) * 0.01
+        gy = torch.randn(4, 65, 129, 256, device=DEV, generator=g)
+
+        def run(xs, ws, gs):
+            xd, wd = (x * xs).requires_grad_(True), (w * ws).requires_grad_(True)
+            y, _ = ops.Conv2dFn.apply(xd, wd, None, ops._PackCache(), 1, 12, 12, False, None)
+            y.backward(gy * gs)
+            return y.detach(), xd.grad, wd.grad
+
+        y0, dx0, dw0 = run(1.0, 1.0, 1.0)
+        y1, dx1, dw1 = run(2.0 ** 9, 2.0 ** -21, 2.0 ** 5)
+        assert torch.equal(y1, y0 * 2.0 ** (9 - 21))
+        assert torch.equal(dx1, dx0 * 2.0 ** (5 - 21))
+        assert torch.equal(dw1, dw0 * 2.0 ** (5 + 9))
+        assert torch.isfinite(y0).all() and y0.abs().max() > 0
+    finally:
+        ops.CONV_MODE = old
