@@ -94,6 +94,21 @@ int onda_conv2d_fwd_h2(const float* x, const float* xamax, const void* w2, const
                        const float* scale, const float* shift, const float* residual, float* stats, float* ws,
                        float* yamax, const OndaConv* c, onda_stream_t s);
 
+/* ---- "f16x2" with BOTH operands pre-split (csrc/conv_l2.hip): activations travel as limb planes
+ *   xl[2][rows][ldx] f16:  xl[0] = f16(x * 2^e),  xl[1] = f16((x * 2^e - xl[0]) * 2^11),  e from xamax (as above),
+ * 4 bytes per element like fp32, written by the kernel that produces the tensor or by onda_split_h2 from an fp32
+ * tensor whose max|x| is known.  The conv kernel then moves both operands HBM/L2 -> LDS by LDS-DMA only (no VALU,
+ * no LDS stores in the K loop), 256 x 128 tiles on a 3-stage ring filled two K-steps ahead.
+ * Replaces the same F.conv2d call sites as onda_conv2d_fwd (deeplabv2.py:53-68, :243-257); c->ldx counts f16
+ * elements of a plane row, xplane the f16 elements between the two planes. */
+int onda_split_h2(const float* x, int64_t rows, int C, int ldx, void* dst, int ldo, int64_t plane, const float* amax,
+                  onda_stream_t s);
+int onda_conv_l2_variant(int64_t M, int Cout);  /* tile shape used for an (M, Cout) problem: 0 256x128, 1 128x128, 2 256x64 */
+int onda_conv_l2_tiles_m(int64_t M, int Cout);  /* rows of the `stats` partials for that tile shape */
+int onda_conv2d_fwd_l2(const void* xl, int64_t xplane, const float* xamax, const void* w2, const float* wamax, float* y,
+                       const float* scale, const float* shift, const float* residual, float* stats, float* ws,
+                       float* yamax, const OndaConv* c, onda_stream_t s);
+
 /* onda_conv2d_wgrad slabs from the two-limb f16 evaluation; xamax / dyamax = max|x| / max|dy| */
 int onda_conv2d_wgrad_h2(const float* x, const float* xamax, const float* dy, const float* dyamax, float* slabs, int lddy,
                          int splitk, const OndaConv* c, onda_stream_t s);

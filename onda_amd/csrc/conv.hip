@@ -508,6 +508,25 @@ int conv_launch_fixup(const ConvK& k, int G, bool wide, hipStream_t st) {
   return ONDA_LAUNCH_RESULT();
 }
 
+// the same for any tile shape (the pre-split kernels of conv_l2.hip: 256 x 128, 128 x 128, 256 x 64)
+int conv_launch_fixup_tile(const ConvK& k, int G, int BM, int BN, hipStream_t st) {
+  const int tiles = k.tilesM * k.tilesN - k.tiles_dp;
+  if (tiles <= 0) return ONDA_LAUNCH_RESULT();
+  float* sums = (tiles * 4 < G) ? k.ws + (size_t)G * 2 * BM * BN : nullptr;
+#define FIXUP_TILE(BM_, BN_)                                                                                                  \
+  do {                                                                                                                        \
+    if (sums) hipLaunchKernelGGL((conv_piece_sum_kernel<BM_, BN_>), dim3(tiles, BM_ * BN_ / 1024), dim3(256), 0, st, k, G, sums); \
+    hipLaunchKernelGGL((conv_fixup_kernel<BM_, BN_>), dim3(tiles), dim3(256), 0, st, k, G, sums);                            \
+  } while (0)
+  if (BM == 256 && BN == 128) FIXUP_TILE(256, 128);
+  else if (BM == 128 && BN == 128) FIXUP_TILE(128, 128);
+  else if (BM == 256 && BN == 64) FIXUP_TILE(256, 64);
+  else if (BM == 128 && BN == 64) FIXUP_TILE(128, 64);
+  else return ONDA_EINVAL;
+#undef FIXUP_TILE
+  return ONDA_LAUNCH_RESULT();
+}
+
 int conv_sched_override() {
   const char* e = getenv("ONDA_CONV_SCHED");
   return e ? atoi(e) : 0;

@@ -152,5 +152,6 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& a, const typename Acc
 
 // conv.hip: sums stream-K partial tiles and runs the epilogue for split tiles
 int conv_launch_fixup(const ConvK& k, int G, bool wide, hipStream_t st);
+int conv_launch_fixup_tile(const ConvK& k, int G, int BM, int BN, hipStream_t st);  // any of the tile shapes of conv_l2.hip
 int conv_resident_workgroups();
 int conv_sched_override();  // debugging aid: environment variable ONDA_CONV_SCHED (0 / unset = automatic)

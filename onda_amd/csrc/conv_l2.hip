@@ -1,0 +1,550 @@
+// "f16x2" convolution with BOTH operands pre-split: forward and data gradient as an implicit GEMM whose
+// activation rows and weight rows arrive in LDS by LDS-DMA only (buffer_load ... lds) -- no VALU work and
+// no ds_write in the K loop (the register-split kernel of conv_h2.hip spends its K-step between two
+// barriers on exactly those, beside the other wave's MFMA stream that starves them).
+//
+// Operand format ("limb planes", the same for activations and weights):
+//   L[2][rows][ld] f16,  L[0] = f16(x * s),  L[1] = f16((x * s - L[0]) * 2^11),  s = 2^e from the tensor's max|x|
+// (conv_h2.hip explains the arithmetic).  Activation planes are written by the kernel that produces the
+// tensor (BatchNorm / GroupNorm apply, BatchNorm backward, pooling, the stem's patch kernel) or by
+// split_h2_kernel below from an fp32 tensor whose max|x| is known; 4 bytes per element, like fp32.
+//
+// Geometry: WM x WN waves, each a 64 x 64 output (4 x 4 MFMA tiles of 16 x 16, two accumulator sets), K-step 32
+// channels of one filter tap, a ring of STAGES LDS stages filled two K-steps ahead:
+//   s_waitcnt vmcnt(own DMAs of the next step)  ->  s_barrier  ->  issue the DMAs of step k+2  ->  fragments + MFMAs
+// one barrier per K-step, never vmcnt(0) inside the loop.  256 x 128 tiles (8 waves, 144 KB, one workgroup per
+// CU) halve the L2 -> LDS bytes per MFMA of the 128 x 128 kernel.  LDS image: 64-byte rows per limb plane,
+// 16-byte chunk index XOR-ed with a function of the row (swz_row) on the DMA's source side and in the
+// fragment read: conflict-free ds_read_b128.
+#include "conv_common.h"
+
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr float LIMB2_SCALE = 2048.f, LIMB2_UNSCALE = 1.f / 2048.f;
+constexpr unsigned OOB = 0x80000000u;  // every operand is < 2 GiB - 4 KiB (checked on the host)
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ int swz_row(int row) {
+  const int q = (row >> 2) & 3;
+  return q ^ ((q & 1) << 1) ^ ((row >> 1) & 1);
+}
+
+struct Scale2 {
+  float s, inv;
+};
+__device__ __forceinline__ Scale2 scale_of(const float* __restrict__ amax) {
+  const float m = amax_read(amax);
+  int e = 0;
+  if (m > 0.f && m < 3.0e38f) {
+    int ex;
+    frexpf(m, &ex);  // m = f * 2^ex, f in [0.5, 1)
+    e = 15 - ex;
+    e = e > 100 ? 100 : (e < -100 ? -100 : e);
+  }
+  return Scale2{ldexpf(1.f, e), ldexpf(1.f, -e)};
+}
+
+__device__ __forceinline__ unsigned cvt2h(float lo, float hi) {
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{lo, hi}, f16x2));
+}
+__device__ __forceinline__ f32x2 unpack2h(unsigned p) {
+  return __builtin_convertvector(__builtin_bit_cast(f16x2, p), f32x2);
+}
+
+// x[rows][ldx] fp32 (C valid channels) -> limb planes dst[2][rows][ldo] f16 with the scale of *amax
+__global__ __launch_bounds__(256) void split_h2_kernel(const float* __restrict__ x, long long rows, int C, int ldx,
+                                                       _Float16* __restrict__ dst, int ldo, long long plane,
+                                                       const float* __restrict__ amax) {
+  const float s = scale_of(amax).s;
+  const int c8 = C >> 3;
+  const long long n = rows * c8;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256) {
+    const long long row = e / c8;
+    const int ch = (int)(e - row * c8) * 8;
+    const f32x4 v0 = *reinterpret_cast<const f32x4*>(x + row * ldx + ch) * s;
+    const f32x4 v1 = *reinterpret_cast<const f32x4*>(x + row * ldx + ch + 4) * s;
+    u32x4 l1, l2;
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      const float a = h < 2 ? v0[2 * h] : v1[2 * h - 4], b = h < 2 ? v0[2 * h + 1] : v1[2 * h - 3];
+      const unsigned p = cvt2h(a, b);
+      const f32x2 f = unpack2h(p);
+      l1[h] = p;
+      l2[h] = cvt2h((a - f[0]) * LIMB2_SCALE, (b - f[1]) * LIMB2_SCALE);
+    }
+    *reinterpret_cast<u32x4*>(dst + row * ldo + ch) = l1;
+    *reinterpret_cast<u32x4*>(dst + plane + row * ldo + ch) = l2;
+  }
+}
+
+// ---- epilogue of a (64*WM) x (64*WN) tile held as 4 x 4 MFMA tiles of 16 x 16 per wave ----------------------------
+// The accumulator layout has a lane's 16 values of one MFMA column 4 rows apart: stored as they stand that is 64
+// four-byte stores per lane in 64-byte runs, and the store ISSUE (not bandwidth) is what a tile then waits for
+// (measured: 26 000 cycles per 256 x 128 tile, more than the K loop of a 1 x 1 convolution with 256 input
+// channels).  So each wave transposes its 64 x 64 sub-tile through LDS, 16 rows at a time, and stores whole
+// 256-byte row segments as 16-byte vectors: 16 stores per lane, scale / shift loaded once per lane.
+// `scratch`: LDS nobody else touches during the epilogue: 4 KiB per wave, then WM*BN*2 + WM*WN floats of statistics.
+template <int WM, int WN>
+__device__ __forceinline__ void l2_epilogue(const ConvK& a, const f32x4 (&acc)[4][4], unsigned char* scratch, int tile_m, int m0,
+                                            int n0, int wm, int wn, int lane) {
+  constexpr int BN = 64 * WN, NW = WM * WN, NT = NW * 64;
+  const OndaConv& c = a.c;
+  const int t = threadIdx.x, wave = t >> 6;
+  float* red = reinterpret_cast<float*>(scratch + NW * 4096);
+  if (a.stats != nullptr) {
+#pragma unroll
+    for (int jn = 0; jn < 4; ++jn) {
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float v = acc[i][jn][e];
+          s1 += v;
+          s2 += v * v;
+        }
+      s1 += __shfl_xor(s1, 16, 64);
+      s2 += __shfl_xor(s2, 16, 64);
+      s1 += __shfl_xor(s1, 32, 64);
+      s2 += __shfl_xor(s2, 32, 64);
+      if (lane < 16) {
+        const int col = (wn * 4 + jn) * 16 + lane;
+        red[(wm * BN + col) * 2 + 0] = s1;
+        red[(wm * BN + col) * 2 + 1] = s2;
+      }
+    }
+  }
+
+  const bool plain = (c.out_os == 1 && c.Hf == c.Ho && c.Wf == c.Wo);
+  // after the transposition: lane -> row 4*r + (lane >> 4) of a 16-row chunk (r = 0..3), columns 4*(lane & 15) .. +3
+  const int cl = (lane & 15) * 4, rl = lane >> 4;
+  const int n = n0 + wn * 64 + cl;
+  const bool vn = n < c.Cout;  // Cout is a multiple of 4
+  f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+  if (vn && a.scale) sc = *reinterpret_cast<const f32x4*>(a.scale + n);
+  if (vn && a.shift) sh = *reinterpret_cast<const f32x4*>(a.shift + n);
+  float* tr = reinterpret_cast<float*>(scratch + wave * 4096);
+  float mx = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    // this wave's own 4 KiB: only its own earlier reads have to be out of the way
+#pragma unroll
+    for (int jn = 0; jn < 4; ++jn)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) tr[(4 * (lane >> 4) + e) * 64 + jn * 16 + (lane & 15)] = acc[i][jn][e];
+    __builtin_amdgcn_wave_barrier();  // one wave, and the LDS executes a wave's instructions in order: no wait, no s_barrier
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 4 * r + rl;
+      f32x4 v = *reinterpret_cast<const f32x4*>(tr + row * 64 + cl);
+      const int m = m0 + (wm * 4 + i) * 16 + row;
+      if (m >= a.M || !vn) continue;
+      v = v * sc + sh;
+      if (a.res) v += *reinterpret_cast<const f32x4*>(a.res + (size_t)m * c.ldr + n);
+      if (c.relu) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
+      }
+      size_t orow = m;
+      if (!plain) {
+        const int wo = m % c.Wo, tq = m / c.Wo;
+        const int ho = tq % c.Ho, b = tq / c.Ho;
+        orow = ((size_t)b * c.Hf + (size_t)ho * c.out_os) * c.Wf + (size_t)wo * c.out_os;
+      }
+      *reinterpret_cast<f32x4*>(a.y + orow * c.ldy + n) = v;
+      mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  float* ar = red + WM * BN * 2;
+  if (a.amax != nullptr) {
+    mx = wave_max(mx);
+    if (lane == 0) ar[wave] = mx;
+  }
+  if (a.stats != nullptr || a.amax != nullptr) __syncthreads();
+  if (a.stats != nullptr) {
+    for (int col = t; col < BN; col += NT) {
+      if (n0 + col >= c.Cout) continue;
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int w_ = 0; w_ < WM; ++w_) {
+        s1 += red[(w_ * BN + col) * 2 + 0];
+        s2 += red[(w_ * BN + col) * 2 + 1];
+      }
+      a.stats[((size_t)tile_m * 2 + 0) * c.Cout + n0 + col] = s1;
+      a.stats[((size_t)tile_m * 2 + 1) * c.Cout + n0 + col] = s2;
+    }
+  }
+  if (a.amax != nullptr && t == 0) {  // one atomic per tile
+    float m = ar[0];
+#pragma unroll
+    for (int w_ = 1; w_ < NW; ++w_) m = fmaxf(m, ar[w_]);
+    if (m > 0.f)
+      atomicMax(reinterpret_cast<unsigned*>(a.amax) + (blockIdx.x & (ONDA_AMAX_SLOTS - 1)) * AMAX_STRIDE, __float_as_uint(m));
+  }
+}
+
+// ---- forward / data gradient ------------------------------------------------------------------------------------------
+template <int WM, int WN, int STAGES, int OCC, bool SK, int DBG = 0>
+__global__ __launch_bounds__(WM * WN * 64, OCC) void conv_l2_kernel(const ConvK a, unsigned xplane, unsigned wplane, unsigned x_bytes,
+                                                                   unsigned w_bytes, const float* __restrict__ xamax,
+                                                                   const float* __restrict__ wamax) {
+  constexpr int NW = WM * WN;
+  constexpr int BM = 64 * WM, BN = 64 * WN;
+  constexpr int PLANE_A = BM * 64, PLANE_B = BN * 64;  // one limb plane of a stage: 64-byte rows
+  constexpr int A_BYTES = 2 * PLANE_A, STAGE = A_BYTES + 2 * PLANE_B;
+  constexpr int APW = (BM / 16) / NW, BPW = (BN / 16) / NW;  // 16-row blocks (2 limbs x 1 KiB) per wave and stage
+  static_assert((BM / 16) % NW == 0 && (BN / 16) % NW == 0, "whole blocks per wave");
+  constexpr int DPW = 2 * (APW + BPW);  // LDS-DMA instructions per wave per K-step
+  static_assert(STAGES >= 3, "ring: one stage being read, two in flight");
+  constexpr bool STAGGER = NW == 8 && DBG != 6;  // two waves per SIMD: the second half of the workgroup runs half a step late
+  __shared__ __attribute__((aligned(16))) unsigned char lds[STAGES * STAGE];
+
+  const OndaConv& c = a.c;
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const bool late = wave >= NW / 2;
+
+  const int nblk = gridDim.x, bid = blockIdx.x;
+  const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
+  const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  const int KT = a.taps * a.kcper;
+  const int tiles_all = a.tilesM * a.tilesN;
+  const int tiles_dp = SK ? a.tiles_dp : tiles_all;
+  const long long U = (long long)(tiles_all - tiles_dp) * KT;
+  long long u = SK ? swz * U / nblk : 0;
+  const long long u_begin = u;
+  const long long u_end = SK ? (swz + 1) * U / nblk : 0;
+  int dp_tile = swz;
+  const int wstride = a.taps * c.Cin;
+  const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, x_bytes), rw = make_rsrc(a.w, w_bytes);
+  const Scale2 sx = scale_of(xamax), sw = scale_of(wamax);
+  const float unscale_a = sx.inv, unscale_b = sw.inv;  // applied one after the other: their product may underflow
+
+  const int lrow = lane >> 2;                          // row inside a 16-row block
+  const unsigned cq16 = (unsigned)(((lane & 3) ^ swz_row(lrow)) << 4);  // source chunk of this lane's LDS slot
+  // fragment read: lane l takes row l & 15 of each 16-row block, data chunk l >> 4
+  const int frag = (lane & 15) * 64 + (((lane >> 4) ^ swz_row(lane & 15)) << 4);
+
+  unsigned long long tk_setup = 0, tk_loop = 0, tk_epi = 0, tk_mark = DBG == 5 ? __builtin_amdgcn_s_memtime() : 0;
+  const unsigned long long tk_start = tk_mark;
+  auto stamp = [&](unsigned long long& acc_) {
+    if (DBG == 5) {
+      const unsigned long long now = __builtin_amdgcn_s_memtime();
+      acc_ += now - tk_mark;
+      tk_mark = now;
+    }
+  };
+  while (dp_tile < tiles_dp || u < u_end) {
+    const bool dp = dp_tile < tiles_dp;
+    const int tile = dp ? dp_tile : tiles_dp + (int)(u / KT);
+    const int k_begin = dp ? 0 : (int)(u - (long long)(tile - tiles_dp) * KT);
+    const int k_end = dp ? KT : (int)min((long long)KT, k_begin + (u_end - u));
+    const int tile_n = tile % a.tilesN, tile_m = tile / a.tilesN;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    int hi0[APW], wi0[APW], bH[APW];
+#pragma unroll
+    for (int d = 0; d < APW; ++d) {
+      const int m = m0 + (wave * APW + d) * 16 + lrow;
+      const bool vm = m < a.M;
+      const int mm = vm ? m : 0;
+      const int wo = mm % c.Wo, tq = mm / c.Wo;
+      const int ho = tq % c.Ho, b = tq / c.Ho;
+      hi0[d] = vm ? ho * c.stride - c.pad : -(1 << 28);
+      wi0[d] = wo * c.stride - c.pad;
+      bH[d] = b * c.Hi;
+    }
+    unsigned bofs[BPW];
+#pragma unroll
+    for (int d = 0; d < BPW; ++d) {
+      const int n = n0 + (wave * BPW + d) * 16 + lrow;
+      bofs[d] = n < c.Cout ? (unsigned)n * wstride * 2u + cq16 : OOB;
+    }
+
+    unsigned aofs[APW];
+    int tap_i = k_begin / a.kcper, c0_i = (k_begin - tap_i * a.kcper) * BK;  // the K-step the next issue() fetches
+    auto set_tap = [&](int tp) {
+      const int rr = tp / c.kw, ss = tp - rr * c.kw;
+#pragma unroll
+      for (int d = 0; d < APW; ++d) {
+        const int hi = hi0[d] + rr * c.dil, wi = wi0[d] + ss * c.dil;
+        const bool ok = (unsigned)hi < (unsigned)c.Hi && (unsigned)wi < (unsigned)c.Wi;
+        aofs[d] = ok ? (unsigned)(((bH[d] + hi) * c.Wi + wi) * c.ldx) * 2u + cq16 : OOB;
+      }
+    };
+    auto issue = [&](int stage_off) {
+#if defined(__HIP_DEVICE_COMPILE__)
+      const int sa = c0_i * 2;
+      const int sb = (tap_i * c.Cin + c0_i) * 2;
+#pragma unroll
+      for (int l = 0; l < 2; ++l) {
+#pragma unroll
+        for (int d = 0; d < APW; ++d) {
+          unsigned char* dst = lds + stage_off + l * PLANE_A + (wave * APW + d) * 1024;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)dst, 16, aofs[d], sa + l * xplane, 0, 0);
+        }
+#pragma unroll
+        for (int d = 0; d < BPW; ++d) {
+          unsigned char* dst = lds + stage_off + A_BYTES + l * PLANE_B + (wave * BPW + d) * 1024;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)dst, 16, bofs[d], sb + l * wplane, 0, 0);
+        }
+      }
+#else
+      (void)stage_off;
+#endif
+      c0_i += BK;
+      if (c0_i == c.Cin) {
+        c0_i = 0;
+        ++tap_i;
+        if (tap_i < a.taps) set_tap(tap_i);
+      }
+    };
+
+    f32x4 acc[4][4], accx[4][4];  // a1*b1, and the cross products (2^11 too large)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[i][j][e] = accx[i][j][e] = 0.f;
+
+    __syncthreads();  // the previous tile's readers (fragments, epilogue scratch) are done with every LDS region
+    set_tap(tap_i);
+    int st_issue = 0, st_read = 0;  // byte offsets of the ring stages
+    const int nsteps = k_end - k_begin;
+    issue(st_issue);
+    st_issue += STAGE;
+    if (nsteps > 1) {
+      issue(st_issue);
+      st_issue += STAGE;
+    }
+    stamp(tk_setup);
+    auto wait_landed = [&](bool more_in_flight) {  // this wave's DMAs of a step have landed; those of the step after may still fly
+      if (DBG == 1) return;
+      if (more_in_flight)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPW) : "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    auto issue_next = [&]() {
+      issue(st_issue);
+      st_issue = st_issue + STAGE == STAGES * STAGE ? 0 : st_issue + STAGE;
+    };
+    // fragments: A limbs stay in registers; B limbs stream 2 -> 1 (smaller products first): a1*b2, a2*b1, a1*b1
+    f16x8 af[4][2], bf[4];
+    const unsigned char *Ab, *Bb;
+    auto prepare = [&]() {  // "P": first fragments of the stage at st_read
+      Ab = lds + st_read + wm * 64 * 64 + frag;
+      Bb = lds + st_read + A_BYTES + wn * 64 * 64 + frag;
+      st_read = st_read + STAGE == STAGES * STAGE ? 0 : st_read + STAGE;
+#pragma unroll
+      for (int l = 0; l < 2; ++l)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[i][l] = *reinterpret_cast<const f16x8*>(Ab + l * PLANE_A + i * 1024);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bf[j] = *reinterpret_cast<const f16x8*>(Bb + PLANE_B + j * 1024);
+    };
+    auto compute = [&]() {  // "C": 48 MFMAs; the b1 fragments are fetched behind the first 16
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) accx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][0], bf[j], accx[i][j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bf[j] = *reinterpret_cast<const f16x8*>(Bb + j * 1024);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) accx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][1], bf[j], accx[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][0], bf[j], acc[i][j], 0, 0, 0);
+    };
+    if constexpr (!STAGGER) {
+      for (int kt = 0; kt < nsteps; ++kt) {
+        wait_landed(kt + 1 < nsteps);
+        __builtin_amdgcn_s_barrier();  // everybody's DMAs of step kt have landed; the stage read in step kt-1 is free
+        if (DBG != 2 && kt + 2 < nsteps) issue_next();
+        prepare();
+        compute();
+      }
+    } else {
+      // Two waves per SIMD.  Left alone they leave every barrier at the same point of the same program: both issue their
+      // DMAs, both wait for their fragments, then their MFMAs queue behind one another (measured: 2 450 cycles per K-step
+      // against 1 536 of MFMA).  So a K-step is cut into two slots, "P" (DMA issue, fragment reads) and "C" (MFMAs),
+      // with a barrier between slots, and the second half of the workgroup runs ONE SLOT LATE: in every slot one wave
+      // of each SIMD computes while the other prepares.  Same code for both halves; only the places of the DMA issue
+      // and of the vmcnt wait differ (each sits where that half's stage is free / has to be published).
+      //   barrier #2k   : early half has waited for its DMAs of step k;  late half for its DMAs of step k (before #2k)
+      //   stage of step k-1 is last read in slot 2k (late C) -> both halves issue the DMAs of step k+2 in slot 2k+1
+      if (late) {
+        wait_landed(nsteps > 1);
+        __builtin_amdgcn_s_barrier();
+      }
+      for (int kt = 0; kt < nsteps; ++kt) {
+        if (!late) wait_landed(kt + 1 < nsteps);
+        __builtin_amdgcn_s_barrier();
+        if (late && DBG != 2 && kt + 2 < nsteps) issue_next();
+        prepare();
+        if (late && kt + 1 < nsteps) wait_landed(kt + 2 < nsteps);
+        __builtin_amdgcn_s_barrier();
+        if (!late && DBG != 2 && kt + 2 < nsteps) issue_next();
+        compute();
+      }
+      if (!late) __builtin_amdgcn_s_barrier();
+    }
+    stamp(tk_loop);
+    // back to the operands' own units (exact: powers of two) before anything reads the accumulators
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = ((acc[i][j] + accx[i][j] * LIMB2_UNSCALE) * unscale_a) * unscale_b;
+    if (dp) dp_tile += nblk; else u += k_end - k_begin;
+    if (SK && (k_begin != 0 || k_end != KT)) {
+      float* slot = a.ws + ((size_t)swz * 2 + (u - (k_end - k_begin) == u_begin ? 0 : 1)) * (BM * BN);
+      conv_store_partial<BN, 4, 4, 16>(slot, acc, wm, wn, lane);
+      continue;
+    }
+    __syncthreads();
+    l2_epilogue<WM, WN>(a, acc, lds, tile_m, m0, n0, wm, wn, lane);
+    if (DBG == 5) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      stamp(tk_epi);
+    }
+  }
+  if (DBG == 5 && t == 0) {
+    unsigned long long* o = reinterpret_cast<unsigned long long*>(a.ws) + (size_t)bid * 4;
+    o[0] = tk_setup; o[1] = tk_loop; o[2] = tk_epi; o[3] = __builtin_amdgcn_s_memtime() - tk_start;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int onda_split_h2(const float* x, int64_t rows, int C, int ldx, void* dst, int ldo, int64_t plane, const float* amax,
+                  onda_stream_t s) {
+  ONDA_REQUIRE(x && dst && amax && rows > 0 && C > 0 && C % 8 == 0 && ldx >= C && ldx % 4 == 0 && ldo >= C && ldo % 8 == 0 &&
+               plane % 8 == 0);
+  if (!ONDA_ALIGNED16(x) || !ONDA_ALIGNED16(dst)) return ONDA_EALIGN;
+  const long long n = rows * (C / 8);
+  const int blocks = (int)(n / 256 / 4 + 1 > 2048 ? 2048 : n / 256 / 4 + 1);
+  hipLaunchKernelGGL(split_h2_kernel, dim3(blocks), dim3(256), 0, ONDA_STREAM(s), x, (long long)rows, C, ldx,
+                     static_cast<_Float16*>(dst), ldo, (long long)plane, amax);
+  return ONDA_LAUNCH_RESULT();
+}
+
+// tile variant of the pre-split conv for an (M, Cout) problem: 0 = 256 x 128 (8 waves), 1 = 128 x 128, 2 = 256 x 64
+int onda_conv_l2_variant(int64_t M, int Cout) {
+  if (const char* e = getenv("ONDA_L2_VARIANT")) return atoi(e);
+  if (Cout <= 64) return 2;
+  const long long t256 = ((M + 255) / 256) * ((Cout + 127) / 128);
+  return t256 >= 200 ? 0 : 1;
+}
+int onda_conv_l2_tiles_m(int64_t M, int Cout) {
+  const int v = onda_conv_l2_variant(M, Cout);
+  return (int)(v == 1 ? (M + 127) / 128 : (M + 255) / 256);
+}
+
+int onda_conv2d_fwd_l2(const void* xl, int64_t xplane, const float* xamax, const void* w2, const float* wamax, float* y,
+                       const float* scale, const float* shift, const float* residual, float* stats, float* ws,
+                       float* yamax, const OndaConv* c, onda_stream_t s) {
+  ONDA_REQUIRE(xl && xamax && w2 && wamax && y && c);
+  ONDA_REQUIRE(c->Cin > 0 && c->Cin % 32 == 0 && c->Cout > 0 && c->Cout % 4 == 0 && c->ldx % 8 == 0 && c->ldx >= c->Cin);
+  ONDA_REQUIRE(c->kh >= 1 && c->kw >= 1 && c->stride >= 1 && c->dil >= 1 && c->out_os >= 1 && xplane > 0 && xplane % 8 == 0);
+  if (!ONDA_ALIGNED16(xl) || !ONDA_ALIGNED16(w2)) return ONDA_EALIGN;
+  // the epilogue stores (and reads the residual in) 16-byte vectors
+  if (c->ldy % 4 != 0 || !ONDA_ALIGNED16(y) || (residual && (c->ldr % 4 != 0 || !ONDA_ALIGNED16(residual)))) return ONDA_EALIGN;
+  if (scale && !ONDA_ALIGNED16(scale)) return ONDA_EALIGN;
+  if (shift && !ONDA_ALIGNED16(shift)) return ONDA_EALIGN;
+  ConvK k;
+  k.x = static_cast<const float*>(xl); k.w = w2; k.y = y; k.scale = scale; k.shift = shift; k.res = residual; k.stats = stats; k.ws = ws;
+  k.amax = yamax;
+  k.c = *c;
+  const long long M = (long long)c->B * c->Ho * c->Wo;
+  ONDA_REQUIRE(M > 0 && M < (1ll << 31));
+  const long long x_total = xplane * 2 + ((long long)c->B * c->Hi * c->Wi - 1) * c->ldx * 2 + c->Cin * 2;  // last byte of plane 1
+  ONDA_REQUIRE(x_total < 0x7FFFF000ll);  // 32-bit byte offsets
+  k.M = (int)M;
+  k.taps = c->kh * c->kw;
+  k.kcper = c->Cin / 32;
+  const int variant = onda_conv_l2_variant(M, c->Cout);
+  const int BM = variant == 1 ? 128 : 256, BN = variant == 2 ? 64 : 128;
+  k.tilesM = (k.M + BM - 1) / BM;
+  k.tilesN = (c->Cout + BN - 1) / BN;
+  const size_t limb_elems = (size_t)c->Cout * k.taps * c->Cin;  // weight planes are [Cout][taps*Cin]
+  ONDA_REQUIRE(limb_elems * 4 < (1ull << 31));
+  const unsigned x_bytes = (unsigned)x_total, w_bytes = (unsigned)(limb_elems * 4);
+  const unsigned xpl = (unsigned)(xplane * 2), wpl = (unsigned)(limb_elems * 2);
+  const int cus = conv_resident_workgroups() / 2;
+  const int G = variant == 1 ? cus : cus;  // one workgroup per CU (144 / 96 / 120 KB of LDS)
+  const int tiles = k.tilesM * k.tilesN, KT = k.taps * k.kcper;
+  const int rem = tiles % G;
+  k.tiles_dp = tiles - rem;
+  const double t_tile_us = 2.0 * BM * BN * k.taps * c->Cin / 1.4e6;  // one tile on one CU at ~360 TF/s chip-wide
+  const double fix_us = 8.0 + (G + 2.0 * rem) * (BM * BN / 16384.0) * 0.03;  // partial tiles written + read
+  bool balanced = ws != nullptr && rem != 0 && KT >= 4 && t_tile_us * (1.0 - (double)rem / G) > fix_us &&
+                  (size_t)G * 2 * BM * BN + (size_t)(rem * 4 < G ? rem : 0) * BM * BN <= (size_t)onda_conv_ws_floats();
+  if (const int force = conv_sched_override()) {  // ONDA_CONV_SCHED: 1 tile-per-workgroup, 2 hybrid
+    if (force == 1 || ws == nullptr) balanced = false;
+    else if (force == 2) balanced = rem != 0;
+  }
+  hipStream_t st = ONDA_STREAM(s);
+#define L2_LAUNCH(WM_, WN_, ST_, OCC_)                                                                                       \
+  do {                                                                                                                       \
+    if (balanced)                                                                                                            \
+      hipLaunchKernelGGL((conv_l2_kernel<WM_, WN_, ST_, OCC_, true>), dim3(G), dim3(WM_ * WN_ * 64), 0, st, k, xpl, wpl, x_bytes, \
+                         w_bytes, xamax, wamax);                                                                            \
+    else                                                                                                                     \
+      hipLaunchKernelGGL((conv_l2_kernel<WM_, WN_, ST_, OCC_, false>), dim3(tiles), dim3(WM_ * WN_ * 64), 0, st, k, xpl, wpl,    \
+                         x_bytes, w_bytes, xamax, wamax);                                                                   \
+  } while (0)
+  static const int dbg = getenv("ONDA_L2_DEBUG") ? atoi(getenv("ONDA_L2_DEBUG")) : 0;
+  if (dbg == 1 && variant == 0) {
+    hipLaunchKernelGGL((conv_l2_kernel<4, 2, 3, 2, false, 1>), dim3(tiles), dim3(512), 0, st, k, xpl, wpl, x_bytes, w_bytes, xamax, wamax);
+    return ONDA_LAUNCH_RESULT();
+  }
+  if (dbg == 2 && variant == 0) {
+    hipLaunchKernelGGL((conv_l2_kernel<4, 2, 3, 2, false, 2>), dim3(tiles), dim3(512), 0, st, k, xpl, wpl, x_bytes, w_bytes, xamax, wamax);
+    return ONDA_LAUNCH_RESULT();
+  }
+  if (dbg == 3 && variant == 0) {  // 128 x 128, five stages, one workgroup per CU
+    k.tilesM = (k.M + 127) / 128;
+    hipLaunchKernelGGL((conv_l2_kernel<2, 2, 5, 1, false>), dim3(k.tilesM * k.tilesN), dim3(256), 0, st, k, xpl, wpl, x_bytes, w_bytes, xamax, wamax);
+    return ONDA_LAUNCH_RESULT();
+  }
+  if (dbg == 5 && variant == 0) {  // persistent grid, whole tiles only (the remainder is dropped), phase stamps into ws
+    k.tiles_dp = tiles - rem;
+    k.tilesM = k.tiles_dp / k.tilesN;  // (not exact for every shape: diagnostic only)
+    hipLaunchKernelGGL((conv_l2_kernel<4, 2, 3, 2, true, 5>), dim3(G), dim3(512), 0, st, k, xpl, wpl, x_bytes, w_bytes, xamax, wamax);
+    return ONDA_LAUNCH_RESULT();
+  }
+  if (dbg == 6 && variant == 0) {  // no stagger
+    if (balanced) hipLaunchKernelGGL((conv_l2_kernel<4, 2, 3, 2, true, 6>), dim3(G), dim3(512), 0, st, k, xpl, wpl, x_bytes, w_bytes, xamax, wamax);
+    else hipLaunchKernelGGL((conv_l2_kernel<4, 2, 3, 2, false, 6>), dim3(tiles), dim3(512), 0, st, k, xpl, wpl, x_bytes, w_bytes, xamax, wamax);
+    if (balanced) return conv_launch_fixup_tile(k, G, BM, BN, st);
+    return ONDA_LAUNCH_RESULT();
+  }
+  if (dbg == 4 && variant == 0) {  // plain one tile per workgroup
+    hipLaunchKernelGGL((conv_l2_kernel<4, 2, 3, 2, false>), dim3(tiles), dim3(512), 0, st, k, xpl, wpl, x_bytes, w_bytes, xamax, wamax);
+    return ONDA_LAUNCH_RESULT();
+  }
+  if (variant == 0) L2_LAUNCH(4, 2, 3, 2);
+  else if (variant == 1) L2_LAUNCH(2, 2, 3, 1);
+  else L2_LAUNCH(4, 1, 3, 1);
+#undef L2_LAUNCH
+  if (balanced) return conv_launch_fixup_tile(k, G, BM, BN, st);
+  return ONDA_LAUNCH_RESULT();
+}
+
+}  // extern "C"

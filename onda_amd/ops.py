@@ -32,6 +32,12 @@ STEM_K = 160   # 7*7*3 = 147 patch values padded to a multiple of 32
 #   "f32"   : v_mfma_f32_32x32x2_f32 (an exact fp32 fmaf chain; csrc/conv.hip).
 CONV_MODE = os.environ.get("ONDA_CONV_MODE", "f16x2")
 
+# "f16x2" only -- where the activation operand of forward / data gradient is split into its two limbs:
+#   "dma": beforehand, as limb planes in HBM (by the producing kernel or one split pass); the conv kernel moves both
+#          operands to LDS by LDS-DMA only (csrc/conv_l2.hip) -- the default;
+#   "reg": inside the conv kernel, in registers between two barriers (csrc/conv_h2.hip).
+H2_PATH = os.environ.get("ONDA_H2_PATH", "dma")
+
 # bench.py sets this to a list to collect (kernel family, algorithmic flops, start event, end event)
 # around every conv launch; the events are recorded on the launch stream (torch's current stream)
 PROFILE = None
@@ -156,6 +162,38 @@ def activation_scale(x):
     return slot
 
 
+class Limbs:
+    """An activation as the two f16 limb planes of x * 2^e (include/onda_hip.h, pre-split section):
+    planes f16[2, rows, ld], `amax` the device floats that define e."""
+    __slots__ = ("planes", "amax", "ld", "plane")
+
+    def __init__(self, planes, amax, ld, plane):
+        self.planes, self.amax, self.ld, self.plane = planes, amax, ld, plane
+
+
+def activation_limbs(x):
+    """Limb planes of an NHWC fp32 activation: left behind by its producer, or one split pass shared by
+    every conv that reads the same tensor object."""
+    hit = getattr(x, "_onda_limbs", None)
+    if hit is not None and hit[0] == x._version:
+        return hit[1]
+    amax = activation_scale(x)
+    B, H, W, C = x.shape
+    rows = B * H * W
+    planes = torch.empty(2, rows, C, device=x.device, dtype=torch.float16)
+    call("onda_split_h2", _p(x), rows, C, nhwc_ld(x), _p(planes), C, rows * C, _p(amax), _stream())
+    lb = Limbs(planes, amax, C, rows * C)
+    try:
+        x._onda_limbs = (x._version, lb)
+    except AttributeError:
+        pass
+    return lb
+
+
+def _use_l2(wp, cin):
+    return isinstance(wp, H2Weight) and H2_PATH == "dma" and cin % 32 == 0
+
+
 def _pack_h2(weight, rows_pad, kp, dgrad, cout_pad):
     cout, cin, kh, kw = weight.shape
     w = weight.detach().contiguous()
@@ -213,15 +251,29 @@ def conv_forward(x, wp, k, stride, dil, pad, cout, out=None, scale=None, shift=N
     Ho, Wo = conv_out_size(Hi, k, stride, dil, pad), conv_out_size(Wi, k, stride, dil, pad)
     if out is None:
         out = torch.empty(B, Ho, Wo, cout, device=x.device, dtype=torch.float32)
-    elif getattr(out, "_onda_scale", None) is not None:
-        del out._onda_scale  # a caller's buffer is rewritten behind torch's version counter: forget its old max|x|
+    else:  # a caller's buffer is rewritten behind torch's version counter: forget its old max|x| / limb planes
+        for attr in ("_onda_scale", "_onda_limbs"):
+            if getattr(out, attr, None) is not None:
+                delattr(out, attr)
     ldy = nhwc_ld(out)
     ldr = nhwc_ld(residual) if residual is not None else 0
     stats, tiles = None, 0
+    l2 = _use_l2(wp, Cin)
     if want_stats:
-        tiles = query("onda_conv_tiles_m", B * Ho * Wo)
+        tiles = query("onda_conv_l2_tiles_m", B * Ho * Wo, cout) if l2 else query("onda_conv_tiles_m", B * Ho * Wo)
         stats = torch.empty(tiles, 2, cout, device=x.device, dtype=torch.float32)
     d = _desc(B, Hi, Wi, Cin, Ho, Wo, cout, k, stride, dil, pad, ldx, ldy, ldr, relu=relu)
+    if l2:
+        xl = activation_limbs(x)
+        d.ldx = xl.ld
+        yamax = amax_slot(x.device) if (scale is not None or relu) else None
+        _launch("conv_l2_kernel<%d>" % query("onda_conv_l2_variant", B * Ho * Wo, cout), 2.0 * B * Ho * Wo * cout * k * k * Cin,
+                "onda_conv2d_fwd_l2", _p(xl.planes), xl.plane, _p(xl.amax), _p(wp.limbs), _p(wp.amax), _p(out), _p(scale),
+                _p(shift), _p(residual), _p(stats), _p(_conv_ws(x.device)), _p(yamax), byref(d), _stream(),
+                tag=("fwd", B * Ho * Wo, cout, Cin, k, stride, dil))
+        if yamax is not None:
+            tag_amax(out, yamax)
+        return out, stats, tiles
     if isinstance(wp, H2Weight):
         # a folded-BN (+ReLU) output is the next conv's input: let the epilogue leave its max|y| behind
         yamax = amax_slot(x.device) if (scale is not None or relu) else None
@@ -253,6 +305,15 @@ def conv_dgrad(dy, wpd, k, stride, dil, pad, cin, in_hw):
             raise RuntimeError("onda_amd: strided data gradient is implemented for 1x1 convs only")
         dx = torch.zeros(B, Hi, Wi, cin, device=dy.device, dtype=torch.float32)
         d = _desc(B, Ho, Wo, Co, Ho, Wo, cin, 1, 1, 1, 0, ldy, cin, out_os=stride, Hf=Hi, Wf=Wi)
+    if _use_l2(wpd, Co):
+        dyl = activation_limbs(dy)
+        d.ldx = dyl.ld
+        Mo = B * Ho * Wo if stride != 1 else B * Hi * Wi
+        _launch("conv_l2_kernel<%d>" % query("onda_conv_l2_variant", Mo, cin), 2.0 * B * Ho * Wo * cin * k * k * Co,
+                "onda_conv2d_fwd_l2", _p(dyl.planes), dyl.plane, _p(dyl.amax), _p(wpd.limbs), _p(wpd.amax), _p(dx), None, None,
+                None, None, _p(_conv_ws(dy.device)), None, byref(d), _stream(),
+                tag=("dgrad", Mo, cin, Co, k, stride, dil))
+        return dx
     if isinstance(wpd, H2Weight):
         _launch("conv_fwd_h2_kernel<128,%d>" % (128 if cin > 64 else 64), 2.0 * B * Ho * Wo * cin * k * k * Co,
                 "onda_conv2d_fwd_h2", _p(dy), _p(activation_scale(dy)), _p(wpd.limbs), _p(wpd.amax), _p(dx), None, None, None,
@@ -470,6 +531,11 @@ class BNTrainFn(torch.autograd.Function):
         rm, rv, nbt = running if running is not None else (None, None, None)
         call("onda_bn_finalize", _p(stats), stats.shape[0], C, M, BN_EPS, _p(mean), _p(invstd), _p(rm), _p(rv), _p(nbt),
              float(momentum), _stream())
+        if running is not None:
+            # the kernel wrote the running buffers through raw pointers: tell torch, so that everything keyed on
+            # their version (HipBatchNorm2d.folded) sees the new statistics
+            for t in running:
+                torch.autograd.graph.increment_version(t)
         out = torch.empty_like(y)
         res = as_nhwc(residual) if residual is not None else None
         if res is not None and nhwc_ld(res) != C:
