@@ -109,6 +109,12 @@ int onda_conv2d_fwd_l2(const void* xl, int64_t xplane, const float* xamax, const
                        const float* scale, const float* shift, const float* residual, float* stats, float* ws,
                        float* yamax, const OndaConv* c, onda_stream_t s);
 
+/* onda_conv2d_wgrad slabs with both operands pre-split: [pixel][channel] limb planes in, LDS-DMA + transposed LDS reads
+ * (ds_read_b64_tr_b16), tiles of 256 x 128 or 128 x 128 (output x input channels) per tap and pixel range */
+int onda_conv_wgrad_l2_variant(int Cout, int Cin);
+int onda_conv2d_wgrad_l2(const void* xl, int64_t xplane, const float* xamax, const void* dyl, int64_t dyplane, const float* dyamax,
+                         float* slabs, int lddy, int splitk, const OndaConv* c, onda_stream_t s);
+
 /* onda_conv2d_wgrad slabs from the two-limb f16 evaluation; xamax / dyamax = max|x| / max|dy| */
 int onda_conv2d_wgrad_h2(const float* x, const float* xamax, const float* dy, const float* dyamax, float* slabs, int lddy,
                          int splitk, const OndaConv* c, onda_stream_t s);

@@ -428,6 +428,301 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_l2_kernel(const ConvK 
   }
 }
 
+
+// ---- weight gradient ----------------------------------------------------------------------------------------------------
+// dw[n][tap][c] = sum over pixels m of dy[m][n] * x[pix(m, tap)][c]: the contraction index (pixels) is the SLOW memory axis
+// of both operands.  Both arrive as they lie in HBM -- [pixel][channel] rows of their limb planes, by LDS-DMA, 4 pixels x 128
+// channels per instruction -- and are read out of LDS TRANSPOSED by ds_read_b64_tr_b16 (4 pixels x 16 channels per 16 lanes,
+// each lane receives one channel's 4 pixels): two of them make the 8 consecutive k of a 16x16x32 MFMA operand.  No VALU
+// split, no register transposition, no LDS stores.  LDS image per limb and 128-channel half: [32 pixels][256 B] with the
+// 16-byte chunk index XOR-ed by ((row & 3) << 2 | (row >> 2) & 3) (conflict-free for the transposed reads), applied on the
+// DMA's source side.  Tile 64*WM output channels x 64*WN input channels per (tap, pixel range); ring and slot stagger as in
+// conv_l2_kernel.  K-steps whose 32 pixels all fall into the padding for this tap are skipped (whole dead rows of a
+// dilated tap: up to half of the ASPP weight-gradient work).
+// The transposed reads are inline assembly: behind the builtin the compiler waits for vmcnt(0) -- every LDS-DMA in flight --
+// before each group of reads (it cannot tell the stage being read from the stages being filled), which serialises the
+// ring.  In assembly nothing is waited for automatically: lds_wait() below is the s_waitcnt lgkmcnt(0) for them, tied to
+// the destination registers so that no MFMA that uses them can be scheduled above it.
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f16x8 tr_read8(unsigned a0, unsigned a1) {
+  u32x2_t lo, hi;
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(a0));
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(hi) : "v"(a1));
+  const u32x4 r = {lo[0], lo[1], hi[0], hi[1]};
+  return __builtin_bit_cast(f16x8, r);
+}
+__device__ __forceinline__ void lds_wait(f16x8& a, f16x8& b, f16x8& c_, f16x8& d) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c_), "+v"(d));
+}
+
+template <int WM, int WN, int STAGES, int OCC>
+__global__ __launch_bounds__(WM * WN * 64, OCC) void conv_wgrad_l2_kernel(const WgradK a, unsigned xplane, unsigned dyplane, unsigned x_bytes,
+                                                                         unsigned dy_bytes, const float* __restrict__ xamax,
+                                                                         const float* __restrict__ dyamax) {
+  constexpr int NW = WM * WN;
+  constexpr int SA = (64 * WM) / 128, SB = (64 * WN) / 128;  // 128-channel sub-images of dy / x
+  static_assert(SA >= 1 && SB >= 1, "tiles are multiples of 128 channels");
+  constexpr int SUB = 32 * 256;                              // one sub-image of one limb: 32 pixels x 256 B
+  constexpr int A_LIMB = SA * SUB, B_LIMB = SB * SUB, A_BYTES = 2 * A_LIMB, STAGE = A_BYTES + 2 * B_LIMB;
+  constexpr int GPW = 8 / NW;                                // 4-pixel groups per wave
+  static_assert(GPW >= 1 && 8 % NW == 0, "8 pixel groups per K-step");
+  constexpr int DPW = GPW * (SA + SB) * 2;                   // LDS-DMA instructions per wave per K-step
+  constexpr bool STAGGER = NW == 8;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[STAGES * STAGE];
+
+  const OndaConv& c = a.c;
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const bool late = wave >= NW / 2;
+
+  int bid = blockIdx.x;
+  const int tile_c = bid % a.tilesC;
+  bid /= a.tilesC;
+  const int tap = bid % a.taps;
+  bid /= a.taps;
+  const int tile_n = bid % a.tilesN;
+  const int ks = bid / a.tilesN;
+  const int n0 = tile_n * (64 * WM), c0 = tile_c * (64 * WN);
+  const int mbeg = ks * a.mchunk;
+  const int mend = min(a.M, mbeg + a.mchunk);
+  const int KT = mend > mbeg ? (mend - mbeg + 31) / 32 : 0;
+  const int rr = tap / c.kw, ss = tap - rr * c.kw;
+  const int dh = rr * c.dil - c.pad, dw = ss * c.dil - c.pad;
+  const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, x_bytes), rdy = make_rsrc(a.dy, dy_bytes);
+  const Scale2 sx = scale_of(xamax), sd = scale_of(dyamax);
+  const float unscale_a = sx.inv, unscale_b = sd.inv;
+
+  // a K-step (32 pixels from m) is dead when every output row it touches maps to an input row outside the image
+  auto step_live = [&](int kt) -> bool {
+    const int m_first = mbeg + kt * 32, m_last = min(mend, m_first + 32) - 1;
+    const int r_first = m_first / c.Wo, r_last = m_last / c.Wo;  // global output row index (b*Ho + ho)
+    for (int r = r_first; r <= r_last; ++r) {
+      const int hi = (r % c.Ho) * c.stride + dh;
+      if ((unsigned)hi < (unsigned)c.Hi) return true;
+    }
+    return false;
+  };
+  auto next_live = [&](int kt) -> int {
+    while (kt < KT && !step_live(kt)) ++kt;
+    return kt;
+  };
+
+  // DMA roles: this wave moves pixel groups grp = wave*GPW + d (4 pixels each) of every K-step, both operands, both limbs
+  const int prow = lane >> 4;  // pixel inside the group
+  unsigned ch_dy[GPW][SA], ch_x[GPW][SB];
+#pragma unroll
+  for (int d = 0; d < GPW; ++d) {
+    const int row = (wave * GPW + d) * 4 + prow;
+    const int swz = ((row & 3) << 2) | ((row >> 2) & 3);
+    const int ch = (lane & 15) ^ swz;  // data chunk (8 channels) that lands in this lane's LDS slot
+#pragma unroll
+    for (int sI = 0; sI < SA; ++sI) {
+      const int n = n0 + sI * 128 + ch * 8;
+      ch_dy[d][sI] = n < c.Cout ? (unsigned)n * 2u : OOB;
+    }
+#pragma unroll
+    for (int sI = 0; sI < SB; ++sI) {
+      const int cc = c0 + sI * 128 + ch * 8;
+      ch_x[d][sI] = cc < c.Cin ? (unsigned)cc * 2u : OOB;
+    }
+  }
+  // this lane's pixel of each group: (image, output row, output column), advanced incrementally (no division in the loop)
+  int p_m[GPW], p_wo[GPW], p_ho[GPW], p_b[GPW];
+#pragma unroll
+  for (int d = 0; d < GPW; ++d) {
+    const int m = mbeg + (wave * GPW + d) * 4 + prow;
+    p_m[d] = m;
+    p_wo[d] = m % c.Wo;
+    const int tq = m / c.Wo;
+    p_ho[d] = tq % c.Ho;
+    p_b[d] = tq / c.Ho;
+  }
+  int k_decoded = 0;  // the K-step p_* stand at
+  auto issue = [&](int kt, int stage_off) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int adv = (kt - k_decoded) * 32;
+    k_decoded = kt;
+#pragma unroll
+    for (int d = 0; d < GPW; ++d) {
+      const int grp = wave * GPW + d;
+      p_m[d] += adv;
+      p_wo[d] += adv;
+      while (p_wo[d] >= c.Wo) {
+        p_wo[d] -= c.Wo;
+        if (++p_ho[d] == c.Ho) {
+          p_ho[d] = 0;
+          ++p_b[d];
+        }
+      }
+      const int m = p_m[d];
+      unsigned pdy = OOB, px = OOB;
+      if (m < mend) {
+        pdy = (unsigned)m * (unsigned)a.lddy * 2u;
+        const int hi = p_ho[d] * c.stride + dh, wi = p_wo[d] * c.stride + dw;
+        if ((unsigned)hi < (unsigned)c.Hi && (unsigned)wi < (unsigned)c.Wi) px = (unsigned)(((p_b[d] * c.Hi + hi) * c.Wi + wi) * c.ldx) * 2u;
+      }
+#pragma unroll
+      for (int l = 0; l < 2; ++l) {
+#pragma unroll
+        for (int sI = 0; sI < SA; ++sI) {
+          unsigned char* dst = lds + stage_off + l * A_LIMB + sI * SUB + grp * 1024;
+          const unsigned vo = (pdy | ch_dy[d][sI]) >= OOB ? OOB : pdy + ch_dy[d][sI];
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rdy, (__attribute__((address_space(3))) void*)dst, 16, vo, l * dyplane, 0, 0);
+        }
+#pragma unroll
+        for (int sI = 0; sI < SB; ++sI) {
+          unsigned char* dst = lds + stage_off + A_BYTES + l * B_LIMB + sI * SUB + grp * 1024;
+          const unsigned vo = (px | ch_x[d][sI]) >= OOB ? OOB : px + ch_x[d][sI];
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)dst, 16, vo, l * xplane, 0, 0);
+        }
+      }
+    }
+#else
+    (void)kt;
+    (void)stage_off;
+#endif
+  };
+
+  // transposed fragment reads: 16-lane group g = k-group (pixels 8g .. 8g+7), lane 4q+p of the group addresses row q,
+  // 8 bytes p & 1 of chunk (p >> 1) of the tile's two chunks
+  unsigned fa[4][2], fb[4][2];
+  {
+    const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int row = 8 * g + 4 * h + q;
+      const int swz = ((row & 3) << 2) | ((row >> 2) & 3);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int cha = (wm & 1) * 8 + 2 * i + (pp >> 1), chb = (wn & 1) * 8 + 2 * i + (pp >> 1);
+        fa[i][h] = (unsigned)((wm >> 1) * SUB + 256 * row + 16 * (cha ^ swz) + 8 * (pp & 1));
+        fb[i][h] = (unsigned)(A_BYTES + (wn >> 1) * SUB + 256 * row + 16 * (chb ^ swz) + 8 * (pp & 1));
+      }
+    }
+  }
+
+  f32x4 acc[4][4], accx[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[i][j][e] = accx[i][j][e] = 0.f;
+
+  // the live K-steps, fetched two ahead
+  int k_cur = next_live(0);
+  int k_iss = k_cur;
+  int st_issue = 0, st_read = 0;
+  auto issue_next = [&]() {
+    issue(k_iss, st_issue);
+    st_issue = st_issue + STAGE == STAGES * STAGE ? 0 : st_issue + STAGE;
+    k_iss = next_live(k_iss + 1);
+  };
+  auto wait_landed = [&](bool more_in_flight) {
+    if (more_in_flight)
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPW) : "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
+  if (k_iss < KT) issue_next();
+  if (k_iss < KT) issue_next();
+  f16x8 af[4][2], bf[4], b1[4];
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
+  unsigned base;
+  auto prepare = [&]() {  // "P": issue the transposed reads of the a1, a2, b2 fragments of the stage at st_read
+    base = lds0 + st_read;
+    st_read = st_read + STAGE == STAGES * STAGE ? 0 : st_read + STAGE;
+#pragma unroll
+    for (int l = 0; l < 2; ++l)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i][l] = tr_read8(base + l * A_LIMB + fa[i][0], base + l * A_LIMB + fa[i][1]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bf[j] = tr_read8(base + B_LIMB + fb[j][0], base + B_LIMB + fb[j][1]);
+  };
+  auto prepared = [&]() {  // ... and wait for them (before the barrier that lets the stage be refilled / before the MFMAs)
+    lds_wait(af[0][0], af[1][0], af[2][0], af[3][0]);
+    lds_wait(af[0][1], af[1][1], af[2][1], af[3][1]);
+    lds_wait(bf[0], bf[1], bf[2], bf[3]);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto compute = [&]() {  // "C": the b1 fragments arrive behind the first 16 MFMAs
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b1[j] = tr_read8(base + fb[j][0], base + fb[j][1]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) accx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][0], bf[j], accx[i][j], 0, 0, 0);
+    lds_wait(b1[0], b1[1], b1[2], b1[3]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) accx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][1], b1[j], accx[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][0], b1[j], acc[i][j], 0, 0, 0);
+  };
+  // (k_cur, its successor, the one after): the loop needs to know how many live steps remain -- count as it goes
+  if constexpr (!STAGGER) {
+    while (k_cur < KT) {
+      const int k_nxt = next_live(k_cur + 1);
+      wait_landed(k_nxt < KT);
+      __builtin_amdgcn_s_barrier();
+      if (k_iss < KT) issue_next();
+      prepare();
+      prepared();
+      compute();
+      k_cur = k_nxt;
+    }
+  } else {
+    if (late && k_cur < KT) {
+      wait_landed(next_live(k_cur + 1) < KT);
+      __builtin_amdgcn_s_barrier();
+    }
+    while (k_cur < KT) {
+      const int k_nxt = next_live(k_cur + 1);
+      if (!late) wait_landed(k_nxt < KT);
+      __builtin_amdgcn_s_barrier();
+      if (late && k_iss < KT) issue_next();
+      prepare();
+      prepared();
+      if (late && k_nxt < KT) wait_landed(next_live(k_nxt + 1) < KT);
+      __builtin_amdgcn_s_barrier();
+      if (!late && k_iss < KT) issue_next();
+      compute();
+      k_cur = k_nxt;
+    }
+    if (!late && next_live(0) < KT) __builtin_amdgcn_s_barrier();
+  }
+
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = ((acc[i][j] + accx[i][j] * LIMB2_UNSCALE) * unscale_a) * unscale_b;
+  __syncthreads();
+  // slab store through the wave's own 4 KiB of LDS: 16 rows (output channels) x 64 input channels at a time, 16-byte stores
+  float* tr = reinterpret_cast<float*>(lds + (t >> 6) * 4096);
+  const int cl = (lane & 15) * 4, rl = lane >> 4;
+  const int cc = c0 + wn * 64 + cl;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int jn = 0; jn < 4; ++jn)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) tr[(4 * (lane >> 4) + e) * 64 + jn * 16 + (lane & 15)] = acc[i][jn][e];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 4 * r + rl;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(tr + row * 64 + cl);
+      const int n = n0 + (wm * 4 + i) * 16 + row;
+      if (n < c.Cout && cc < c.Cin) *reinterpret_cast<f32x4*>(a.slabs + (((size_t)ks * c.Cout + n) * a.taps + tap) * c.Cin + cc) = v;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -544,6 +839,46 @@ int onda_conv2d_fwd_l2(const void* xl, int64_t xplane, const float* xamax, const
   else L2_LAUNCH(4, 1, 3, 1);
 #undef L2_LAUNCH
   if (balanced) return conv_launch_fixup_tile(k, G, BM, BN, st);
+  return ONDA_LAUNCH_RESULT();
+}
+
+// weight-gradient tile of the pre-split kernel for a (Cout, Cin) problem: 0 = 256 output x 128 input channels (8 waves),
+// 1 = 128 x 128 (4 waves)
+int onda_conv_wgrad_l2_variant(int Cout, int Cin) {
+  (void)Cin;
+  if (const char* e = getenv("ONDA_WGRAD_L2_VARIANT")) return atoi(e);
+  return Cout >= 256 ? 0 : 1;
+}
+
+int onda_conv2d_wgrad_l2(const void* xl, int64_t xplane, const float* xamax, const void* dyl, int64_t dyplane, const float* dyamax,
+                         float* slabs, int lddy, int splitk, const OndaConv* c, onda_stream_t s) {
+  ONDA_REQUIRE(xl && dyl && xamax && dyamax && slabs && c && splitk >= 1 && xplane > 0 && dyplane > 0);
+  ONDA_REQUIRE(c->Cin % 8 == 0 && c->Cout % 8 == 0 && c->ldx % 8 == 0 && lddy % 8 == 0 && xplane % 8 == 0 && dyplane % 8 == 0);
+  if (!ONDA_ALIGNED16(xl) || !ONDA_ALIGNED16(dyl) || !ONDA_ALIGNED16(slabs)) return ONDA_EALIGN;
+  const long long M = (long long)c->B * c->Ho * c->Wo;
+  ONDA_REQUIRE(M > 0 && M < (1ll << 31));
+  const long long x_total = xplane * 2 + ((long long)c->B * c->Hi * c->Wi - 1) * c->ldx * 2 + c->Cin * 2;
+  const long long dy_total = dyplane * 2 + (M - 1) * lddy * 2 + c->Cout * 2;
+  ONDA_REQUIRE(x_total < 0x7FFF0000ll && dy_total < 0x7FFF0000ll);
+  WgradK k;
+  k.x = static_cast<const float*>(xl); k.dy = static_cast<const float*>(dyl); k.slabs = slabs; k.c = *c;
+  k.M = (int)M;
+  k.lddy = lddy;
+  k.splitk = splitk;
+  k.mchunk = (int)(((M + splitk - 1) / splitk + 31) / 32 * 32);
+  k.taps = c->kh * c->kw;
+  const int variant = onda_conv_wgrad_l2_variant(c->Cout, c->Cin);
+  const int TN = variant == 0 ? 256 : 128;
+  k.tilesN = (c->Cout + TN - 1) / TN;
+  k.tilesC = (c->Cin + 127) / 128;
+  const unsigned grid = (unsigned)(k.tilesN * k.tilesC * k.taps * splitk);
+  const unsigned xpl = (unsigned)(xplane * 2), dypl = (unsigned)(dyplane * 2);
+  if (variant == 0)
+    hipLaunchKernelGGL((conv_wgrad_l2_kernel<4, 2, 3, 2>), dim3(grid), dim3(512), 0, ONDA_STREAM(s), k, xpl, dypl, (unsigned)x_total,
+                       (unsigned)dy_total, xamax, dyamax);
+  else
+    hipLaunchKernelGGL((conv_wgrad_l2_kernel<2, 2, 3, 1>), dim3(grid), dim3(256), 0, ONDA_STREAM(s), k, xpl, dypl, (unsigned)x_total,
+                       (unsigned)dy_total, xamax, dyamax);
   return ONDA_LAUNCH_RESULT();
 }
 

@@ -110,6 +110,14 @@ class prototype_handler:
 
     def append(self, feat, out, classes=None):
         sums, counts, K, C = self._class_sums(feat, out, classes)
+        self._append_sums(sums, counts, K, C)
+
+    def append_from_statistics(self, flat, K, C):
+        """`append` from the flat [sum feat | sum feat^2 | count] buffer of class_statistics (the multi-GPU path
+        sums it over ranks first, so that every rank starts from the same prototypes)."""
+        self._append_sums(flat[: 2 * K * C].reshape(2, K, C), flat[2 * K * C:], K, C)
+
+    def _append_sums(self, sums, counts, K, C):
         if type(self.prototypes) == int:
             self.prototypes = torch.zeros(K, C, device=sums.device)
             self.squared_mean = torch.zeros(K, C, device=sums.device)
@@ -166,12 +174,14 @@ class prototype_handler:
         self._stats_host = None
         return self._cache
 
-    def assign_stats(self, feat, prior):
+    def assign_stats(self, feat, prior, reduce=None):
         """(labels i64[N,1], soft f32[N,K], [mean max softmax(-D/tau), mean max posterior,
-        mean max prior] read back to the host once) -- everything one pass produces."""
+        mean max prior] read back to the host once) -- everything one pass produces.  `reduce` (the
+        multi-GPU path: mean over ranks) is applied to the three device scalars before the read-back, so that
+        every rank's monitor -- and the tau bump it drives -- sees the same numbers."""
         out = self._assign(feat, prior)
         if self._stats_host is None:
-            self._stats_host = out[2].tolist()
+            self._stats_host = (reduce(out[2].clone()) if reduce is not None else out[2]).tolist()
         return out[0], out[1], self._stats_host
 
     def pseudo_labels(self, feat, prior=None, soft=False, confidence_monitor=None):

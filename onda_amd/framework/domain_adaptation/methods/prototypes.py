@@ -115,9 +115,13 @@ class online_proDA(da_model):
                     # sums kernel drops those pixels (the reference masks them out, :144-153)
                     _, channels, height, width = out.size()
                     labels = F.interpolate(batch["label"].unsqueeze(1).float(), size=(height, width)).view(-1)
-                    self.prototypes.append(feat, channels, classes=labels)
+                    flat, K, C = self.prototypes.class_statistics(feat, channels, classes=labels)
                 else:
-                    self.prototypes.append(feat, out)
+                    flat, K, C = self.prototypes.class_statistics(feat, out)
+                # sharded loaders: the class sums / counts of all ranks make ONE running mean, so that every
+                # rank starts from the same prototypes (each rank must see the same number of batches)
+                odist.all_reduce_sum(flat)
+                self.prototypes.append_from_statistics(flat, K, C)
         if save:
             import os
             os.makedirs(self.cfg.OTHERS.SNAPSHOT_DIR, exist_ok=True)
@@ -143,7 +147,10 @@ class online_proDA(da_model):
     def _rank_mean(self, *confs):
         """Device scalars -> Python floats with ONE read-back; averaged over ranks first so that
         every rank's monitor (and therefore every switch decision) sees the same numbers."""
-        return odist.all_reduce_mean(torch.stack(list(confs))).tolist()
+        vals = torch.stack(list(confs))
+        if not self.intensity_ma.freeze:  # evaluation: the monitor ignores the values, and ranks may see different batch counts
+            odist.all_reduce_mean(vals)
+        return vals.tolist()
 
     def _teacher_and_static(self, batch):
         """The part every prototype method shares: EMA-teacher pass (train mode), optional static
@@ -187,10 +194,14 @@ class online_proDA(da_model):
     def _labels_from(self, pred_ema, prior, cls_ema):
         feat = pred_ema["feat"]
         # one pass + one read-back: [prototype confidence, posterior confidence, prior confidence]
-        labels, soft, s = self.prototypes.assign_stats(feat, prior)
+        labels, soft, s = self.prototypes.assign_stats(
+            feat, prior, reduce=None if self.intensity_ma.freeze else odist.all_reduce_mean)
         self.intensity_ma.add({"prior": s[2]})
         pseudolabels = self.prototypes.pseudo_labels(feat, prior, confidence_monitor=self.intensity_ma)
         soft_predictions = self.prototypes.pseudo_labels(feat, prior, soft=True)
+        # the reference takes this mean from the soft map of the SECOND call, i.e. after a possible tau bump
+        # (prototype_handler.py:148-156): re-read the statistics of whatever pass produced `soft_predictions`
+        s = self.prototypes.assign_stats(feat, prior, reduce=None if self.intensity_ma.freeze else odist.all_reduce_mean)[2]
         self.intensity_ma.add({"pseudolabel confidence": s[1]})
         return {"ema_model": pred_ema, "pseudolabels": pseudolabels, "soft_predictions": soft_predictions,
                 "ema_classes": cls_ema}

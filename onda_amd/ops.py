@@ -328,13 +328,22 @@ def conv_dgrad(dy, wpd, k, stride, dil, pad, cin, in_hw):
     return dx
 
 
-def _wgrad_splitk(M, cout, cin, taps):
+def _wgrad_splitk(M, cout, cin, taps, l2=False):
     """Split count over the pixel (K) range: pick the one whose workgroup count best fills whole
     rounds of the resident workgroups (tail effect) net of the slab write+read it costs."""
+    if l2:  # pre-split kernel: 256 x 128 or 128 x 128 tiles, one workgroup per CU
+        tn = 256 if query("onda_conv_wgrad_l2_variant", cout, cin) == 0 else 128
+        tiles = -(-cout // tn) * -(-cin // 128) * taps
+        G = query("onda_conv_ws_floats") // (3 * 128 * 128) // 2
+        return _best_splitk(M, cout, cin, taps, tiles, G, 3.2e14 if tn == 256 else 2.0e14)
     t = 128 if (cout > 64 and cin > 64) else 64
     tiles = -(-cout // t) * -(-cin // t) * taps
     G = query("onda_conv_ws_floats") // (3 * 128 * 128) * (1 if t == 128 else 2)
-    t_ideal = 2.0 * M * cout * cin * taps / 1.2e14            # seconds at ~120 TFLOP/s
+    return _best_splitk(M, cout, cin, taps, tiles, G, 1.2e14)
+
+
+def _best_splitk(M, cout, cin, taps, tiles, G, rate):
+    t_ideal = 2.0 * M * cout * cin * taps / rate              # seconds at the kernel's typical rate
     wbytes = 4.0 * cout * cin * taps
     best, best_t = 1, None
     for sk in range(1, 129):
@@ -348,7 +357,7 @@ def _wgrad_splitk(M, cout, cin, taps):
     return best
 
 
-def conv_wgrad(x, dy, k, stride, dil, pad, cout_real, cin_real, flat_k=0, into=None, xscale=None):
+def conv_wgrad(x, dy, k, stride, dil, pad, cout_real, cin_real, flat_k=0, into=None, xscale=None, xlimbs=None):
     """Weight gradient in OIHW.  x NHWC input of the conv, dy NHWC output gradient.  With `into`
     (an existing contiguous gradient tensor) the result is ADDED to it and None is returned.
     xscale: the per-tensor scale of x when the forward pass already computed it ("f16x2" mode)."""
@@ -356,10 +365,18 @@ def conv_wgrad(x, dy, k, stride, dil, pad, cout_real, cin_real, flat_k=0, into=N
     _, Ho, Wo, Co = dy.shape
     taps = k * k
     M = B * Ho * Wo
-    sk = _wgrad_splitk(M, Co, Cin, taps)
+    l2 = CONV_MODE == "f16x2" and H2_PATH == "dma" and Cin % 8 == 0 and Co % 8 == 0
+    sk = _wgrad_splitk(M, Co, Cin, taps, l2)
     slabs = torch.empty(sk, Co, taps, Cin, device=x.device, dtype=torch.float32)
     d = _desc(B, Hi, Wi, Cin, Ho, Wo, Co, k, stride, dil, pad, nhwc_ld(x), Co)
-    if CONV_MODE == "f16x2" and Cin % 4 == 0 and Co % 4 == 0:
+    if l2:
+        xl = xlimbs if xlimbs is not None else activation_limbs(x)
+        dyl = activation_limbs(dy)
+        d.ldx = xl.ld
+        _launch("conv_wgrad_l2_kernel<%d>" % query("onda_conv_wgrad_l2_variant", Co, Cin), 2.0 * M * Co * taps * Cin,
+                "onda_conv2d_wgrad_l2", _p(xl.planes), xl.plane, _p(xl.amax), _p(dyl.planes), dyl.plane, _p(dyl.amax), _p(slabs),
+                dyl.ld, sk, byref(d), _stream(), tag=("wgrad", M, Co, Cin, k, stride, dil, sk))
+    elif CONV_MODE == "f16x2" and Cin % 4 == 0 and Co % 4 == 0:
         xs = xscale if xscale is not None else activation_scale(x)
         _launch("conv_wgrad_h2_kernel<%s>" % ("128,128" if (Co > 64 and Cin > 64) else "64,64"), 2.0 * M * Co * taps * Cin,
                 "onda_conv2d_wgrad_h2", _p(x), _p(xs), _p(dy), _p(activation_scale(dy)), _p(slabs), nhwc_ld(dy), sk, byref(d),
@@ -447,6 +464,8 @@ class Conv2dFn(torch.autograd.Function):
         y, stats, _tiles = conv_forward(x, wp, k, stride, dil, pad, co, shift=_pad_vec(bias, co), want_stats=want_stats)
         ctx.save_for_backward(x, weight)
         ctx.xscale = known_amax(x)  # "f16x2": max|x| of the input, reused by the weight gradient
+        hit = getattr(x, "_onda_limbs", None)
+        ctx.xlimbs = hit[1] if hit is not None and hit[0] == x._version else None  # ... and its limb planes
         ctx.weight_param = weight  # the Parameter itself: its .grad is the accumulation target
         ctx.cache, ctx.geom, ctx.has_bias = cache, (k, stride, dil, pad, cout, cin, cout_pad), bias is not None
         if want_stats:
@@ -463,7 +482,8 @@ class Conv2dFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = conv_dgrad(dy, ctx.cache.get_dgrad(weight, cout_pad), k, stride, dil, pad, cin, x.shape[1:3])
         if ctx.needs_input_grad[1]:
-            dw = conv_wgrad(x, dy, k, stride, dil, pad, cout, cin, into=_accumulate_target(ctx.weight_param), xscale=ctx.xscale)
+            dw = conv_wgrad(x, dy, k, stride, dil, pad, cout, cin, into=_accumulate_target(ctx.weight_param), xscale=ctx.xscale,
+                            xlimbs=ctx.xlimbs)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = colsum(dy)[:cout]
         return dx, dw, db, None, None, None, None, None, None

@@ -31,7 +31,9 @@ def main():
         torch.manual_seed(5)  # same dropout draws on every rank are not required, same prototypes are
         da.update_dynamic()
         switch_batch_statistics(da.model, False)
-        da.calculate_prototypes([synth_batch(2, 64, 128, seed=50), synth_batch(2, 64, 128, seed=51)], save=False)
+        # rank-specific batches (sharded loader): the class statistics are summed over ranks before the append
+        da.calculate_prototypes([synth_batch(2, 64, 128, seed=50 + 3 * rank), synth_batch(2, 64, 128, seed=51 + 3 * rank)],
+                                save=False)
         switch_batch_statistics(da.model, True)
         da.optimizer.zero_grad()
         for s in range(2):
@@ -45,6 +47,9 @@ def main():
             for b in mod.buffers():
                 vals.append(b.detach().double().sum())
         vals.append(da.prototypes.prototypes.double().sum())
+        vals.append(da.prototypes.squared_mean.double().sum())
+        vals.append(da.prototypes.counter.double().sum())
+        vals.append(torch.tensor(float(da.prototypes.tau), device=dev, dtype=torch.float64))
         vals.append(torch.tensor(float(da.model_select.current), device=dev, dtype=torch.float64))
         mine = torch.stack(vals)
         gathered = [torch.empty_like(mine) for _ in range(world)]
