@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libonda_hip.so")
-SOURCES = ["conv.hip", "conv_bf3.hip", "conv_h2.hip", "conv_l2.hip", "norm.hip", "pointwise.hip", "loss_proto.hip", "pipeline.hip"]
+SOURCES = ["conv.hip", "conv_bf3.hip", "conv_h2.hip", "conv_l2.hip", "norm.hip", "norm_l2.hip", "pointwise.hip", "loss_proto.hip", "pipeline.hip"]
 
 
 def _stale(target, deps):

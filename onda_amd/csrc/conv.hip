@@ -241,6 +241,7 @@ __global__ __launch_bounds__(256) void conv_fixup_kernel(const ConvK a, int G, c
   __syncthreads();
 
   f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 vmin = {3.0e38f, 3.0e38f, 3.0e38f, 3.0e38f}, vmax = {-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
   float mx = 0.f;
 #pragma unroll 2
   for (int i = 0; i < RPT; ++i) {
@@ -258,6 +259,11 @@ __global__ __launch_bounds__(256) void conv_fixup_kernel(const ConvK a, int G, c
     }
     s1 += v;
     s2 += v * v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      vmin[j] = fminf(vmin[j], v[j]);
+      vmax[j] = fmaxf(vmax[j], v[j]);
+    }
     const int m = m0 + row;
     if (m >= a.M || !vn) continue;
     f32x4 o = v * sc + sh;
@@ -278,6 +284,7 @@ __global__ __launch_bounds__(256) void conv_fixup_kernel(const ConvK a, int G, c
   __shared__ float amax_red[4];
   if (a.amax != nullptr) amax_update_block(a.amax, mx, amax_red);
   if (a.stats != nullptr) {
+    const int SR = a.stats_rows;
     red[0][t] = s1;
     red[1][t] = s2;
     __syncthreads();
@@ -286,8 +293,25 @@ __global__ __launch_bounds__(256) void conv_fixup_kernel(const ConvK a, int G, c
         s1 += red[0][g * C4 + t];
         s2 += red[1][g * C4 + t];
       }
-      *reinterpret_cast<f32x4*>(a.stats + ((size_t)tile_m * 2 + 0) * c.Cout + n) = s1;
-      *reinterpret_cast<f32x4*>(a.stats + ((size_t)tile_m * 2 + 1) * c.Cout + n) = s2;
+      *reinterpret_cast<f32x4*>(a.stats + ((size_t)tile_m * SR + 0) * c.Cout + n) = s1;
+      *reinterpret_cast<f32x4*>(a.stats + ((size_t)tile_m * SR + 1) * c.Cout + n) = s2;
+    }
+    if (SR == 4) {  // the extrema of the raw tile (conv_l2.hip / norm_l2.hip)
+      __syncthreads();
+      red[0][t] = vmin;
+      red[1][t] = vmax;
+      __syncthreads();
+      if (rg == 0 && vn) {
+        for (int g = 1; g < RG; ++g) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            vmin[j] = fminf(vmin[j], red[0][g * C4 + t][j]);
+            vmax[j] = fmaxf(vmax[j], red[1][g * C4 + t][j]);
+          }
+        }
+        *reinterpret_cast<f32x4*>(a.stats + ((size_t)tile_m * 4 + 2) * c.Cout + n) = vmin;
+        *reinterpret_cast<f32x4*>(a.stats + ((size_t)tile_m * 4 + 3) * c.Cout + n) = vmax;
+      }
     }
   }
 }

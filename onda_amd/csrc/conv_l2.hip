@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void split_h2_kernel(const float* __restrict__
 // (measured: 26 000 cycles per 256 x 128 tile, more than the K loop of a 1 x 1 convolution with 256 input
 // channels).  So each wave transposes its 64 x 64 sub-tile through LDS, 16 rows at a time, and stores whole
 // 256-byte row segments as 16-byte vectors: 16 stores per lane, scale / shift loaded once per lane.
-// `scratch`: LDS nobody else touches during the epilogue: 4 KiB per wave, then WM*BN*2 + WM*WN floats of statistics.
+// `scratch`: LDS nobody else touches during the epilogue: 4 KiB per wave, then WM*BN*4 + WM*WN floats of statistics.
 template <int WM, int WN>
 __device__ __forceinline__ void l2_epilogue(const ConvK& a, const f32x4 (&acc)[4][4], unsigned char* scratch, int tile_m, int m0,
                                             int n0, int wm, int wn, int lane) {
@@ -100,10 +100,12 @@ __device__ __forceinline__ void l2_epilogue(const ConvK& a, const f32x4 (&acc)[4
   const OndaConv& c = a.c;
   const int t = threadIdx.x, wave = t >> 6;
   float* red = reinterpret_cast<float*>(scratch + NW * 4096);
+  const int SR = a.stats_rows;  // 2, or 4 with the per-channel min / max of the raw tile (rows past M count as zeros:
+                                // the extrema only have to BOUND the tensor's, norm_l2.hip)
   if (a.stats != nullptr) {
 #pragma unroll
     for (int jn = 0; jn < 4; ++jn) {
-      float s1 = 0.f, s2 = 0.f;
+      float s1 = 0.f, s2 = 0.f, mn = 3.0e38f, mxv = -3.0e38f;
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -111,15 +113,25 @@ __device__ __forceinline__ void l2_epilogue(const ConvK& a, const f32x4 (&acc)[4
           const float v = acc[i][jn][e];
           s1 += v;
           s2 += v * v;
+          mn = fminf(mn, v);
+          mxv = fmaxf(mxv, v);
         }
       s1 += __shfl_xor(s1, 16, 64);
       s2 += __shfl_xor(s2, 16, 64);
       s1 += __shfl_xor(s1, 32, 64);
       s2 += __shfl_xor(s2, 32, 64);
+      if (SR == 4) {
+        mn = fminf(mn, __shfl_xor(mn, 16, 64));
+        mxv = fmaxf(mxv, __shfl_xor(mxv, 16, 64));
+        mn = fminf(mn, __shfl_xor(mn, 32, 64));
+        mxv = fmaxf(mxv, __shfl_xor(mxv, 32, 64));
+      }
       if (lane < 16) {
         const int col = (wn * 4 + jn) * 16 + lane;
-        red[(wm * BN + col) * 2 + 0] = s1;
-        red[(wm * BN + col) * 2 + 1] = s2;
+        red[(wm * BN + col) * 4 + 0] = s1;
+        red[(wm * BN + col) * 4 + 1] = s2;
+        red[(wm * BN + col) * 4 + 2] = mn;
+        red[(wm * BN + col) * 4 + 3] = mxv;
       }
     }
   }
@@ -165,7 +177,7 @@ __device__ __forceinline__ void l2_epilogue(const ConvK& a, const f32x4 (&acc)[4
     }
     __builtin_amdgcn_wave_barrier();
   }
-  float* ar = red + WM * BN * 2;
+  float* ar = red + WM * BN * 4;
   if (a.amax != nullptr) {
     mx = wave_max(mx);
     if (lane == 0) ar[wave] = mx;
@@ -174,14 +186,21 @@ __device__ __forceinline__ void l2_epilogue(const ConvK& a, const f32x4 (&acc)[4
   if (a.stats != nullptr) {
     for (int col = t; col < BN; col += NT) {
       if (n0 + col >= c.Cout) continue;
-      float s1 = 0.f, s2 = 0.f;
+      float s1 = 0.f, s2 = 0.f, mn = 3.0e38f, mxv = -3.0e38f;
 #pragma unroll
       for (int w_ = 0; w_ < WM; ++w_) {
-        s1 += red[(w_ * BN + col) * 2 + 0];
-        s2 += red[(w_ * BN + col) * 2 + 1];
+        s1 += red[(w_ * BN + col) * 4 + 0];
+        s2 += red[(w_ * BN + col) * 4 + 1];
+        mn = fminf(mn, red[(w_ * BN + col) * 4 + 2]);
+        mxv = fmaxf(mxv, red[(w_ * BN + col) * 4 + 3]);
       }
-      a.stats[((size_t)tile_m * 2 + 0) * c.Cout + n0 + col] = s1;
-      a.stats[((size_t)tile_m * 2 + 1) * c.Cout + n0 + col] = s2;
+      float* dst = a.stats + (size_t)tile_m * SR * c.Cout + n0 + col;
+      dst[0] = s1;
+      dst[c.Cout] = s2;
+      if (SR == 4) {
+        dst[2 * c.Cout] = mn;
+        dst[3 * c.Cout] = mxv;
+      }
     }
   }
   if (a.amax != nullptr && t == 0) {  // one atomic per tile
@@ -752,9 +771,9 @@ int onda_conv_l2_tiles_m(int64_t M, int Cout) {
 }
 
 int onda_conv2d_fwd_l2(const void* xl, int64_t xplane, const float* xamax, const void* w2, const float* wamax, float* y,
-                       const float* scale, const float* shift, const float* residual, float* stats, float* ws,
+                       const float* scale, const float* shift, const float* residual, float* stats, int stats_rows, float* ws,
                        float* yamax, const OndaConv* c, onda_stream_t s) {
-  ONDA_REQUIRE(xl && xamax && w2 && wamax && y && c);
+  ONDA_REQUIRE(xl && xamax && w2 && wamax && y && c && (stats_rows == 2 || stats_rows == 4));
   ONDA_REQUIRE(c->Cin > 0 && c->Cin % 32 == 0 && c->Cout > 0 && c->Cout % 4 == 0 && c->ldx % 8 == 0 && c->ldx >= c->Cin);
   ONDA_REQUIRE(c->kh >= 1 && c->kw >= 1 && c->stride >= 1 && c->dil >= 1 && c->out_os >= 1 && xplane > 0 && xplane % 8 == 0);
   if (!ONDA_ALIGNED16(xl) || !ONDA_ALIGNED16(w2)) return ONDA_EALIGN;
@@ -765,6 +784,7 @@ int onda_conv2d_fwd_l2(const void* xl, int64_t xplane, const float* xamax, const
   ConvK k;
   k.x = static_cast<const float*>(xl); k.w = w2; k.y = y; k.scale = scale; k.shift = shift; k.res = residual; k.stats = stats; k.ws = ws;
   k.amax = yamax;
+  k.stats_rows = stats_rows;
   k.c = *c;
   const long long M = (long long)c->B * c->Ho * c->Wo;
   ONDA_REQUIRE(M > 0 && M < (1ll << 31));

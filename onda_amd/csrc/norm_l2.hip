@@ -1,0 +1,361 @@
+// BatchNorm around the pre-split convolutions (conv_l2.hip): the kernels that PRODUCE a conv operand write it
+// as limb planes (out[2][M][C] f16, 4 bytes per element like fp32) instead of fp32 + a later split pass.
+//
+// A limb plane needs its tensor's power-of-two scale BEFORE the first element is written, i.e. an upper bound
+// of max|out| from quantities that exist before the apply pass:
+//   forward : the conv epilogue leaves per-channel min / max of the raw conv output next to sum / sum of squares
+//             (stats[tile][4][C]); out = relu(gamma*(x-mean)*invstd + beta (+ res)) is monotone in x per channel,
+//             so max|out| <= max_c max(|f_c(min_c)|, |f_c(max_c)|) (+ max|res|): exact without a residual;
+//   backward: dx = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)) with g = dout*[out > 0]:
+//             |dx| <= |gamma*invstd| * (max|g| + |mean g| + max|xhat| * |mean g*xhat|) per channel; max|g| comes
+//             out of the reduction pass that already reads every element.
+// A bound instead of the maximum costs precision only at the far small end of a tensor (a bound 2^k too large:
+// full two-limb accuracy down to 2^-(28-k) of the maximum instead of 2^-28; conv_h2.hip).
+#include "common.h"
+
+namespace {
+
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr float LIMB2_SCALE = 2048.f, LIMB2_UNSCALE = 1.f / 2048.f;
+
+struct Scale2 {
+  float s, inv;
+};
+__device__ __forceinline__ Scale2 scale_of(const float* __restrict__ amax) {
+  const float m = amax_read(amax);
+  int e = 0;
+  if (m > 0.f && m < 3.0e38f) {
+    int ex;
+    frexpf(m, &ex);
+    e = 15 - ex;
+    e = e > 100 ? 100 : (e < -100 ? -100 : e);
+  }
+  return Scale2{ldexpf(1.f, e), ldexpf(1.f, -e)};
+}
+__device__ __forceinline__ unsigned cvt2h(float lo, float hi) {
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{lo, hi}, f16x2));
+}
+__device__ __forceinline__ f32x2 unpack2h(unsigned p) {
+  return __builtin_convertvector(__builtin_bit_cast(f16x2, p), f32x2);
+}
+// 8 scaled floats -> 8 + 8 f16 (16 bytes per limb)
+__device__ __forceinline__ void split8(const f32x4 v0, const f32x4 v1, u32x4& l1, u32x4& l2) {
+#pragma unroll
+  for (int h = 0; h < 4; ++h) {
+    const float a = h < 2 ? v0[2 * h] : v1[2 * h - 4], b = h < 2 ? v0[2 * h + 1] : v1[2 * h - 3];
+    const unsigned p = cvt2h(a, b);
+    const f32x2 f = unpack2h(p);
+    l1[h] = p;
+    l2[h] = cvt2h((a - f[0]) * LIMB2_SCALE, (b - f[1]) * LIMB2_SCALE);
+  }
+}
+// 8 + 8 f16 -> 8 floats (still scaled)
+__device__ __forceinline__ void join8(const u32x4 l1, const u32x4 l2, f32x4& v0, f32x4& v1) {
+#pragma unroll
+  for (int h = 0; h < 4; ++h) {
+    const f32x2 a = unpack2h(l1[h]), b = unpack2h(l2[h]);
+    const float x0 = a[0] + b[0] * LIMB2_UNSCALE, x1 = a[1] + b[1] * LIMB2_UNSCALE;
+    if (h < 2) {
+      v0[2 * h] = x0;
+      v0[2 * h + 1] = x1;
+    } else {
+      v1[2 * h - 4] = x0;
+      v1[2 * h - 3] = x1;
+    }
+  }
+}
+
+#define LD4(p) (*reinterpret_cast<const f32x4*>(p))
+
+// One wave per channel: tile partials [tiles][4][C] = (sum, sum of squares, min, max) -> mean, invstd, running statistics,
+// xhat_amax[C] = max|(x - mean) * invstd| (for the backward bound) and the bound of max|out| folded into out_amax.
+__global__ __launch_bounds__(256) void bn_finalize_l2_kernel(const float* __restrict__ partials, int tiles, int C, double count, float eps,
+                                                             float* mean, float* invstd, float* rmean, float* rvar, int64_t* nbt,
+                                                             float momentum, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, const float* __restrict__ res_amax,
+                                                             int relu, float* __restrict__ xhat_amax, float* __restrict__ out_amax) {
+  const int lane = threadIdx.x & 63;
+  const int ch = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) *nbt += 1;
+  float bound = 0.f;
+  if (ch < C) {
+    double s1 = 0.0, s2 = 0.0;
+    float mn = 3.0e38f, mx = -3.0e38f;
+    for (int tl = lane; tl < tiles; tl += 64) {
+      const float* p = partials + (size_t)tl * 4 * C + ch;
+      s1 += (double)p[0];
+      s2 += (double)p[C];
+      mn = fminf(mn, p[2 * C]);
+      mx = fmaxf(mx, p[3 * C]);
+    }
+    s1 = wave_sum_d(s1);
+    s2 = wave_sum_d(s2);
+    mn = -wave_max(-mn);
+    mx = wave_max(mx);
+    const double mu = s1 / count;
+    double var = s2 / count - mu * mu;
+    if (var < 0.0) var = 0.0;
+    const float muf = (float)mu, is = (float)(1.0 / sqrt(var + (double)eps));
+    const float lo = (mn - muf) * is, hi = (mx - muf) * is;
+    const float g = gamma[ch], b = beta[ch];
+    const float f_lo = lo * g + b, f_hi = hi * g + b;
+    bound = relu ? fmaxf(0.f, fmaxf(f_lo, f_hi)) : fmaxf(fabsf(f_lo), fabsf(f_hi));  // behind a ReLU only the positive side counts
+    if (lane == 0) {
+      mean[ch] = muf;
+      invstd[ch] = is;
+      xhat_amax[ch] = fmaxf(fabsf(lo), fabsf(hi));
+      if (rmean) {
+        const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+        rmean[ch] = (1.f - momentum) * rmean[ch] + momentum * muf;
+        rvar[ch] = (1.f - momentum) * rvar[ch] + momentum * (float)unbiased;
+      }
+    }
+  }
+  if (res_amax != nullptr) bound += amax_read(res_amax);
+  bound *= 1.0000005f;  // the apply pass rounds differently; the scale leaves a factor 2 of headroom anyway
+  __shared__ float red[4];
+  amax_update_block(out_amax, bound, red);
+}
+
+// out limbs = [relu]( (x - mean)*invstd*gamma + beta [+ residual limbs] ), 8 channels per thread
+__global__ __launch_bounds__(256) void bn_apply_l2_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                                          const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, const _Float16* __restrict__ res,
+                                                          size_t res_plane, const float* __restrict__ res_amax,
+                                                          _Float16* __restrict__ out, size_t out_plane,
+                                                          const float* __restrict__ out_amax, size_t total8, int C, int relu) {
+  const int c8 = C / 8;
+  const float so = scale_of(out_amax).s;
+  const float ri = res ? scale_of(res_amax).inv : 0.f;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total8; e += (size_t)gridDim.x * blockDim.x) {
+    const int col = (int)(e % c8) * 8;
+    f32x4 v0, v1;
+    {
+      const f32x4 sc0 = LD4(invstd + col) * LD4(gamma + col), sc1 = LD4(invstd + col + 4) * LD4(gamma + col + 4);
+      v0 = (LD4(x + e * 8) - LD4(mean + col)) * sc0 + LD4(beta + col);
+      v1 = (LD4(x + e * 8 + 4) - LD4(mean + col + 4)) * sc1 + LD4(beta + col + 4);
+    }
+    if (res) {
+      f32x4 r0, r1;
+      join8(*reinterpret_cast<const u32x4*>(res + e * 8), *reinterpret_cast<const u32x4*>(res + res_plane + e * 8), r0, r1);
+      v0 += r0 * ri;
+      v1 += r1 * ri;
+    }
+    if (relu) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        v0[j] = fmaxf(v0[j], 0.f);
+        v1[j] = fmaxf(v1[j], 0.f);
+      }
+    }
+    u32x4 l1, l2;
+    split8(v0 * so, v1 * so, l1, l2);
+    *reinterpret_cast<u32x4*>(out + e * 8) = l1;
+    *reinterpret_cast<u32x4*>(out + out_plane + e * 8) = l2;
+  }
+}
+
+// ---- backward ------------------------------------------------------------------------------------------------------------
+// pass 1: per-channel partial sums of g and g*xhat and the partial max|g|; g = dout * [out > 0] (sign of the first limb:
+// an element whose first limb rounds to zero is below 2^-24 of the tensor maximum... its second limb decides), dres = g
+struct ColPlan3 {
+  int cx, ry, gridx, chunks;
+  int64_t rows_per_chunk;
+};
+static inline ColPlan3 col_plan3(int64_t M, int C) {
+  ColPlan3 p;
+  const int c4 = C / 4;
+  p.cx = 1;
+  while (p.cx < c4 && p.cx < 64) p.cx <<= 1;
+  p.ry = 256 / p.cx;
+  p.gridx = (c4 + p.cx - 1) / p.cx;
+  int64_t target = 2048 / p.gridx;
+  if (target < 1) target = 1;
+  int64_t rpc = (M + target - 1) / target;
+  const int64_t min_rows = (int64_t)p.ry * 8;
+  if (rpc < min_rows) rpc = min_rows;
+  p.rows_per_chunk = rpc;
+  p.chunks = (int)((M + rpc - 1) / rpc);
+  return p;
+}
+
+__device__ __forceinline__ f32x4 relu_mask4(const _Float16* __restrict__ out, size_t plane, size_t o, f32x4 g) {
+  const u32x2 h1 = *reinterpret_cast<const u32x2*>(out + o), h2 = *reinterpret_cast<const u32x2*>(out + plane + o);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const f32x2 a = unpack2h(h1[j]), b = unpack2h(h2[j]);
+    g[2 * j] = (a[0] > 0.f || (a[0] == 0.f && b[0] > 0.f)) ? g[2 * j] : 0.f;
+    g[2 * j + 1] = (a[1] > 0.f || (a[1] == 0.f && b[1] > 0.f)) ? g[2 * j + 1] : 0.f;
+  }
+  return g;
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_reduce_l2_kernel(const float* __restrict__ dout, const _Float16* __restrict__ out,
+                                                               size_t out_plane, const float* __restrict__ x,
+                                                               const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                               float* __restrict__ dres, int64_t M, int C, int relu, int cx,
+                                                               int64_t rows_per_chunk, float* __restrict__ partials) {
+  __shared__ f32x4 red[3][256];
+  const int t = threadIdx.x;
+  const int ry_n = 256 / cx;
+  const int tx = t % cx, ty = t / cx;
+  const int col = (blockIdx.x * cx + tx) * 4;
+  const int chunk = blockIdx.y;
+  const int64_t r0 = (int64_t)chunk * rows_per_chunk;
+  const int64_t r1 = min(M, r0 + rows_per_chunk);
+  f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f}, s3 = {0.f, 0.f, 0.f, 0.f};
+  if (col < C) {
+    const f32x4 mu = LD4(mean + col), is = LD4(invstd + col);
+    for (int64_t r = r0 + ty; r < r1; r += ry_n) {
+      const size_t o = (size_t)r * C + col;
+      f32x4 g = LD4(dout + o);
+      if (relu) g = relu_mask4(out, out_plane, o, g);
+      if (dres) *reinterpret_cast<f32x4*>(dres + o) = g;
+      const f32x4 xh = (LD4(x + o) - mu) * is;
+      s1 += g;
+      s2 += g * xh;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s3[j] = fmaxf(s3[j], fabsf(g[j]));
+    }
+  }
+  red[0][t] = s1;
+  red[1][t] = s2;
+  red[2][t] = s3;
+  __syncthreads();
+  if (ty == 0 && col < C) {
+    for (int y = 1; y < ry_n; ++y) {
+      s1 += red[0][y * cx + tx];
+      s2 += red[1][y * cx + tx];
+      const f32x4 o3 = red[2][y * cx + tx];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s3[j] = fmaxf(s3[j], o3[j]);
+    }
+    float* dst = partials + ((size_t)chunk * 3) * C + col;
+    *reinterpret_cast<f32x4*>(dst) = s1;
+    *reinterpret_cast<f32x4*>(dst + C) = s2;
+    *reinterpret_cast<f32x4*>(dst + 2 * C) = s3;
+  }
+}
+
+// pass 2: one wave per channel -> sums[2][C] and the bound of max|dx| into dx_amax
+__global__ __launch_bounds__(256) void bn_bwd_sums_l2_kernel(const float* __restrict__ partials, int chunks, int C, double inv_m,
+                                                             const float* __restrict__ gamma, const float* __restrict__ invstd,
+                                                             const float* __restrict__ xhat_amax, float* __restrict__ sums,
+                                                             float* __restrict__ dx_amax) {
+  const int lane = threadIdx.x & 63;
+  const int ch = blockIdx.x * 4 + (threadIdx.x >> 6);
+  float bound = 0.f;
+  if (ch < C) {
+    double s1 = 0.0, s2 = 0.0;
+    float gm = 0.f;
+    for (int k = lane; k < chunks; k += 64) {
+      const float* p = partials + (size_t)k * 3 * C + ch;
+      s1 += (double)p[0];
+      s2 += (double)p[C];
+      gm = fmaxf(gm, p[2 * C]);
+    }
+    s1 = wave_sum_d(s1);
+    s2 = wave_sum_d(s2);
+    gm = wave_max(gm);
+    if (lane == 0) {
+      sums[ch] = (float)s1;
+      sums[C + ch] = (float)s2;
+    }
+    bound = fabsf(gamma[ch] * invstd[ch]) * (gm + (float)(fabs(s1) * inv_m) + xhat_amax[ch] * (float)(fabs(s2) * inv_m));
+  }
+  bound *= 1.000001f;
+  __shared__ float red[4];
+  amax_update_block(dx_amax, bound, red);
+}
+
+// pass 3: dx limbs
+__global__ __launch_bounds__(256) void bn_bwd_apply_l2_kernel(const float* __restrict__ dout, const _Float16* __restrict__ out,
+                                                              size_t out_plane, const float* __restrict__ x,
+                                                              const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                              const float* __restrict__ gamma, const float* __restrict__ sums,
+                                                              _Float16* __restrict__ dx, size_t dx_plane,
+                                                              const float* __restrict__ dx_amax, size_t total8, int C, float inv_m,
+                                                              int relu) {
+  const int c8 = C / 8;
+  const float sd = scale_of(dx_amax).s;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total8; e += (size_t)gridDim.x * blockDim.x) {
+    const int col = (int)(e % c8) * 8;
+    f32x4 v[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const size_t o = e * 8 + 4 * h;
+      const int cc = col + 4 * h;
+      f32x4 g = LD4(dout + o);
+      if (relu) g = relu_mask4(out, out_plane, o, g);
+      const f32x4 is = LD4(invstd + cc);
+      const f32x4 xh = (LD4(x + o) - LD4(mean + cc)) * is;
+      v[h] = LD4(gamma + cc) * is * (g - LD4(sums + cc) * inv_m - xh * (LD4(sums + C + cc) * inv_m));
+    }
+    u32x4 l1, l2;
+    split8(v[0] * sd, v[1] * sd, l1, l2);
+    *reinterpret_cast<u32x4*>(dx + e * 8) = l1;
+    *reinterpret_cast<u32x4*>(dx + dx_plane + e * 8) = l2;
+  }
+}
+
+static inline unsigned ew_grid(size_t total) {
+  size_t g = (total + 255) / 256;
+  if (g > 8192) g = 8192;
+  if (g < 1) g = 1;
+  return (unsigned)g;
+}
+
+}  // namespace
+
+extern "C" {
+
+int onda_bn_finalize_l2(const float* partials, int tiles, int C, int64_t count, float eps, float* mean, float* invstd,
+                        float* running_mean, float* running_var, int64_t* nbt, float momentum, const float* gamma,
+                        const float* beta, const float* res_amax, int relu, float* xhat_amax, float* out_amax, onda_stream_t s) {
+  ONDA_REQUIRE(partials && mean && invstd && gamma && beta && xhat_amax && out_amax && tiles >= 1 && C >= 1 && count >= 1);
+  hipLaunchKernelGGL(bn_finalize_l2_kernel, dim3((C + 3) / 4), dim3(256), 0, ONDA_STREAM(s), partials, tiles, C, (double)count, eps,
+                     mean, invstd, running_mean, running_var, nbt, momentum, gamma, beta, res_amax, relu, xhat_amax, out_amax);
+  return ONDA_LAUNCH_RESULT();
+}
+
+int onda_bn_apply_l2(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                     const void* res, int64_t res_plane, const float* res_amax, void* out, int64_t out_plane,
+                     const float* out_amax, int64_t M, int C, int relu, onda_stream_t s) {
+  ONDA_REQUIRE(x && mean && invstd && gamma && beta && out && out_amax && C % 8 == 0 && out_plane % 8 == 0 && (!res || res_amax));
+  if (!ONDA_ALIGNED16(x) || !ONDA_ALIGNED16(out) || (res && !ONDA_ALIGNED16(res))) return ONDA_EALIGN;
+  const size_t total8 = (size_t)M * C / 8;
+  hipLaunchKernelGGL(bn_apply_l2_kernel, dim3(ew_grid(total8)), dim3(256), 0, ONDA_STREAM(s), x, mean, invstd, gamma, beta,
+                     static_cast<const _Float16*>(res), (size_t)res_plane, res_amax, static_cast<_Float16*>(out), (size_t)out_plane,
+                     out_amax, total8, C, relu);
+  return ONDA_LAUNCH_RESULT();
+}
+
+int64_t onda_bn_bwd_l2_ws(int64_t M, int C) {
+  const ColPlan3 p = col_plan3(M, C);
+  return (int64_t)p.chunks * 3 * C + 2 * C;
+}
+
+int onda_bn_bwd_l2(const float* dout, const void* out, int64_t out_plane, const float* x, const float* mean, const float* invstd,
+                   const float* gamma, const float* xhat_amax, void* dx, int64_t dx_plane, float* dx_amax, float* dres, float* ws,
+                   int64_t M, int C, int relu, onda_stream_t s) {
+  ONDA_REQUIRE(dout && x && mean && invstd && gamma && xhat_amax && dx && dx_amax && ws && C % 8 == 0 && (!relu || out));
+  if (!ONDA_ALIGNED16(dout) || !ONDA_ALIGNED16(x) || !ONDA_ALIGNED16(dx) || (out && !ONDA_ALIGNED16(out))) return ONDA_EALIGN;
+  const ColPlan3 p = col_plan3(M, C);
+  float* sums = ws + (size_t)p.chunks * 3 * C;
+  hipStream_t st = ONDA_STREAM(s);
+  hipLaunchKernelGGL(bn_bwd_reduce_l2_kernel, dim3(p.gridx, p.chunks), dim3(256), 0, st, dout, static_cast<const _Float16*>(out),
+                     (size_t)out_plane, x, mean, invstd, dres, M, C, relu, p.cx, p.rows_per_chunk, ws);
+  hipLaunchKernelGGL(bn_bwd_sums_l2_kernel, dim3((C + 3) / 4), dim3(256), 0, st, ws, p.chunks, C, 1.0 / (double)M, gamma, invstd,
+                     xhat_amax, sums, dx_amax);
+  const size_t total8 = (size_t)M * C / 8;
+  hipLaunchKernelGGL(bn_bwd_apply_l2_kernel, dim3(ew_grid(total8)), dim3(256), 0, st, dout, static_cast<const _Float16*>(out),
+                     (size_t)out_plane, x, mean, invstd, gamma, sums, static_cast<_Float16*>(dx), (size_t)dx_plane, dx_amax, total8,
+                     C, (float)(1.0 / (double)M), relu);
+  return ONDA_LAUNCH_RESULT();
+}
+
+}  // extern "C"

@@ -68,11 +68,15 @@ def conv_bn(conv, bn, x, relu, residual=None):
     eval mode (static / dynamic models, evaluation): BN folded into the conv epilogue."""
     k, stride, dil, pad = conv.geom()
     if bn.training:
-        y, stats = conv(x, want_stats=True)
+        # "f16x2" with pre-split operands: the BatchNorm output is written as limb planes only (what the next conv, the
+        # residual add and the backward mask read); the conv epilogue then also leaves per-channel extrema (4 stat rows)
+        limbs = ops.limb_mode(conv.out_channels)
+        y, stats = conv(x, want_stats=4 if limbs else True)
         running = (bn.running_mean, bn.running_var, bn.num_batches_tracked) if bn.track_running_stats else None
         if bn.momentum is None:
             raise NotImplementedError("onda_amd: cumulative-average BatchNorm (momentum=None) is not on the hot path")
-        return ops.BNTrainFn.apply(y, stats, bn.weight, bn.bias, residual, relu, running, bn.momentum)
+        fn = ops.BNTrainLimbFn if stats.shape[1] == 4 else ops.BNTrainFn
+        return fn.apply(y, stats, bn.weight, bn.bias, residual, relu, running, bn.momentum)
     scale, shift = bn.folded()
     with torch.no_grad():
         y, _, _ = ops.conv_forward(x, conv._pack.get_fwd(conv.weight), k, stride, dil, pad, conv.out_channels,

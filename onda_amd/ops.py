@@ -190,6 +190,49 @@ def activation_limbs(x):
     return lb
 
 
+def limb_only(shape, device, limbs):
+    """A limb-only activation as autograd sees it: an fp32 [B,H,W,C]-SHAPED tensor without storage behind it (every
+    stride 0) that carries the limb planes; gradients with respect to it are ordinary fp32 tensors of that shape."""
+    t = torch.empty(1, device=device, dtype=torch.float32).as_strided(tuple(shape), (0,) * len(shape))
+    t._onda_limbs = (t._version, limbs)
+    return t
+
+
+def is_limb_only(t):
+    return t.dim() == 4 and t.stride() == (0, 0, 0, 0) and t.numel() > 1
+
+
+def limbs_of(x):
+    """Limb planes of an activation: carried by the tensor (its producer wrote them), or one split pass."""
+    hit = getattr(x, "_onda_limbs", None)
+    if hit is not None and hit[0] == x._version:
+        return hit[1]
+    if is_limb_only(x):
+        raise RuntimeError("onda_amd: a limb-only activation lost its limb planes (it was copied or re-wrapped on the way "
+                           "to its consumer); this is a bug in the caller, there is no fp32 copy to fall back to")
+    return activation_limbs(x)
+
+
+def limb_mode(channels):
+    """Do the BatchNorm kernels write their output as limb planes only (no fp32 copy)?"""
+    return CONV_MODE == "f16x2" and H2_PATH == "dma" and channels % 8 == 0 and LIMB_ONLY
+
+
+LIMB_ONLY = os.environ.get("ONDA_LIMB_ONLY", "1") != "0"
+
+
+def materialize(x):
+    """fp32 NHWC copy of an activation (diagnostics and tests): limb-only tensors are rebuilt from their planes."""
+    if not is_limb_only(x):
+        return x
+    lb = limbs_of(x)
+    B, H, W, C = x.shape
+    planes = lb.planes.reshape(2, B * H * W, lb.ld)[:, :, :C].float()
+    amax = lb.amax.max()
+    e = torch.where((amax > 0) & (amax < 3e38), 15 - torch.frexp(amax)[1], torch.zeros((), dtype=torch.int32, device=x.device))
+    return ((planes[0] + planes[1] / 2048.0) * torch.ldexp(torch.ones((), device=x.device), -e)).reshape(B, H, W, C)
+
+
 def _use_l2(wp, cin):
     return isinstance(wp, H2Weight) and H2_PATH == "dma" and cin % 32 == 0
 
@@ -247,7 +290,7 @@ def conv_forward(x, wp, k, stride, dil, pad, cout, out=None, scale=None, shift=N
     """x NHWC view, wp packed [cout][k*k*Cin].  Returns (y, stats partials or None, tiles)."""
     _require_cuda(x, "conv input")
     B, Hi, Wi, Cin = x.shape
-    ldx = nhwc_ld(x)
+    ldx = 0 if is_limb_only(x) else nhwc_ld(x)
     Ho, Wo = conv_out_size(Hi, k, stride, dil, pad), conv_out_size(Wi, k, stride, dil, pad)
     if out is None:
         out = torch.empty(B, Ho, Wo, cout, device=x.device, dtype=torch.float32)
@@ -259,17 +302,20 @@ def conv_forward(x, wp, k, stride, dil, pad, cout, out=None, scale=None, shift=N
     ldr = nhwc_ld(residual) if residual is not None else 0
     stats, tiles = None, 0
     l2 = _use_l2(wp, Cin)
+    if not l2 and is_limb_only(x):
+        raise RuntimeError("onda_amd: a limb-only activation reached a conv that does not take limb planes")
+    stats_rows = 4 if (l2 and want_stats == 4) else 2  # 4: + per-channel min / max, for the limb-writing BatchNorm
     if want_stats:
         tiles = query("onda_conv_l2_tiles_m", B * Ho * Wo, cout) if l2 else query("onda_conv_tiles_m", B * Ho * Wo)
-        stats = torch.empty(tiles, 2, cout, device=x.device, dtype=torch.float32)
+        stats = torch.empty(tiles, stats_rows, cout, device=x.device, dtype=torch.float32)
     d = _desc(B, Hi, Wi, Cin, Ho, Wo, cout, k, stride, dil, pad, ldx, ldy, ldr, relu=relu)
     if l2:
-        xl = activation_limbs(x)
+        xl = limbs_of(x)
         d.ldx = xl.ld
         yamax = amax_slot(x.device) if (scale is not None or relu) else None
         _launch("conv_l2_kernel<%d>" % query("onda_conv_l2_variant", B * Ho * Wo, cout), 2.0 * B * Ho * Wo * cout * k * k * Cin,
                 "onda_conv2d_fwd_l2", _p(xl.planes), xl.plane, _p(xl.amax), _p(wp.limbs), _p(wp.amax), _p(out), _p(scale),
-                _p(shift), _p(residual), _p(stats), _p(_conv_ws(x.device)), _p(yamax), byref(d), _stream(),
+                _p(shift), _p(residual), _p(stats), stats_rows, _p(_conv_ws(x.device)), _p(yamax), byref(d), _stream(),
                 tag=("fwd", B * Ho * Wo, cout, Cin, k, stride, dil))
         if yamax is not None:
             tag_amax(out, yamax)
@@ -296,7 +342,7 @@ def conv_dgrad(dy, wpd, k, stride, dil, pad, cin, in_hw):
     """Data gradient.  dy NHWC [B,Ho,Wo,Cout(_pad)], wpd = pack_weight_dgrad(weight)."""
     B, Ho, Wo, Co = dy.shape
     Hi, Wi = in_hw
-    ldy = nhwc_ld(dy)
+    ldy = 0 if is_limb_only(dy) else nhwc_ld(dy)
     if stride == 1:
         dx = torch.empty(B, Hi, Wi, cin, device=dy.device, dtype=torch.float32)
         d = _desc(B, Ho, Wo, Co, Hi, Wi, cin, k, 1, dil, dil * (k - 1) - pad, ldy, cin)
@@ -306,14 +352,16 @@ def conv_dgrad(dy, wpd, k, stride, dil, pad, cin, in_hw):
         dx = torch.zeros(B, Hi, Wi, cin, device=dy.device, dtype=torch.float32)
         d = _desc(B, Ho, Wo, Co, Ho, Wo, cin, 1, 1, 1, 0, ldy, cin, out_os=stride, Hf=Hi, Wf=Wi)
     if _use_l2(wpd, Co):
-        dyl = activation_limbs(dy)
+        dyl = limbs_of(dy)
         d.ldx = dyl.ld
         Mo = B * Ho * Wo if stride != 1 else B * Hi * Wi
         _launch("conv_l2_kernel<%d>" % query("onda_conv_l2_variant", Mo, cin), 2.0 * B * Ho * Wo * cin * k * k * Co,
                 "onda_conv2d_fwd_l2", _p(dyl.planes), dyl.plane, _p(dyl.amax), _p(wpd.limbs), _p(wpd.amax), _p(dx), None, None,
-                None, None, _p(_conv_ws(dy.device)), None, byref(d), _stream(),
+                None, None, 2, _p(_conv_ws(dy.device)), None, byref(d), _stream(),
                 tag=("dgrad", Mo, cin, Co, k, stride, dil))
         return dx
+    if is_limb_only(dy):
+        raise RuntimeError("onda_amd: a limb-only gradient reached a data-gradient kernel that does not take limb planes")
     if isinstance(wpd, H2Weight):
         _launch("conv_fwd_h2_kernel<128,%d>" % (128 if cin > 64 else 64), 2.0 * B * Ho * Wo * cin * k * k * Co,
                 "onda_conv2d_fwd_h2", _p(dy), _p(activation_scale(dy)), _p(wpd.limbs), _p(wpd.amax), _p(dx), None, None, None,
@@ -368,10 +416,12 @@ def conv_wgrad(x, dy, k, stride, dil, pad, cout_real, cin_real, flat_k=0, into=N
     l2 = CONV_MODE == "f16x2" and H2_PATH == "dma" and Cin % 8 == 0 and Co % 8 == 0
     sk = _wgrad_splitk(M, Co, Cin, taps, l2)
     slabs = torch.empty(sk, Co, taps, Cin, device=x.device, dtype=torch.float32)
-    d = _desc(B, Hi, Wi, Cin, Ho, Wo, Co, k, stride, dil, pad, nhwc_ld(x), Co)
+    d = _desc(B, Hi, Wi, Cin, Ho, Wo, Co, k, stride, dil, pad, 0 if is_limb_only(x) else nhwc_ld(x), Co)
+    if not l2 and (is_limb_only(x) or is_limb_only(dy)):
+        raise RuntimeError("onda_amd: a limb-only tensor reached a weight-gradient kernel that does not take limb planes")
     if l2:
-        xl = xlimbs if xlimbs is not None else activation_limbs(x)
-        dyl = activation_limbs(dy)
+        xl = xlimbs if xlimbs is not None else limbs_of(x)
+        dyl = limbs_of(dy)
         d.ldx = xl.ld
         _launch("conv_wgrad_l2_kernel<%d>" % query("onda_conv_wgrad_l2_variant", Co, Cin), 2.0 * M * Co * taps * Cin,
                 "onda_conv2d_wgrad_l2", _p(xl.planes), xl.plane, _p(xl.amax), _p(dyl.planes), dyl.plane, _p(dyl.amax), _p(slabs),
@@ -477,7 +527,8 @@ class Conv2dFn(torch.autograd.Function):
     def backward(ctx, dy, _dstats):
         x, weight = ctx.saved_tensors
         k, stride, dil, pad, cout, cin, cout_pad = ctx.geom
-        dy = as_nhwc(dy)
+        if not is_limb_only(dy):
+            dy = as_nhwc(dy)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = conv_dgrad(dy, ctx.cache.get_dgrad(weight, cout_pad), k, stride, dil, pad, cin, x.shape[1:3])
@@ -586,6 +637,67 @@ class BNTrainFn(torch.autograd.Function):
              _p(dres) if (need_res and ctx.relu) else None, _p(ws), M, C, int(ctx.relu), _p(amax), _stream())
         if amax is not None:
             tag_amax(dx, amax)  # dx is the dy of the conv below: data gradient and weight gradient read it
+        return dx, None, None, None, dres, None, None, None
+
+
+class BNTrainLimbFn(torch.autograd.Function):
+    """BNTrainFn whose output exists as limb planes only ("f16x2" / "dma"): the output of a train-mode BatchNorm
+    (+residual, +ReLU) is consumed by convolutions, a later residual add and its own backward mask -- all of which
+    read limb planes -- so no fp32 copy is written.  `stats`: the conv epilogue's [tiles][4][C] partials (sum, sum of
+    squares, min, max); the extrema bound max|out| before the apply pass (csrc/norm_l2.hip).  Backward: dout is an
+    ordinary fp32 tensor, the gradient of the conv output goes out as limb planes again (consumed by the data- and
+    weight-gradient kernels only)."""
+
+    @staticmethod
+    def forward(ctx, y, stats, gamma, beta, residual, relu, running, momentum):
+        B, H, W, C = y.shape
+        M = B * H * W
+        dev = y.device
+        mean = torch.empty(C, device=dev, dtype=torch.float32)
+        invstd = torch.empty_like(mean)
+        xhat_amax = torch.empty_like(mean)
+        rm, rv, nbt = running if running is not None else (None, None, None)
+        res = limbs_of(residual) if residual is not None else None
+        if res is not None and (res.ld != C or tuple(residual.shape) != (B, H, W, C)):
+            raise RuntimeError("onda_amd: residual of a BatchNorm must be a dense [B,H,W,C] activation")
+        out_amax = amax_slot(dev)
+        call("onda_bn_finalize_l2", _p(stats), stats.shape[0], C, M, BN_EPS, _p(mean), _p(invstd), _p(rm), _p(rv), _p(nbt),
+             float(momentum), _p(gamma), _p(beta), _p(res.amax) if res is not None else None, int(relu), _p(xhat_amax),
+             _p(out_amax), _stream())
+        if running is not None:
+            for t in running:
+                torch.autograd.graph.increment_version(t)
+        planes = torch.empty(2, M, C, device=dev, dtype=torch.float16)
+        call("onda_bn_apply_l2", _p(y), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(res.planes) if res is not None else None,
+             res.plane if res is not None else 0, _p(res.amax) if res is not None else None, _p(planes), M * C, _p(out_amax),
+             M, C, int(relu), _stream())
+        lb = Limbs(planes, out_amax, C, M * C)
+        ctx.save_for_backward(y, mean, invstd, gamma, xhat_amax)
+        ctx.out_limbs = lb if relu else None
+        ctx.relu, ctx.has_res = relu, residual is not None
+        return limb_only((B, H, W, C), dev, lb)
+
+    @staticmethod
+    def backward(ctx, dout):
+        y, mean, invstd, gamma, xhat_amax = ctx.saved_tensors
+        B, H, W, C = y.shape
+        M = B * H * W
+        dev = y.device
+        if is_limb_only(dout):
+            raise RuntimeError("onda_amd: the gradient of a BatchNorm output must be an fp32 tensor")
+        dout = dout.contiguous()
+        ws = torch.empty(query("onda_bn_bwd_l2_ws", M, C), device=dev, dtype=torch.float32)
+        planes = torch.empty(2, M, C, device=dev, dtype=torch.float16)
+        dx_amax = amax_slot(dev)
+        need_res = ctx.has_res and ctx.needs_input_grad[4]
+        dres = None
+        if need_res:
+            dres = torch.empty_like(y) if ctx.relu else dout
+        ol = ctx.out_limbs
+        call("onda_bn_bwd_l2", _p(dout), _p(ol.planes) if ol is not None else None, ol.plane if ol is not None else 0, _p(y),
+             _p(mean), _p(invstd), _p(gamma), _p(xhat_amax), _p(planes), M * C, _p(dx_amax),
+             _p(dres) if (need_res and ctx.relu) else None, _p(ws), M, C, int(ctx.relu), _stream())
+        dx = limb_only((B, H, W, C), dev, Limbs(planes, dx_amax, C, M * C))
         return dx, None, None, None, dres, None, None, None
 
 

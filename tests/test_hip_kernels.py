@@ -177,6 +177,65 @@ def test_batchnorm_train(C, H, W, relu, res, track):
         assert torch.equal(rm_d.cpu(), rm)
 
 
+@pytest.mark.parametrize("C,H,W,relu,res,track", [(64, 17, 33, True, False, True), (256, 9, 17, True, True, False),
+                                                    (512, 9, 17, False, False, True), (256, 33, 65, True, True, True)])
+def test_batchnorm_train_limb_planes(C, H, W, relu, res, track):
+    """The limb-writing BatchNorm of the pre-split path (csrc/norm_l2.hip): conv(1x1) -> BN (+residual, +ReLU) -> conv(3x3),
+    the BN output existing as limb planes only.  Forward values (rebuilt from the planes), the scale bound, the second
+    conv's output, and every gradient (input, residual, both weights) against fp32 torch on the CPU."""
+    from onda_amd import ops
+    if not (ops.CONV_MODE == "f16x2" and ops.H2_PATH == "dma"):
+        pytest.skip("limb planes exist in the f16x2 / dma configuration only")
+    g = torch.Generator().manual_seed(C + H + relu)
+    B, Cin = 2, 64
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w1 = torch.randn(C, Cin, 1, 1, generator=g) / Cin ** 0.5
+    w2 = torch.randn(64, C, 3, 3, generator=g) / (9 * C) ** 0.5
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    r = torch.randn(B, C, H, W, generator=g) * 3 if res else None
+    rm, rv = torch.randn(C, generator=g) * 0.1, torch.rand(C, generator=g) + 0.5
+    xr, w1r, w2r = (t.clone().requires_grad_(True) for t in (x, w1, w2))
+    rr = r.clone().requires_grad_(True) if res else None
+    rm_r, rv_r = rm.clone(), rv.clone()
+    y1 = F.conv2d(xr, w1r)
+    z = F.batch_norm(y1, rm_r if track else None, rv_r if track else None, gamma, beta, True, 0.1, 1e-5)
+    if res:
+        z = z + rr
+    if relu:
+        z = F.relu(z)
+    y2 = F.conv2d(z, w2r, None, 1, 2, 2)
+    gy = torch.randn(y2.shape, generator=g)
+    y2.backward(gy)
+
+    xd = nhwc(x).to(DEV).requires_grad_(True)
+    w1d, w2d = w1.to(DEV).requires_grad_(True), w2.to(DEV).requires_grad_(True)
+    rd = nhwc(r).to(DEV).requires_grad_(True) if res else None
+    rm_d, rv_d, nbt = rm.to(DEV), rv.to(DEV), torch.zeros((), dtype=torch.int64, device=DEV)
+    yd, stats = ops.Conv2dFn.apply(xd, w1d, None, ops._PackCache(), 1, 1, 0, 4, None)
+    assert stats.shape[1] == 4
+    ext = stats.cpu()
+    assert torch.all(ext[:, 2].min(0).values <= y1.detach().amin((0, 2, 3)) + 1e-5)
+    assert torch.all(ext[:, 3].max(0).values >= y1.detach().amax((0, 2, 3)) - 1e-5)
+    zd = ops.BNTrainLimbFn.apply(yd, stats, gamma.to(DEV), beta.to(DEV), rd, relu, (rm_d, rv_d, nbt) if track else None, 0.1)
+    assert ops.is_limb_only(zd) and zd.shape == (B, H, W, C)
+    lb = ops.limbs_of(zd)
+    bound, true_max = float(lb.amax.max()), float(z.detach().abs().max())
+    assert true_max <= bound * (1 + 1e-6) and bound <= (2.0 if res else 1.0 + 1e-4) * true_max + 1e-6, (bound, true_max)
+    close(nchw(ops.materialize(zd)), z, 2e-5, "bn fwd (limb planes)")
+    y2d, _ = ops.Conv2dFn.apply(zd, w2d, None, ops._PackCache(), 1, 2, 2, False, None)
+    close(nchw(y2d), y2, 3e-5, "conv on limb planes")
+    y2d.backward(nhwc(gy).to(DEV))
+    close(nchw(xd.grad), xr.grad, 2e-4, "dx through BN")
+    close(w2d.grad, w2r.grad, 1e-4, "wgrad from limb-only x")
+    close(w1d.grad, w1r.grad, 2e-4, "wgrad from limb-only dy")
+    if res:
+        close(nchw(rd.grad), rr.grad, 1e-4, "bn dres")
+    if track:
+        close(rm_d, rm_r, 1e-5, "running mean")
+        close(rv_d, rv_r, 1e-5, "running var")
+        assert int(nbt) == 1
+
+
 def test_bn_fold_matches_eval_batchnorm():
     from onda_amd import ops
     g = torch.Generator().manual_seed(9)

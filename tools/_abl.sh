@@ -1,1 +1,1 @@
-timeout 600 python tools/wgrad_l2_bench.py 2>&1 | tail -16 | cut -c1-190
+timeout 900 python -m pytest tests/test_hip_kernels.py -m gpu -x -q -k "limb_planes or batchnorm or conv_fwd_bwd" 2>&1 | tail -15
