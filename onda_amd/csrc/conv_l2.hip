@@ -494,7 +494,14 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_wgrad_l2_kernel(const 
   const int wm = wave / WN, wn = wave % WN;
   const bool late = wave >= NW / 2;
 
-  int bid = blockIdx.x;
+  // workgroups are dealt round-robin over the 8 XCDs: hand each XCD a contiguous band of the (pixel range, tap,
+  // channel tile) order, so that the workgroups that stream the same dy rows (all input-channel tiles of one tap and
+  // pixel range) and the same x rows (the taps of one pixel range) find them in one L2
+  int bid;
+  {
+    const int nblk = gridDim.x, q = nblk >> 3, r = nblk & 7, xcd = blockIdx.x & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+  }
   const int tile_c = bid % a.tilesC;
   bid /= a.tilesC;
   const int tap = bid % a.taps;

@@ -131,14 +131,15 @@ __global__ __launch_bounds__(256) void bn_apply_l2_kernel(const float* __restric
   const int c8 = C / 8;
   const float so = scale_of(out_amax).s;
   const float ri = res ? scale_of(res_amax).inv : 0.f;
-  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total8; e += (size_t)gridDim.x * blockDim.x) {
-    const int col = (int)(e % c8) * 8;
-    f32x4 v0, v1;
-    {
-      const f32x4 sc0 = LD4(invstd + col) * LD4(gamma + col), sc1 = LD4(invstd + col + 4) * LD4(gamma + col + 4);
-      v0 = (LD4(x + e * 8) - LD4(mean + col)) * sc0 + LD4(beta + col);
-      v1 = (LD4(x + e * 8 + 4) - LD4(mean + col + 4)) * sc1 + LD4(beta + col + 4);
-    }
+  // the grid stride (a multiple of 256) is a multiple of c8 (a power of two <= 256 in this network; checked on the host):
+  // a thread stays on its 8 channels, so their parameters are loaded once
+  const size_t e0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int col = (int)(e0 % c8) * 8;
+  const f32x4 sc0 = LD4(invstd + col) * LD4(gamma + col), sc1 = LD4(invstd + col + 4) * LD4(gamma + col + 4);
+  const f32x4 mu0 = LD4(mean + col), mu1 = LD4(mean + col + 4), be0 = LD4(beta + col), be1 = LD4(beta + col + 4);
+  for (size_t e = e0; e < total8; e += (size_t)gridDim.x * blockDim.x) {
+    f32x4 v0 = (LD4(x + e * 8) - mu0) * sc0 + be0;
+    f32x4 v1 = (LD4(x + e * 8 + 4) - mu1) * sc1 + be1;
     if (res) {
       f32x4 r0, r1;
       join8(*reinterpret_cast<const u32x4*>(res + e * 8), *reinterpret_cast<const u32x4*>(res + res_plane + e * 8), r0, r1);
@@ -183,13 +184,16 @@ static inline ColPlan3 col_plan3(int64_t M, int C) {
   return p;
 }
 
-__device__ __forceinline__ f32x4 relu_mask4(const _Float16* __restrict__ out, size_t plane, size_t o, f32x4 g) {
-  const u32x2 h1 = *reinterpret_cast<const u32x2*>(out + o), h2 = *reinterpret_cast<const u32x2*>(out + plane + o);
+// g * [out > 0] from the FIRST limb of out (2 bytes per element).  The first limb of a positive element is zero only below
+// 2^-40 of the tensor maximum (f16 subnormals reach 2^-24, the scale puts the maximum at 2^15): there the gradient is
+// dropped, at the kink of the ReLU.
+__device__ __forceinline__ f32x4 relu_mask4(const _Float16* __restrict__ out, size_t o, f32x4 g) {
+  const u32x2 h1 = *reinterpret_cast<const u32x2*>(out + o);
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
-    const f32x2 a = unpack2h(h1[j]), b = unpack2h(h2[j]);
-    g[2 * j] = (a[0] > 0.f || (a[0] == 0.f && b[0] > 0.f)) ? g[2 * j] : 0.f;
-    g[2 * j + 1] = (a[1] > 0.f || (a[1] == 0.f && b[1] > 0.f)) ? g[2 * j + 1] : 0.f;
+    const f32x2 a = unpack2h(h1[j]);
+    g[2 * j] = a[0] > 0.f ? g[2 * j] : 0.f;
+    g[2 * j + 1] = a[1] > 0.f ? g[2 * j + 1] : 0.f;
   }
   return g;
 }
@@ -213,7 +217,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_l2_kernel(const float* __re
     for (int64_t r = r0 + ty; r < r1; r += ry_n) {
       const size_t o = (size_t)r * C + col;
       f32x4 g = LD4(dout + o);
-      if (relu) g = relu_mask4(out, out_plane, o, g);
+      if (relu) g = relu_mask4(out, o, g);
       if (dres) *reinterpret_cast<f32x4*>(dres + o) = g;
       const f32x4 xh = (LD4(x + o) - mu) * is;
       s1 += g;
@@ -282,18 +286,27 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_l2_kernel(const float* __res
                                                               int relu) {
   const int c8 = C / 8;
   const float sd = scale_of(dx_amax).s;
-  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total8; e += (size_t)gridDim.x * blockDim.x) {
-    const int col = (int)(e % c8) * 8;
+  const size_t e0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int col = (int)(e0 % c8) * 8;  // fixed per thread (see bn_apply_l2_kernel)
+  f32x4 is[2], mu[2], gi[2], m1[2], m2[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int cc = col + 4 * h;
+    is[h] = LD4(invstd + cc);
+    mu[h] = LD4(mean + cc);
+    gi[h] = LD4(gamma + cc) * is[h];
+    m1[h] = LD4(sums + cc) * inv_m;
+    m2[h] = LD4(sums + C + cc) * inv_m;
+  }
+  for (size_t e = e0; e < total8; e += (size_t)gridDim.x * blockDim.x) {
     f32x4 v[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const size_t o = e * 8 + 4 * h;
-      const int cc = col + 4 * h;
       f32x4 g = LD4(dout + o);
-      if (relu) g = relu_mask4(out, out_plane, o, g);
-      const f32x4 is = LD4(invstd + cc);
-      const f32x4 xh = (LD4(x + o) - LD4(mean + cc)) * is;
-      v[h] = LD4(gamma + cc) * is * (g - LD4(sums + cc) * inv_m - xh * (LD4(sums + C + cc) * inv_m));
+      if (relu) g = relu_mask4(out, o, g);
+      const f32x4 xh = (LD4(x + o) - mu[h]) * is[h];
+      v[h] = gi[h] * (g - m1[h] - xh * m2[h]);
     }
     u32x4 l1, l2;
     split8(v[0] * sd, v[1] * sd, l1, l2);
@@ -326,6 +339,7 @@ int onda_bn_apply_l2(const float* x, const float* mean, const float* invstd, con
                      const void* res, int64_t res_plane, const float* res_amax, void* out, int64_t out_plane,
                      const float* out_amax, int64_t M, int C, int relu, onda_stream_t s) {
   ONDA_REQUIRE(x && mean && invstd && gamma && beta && out && out_amax && C % 8 == 0 && out_plane % 8 == 0 && (!res || res_amax));
+  ONDA_REQUIRE(256 % (C / 8) == 0 || (C / 8) % 256 == 0);  // a thread keeps its channel group across the grid stride
   if (!ONDA_ALIGNED16(x) || !ONDA_ALIGNED16(out) || (res && !ONDA_ALIGNED16(res))) return ONDA_EALIGN;
   const size_t total8 = (size_t)M * C / 8;
   hipLaunchKernelGGL(bn_apply_l2_kernel, dim3(ew_grid(total8)), dim3(256), 0, ONDA_STREAM(s), x, mean, invstd, gamma, beta,
@@ -343,6 +357,7 @@ int onda_bn_bwd_l2(const float* dout, const void* out, int64_t out_plane, const 
                    const float* gamma, const float* xhat_amax, void* dx, int64_t dx_plane, float* dx_amax, float* dres, float* ws,
                    int64_t M, int C, int relu, onda_stream_t s) {
   ONDA_REQUIRE(dout && x && mean && invstd && gamma && xhat_amax && dx && dx_amax && ws && C % 8 == 0 && (!relu || out));
+  ONDA_REQUIRE(256 % (C / 8) == 0 || (C / 8) % 256 == 0);
   if (!ONDA_ALIGNED16(dout) || !ONDA_ALIGNED16(x) || !ONDA_ALIGNED16(dx) || (out && !ONDA_ALIGNED16(out))) return ONDA_EALIGN;
   const ColPlan3 p = col_plan3(M, C);
   float* sums = ws + (size_t)p.chunks * 3 * C;

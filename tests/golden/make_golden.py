@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Generate the golden vectors (G1-G9) by IMPORTING the reference on CPU.
+"""Generate the golden vectors (G1-G11) by IMPORTING the reference on CPU.
 
 Run in the build container only (the reference does not exist on the GPU box):
 
@@ -410,7 +410,66 @@ def g9():
     save("g9_pipeline", **res)
 
 
+def g10():
+    """One full hybrid_proDA step (+update_ema) at the BASELINE size -- 512x1024, batch 4, static branch -- on the
+    reference (CPU: a few minutes, ~12 GB): log dict, pseudo-label map with its tie mask, prototypes before / after,
+    strided digests of every student / teacher tensor after the step."""
+    import warnings
+    with tempfile.TemporaryDirectory() as tmp:
+        cfg, spec = make_cfg(tmp)
+        cfg.SCHEME.RESOLUTION = [1024, 512]
+        cfg.TRAINING.BATCH_SIZE = 4
+        model = ref_model(1, 40.0)
+        da = hybrid_proDA(model, cfg, spec)
+        src = [synth_batch(4, 512, 1024, seed=1000 + i) for i in range(2)]
+        trg = synth_batch(4, 512, 1024, seed=2000)
+        torch.manual_seed(123)
+        da.update_dynamic()
+        switch_batch_statistics(da.model, False)
+        da.calculate_prototypes(src)
+        switch_batch_statistics(da.model, True)
+        res = {"proto0": da.prototypes.prototypes.clone(), "counter0": da.prototypes.counter.clone()}
+        da.optimizer.zero_grad()
+        da.adjust_learning_rate(0, 6)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            log = da.step([src[0]], trg)
+        da.update_ema()
+        lg = tolog(log)
+        res["log_json"] = np.array(json.dumps({k: v for k, v in lg.items() if np.isscalar(v)}))
+        soft = trg["stored_predictions"].to(torch.float32)  # [4,19,65,129]
+        top2 = soft.topk(2, dim=1)[0]
+        res["labels"] = soft.argmax(1).to(torch.uint8)
+        res["tie_mask"] = np.packbits(((top2[:, 0] - top2[:, 1]) < 2e-3).numpy())
+        res["soft_digest"] = digest(soft, 4096)
+        res["soft_max"] = soft.max(1)[0].to(torch.float16)
+        res["proto1"], res["sqmean1"] = da.prototypes.prototypes.clone(), da.prototypes.squared_mean.clone()
+        res["branch"] = np.array(da.model_select.current)
+        names, dig = [], []
+        for who, mod in (("student.", da.model), ("teacher.", da.ema_model)):
+            for n, p in mod.state_dict().items():
+                names.append(who + n)
+                dig.append(digest(p.float(), 64))
+        res["state_names"], res["state_digest"] = np.array(names), np.stack(dig)
+        save("g10_step_full", **res)
+        print("g10 branch", res["branch"], {k: round(v, 5) for k, v in lg.items() if np.isscalar(v)})
+
+
+def g11():
+    """Eval-mode forward of one full-resolution frame of BASELINE config 5 (1 x 3 x 1024 x 2048): class map of
+    interp(out).softmax.argmax, its tie mask, the logits on a 4-pixel grid and digests."""
+    m = ref_model(1, 3.0).eval()
+    b = synth_batch(1, 1024, 2048, seed=11)
+    with torch.no_grad():
+        _, o = m(b["image"])
+        up, amap = interp_argmax(o["out"], (1024, 2048))
+    top2 = up.topk(2, dim=1)[0]
+    tie = (top2[:, 0] - top2[:, 1]) < 1e-3 * up.abs().max()
+    save("g11_eval_1024x2048", argmax=amap.to(torch.uint8), tie_mask=np.packbits(tie.numpy()), out_grid=o["out"][:, :, ::4, ::4],
+         out_digest=digest(o["out"], 4096), feat_digest=digest(o["feat"], 4096), out_absmax=o["out"].abs().max())
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
     for w in which:
         globals()[w]()

@@ -52,6 +52,44 @@ def conv_mode(request):
     ops.CONV_MODE = old
 
 
+# the dominant shapes at the BASELINE size (4 x 65 x 129 pixels; layer1 at 4 x 129 x 257): what only full-size problems
+# reach -- whole rounds of 256 x 128 tiles + a stream-K remainder, split-K weight gradients, offsets past 2^31 / 4
+FULL_SIZE_CASES = [
+    # cin, cout, k, dil, H, W
+    (2048, 256, 3, 6, 65, 129),
+    (2048, 256, 3, 24, 65, 129),
+    (512, 512, 3, 4, 65, 129),
+    (1024, 256, 1, 1, 65, 129),
+    (64, 256, 1, 1, 129, 257),
+]
+
+
+@pytest.mark.parametrize("case", FULL_SIZE_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_conv_full_size_against_torch_cpu(case):
+    """Forward, data gradient and weight gradient of the default conv path at the BASELINE problem size against
+    fp32 torch on the CPU (max-norm, relative to the largest reference value)."""
+    from onda_amd import ops
+    cin, cout, k, dil, H, W = case
+    g = torch.Generator().manual_seed(sum(case))
+    B, pad = 4, dil * (k - 1) // 2
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    yr = F.conv2d(xr, wr, None, 1, pad, dil)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    xd = nhwc(x).to(DEV).requires_grad_(True)
+    wd = w.to(DEV).requires_grad_(True)
+    y, stats = ops.Conv2dFn.apply(xd, wd, None, ops._PackCache(), 1, dil, pad, True, None)
+    close(nchw(y), yr, 2e-5, "conv fwd")
+    s = stats.sum(0).cpu()
+    close(s[0], yr.sum((0, 2, 3)), 1e-4, "stats sum")
+    close(s[1], (yr ** 2).sum((0, 2, 3)), 1e-4, "stats sumsq")
+    y.backward(nhwc(gy).to(DEV))
+    close(nchw(xd.grad), xr.grad, 2e-5, "dgrad")
+    close(wd.grad, wr.grad, 1e-4, "wgrad")
+
+
 @pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "x".join(map(str, c[:6])))
 def test_conv_fwd_bwd(case, conv_mode):
     from onda_amd import ops

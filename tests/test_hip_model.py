@@ -244,6 +244,113 @@ def test_full_step_golden(golden, tmp_path, tag, head_scale):
         deeplabv2.drop_mask_fn = deeplabv2._default_drop_mask
 
 
+def test_full_size_step_golden(golden, tmp_path, conv_mode):
+    """The measured unit itself: ONE hybrid_proDA step (+update_ema) at 512x1024, batch 4 (BASELINE config 3), against
+    the reference's run of the same step (fixture G10): branch, log dict, pseudo-label map (outside the reference's own
+    numerical ties), prototypes before / after, post-step weight updates."""
+    if conv_mode != "f16x2":
+        pytest.skip("full-size step: default conv mode only (the small-size step runs in all three)")
+    from onda_amd.config import hybrid_switch_cfg
+    from onda_amd.framework.handlers import get_adapt_method, get_model
+    from onda_amd.framework.model import deeplabv2
+    from onda_amd.framework.domain_adaptation.methods.adaptation_model import switch_batch_statistics
+    from onda_amd.synthetic import fill_state_dict, synth_batch
+    from oracle import model as omodel
+    g = golden("g10_step_full")
+    cfg, spec = hybrid_switch_cfg(1024, 512, DEV, str(tmp_path), batch_size=4)
+    model = get_model(cfg, 19)
+    fill_state_dict(model, 1, 40.0)
+    da = get_adapt_method(cfg)(model, cfg, spec)
+    src = [synth_batch(4, 512, 1024, seed=1000 + i) for i in range(2)]
+    trg = synth_batch(4, 512, 1024, seed=2000)
+    torch.manual_seed(123)
+    masks = iter([omodel.draw_drop_mask(4) for _ in range(6)])  # same CPU draws as the reference run
+    deeplabv2.drop_mask_fn = lambda B, C, p, dev: next(masks).to(dev)
+    try:
+        da.update_dynamic()
+        switch_batch_statistics(da.model, False)
+        da.calculate_prototypes(src, save=False)
+        switch_batch_statistics(da.model, True)
+        np.testing.assert_allclose(da.prototypes.prototypes.cpu().numpy(), g["proto0"], rtol=1e-3, atol=1e-4)
+        np.testing.assert_allclose(da.prototypes.counter.cpu().numpy(), g["counter0"])
+        da.optimizer.zero_grad()
+        before = {who + k: digest(v.float(), 64)[2:] for who, mod in (("student.", da.model), ("teacher.", da.ema_model))
+                  for k, v in mod.state_dict().items()}
+        da.adjust_learning_rate(0, 6)
+        log = da.step([src[0]], trg)
+        da.update_ema()
+    finally:
+        deeplabv2.drop_mask_fn = deeplabv2._default_drop_mask
+    assert int(g["branch"]) == da.model_select.current
+    soft = trg["stored_predictions"].float().cpu()
+    labels = soft.argmax(1).to(torch.uint8).numpy()
+    tie = np.unpackbits(g["tie_mask"])[: labels.size].reshape(labels.shape).astype(bool)
+    wrong = (labels != g["labels"]) & ~tie
+    assert wrong.sum() == 0, int(wrong.sum())
+    assert np.abs(soft.max(1)[0].numpy() - g["soft_max"].astype(np.float32)).max() < 3e-3
+    for k, v in json.loads(str(g["log_json"])).items():
+        mine = log[k]
+        mine = mine.item() if isinstance(mine, torch.Tensor) else float(mine)
+        assert _log_close(mine, v, k, 0, labels.size), (k, mine, v)
+    np.testing.assert_allclose(da.prototypes.prototypes.cpu().numpy(), g["proto1"], rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(da.prototypes.squared_mean.cpu().numpy(), g["sqmean1"], rtol=1e-3, atol=1e-4)
+    names, dg = list(g["state_names"]), g["state_digest"]
+    num = den = 0.0
+    for who, mod in (("student.", da.model), ("teacher.", da.ema_model)):
+        for k, v in mod.state_dict().items():
+            if not v.is_floating_point() or v.dim() == 0:
+                continue
+            row = dg[names.index(who + k)][2:]
+            num += ((digest(v.float(), 64)[2:] - row) ** 2).sum()
+            den += ((row - before[who + k]) ** 2).sum()
+    assert (num / den) ** 0.5 <= 0.02, (num / den) ** 0.5  # post-step weights, as updates (see test_full_step_golden)
+
+
+def test_eval_forward_1024x2048_golden(golden, conv_mode):
+    """One frame at the resolution of BASELINE config 5: class map against the reference's (fixture G11)."""
+    from onda_amd import ops
+    from onda_amd.synthetic import synth_batch
+    g = golden("g11_eval_1024x2048")
+    m = build_model(1, 3.0).eval()
+    x = synth_batch(1, 1024, 2048, seed=11)["image"].to(DEV)
+    with torch.no_grad():
+        _, o = m(x)
+        cls = ops.upsample_argmax(o["out"], (1024, 2048)).cpu().numpy()
+    assert o["out"].shape == (1, 19, 129, 257)
+    grid = o["out"][:, :, ::4, ::4].cpu().numpy()
+    assert np.abs(grid - g["out_grid"]).max() <= 1e-3 * float(g["out_absmax"])
+    tie = np.unpackbits(g["tie_mask"])[: cls.size].reshape(cls.shape).astype(bool)
+    diff = cls != g["argmax"]
+    assert (diff & ~tie).sum() == 0 and diff.mean() < 1e-5, (int((diff & ~tie).sum()), float(diff.mean()))
+    np.testing.assert_allclose(digest(o["feat"], 4096)[2:], g["feat_digest"][2:], rtol=0,
+                               atol=1e-3 * np.abs(g["feat_digest"][2:]).max())
+
+
+def test_eval_after_train_step_uses_fresh_running_statistics():
+    """eval forward -> one train-mode forward that moves the running statistics -> eval forward again: the folded
+    BatchNorm of the second eval pass must be rebuilt (the kernel writes the buffers behind torch's back)."""
+    from onda_amd.framework.domain_adaptation.methods.adaptation_model import switch_batch_statistics
+    m = build_model(3, 3.0)
+    x = torch.randn(2, 3, 64, 128, device=DEV)
+    m.eval()
+    with torch.no_grad():
+        a = m(x)[1]["out"].clone()
+    m.train()
+    switch_batch_statistics(m, True)
+    with torch.no_grad():
+        m(x * 2 + 1)
+    m.eval()
+    with torch.no_grad():
+        b = m(x)[1]["out"].clone()
+        fresh = deepcopy(m)
+        for mod in fresh.modules():
+            mod.__dict__.pop("_fold", None)
+            mod.__dict__.pop("_fold_key", None)
+        c = fresh(x)[1]["out"]
+    assert not torch.equal(a, b)
+    assert torch.equal(b, c)
+
+
 def test_evaluate_path_matches_oracle(tmp_path):
     """da_model.evaluate: forward -> fused upsample/argmax/confusion-matrix on the GPU
     against the oracle's interp -> softmax -> argmax -> np.bincount (BASELINE config 1 flow, small)."""
