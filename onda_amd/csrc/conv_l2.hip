@@ -487,7 +487,8 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_wgrad_l2_kernel(const 
   static_assert(GPW >= 1 && 8 % NW == 0, "8 pixel groups per K-step");
   constexpr int DPW = GPW * (SA + SB) * 2;                   // LDS-DMA instructions per wave per K-step
   constexpr bool STAGGER = NW == 8;
-  __shared__ __attribute__((aligned(16))) unsigned char lds[STAGES * STAGE];
+  constexpr int MAX_KT = 2048;  // K-steps of one workgroup (pixel range / 32); the host splits longer ranges
+  __shared__ __attribute__((aligned(16))) unsigned char lds[STAGES * STAGE + MAX_KT * 2];
 
   const OndaConv& c = a.c;
   const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -518,20 +519,30 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_wgrad_l2_kernel(const 
   const Scale2 sx = scale_of(xamax), sd = scale_of(dyamax);
   const float unscale_a = sx.inv, unscale_b = sd.inv;
 
-  // a K-step (32 pixels from m) is dead when every output row it touches maps to an input row outside the image
-  auto step_live = [&](int kt) -> bool {
-    const int m_first = mbeg + kt * 32, m_last = min(mend, m_first + 32) - 1;
-    const int r_first = m_first / c.Wo, r_last = m_last / c.Wo;  // global output row index (b*Ho + ho)
-    for (int r = r_first; r <= r_last; ++r) {
-      const int hi = (r % c.Ho) * c.stride + dh;
-      if ((unsigned)hi < (unsigned)c.Hi) return true;
+  // The live K-steps of this workgroup, listed once into LDS (a K-step -- 32 pixels -- is dead when every output row it
+  // touches maps to an input row outside the image for this tap: whole rows of a dilated tap).  The integer divisions
+  // happen here, a few per thread, instead of several per K-step on the scalar unit.
+  unsigned short* live_list = reinterpret_cast<unsigned short*>(lds + STAGES * STAGE);
+  int nlive = 0;
+  {
+    unsigned char* flags = lds;  // scratch: the ring is not in use yet
+    for (int kt = t; kt < KT; kt += NW * 64) {
+      const int m_first = mbeg + kt * 32, m_last = min(mend, m_first + 32) - 1;
+      const int r_first = m_first / c.Wo, r_last = m_last / c.Wo;  // global output row (b*Ho + ho)
+      bool live = false;
+      for (int r = r_first; r <= r_last; ++r) live |= (unsigned)((r % c.Ho) * c.stride + dh) < (unsigned)c.Hi;
+      flags[kt] = live;
     }
-    return false;
-  };
-  auto next_live = [&](int kt) -> int {
-    while (kt < KT && !step_live(kt)) ++kt;
-    return kt;
-  };
+    __syncthreads();
+    for (int base = 0; base < KT; base += 64) {  // every wave compacts the whole list (same result; no second barrier needed
+      const bool f = base + lane < KT && flags[base + lane];  // before the list is read: each wave reads what it wrote)
+      const unsigned long long mask = __ballot(f);
+      if (f) live_list[nlive + __popcll(mask & ((1ull << lane) - 1))] = (unsigned short)(base + lane);
+      nlive += __popcll(mask);
+    }
+    __syncthreads();  // (all waves wrote identical values; the barrier also frees `flags` for the ring)
+  }
+  auto live_at = [&](int i) -> int { return __builtin_amdgcn_readfirstlane((int)live_list[i]); };
 
   // DMA roles: this wave moves pixel groups grp = wave*GPW + d (4 pixels each) of every K-step, both operands, both limbs
   const int prow = lane >> 4;  // pixel inside the group
@@ -544,12 +555,12 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_wgrad_l2_kernel(const 
 #pragma unroll
     for (int sI = 0; sI < SA; ++sI) {
       const int n = n0 + sI * 128 + ch * 8;
-      ch_dy[d][sI] = n < c.Cout ? (unsigned)n * 2u : OOB;
+      ch_dy[d][sI] = n < c.Cout ? (unsigned)n * 2u : dy_bytes;  // past the buffer whatever pixel offset is added
     }
 #pragma unroll
     for (int sI = 0; sI < SB; ++sI) {
       const int cc = c0 + sI * 128 + ch * 8;
-      ch_x[d][sI] = cc < c.Cin ? (unsigned)cc * 2u : OOB;
+      ch_x[d][sI] = cc < c.Cin ? (unsigned)cc * 2u : x_bytes;
     }
   }
   // this lane's pixel of each group: (image, output row, output column), advanced incrementally (no division in the loop)
@@ -592,13 +603,13 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_wgrad_l2_kernel(const 
 #pragma unroll
         for (int sI = 0; sI < SA; ++sI) {
           unsigned char* dst = lds + stage_off + l * A_LIMB + sI * SUB + grp * 1024;
-          const unsigned vo = (pdy | ch_dy[d][sI]) >= OOB ? OOB : pdy + ch_dy[d][sI];
+          const unsigned vo = pdy + ch_dy[d][sI];  // OOB (2^31) + anything below 2^31 stays out of range, no wrap
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rdy, (__attribute__((address_space(3))) void*)dst, 16, vo, l * dyplane, 0, 0);
         }
 #pragma unroll
         for (int sI = 0; sI < SB; ++sI) {
           unsigned char* dst = lds + stage_off + A_BYTES + l * B_LIMB + sI * SUB + grp * 1024;
-          const unsigned vo = (px | ch_x[d][sI]) >= OOB ? OOB : px + ch_x[d][sI];
+          const unsigned vo = px + ch_x[d][sI];
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)dst, 16, vo, l * xplane, 0, 0);
         }
       }
@@ -636,13 +647,12 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_wgrad_l2_kernel(const 
       for (int e = 0; e < 4; ++e) acc[i][j][e] = accx[i][j][e] = 0.f;
 
   // the live K-steps, fetched two ahead
-  int k_cur = next_live(0);
-  int k_iss = k_cur;
+  int i_cur = 0, i_iss = 0;
   int st_issue = 0, st_read = 0;
   auto issue_next = [&]() {
-    issue(k_iss, st_issue);
+    issue(live_at(i_iss), st_issue);
     st_issue = st_issue + STAGE == STAGES * STAGE ? 0 : st_issue + STAGE;
-    k_iss = next_live(k_iss + 1);
+    ++i_iss;
   };
   auto wait_landed = [&](bool more_in_flight) {
     if (more_in_flight)
@@ -650,8 +660,8 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_wgrad_l2_kernel(const 
     else
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   };
-  if (k_iss < KT) issue_next();
-  if (k_iss < KT) issue_next();
+  if (i_iss < nlive) issue_next();
+  if (i_iss < nlive) issue_next();
   f16x8 af[4][2], bf[4], b1[4];
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
   unsigned base;
@@ -689,37 +699,32 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_wgrad_l2_kernel(const 
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][0], b1[j], acc[i][j], 0, 0, 0);
   };
-  // (k_cur, its successor, the one after): the loop needs to know how many live steps remain -- count as it goes
   if constexpr (!STAGGER) {
-    while (k_cur < KT) {
-      const int k_nxt = next_live(k_cur + 1);
-      wait_landed(k_nxt < KT);
+    for (; i_cur < nlive; ++i_cur) {
+      wait_landed(i_cur + 1 < nlive);
       __builtin_amdgcn_s_barrier();
-      if (k_iss < KT) issue_next();
+      if (i_iss < nlive) issue_next();
       prepare();
       prepared();
       compute();
-      k_cur = k_nxt;
     }
   } else {
-    if (late && k_cur < KT) {
-      wait_landed(next_live(k_cur + 1) < KT);
+    if (late && nlive > 0) {
+      wait_landed(nlive > 1);
       __builtin_amdgcn_s_barrier();
     }
-    while (k_cur < KT) {
-      const int k_nxt = next_live(k_cur + 1);
-      if (!late) wait_landed(k_nxt < KT);
+    for (; i_cur < nlive; ++i_cur) {
+      if (!late) wait_landed(i_cur + 1 < nlive);
       __builtin_amdgcn_s_barrier();
-      if (late && k_iss < KT) issue_next();
+      if (late && i_iss < nlive) issue_next();
       prepare();
       prepared();
-      if (late && k_nxt < KT) wait_landed(next_live(k_nxt + 1) < KT);
+      if (late && i_cur + 1 < nlive) wait_landed(i_cur + 2 < nlive);
       __builtin_amdgcn_s_barrier();
-      if (!late && k_iss < KT) issue_next();
+      if (!late && i_iss < nlive) issue_next();
       compute();
-      k_cur = k_nxt;
     }
-    if (!late && next_live(0) < KT) __builtin_amdgcn_s_barrier();
+    if (!late && nlive > 0) __builtin_amdgcn_s_barrier();
   }
 
 #pragma unroll
@@ -893,6 +898,7 @@ int onda_conv2d_wgrad_l2(const void* xl, int64_t xplane, const float* xamax, con
   k.lddy = lddy;
   k.splitk = splitk;
   k.mchunk = (int)(((M + splitk - 1) / splitk + 31) / 32 * 32);
+  ONDA_REQUIRE(k.mchunk / 32 <= 2048);  // the kernel lists a workgroup's live K-steps in LDS (MAX_KT); raise splitk beyond that
   k.taps = c->kh * c->kw;
   const int variant = onda_conv_wgrad_l2_variant(c->Cout, c->Cin);
   const int TN = variant == 0 ? 256 : 128;

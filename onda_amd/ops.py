@@ -383,7 +383,8 @@ def _wgrad_splitk(M, cout, cin, taps, l2=False):
         tn = 256 if query("onda_conv_wgrad_l2_variant", cout, cin) == 0 else 128
         tiles = -(-cout // tn) * -(-cin // 128) * taps
         G = query("onda_conv_ws_floats") // (3 * 128 * 128) // 2
-        return _best_splitk(M, cout, cin, taps, tiles, G, 3.2e14 if tn == 256 else 2.0e14)
+        # (the kernel lists a workgroup's K-steps in LDS: at most 2048 steps of 32 pixels per split)
+        return max(_best_splitk(M, cout, cin, taps, tiles, G, 3.2e14 if tn == 256 else 2.0e14), -(-M // 65536))
     t = 128 if (cout > 64 and cin > 64) else 64
     tiles = -(-cout // t) * -(-cin // t) * taps
     G = query("onda_conv_ws_floats") // (3 * 128 * 128) * (1 if t == 128 else 2)
