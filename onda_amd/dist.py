@@ -1,16 +1,18 @@
-"""Multi-GPU exchange for the batch-sharded adaptation step: one process per GPU,
-``torch.distributed`` (backend "nccl" = RCCL over xGMI on ROCm; "gloo" in the CPU tests).
+"""Multi-GPU exchange for the batch-sharded adaptation step: one process per GPU, ``torch.distributed`` (backend
+"nccl" = RCCL over xGMI on ROCm; "gloo" in the CPU tests and when several ranks share one GPU).
 
-Per step there are exactly three exchanges, all of them skipped when the
-process group is absent or has one rank:
-  1. gradients: ONE all-reduce of a flat 46 M-float bucket after the second backward
-     (source + target gradients are accumulated locally first);
-  2. prototype statistics [sum feat | sum feat^2 | count] (9 747 floats) before the EMA
-     blend, so the blend equals the global-batch formula;
-  3. the switch scalars (mean max-probabilities) so that every rank's ``model_select``
-     takes the same static/dynamic branch.
-BatchNorm statistics stay rank-local (each rank normalises over its own micro-batch, like
-the bs=4 reference); teacher EMA and SGD are replicated (identical inputs, identical result).
+The step shards by batch and has ONE real exchange.  Per step there are two collectives:
+  1. a handful of switch scalars (mean max-probabilities of teacher and static model) right after those two forward
+     passes -- every rank's ``model_select`` must take the same static / dynamic branch.  The all-reduce and the copy to
+     the host are enqueued behind the forward passes and read only after the student's target forward has been
+     launched, so neither the GPU nor the link ever waits for the host;
+  2. the gradient exchange: every parameter's ``.grad`` is a VIEW into one persistent flat buffer (no ``cat``, no copy
+     back); the buffer is cut into buckets that are all-reduced asynchronously as soon as the last backward pass has
+     produced their gradients (hooks), i.e. overlapped with the rest of that backward pass.  The prototype statistics
+     [sum feat | sum feat^2 | count], the deferred monitor scalars and the BatchNorm running statistics ride in the tail
+     of the same buffer, so they cost no collective of their own.
+BatchNorm batch statistics stay rank-local (each rank normalises over its own micro-batch, like the bs=4 reference);
+SGD and the teacher EMA are replicated (identical inputs, identical result).
 """
 import os
 
@@ -76,30 +78,133 @@ def barrier():
         dist.barrier()
 
 
+def seed_offset():
+    """Per-rank offset for random draws that must DIFFER between ranks (Dropout2d masks): with the same seed on every
+    rank, all ranks would drop the same feature channels of their different micro-batches."""
+    return rank() * 1000003
+
+
 class GradSync:
-    """Averages the gradients of `module` over ranks with one flat all-reduce."""
+    """Gradient exchange of `module`: flat buffer, bucketed, overlapped with the last backward pass of a step.
 
-    def __init__(self, module):
+    `tail_floats` extra floats behind the gradients travel with the last bucket (``tail`` view): the caller fills them
+    before ``finish()`` and reads the rank-SUM afterwards (gradients come back as the rank-MEAN).
+    Without a process group (or with one rank) nothing is allocated and every call is a no-op."""
+
+    def __init__(self, module, tail_floats=0, bucket_floats=8 << 20, skip=None):
         self.module = module
-
-    def params_with_grad(self):
-        seen, out = set(), []
-        for p in self.module.parameters():
-            if p.grad is not None and id(p) not in seen:
+        self.active = is_on()
+        self.tail_floats = tail_floats
+        self.flat = self.tail = None
+        self._armed = False
+        self._pending = []
+        if not self.active:
+            return
+        seen, params = set(), []
+        for name, p in module.named_parameters():
+            # `skip(name)`: parameters that never receive a gradient (the unused auxiliary head) stay out of the buffer
+            if p.requires_grad and id(p) not in seen and not (skip is not None and skip(name)):
                 seen.add(id(p))
-                out.append(p)
-        return out
+                params.append(p)
+        # backward produces gradients roughly in reverse registration order: lay the buffer out that way so that buckets
+        # complete front to back
+        params.reverse()
+        self.params = params
+        total = sum(p.numel() for p in params)
+        dev = params[0].device
+        self.flat = torch.zeros(total + tail_floats, device=dev, dtype=torch.float32)
+        self.tail = self.flat[total:]
+        self._slot, self._bucket_of, self.buckets = {}, {}, []
+        off, start, members = 0, 0, []
+        for p in params:
+            n = p.numel()
+            self._slot[id(p)] = (off, n)
+            if p.grad is not None:
+                self.flat[off:off + n].copy_(p.grad.detach().reshape(-1))
+            p.grad = self.flat[off:off + n].view_as(p)
+            members.append(id(p))
+            off += n
+            if off - start >= bucket_floats:
+                self._close_bucket(start, off, members)
+                start, members = off, []
+        # the last bucket carries the tail
+        self._close_bucket(start, total + tail_floats, members)
+        self._remaining = [0] * len(self.buckets)
+        for p in params:
+            p.register_post_accumulate_grad_hook(self._on_grad)
+
+    def _close_bucket(self, start, end, members):
+        idx = len(self.buckets)
+        self.buckets.append((start, end, list(members)))
+        for m in members:
+            self._bucket_of[m] = idx
+
+    # ---- per-step protocol -------------------------------------------------------------------------------------------
+    def zero(self):
+        """optimizer.zero_grad() for the flat layout: gradients stay views of the buffer."""
+        if self.active:
+            self.flat.zero_()
+
+    def arm(self):
+        """Call right before the LAST backward pass of the step: from now on a bucket is all-reduced as soon as every one
+        of its parameters has received its gradient."""
+        if not self.active:
+            return
+        self._armed = True
+        self._pending = []
+        self._launched = [False] * len(self.buckets)
+        for i, (_, _, members) in enumerate(self.buckets):
+            self._remaining[i] = len(members)
+
+    def _on_grad(self, p):
+        self.grad_ready(p)
+
+    def grad_ready(self, p):
+        """A parameter's gradient for this step is complete (autograd hook, or ops.Conv2dFn after it has accumulated the
+        weight gradient in place)."""
+        if not (self.active and self._armed):
+            return
+        i = self._bucket_of.get(id(p))
+        if i is None or self._launched[i]:
+            return
+        self._remaining[i] -= 1
+        if self._remaining[i] <= 0 and i != len(self.buckets) - 1:  # the last bucket waits for the tail (finish)
+            self._launch(i)
+
+    def _launch(self, i):
+        start, end, _ = self.buckets[i]
+        self._launched[i] = True
+        self._pending.append(dist.all_reduce(self.flat[start:end], op=dist.ReduceOp.SUM, async_op=True))
 
     @torch.no_grad()
+    def finish(self):
+        """After the last backward pass: exchange whatever has not gone out yet (parameters without a gradient this step,
+        the tail), wait, and turn gradient sums into means.  Returns the number of floats exchanged."""
+        if not self.active:
+            return 0
+        if not self._armed:
+            self.arm()
+        self._armed = False
+        # a gradient that autograd re-allocated (someone set .grad to None) is copied into its slot
+        for p in self.params:
+            off, n = self._slot[id(p)]
+            g = p.grad
+            if g is None:
+                p.grad = self.flat[off:off + n].view_as(p)
+            elif g.data_ptr() != self.flat.data_ptr() + 4 * off:
+                self.flat[off:off + n].copy_(g.reshape(-1))
+                p.grad = self.flat[off:off + n].view_as(p)
+        for i in range(len(self.buckets)):
+            if not self._launched[i]:
+                self._launch(i)
+        for work in self._pending:
+            work.wait()
+        self._pending = []
+        ngrad = self.flat.numel() - self.tail_floats
+        self.flat[:ngrad] /= dist.get_world_size()
+        return self.flat.numel()
+
+    # ---- the round-1 entry point (gradients only, no overlap) --------------------------------------------------------
+    @torch.no_grad()
     def all_reduce(self):
-        if not is_on():
-            return 0
-        params = self.params_with_grad()
-        if not params:
-            return 0
-        grads = [p.grad for p in params]
-        flat = torch.cat([g.reshape(-1) for g in grads])
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-        flat /= dist.get_world_size()
-        torch._foreach_copy_(grads, [v.view_as(g) for v, g in zip(flat.split([g.numel() for g in grads]), grads)])
-        return flat.numel()
+        return self.finish()

@@ -28,33 +28,35 @@ def switch_batch_statistics(model, setting):
             m.track_running_stats = setting
 
 
+def _batchnorms(model):
+    return [(name, m) for name, m in model.named_modules() if isinstance(m, nn.BatchNorm2d)]
+
+
 class batchnorm_stats:
+    """A second set of BatchNorm states next to the live one (BN_POLICY "double": source and target statistics are
+    swapped around the source pass).  Same methods as the reference's class (:39-72)."""
+
     def __init__(self, model) -> None:
-        self.memory = {}
         self.model = model
+        self.memory = {}
         self.save()
 
-    def _bn(self):
-        return ((n, m) for n, m in self.model.named_modules() if isinstance(m, nn.BatchNorm2d))
-
     def save(self):
-        for name, module in self._bn():
-            self.memory[name] = deepcopy(module.state_dict())
+        self.memory = {name: deepcopy(m.state_dict()) for name, m in _batchnorms(self.model)}
 
     def load(self):
-        for name, module in self._bn():
-            module.load_state_dict(self.memory[name])
+        for name, m in _batchnorms(self.model):
+            m.load_state_dict(self.memory[name])
 
     def exchange(self):
-        for name, module in self._bn():
-            current = deepcopy(module.state_dict())
-            module.load_state_dict(self.memory[name])
-            self.memory[name] = current
+        live = {name: deepcopy(m.state_dict()) for name, m in _batchnorms(self.model)}
+        self.load()
+        self.memory = live
 
     def compare(self):
-        for name, module in self._bn():
-            print({"model": module.running_mean, "memory": self.memory[name]["running_mean"],
-                   "diff": module.running_mean - self.memory[name]["running_mean"]})
+        for name, m in _batchnorms(self.model):
+            kept = self.memory[name]["running_mean"]
+            print({"model": m.running_mean, "memory": kept, "diff": m.running_mean - kept})
 
 
 class _Interp(nn.Module):
@@ -70,23 +72,20 @@ class _Interp(nn.Module):
 
 class da_model:
     def __init__(self, model, cfg, cfg_spec) -> None:
-        self.model = model
-        self.bn = batchnorm_stats(model)
-        self.cfg = cfg
-        self.cfg_spec = cfg_spec
+        self.model, self.cfg, self.cfg_spec = model, cfg, cfg_spec
         self.device = cfg.OTHERS.DEVICE
-        input_size_source = cfg.SCHEME.RESOLUTION
-        learning_rate = cfg_spec.LEARNING_RATE
-        # same parameter groups (duplicates included) and hyper-parameters as the reference's
-        # torch.optim.SGD(...); ReplaySGD replays its for-loop semantics in one HIP launch
-        self.optimizer = ReplaySGD(model.optim_parameters(learning_rate), lr=learning_rate,
-                                   momentum=cfg_spec.MOMENTUM, weight_decay=cfg_spec.WEIGHT_DECAY)
-        self.interp = _Interp((input_size_source[1], input_size_source[0]))
-        self.eval_metric_list = []
-        self.ece_record = not (isinstance(cfg.OTHERS.ECE_SKIP, bool) and cfg.OTHERS.ECE_SKIP)
-        if self.ece_record:
+        self.bn = batchnorm_stats(model)
+        if not (isinstance(cfg.OTHERS.ECE_SKIP, bool) and cfg.OTHERS.ECE_SKIP):
             raise NotImplementedError("onda_amd: ECE recording is outside the hot path; set OTHERS.ECE_SKIP: True "
                                       "(as hybrid_switch.yml / static_model.yml do)")
+        self.ece_record = False
+        # the reference's torch.optim.SGD(model.optim_parameters(lr), ...) (:88-93): same parameter groups, duplicates
+        # included; ReplaySGD replays the for-loop semantics of those duplicates in one HIP launch
+        self.optimizer = ReplaySGD(model.optim_parameters(cfg_spec.LEARNING_RATE), lr=cfg_spec.LEARNING_RATE,
+                                   momentum=cfg_spec.MOMENTUM, weight_decay=cfg_spec.WEIGHT_DECAY)
+        width, height = cfg.SCHEME.RESOLUTION
+        self.interp = _Interp((height, width))
+        self.eval_metric_list = []
         self.prediction_counter = {}
 
     @abc.abstractmethod
@@ -101,13 +100,12 @@ class da_model:
         self.cfg_spec = new_cfg
 
     def adjust_learning_rate(self, step, total_steps):
+        """Poly schedule, scaled per parameter group by MODEL.LR_RATIO ("80:10" in hybrid_switch.yml; reference :116-125)."""
         if unset(self.cfg.MODEL.LR_RATIO):
             self.cfg.MODEL.LR_RATIO = "1:10"
-        ratios = [int(v) for v in self.cfg.MODEL.LR_RATIO.split(":")]
-        learning_rate = lr_poly(self.cfg_spec.LEARNING_RATE, step, total_steps, self.cfg_spec.POWER)
-        self.optimizer.param_groups[0]["lr"] = learning_rate * ratios[0]
-        if len(self.optimizer.param_groups) > 1:
-            self.optimizer.param_groups[1]["lr"] = learning_rate * ratios[1]
+        base = lr_poly(self.cfg_spec.LEARNING_RATE, step, total_steps, self.cfg_spec.POWER)
+        for group, ratio in zip(self.optimizer.param_groups, self.cfg.MODEL.LR_RATIO.split(":")):
+            group["lr"] = base * int(ratio)
 
     def evaluate(self, validation_loader, additional_func={}):
         """mIoU of the student (and of any extra prediction function) over a loader."""
@@ -126,15 +124,15 @@ class da_model:
         return {key: per_class_iu(count.cpu().numpy()) for key, count in counters.items()}
 
     def evaluate_all(self, validation_loaders):
-        validation_log = {}
-        for val_set, val_loader in validation_loaders.items():
-            for key, value in self.evaluate(val_loader).items():
-                validation_log[f"Val mIoU {key} of {val_set}"] = np.nanmean(value)
-                validation_log[f"Val std IoU {key} of {val_set}"] = np.nanstd(value)
-            for name, value in self.eval_metric_list:
-                validation_log[f"{name} {val_set}"] = value
+        """{"Val mIoU <predictor> of <set>", "Val std IoU ..."} for every validation set (+ the pending extra metrics)."""
+        report = {}
+        for set_name, loader in validation_loaders.items():
+            for predictor, iou in self.evaluate(loader).items():
+                report[f"Val mIoU {predictor} of {set_name}"] = np.nanmean(iou)
+                report[f"Val std IoU {predictor} of {set_name}"] = np.nanstd(iou)
+            report.update({f"{metric} {set_name}": value for metric, value in self.eval_metric_list})
             self.eval_metric_list = []
-        return validation_log
+        return report
 
     def save_model(self, model_dict=None, prefix=""):
         if model_dict is None:
@@ -150,12 +148,14 @@ class da_model:
 
 
 class evaluation(da_model):
+    """Evaluation-only wrapper: loads the newest ``*.pth`` of OTHERS.SNAPSHOT_DIR (unless it is "NONE")."""
+
     def __init__(self, model, cfg, cfg_spec) -> None:
         super().__init__(model, cfg, cfg_spec)
-        dirpath = self.cfg.OTHERS.SNAPSHOT_DIR
-        if dirpath != "NONE":
-            paths = sorted(Path(dirpath).iterdir(), reverse=True, key=os.path.getmtime)
-            super().load_model([p for p in paths if "pth" in str(p)][0])
+        folder = self.cfg.OTHERS.SNAPSHOT_DIR
+        if folder != "NONE":
+            checkpoints = [p for p in Path(folder).iterdir() if "pth" in str(p)]
+            super().load_model(max(checkpoints, key=os.path.getmtime))
 
     def models_eval(self):
         self.model.eval()

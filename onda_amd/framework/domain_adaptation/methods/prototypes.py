@@ -1,14 +1,22 @@
-"""Drop-in for ``framework/domain_adaptation/methods/prototypes.py``: ``online_proDA`` -- the
-online prototype adaptation loop whose ``step()`` (:418-450) is the unit BASELINE.json
-measures -- plus ``regular_loss`` (:29-39).
+"""Drop-in for ``framework/domain_adaptation/methods/prototypes.py``: ``online_proDA`` -- the online prototype
+adaptation loop whose ``step()`` (:418-450) is the unit BASELINE.json measures -- plus ``regular_loss`` (:29-39).
 
-Control flow, state and log keys follow the reference; what changes is where the work runs:
-every forward/backward is HIP kernels, the three target losses are one fused kernel, the
-teacher's softmax / argmax / confidence means come from one kernel per logits map, the
-pseudo-labels + soft map + monitor means come from one pass over the features, optimizer
-and teacher EMA are single multi-tensor launches, and the target batch is uploaded once.
-With ``torch.distributed`` initialised, gradients, prototype statistics and the switch
-scalars are all-reduced (RCCL) so every rank takes the same decisions.
+Same classes, methods, arguments, state and log keys as the reference; a different machine underneath:
+
+* every forward / backward is HIP kernels; the three target losses are one fused kernel; softmax / argmax / confidence
+  means of a logits map come from one kernel; pseudo-labels + soft map + monitor means come from one pass over the
+  features; optimizer and teacher EMA are single multi-tensor launches; the target batch is uploaded once;
+* the step is ordered for the GPU, not for the host: teacher and static forward passes run FIRST, their two confidence
+  scalars start travelling to the host (all-reduced over ranks on the way) while the student's target forward pass is
+  launched, and the static / dynamic decision reads them only afterwards -- the one host decision of a step never
+  leaves the GPU idle.  Dropout2d masks are still drawn in the reference's order (source student, target student,
+  teacher);
+* everything else the monitor sees (student / dynamic / prototype / posterior / prior confidences) is read back ONCE,
+  after the target backward pass has been launched; with several ranks those scalars, the prototype statistics and the
+  BatchNorm running statistics ride in the tail of the gradient buffer (onda_amd/dist.py): two collectives per step;
+* ``step_sharded`` processes several micro-batches per optimizer step with exactly the arithmetic of that many ranks
+  (rank-local batch statistics, averaged gradients, summed prototype statistics, one switch decision): the
+  strong-scaling mode of bench.py and the sequential emulation the multi-rank tests compare against.
 """
 from copy import deepcopy
 
@@ -18,12 +26,12 @@ from torch import nn
 from torch.functional import F
 
 from onda_amd import dist as odist
+from onda_amd import logging as olog
 from onda_amd import ops
 from onda_amd.config import unset
 from onda_amd.framework.domain_adaptation.methods.adaptation_model import da_model, switch_batch_statistics
 from onda_amd.framework.domain_adaptation.methods.prototype_handler import prototype_handler
-from onda_amd.framework.utils.func import loss_calc
-from onda_amd.framework.utils.loss import rce
+from onda_amd.framework.model import deeplabv2
 from onda_amd.framework.utils.monitoring import Monitor
 
 
@@ -37,46 +45,67 @@ def regular_loss(regularizer, activation):
     return 0
 
 
+def _positive(v):
+    return v if v > 0 else 0.0
+
+
+class _Scalars:
+    """Device scalars waiting for ONE transfer to the host (optionally averaged over ranks first)."""
+
+    def __init__(self):
+        self.keys, self.values = [], []
+
+    def put(self, key, value):
+        self.keys.append(key)
+        self.values.append(value.detach().reshape(()).float())
+
+    def packed(self):
+        return torch.stack(self.values) if self.values else None
+
+
 class online_proDA(da_model):
+    # ------------------------------------------------------------------------------------------------ construction
     def __init__(self, model, cfg, cfg_spec) -> None:
-        super(online_proDA, self).__init__(model, cfg, cfg_spec)
-        self.ema_model = deepcopy(model)
-        self.dynamic_model = deepcopy(model)
-        self.static_model = deepcopy(model)
-        args = [cfg_spec.AVG_MONITOR_SIZE]
-        if not unset(cfg_spec.EXP_MONITOR_CONST):
-            args.append(cfg_spec.EXP_MONITOR_CONST)
-        if not unset(cfg_spec.DEV_MONITOR_FUNC):
-            args.append(cfg_spec.DEV_MONITOR_FUNC)
-        self.intensity_ma = Monitor(*args)
-        for module in self.static_model.modules():
-            if isinstance(module, nn.BatchNorm2d):
-                module.momentum = cfg_spec.BN_MOMENTUM
+        super().__init__(model, cfg, cfg_spec)
+        spec = cfg_spec
+        self.ema_model, self.dynamic_model, self.static_model = (deepcopy(model) for _ in range(3))
+        monitor_args = [spec.AVG_MONITOR_SIZE]
+        for optional in (spec.EXP_MONITOR_CONST, spec.DEV_MONITOR_FUNC):
+            if unset(optional):
+                break
+            monitor_args.append(optional)
+        self.intensity_ma = Monitor(*monitor_args)
+        for m in self.static_model.modules():  # the static model's own BN momentum (reference :55-57)
+            if isinstance(m, nn.BatchNorm2d):
+                m.momentum = spec.BN_MOMENTUM
         self.models_default_config()
-        self.prototypes = prototype_handler(
-            ma_lambda=cfg_spec.MA_LAMBDA, tau=cfg_spec.TAU, thresh=cfg_spec.PSEUDO_THRESH,
-            distance_metric=cfg_spec.DISTANCE_MEASURE,
-            confidence_regularization_threshold=cfg_spec.CONFIDENCE_REGULARIZATION_THRESHOLD)
-        self.skip_proto = False
-        if isinstance(cfg_spec.LOAD_PROTO, str):
-            self.prototypes.load(cfg_spec.LOAD_PROTO)
+        self.prototypes = prototype_handler(ma_lambda=spec.MA_LAMBDA, tau=spec.TAU, thresh=spec.PSEUDO_THRESH,
+                                            distance_metric=spec.DISTANCE_MEASURE,
+                                            confidence_regularization_threshold=spec.CONFIDENCE_REGULARIZATION_THRESHOLD)
+        self.skip_proto = isinstance(spec.LOAD_PROTO, str)
+        if self.skip_proto:
+            self.prototypes.load(spec.LOAD_PROTO)
             self.prototypes.to(self.device)
-            self.skip_proto = True
-        self.proto_loc = cfg.OTHERS.SNAPSHOT_DIR + f"/proto_{cfg_spec.set_}.pickle"
-        self.proto_cur = cfg.OTHERS.SNAPSHOT_DIR + "/proto_current.pickle"
-        self.probability_per_step = 0 if unset(cfg.TRAINING.PERC_FILL_PER_DOMAIN) else cfg.TRAINING.PERC_FILL_PER_DOMAIN
-        self.probability_per_step *= 1.0 * cfg.TRAINING.REPLAY_BUFFER / cfg.TRAINING.BATCH_SIZE
-        if not unset(self.cfg_spec.MODEL_REGULARIZATION) and self.cfg_spec.MODEL_REGULARIZATION > 0:
+        snap = cfg.OTHERS.SNAPSHOT_DIR
+        self.proto_loc, self.proto_cur = f"{snap}/proto_{spec.set_}.pickle", f"{snap}/proto_current.pickle"
+        fill = 0 if unset(cfg.TRAINING.PERC_FILL_PER_DOMAIN) else cfg.TRAINING.PERC_FILL_PER_DOMAIN
+        self.probability_per_step = fill * 1.0 * cfg.TRAINING.REPLAY_BUFFER / cfg.TRAINING.BATCH_SIZE
+        if not unset(spec.MODEL_REGULARIZATION) and spec.MODEL_REGULARIZATION > 0:
             raise NotImplementedError("onda_amd: EWC model regularisation is disabled in every shipped config")
         self.model_regularization = None
-        if isinstance(cfg_spec.BN_POLICY, dict):
+        if isinstance(spec.BN_POLICY, dict):
             self.cfg_spec.BN_POLICY = "freeze"
-        if not unset(cfg_spec.LOAD_MODEL) and cfg_spec.LOAD_MODEL:
-            super().load_model(cfg_spec.LOAD_MODEL)
+        if not unset(spec.LOAD_MODEL) and spec.LOAD_MODEL:
+            super().load_model(spec.LOAD_MODEL)
         self.dynamic_update_counter = 0
-        self._grad_sync = odist.GradSync(self.model)
+        self._img_cache = None
+        self._grad_sync = odist.GradSync(self.model, tail_floats=self._tail_size(),
+                                         skip=(lambda name: name.startswith("layer5.")) if not self.model.multi_level else None)
+        if self._grad_sync.active:
+            ops.GRAD_READY = self._grad_sync.grad_ready
+            self.optimizer.flat_zero = self._grad_sync.zero
 
-    # ---- model bookkeeping -----------------------------------------------------------------
+    # ------------------------------------------------------------------------------------------- model bookkeeping
     def update_dynamic(self):
         self.dynamic_model = deepcopy(self.model)
         self.models_default_config()
@@ -89,11 +118,8 @@ class online_proDA(da_model):
         self.intensity_ma.train()
 
     def models_eval(self):
-        self.model.eval()
-        self.ema_model.eval()
-        self.dynamic_model.eval()
-        self.static_model.eval()
-        self.intensity_ma.eval()
+        for m in (self.model, self.ema_model, self.dynamic_model, self.static_model, self.intensity_ma):
+            m.eval()
 
     def update_cfg_spec(self, new_cfg):
         super().update_cfg_spec(new_cfg)
@@ -105,21 +131,20 @@ class online_proDA(da_model):
 
     def calculate_prototypes(self, dataloader, save=True):
         """Initial prototypes as running class means over a loader (reference :128-155)."""
+        buffered = isinstance(self.cfg.TRAINING.BUFFER_DYNAMIC, bool) and self.cfg.TRAINING.BUFFER_DYNAMIC
         with torch.no_grad():
-            buffered = isinstance(self.cfg.TRAINING.BUFFER_DYNAMIC, bool) and self.cfg.TRAINING.BUFFER_DYNAMIC
             for batch in (dataloader.sequential() if buffered else dataloader):
-                _, pred = self.model(batch["image"].to(self.device))
+                pred = self.model(batch["image"].to(self.device))[1]
                 feat, out = pred["feat"], pred["out"]
                 if self.cfg_spec.STARTING_PROTO == "source":
-                    # classes from the nearest-resized ground truth; 255 matches no class, so the
-                    # sums kernel drops those pixels (the reference masks them out, :144-153)
-                    _, channels, height, width = out.size()
-                    labels = F.interpolate(batch["label"].unsqueeze(1).float(), size=(height, width)).view(-1)
-                    flat, K, C = self.prototypes.class_statistics(feat, channels, classes=labels)
+                    # classes from the nearest-resized ground truth; 255 matches no class, so the sums kernel drops
+                    # those pixels (the reference masks them out, :144-153)
+                    classes = F.interpolate(batch["label"].unsqueeze(1).float(), size=tuple(out.shape[2:])).view(-1)
+                    flat, K, C = self.prototypes.class_statistics(feat, out.shape[1], classes=classes)
                 else:
                     flat, K, C = self.prototypes.class_statistics(feat, out)
-                # sharded loaders: the class sums / counts of all ranks make ONE running mean, so that every
-                # rank starts from the same prototypes (each rank must see the same number of batches)
+                # sharded loaders: the class sums / counts of all ranks make ONE running mean, so that every rank
+                # starts from the same prototypes (each rank must see the same number of batches)
                 odist.all_reduce_sum(flat)
                 self.prototypes.append_from_statistics(flat, K, C)
         if save:
@@ -127,125 +152,146 @@ class online_proDA(da_model):
             os.makedirs(self.cfg.OTHERS.SNAPSHOT_DIR, exist_ok=True)
             self.prototypes.save(self.proto_cur)
 
-    # ---- losses ---------------------------------------------------------------------------------
+    # ------------------------------------------------------------------------------------------------------ losses
     def supervised_loss(self, batch):
         """CE (and optionally RCE) of the student on a source-replay batch (reference :157-189)."""
-        _, pred = self.model(batch["image"].to(self.device))
-        out = pred["out"]
+        out = self.model(batch["image"].to(self.device))[1]["out"]
         label = batch["stored_predictions"] if "stored_predictions" in batch.keys() else batch["label_res"]
-        w_ce = self.cfg_spec.BUFF_CE if self.cfg_spec.BUFF_CE > 0 else 0.0
-        w_rce = self.cfg_spec.BUFF_RCE if self.cfg_spec.BUFF_RCE > 0 else 0.0
+        w_ce, w_rce = _positive(self.cfg_spec.BUFF_CE), _positive(self.cfg_spec.BUFF_RCE)
         total, ce, rc, _ = ops.seg_losses(out, label.long().to(self.device), w_ce, w_rce, 0.0)
         return {"buff_ce_loss": ce if w_ce > 0 else 0, "buff_rce_loss": rc if w_rce > 0 else 0, "buff_loss": total}
 
-    def _prior_of(self, model, image, key):
-        """softmax prior of one no-grad model pass + its mean max-probability (device scalar)."""
-        _, pred = model(image)
-        conf, probs, am = ops.softmax_stats(pred["out"], want_probs=True, want_argmax=(key == "prior EMA"))
-        return pred, probs, conf, am
-
-    def _rank_mean(self, *confs):
-        """Device scalars -> Python floats with ONE read-back; averaged over ranks first so that
-        every rank's monitor (and therefore every switch decision) sees the same numbers."""
-        vals = torch.stack(list(confs))
-        if not self.intensity_ma.freeze:  # evaluation: the monitor ignores the values, and ranks may see different batch counts
-            odist.all_reduce_mean(vals)
-        return vals.tolist()
-
-    def _teacher_and_static(self, batch):
-        """The part every prototype method shares: EMA-teacher pass (train mode), optional static
-        pass, their mean max-probabilities into the monitor.  Returns (image, teacher output, prior
-        so far, teacher argmax)."""
-        image = self._device_image(batch)
-        pred_ema, prior_ema, conf_ema, cls_ema = self._prior_of(self.ema_model, image, "prior EMA")
-        prior = self.cfg_spec.EMA_LAMBDA * prior_ema
-        if self.cfg_spec.STATIC_LAMBDA > 0:
-            _, prior_static, conf_static, _ = self._prior_of(self.static_model, image, "prior static")
-            vals = self._rank_mean(conf_ema, conf_static)
-            self.intensity_ma.add({"prior EMA": vals[0]})
-            self.intensity_ma.add({"prior static": vals[1]})
-            prior += self.cfg_spec.STATIC_LAMBDA * prior_static
-        else:
-            self.intensity_ma.add({"prior EMA": self._rank_mean(conf_ema)[0]})
-        return image, pred_ema, prior, cls_ema
-
-    def _dynamic_prior(self, image):
-        _, prior_dynamic, conf_dyn, _ = self._prior_of(self.dynamic_model, image, "prior dynamic")
-        self.intensity_ma.add({"prior dynamic": self._rank_mean(conf_dyn)[0]})
-        return prior_dynamic
-
-    def prototype_predictions(self, batch):
-        """Teacher / static / dynamic priors and prototype pseudo-labels (reference :208-273)."""
-        with torch.no_grad():
-            image, pred_ema, prior, cls_ema = self._teacher_and_static(batch)
-            calculate_dyn, replace_dyn = True, False
-            thr = self.cfg_spec.SWITCH_PRIOR_THRESH
-            thr = 0 if unset(thr) else thr
-            if thr > 0 and self.intensity_ma.avg("prior static") < thr:
-                replace_dyn = True
-            elif thr > 0:
-                calculate_dyn = False
-            if self.cfg_spec.DYNAMIC_LAMBDA > 0 and calculate_dyn:
-                prior_dynamic = self._dynamic_prior(image)
-                prior = self.cfg_spec.DYNAMIC_LAMBDA * prior_dynamic if replace_dyn else \
-                    prior + self.cfg_spec.DYNAMIC_LAMBDA * prior_dynamic
-        return self._labels_from(pred_ema, prior, cls_ema)
-
-    def _labels_from(self, pred_ema, prior, cls_ema):
-        feat = pred_ema["feat"]
-        # one pass + one read-back: [prototype confidence, posterior confidence, prior confidence]
-        labels, soft, s = self.prototypes.assign_stats(
-            feat, prior, reduce=None if self.intensity_ma.freeze else odist.all_reduce_mean)
-        self.intensity_ma.add({"prior": s[2]})
-        pseudolabels = self.prototypes.pseudo_labels(feat, prior, confidence_monitor=self.intensity_ma)
-        soft_predictions = self.prototypes.pseudo_labels(feat, prior, soft=True)
-        # the reference takes this mean from the soft map of the SECOND call, i.e. after a possible tau bump
-        # (prototype_handler.py:148-156): re-read the statistics of whatever pass produced `soft_predictions`
-        s = self.prototypes.assign_stats(feat, prior, reduce=None if self.intensity_ma.freeze else odist.all_reduce_mean)[2]
-        self.intensity_ma.add({"pseudolabel confidence": s[1]})
-        return {"ema_model": pred_ema, "pseudolabels": pseudolabels, "soft_predictions": soft_predictions,
-                "ema_classes": cls_ema}
-
+    # ---- pieces of the target side ---------------------------------------------------------------------------------
     def _device_image(self, batch):
         img = batch["image"]
-        cached = getattr(self, "_img_cache", None)
-        if cached is not None and cached[0] is img:
-            return cached[1]
+        if self._img_cache is not None and self._img_cache[0] is img:
+            return self._img_cache[1]
         dev = img.to(self.device, non_blocking=True)
         self._img_cache = (img, dev)
         return dev
 
-    def pseudolabel_loss(self, batch):
-        """Target loss from prototype pseudo-labels (reference :275-372)."""
-        if not unset(self.cfg_spec.SOFT_LABELS) and self.cfg_spec.SOFT_LABELS:
-            raise NotImplementedError("onda_amd: SOFT_LABELS is unset in the BASELINE configs; hard labels only")
-        if not unset(self.cfg_spec.PREDICTION_SAVE):
-            raise NotImplementedError("onda_amd: PREDICTION_SAVE is a logging feature outside the hot path")
-        image = self._device_image(batch)
-        _, pred = self.model(image)
-        out = pred["out"]
+    def _forward_prior(self, model, image, want_argmax=False, mask=None):
+        """One no-grad forward: (output dict, softmax map [N,K], mean max-probability (device scalar), argmax or None)."""
+        if mask is not None:
+            deeplabv2.force_mask(mask)
+        pred = model(image)[1]
+        conf, probs, am = ops.softmax_stats(pred["out"], want_probs=True, want_argmax=want_argmax)
+        return pred, probs, conf, am
+
+    def _teacher_static(self, image, teacher_mask=None):
+        """Teacher pass (train mode) and, with STATIC_LAMBDA > 0, the static model's pass; their confidences are NOT
+        read here."""
+        t = {}
+        t["pred"], prior_ema, t["conf_ema"], t["cls"] = self._forward_prior(self.ema_model, image, True, teacher_mask)
+        t["prior"] = self.cfg_spec.EMA_LAMBDA * prior_ema
+        t["conf_static"] = None
+        if self.cfg_spec.STATIC_LAMBDA > 0:
+            _, prior_static, t["conf_static"], _ = self._forward_prior(self.static_model, image)
+            t["prior"] += self.cfg_spec.STATIC_LAMBDA * prior_static
+        return t
+
+    def _switch_scalars(self, ts):
+        """[conf_ema, conf_static] averaged over the given teacher/static results (micro-batches) and over ranks, on its
+        way to the host: returns a zero-argument function that yields the two floats (blocking only if they have not
+        arrived yet)."""
+        rows = [torch.stack([t["conf_ema"], t["conf_static"] if t["conf_static"] is not None else t["conf_ema"]]) for t in ts]
+        vals = rows[0] if len(rows) == 1 else torch.stack(rows).mean(0)
+        if not self.intensity_ma.freeze:
+            odist.all_reduce_mean(vals)
+        if not vals.is_cuda:
+            return vals.tolist
+        host = torch.empty(2, dtype=torch.float32, pin_memory=True)
+        host.copy_(vals, non_blocking=True)
+        done = torch.cuda.Event()
+        done.record()
+
+        def fetch():
+            done.synchronize()
+            return host.tolist()
+        return fetch
+
+    def _record_switch_scalars(self, t, fetch):
+        ema, static = fetch()
+        self.intensity_ma.add({"prior EMA": ema})
+        if t["conf_static"] is not None:
+            self.intensity_ma.add({"prior static": static})
+
+    def _prior_plan(self):
+        """(weight of the teacher/static prior, weight of the dynamic prior) once "prior static" is in the monitor --
+        ``online_proDA``: the SWITCH_PRIOR_THRESH rule (reference :232-255); sub-classes put their switch here."""
+        thr = self.cfg_spec.SWITCH_PRIOR_THRESH
+        thr = 0 if unset(thr) else thr
+        lam = self.cfg_spec.DYNAMIC_LAMBDA
+        if lam <= 0:
+            return 1.0, 0.0
+        if thr > 0:
+            return (0.0, lam) if self.intensity_ma.avg("prior static") < thr else (1.0, 0.0)
+        return 1.0, lam
+
+    def _mixed_prior(self, t, image, deferred):
+        keep, w_dyn = self._prior_plan()
+        prior = t["prior"]
+        if w_dyn > 0:
+            _, prior_dynamic, conf_dyn, _ = self._forward_prior(self.dynamic_model, image)
+            deferred.put("prior dynamic", conf_dyn)
+            if keep == 0:
+                prior = w_dyn * prior_dynamic
+            else:
+                prior = (prior if keep == 1 else keep * prior) + w_dyn * prior_dynamic
+        elif keep != 1:
+            prior = keep * prior
+        return prior
+
+    def _labels(self, t, prior, deferred):
+        """Pseudo-labels, soft map and the three monitor means of one pass over the teacher's features."""
+        feat = t["pred"]["feat"]
+        crt = self.prototypes.confidence_regularization_threshold
+        if crt < 1 and not self.intensity_ma.freeze:
+            # tau regularisation is ON (not in the shipped configs): the reference bumps tau between its two
+            # pseudo_labels calls from the monitor's median -- that needs the numbers on the host right here
+            labels, soft, s = self.prototypes.assign_stats(feat, prior, reduce=odist.all_reduce_mean)
+            self.intensity_ma.add({"prior": s[2]})
+            labels = self.prototypes.pseudo_labels(feat, prior, confidence_monitor=self.intensity_ma)
+            soft = self.prototypes.pseudo_labels(feat, prior, soft=True)
+            s = self.prototypes.assign_stats(feat, prior, reduce=odist.all_reduce_mean)[2]
+            self.intensity_ma.add({"pseudolabel confidence": s[1]})
+        else:
+            labels, soft, stats = self.prototypes._assign(feat, prior)
+            deferred.put("prior", stats[2])
+            deferred.put("prototypes", stats[0])
+            deferred.put("pseudolabel confidence", stats[1])
+        return {"ema_model": t["pred"], "pseudolabels": labels, "soft_predictions": soft, "ema_classes": t["cls"]}
+
+    def prototype_predictions(self, batch):
+        """Teacher / static / dynamic priors and prototype pseudo-labels (reference :208-273), everything at once."""
         with torch.no_grad():
-            conf_model, _, cls_model = ops.softmax_stats(out, want_argmax=True)
-        self.intensity_ma.add({"model": conf_model})
-        proto_pred = self.prototype_predictions(batch)
-        ema = proto_pred["ema_model"]
-        self._prototype_ema(ema["feat"], ema["out"], proto_pred.get("ema_classes"))
+            image = self._device_image(batch)
+            t = self._teacher_static(image)
+            if not self.intensity_ma.freeze:
+                self._record_switch_scalars(t, self._switch_scalars([t]))
+            deferred = _Scalars()
+            out = self._labels(t, self._mixed_prior(t, image, deferred), deferred)
+            packed = deferred.packed()
+            if packed is not None and not self.intensity_ma.freeze:
+                self.intensity_ma.add_device(deferred.keys, odist.all_reduce_mean(packed))
+        return out
+
+    # ---- the target loss, pipelined ----------------------------------------------------------------------------------
+    def _target_losses(self, out, proto_pred, cls_model):
+        spec = self.cfg_spec
         batch_size, channels, w, h = out.size()
         predictions = proto_pred["pseudolabels"].reshape(batch_size, w, h)
-        w_ce = self.cfg_spec.RCE_ALPHA if self.cfg_spec.RCE_ALPHA > 0 else 0.0
-        w_rce = self.cfg_spec.RCE_BETA if self.cfg_spec.RCE_BETA > 0 else 0.0
-        w_reg = self.cfg_spec.REGULARIZER_WEIGHT if self.cfg_spec.REGULARIZER_WEIGHT > 0 else 0.0
-        if w_reg > 0 and self.cfg_spec.REGULARIZER != "MRKLD":
+        w_ce, w_rce, w_reg = _positive(spec.RCE_ALPHA), _positive(spec.RCE_BETA), _positive(spec.REGULARIZER_WEIGHT)
+        if w_reg > 0 and spec.REGULARIZER != "MRKLD":
             raise NotImplementedError("onda_amd: only the MRKLD regulariser is implemented")
-        if self.cfg_spec.JS_D > 0:
+        if spec.JS_D > 0:
             raise NotImplementedError("onda_amd: JS_D is 0 in every shipped config")
         total, ce_loss, rce_loss, reg_loss = ops.seg_losses(out, predictions, w_ce, w_rce, w_reg)
         flat = proto_pred["pseudolabels"].reshape(-1)
-        current_losses = {
+        return {
             "ce_loss": ce_loss if w_ce > 0 else 0,
             "pseudolabel_pixel_num": ((flat >= 0) * (flat != 255)).float().sum(),
             "output & prototype agreement": (flat == cls_model.long()).float().mean(),
-            "mean_prototype_intensity_values": (self.prototypes.prototypes ** 2).mean(),
             "rce_loss": rce_loss if w_rce > 0 else 0,
             "sym_loss": total,  # the reference aliases total_loss = sym_loss (SURVEY 8a-9)
             "regularization_loss": reg_loss if w_reg > 0 else 0,
@@ -253,19 +299,99 @@ class online_proDA(da_model):
             "Total target loss": total,
             "model regularization": 0,
         }
-        for name, value in self.intensity_ma.avg().items():
-            current_losses[f"{name} confidence ma"] = value
-        for name, value in self.intensity_ma.exp().items():
-            current_losses[f"{name} exp confidence ma"] = value
-        current_losses["dev avg prior static"] = self.intensity_ma.dev_avg("prior static")
-        batch["stored_predictions"] = proto_pred["soft_predictions"].reshape(batch_size, w, h, channels).permute(0, 3, 1, 2)
-        return current_losses
 
-    def _prototype_ema(self, feat, out, classes=None):
-        """prototypes.ma with the batch statistics summed over all ranks first."""
-        flat, K, C = self.prototypes.class_statistics(feat, out)
-        odist.all_reduce_sum(flat)
-        self.prototypes.ma_from_statistics(flat, K, C)
+    def _monitor_log(self, losses):
+        losses["mean_prototype_intensity_values"] = (self.prototypes.prototypes ** 2).mean()
+        for name, value in self.intensity_ma.avg().items():
+            losses[f"{name} confidence ma"] = value
+        for name, value in self.intensity_ma.exp().items():
+            losses[f"{name} exp confidence ma"] = value
+        losses["dev avg prior static"] = self.intensity_ma.dev_avg("prior static")
+        return losses
+
+    def _target_prepare(self, batch):
+        """First half of the target side: Dropout2d masks (in the reference's order of draws: the student's target pass,
+        then the teacher's), teacher and static forward passes.  Nothing is read back."""
+        if not unset(self.cfg_spec.SOFT_LABELS) and self.cfg_spec.SOFT_LABELS:
+            raise NotImplementedError("onda_amd: SOFT_LABELS is unset in the BASELINE configs; hard labels only")
+        if not unset(self.cfg_spec.PREDICTION_SAVE):
+            raise NotImplementedError("onda_amd: PREDICTION_SAVE is a logging feature outside the hot path")
+        image = self._device_image(batch)
+        student_mask = deeplabv2.draw_mask(self.model, image.shape[0], image.device)
+        teacher_mask = deeplabv2.draw_mask(self.ema_model, image.shape[0], image.device)
+        with torch.no_grad():
+            t = self._teacher_static(image, teacher_mask)
+        t["image"], t["student_mask"] = image, student_mask
+        return t
+
+    def _target_finish(self, batch, t, deferred, fetch=None):
+        """Second half: the student's forward pass (launched BEFORE the switch scalars are read: `fetch`, given for the
+        first micro-batch of a step), prior mixing, pseudo-labels, the losses.  The prototype EMA and the monitor
+        entries stay pending (``_settle``)."""
+        image = t["image"]
+        if t["student_mask"] is not None:
+            deeplabv2.force_mask(t["student_mask"])
+        out = self.model(image)[1]["out"]
+        with torch.no_grad():
+            conf_model, _, cls_model = ops.softmax_stats(out, want_argmax=True)
+            deferred.put("model", conf_model)
+            if fetch is not None:
+                self._record_switch_scalars(t, fetch)
+            proto_pred = self._labels(t, self._mixed_prior(t, image, deferred), deferred)
+        losses = self._target_losses(out, proto_pred, cls_model)
+        b, k, w, h = out.size()
+        batch["stored_predictions"] = proto_pred["soft_predictions"].reshape(b, w, h, k).permute(0, 3, 1, 2)
+        return losses
+
+    def _settle(self, losses, teacher_results, deferred):
+        """After the target backward pass has been launched: prototype EMA from the (rank-summed) class statistics, the
+        deferred scalars into the monitor (rank-mean), running statistics averaged over ranks, the monitor's log entries."""
+        sync = self._grad_sync
+        stats = None
+        for t in teacher_results:
+            flat, K, C = self.prototypes.class_statistics(t["pred"]["feat"], t["pred"]["out"], t["cls"])
+            stats = flat if stats is None else stats + flat
+        keys, packed = deferred.keys, deferred.packed()
+        if len(teacher_results) > 1:  # several micro-batches: the mean of each key over them
+            keys = list(dict.fromkeys(deferred.keys))
+            packed = torch.stack([torch.stack([v for k_, v in zip(deferred.keys, deferred.values) if k_ == key]).mean()
+                                  for key in keys])
+        if sync.active:
+            tail, n1 = sync.tail, stats.numel()
+            tail[:n1].copy_(stats)
+            tail[n1:n1 + packed.numel()].copy_(packed)
+            bufs = self._float_buffers()
+            nb = sum(b.numel() for b in bufs)
+            if bufs:
+                torch.cat([b.reshape(-1) for b in bufs], out=tail[n1 + 16:n1 + 16 + nb])
+            sync.finish()
+            world = odist.world_size()
+            stats = tail[:n1]
+            packed = tail[n1:n1 + packed.numel()] / world
+            if bufs:
+                mean = tail[n1 + 16:n1 + 16 + nb] / world
+                torch._foreach_copy_(bufs, [v.view_as(b) for v, b in zip(mean.split([b.numel() for b in bufs]), bufs)])
+                for b in bufs:
+                    torch.autograd.graph.increment_version(b)
+        self.prototypes.ma_from_statistics(stats, K, C)
+        if packed is not None:
+            self.intensity_ma.add_device(keys, packed)
+        return self._monitor_log(losses)
+
+    def _float_buffers(self):
+        return [b for b in self.model.buffers() if b.dtype == torch.float32]
+
+    def _tail_size(self):
+        K, C = self.cfg.NUM_CLASSES, 256
+        return 2 * K * C + K + 16 + sum(b.numel() for b in self.model.buffers() if b.dtype == torch.float32)
+
+    def pseudolabel_loss(self, batch):
+        """Target loss from prototype pseudo-labels (reference :275-372), complete with monitor entries (the step itself
+        uses the pipelined pieces and settles after the backward pass)."""
+        deferred = _Scalars()
+        t = self._target_prepare(batch)
+        losses = self._target_finish(batch, t, deferred, self._switch_scalars([t]))
+        return self._settle(losses, [t], deferred)
 
     def evaluate(self, validation_loader):
         def proto_func(batch):
@@ -278,27 +404,18 @@ class online_proDA(da_model):
         return super().evaluate(validation_loader, {"proto": proto_func})
 
     def evaluate_update_dynamic(self):
-        if not unset(self.cfg_spec.AUTO_DYNAMIC) and self.cfg_spec.AUTO_DYNAMIC:
-            self.dynamic_update_counter += 1
-            if self.dynamic_update_counter > 500:
-                x = self.intensity_ma.dev_avg("prior static")
-                if np.abs(x) > self.cfg_spec.DEV_THRESH:
-                    self.update_dynamic()
-                    self.dynamic_update_counter = 0
+        if unset(self.cfg_spec.AUTO_DYNAMIC) or not self.cfg_spec.AUTO_DYNAMIC:
+            return
+        self.dynamic_update_counter += 1
+        if self.dynamic_update_counter > 500 and np.abs(self.intensity_ma.dev_avg("prior static")) > self.cfg_spec.DEV_THRESH:
+            self.update_dynamic()
+            self.dynamic_update_counter = 0
 
     @torch.no_grad()
     def update_ema(self):
-        """teacher = keep*teacher + (1-keep)*student for all 217 parameters, buffers copied
-        (reference :407-416), as one multi-tensor launch."""
+        """teacher = keep*teacher + (1-keep)*student for all 217 parameters, buffers copied (reference :407-416), as one
+        multi-tensor launch.  (With several ranks the student's running statistics were averaged in the step's exchange.)"""
         keep = self.cfg_spec.EMA_UPDATE
-        if odist.is_on():
-            # BatchNorm normalises with rank-local batch statistics (like the bs=4 reference on each
-            # GPU); the RUNNING statistics are averaged over ranks here so that replicas -- and the
-            # teacher / dynamic copies taken from them -- stay identical
-            bufs = [b for b in self.model.buffers() if b.dtype == torch.float32]
-            flat = torch.cat([b.reshape(-1) for b in bufs])
-            odist.all_reduce_mean(flat)
-            torch._foreach_copy_(bufs, [v.view_as(b) for v, b in zip(flat.split([b.numel() for b in bufs]), bufs)])
         items = [(k, q, keep, 1.0 - keep) for q, k in zip(self.model.parameters(), self.ema_model.parameters())]
         ints_q, ints_k = [], []
         for bq, bk in zip(self.model.buffers(), self.ema_model.buffers()):
@@ -311,68 +428,136 @@ class online_proDA(da_model):
         if ints_k:
             torch._foreach_copy_(ints_k, ints_q)
 
-    def step(self, batches_source, batch_target):
-        """One adaptation step: source replay fwd+bwd (BN statistics frozen), target fwd, teacher /
-        static / (dynamic) fwd, pseudo-labels, prototype EMA, target bwd, optimizer step."""
-        loss_seg_src_main = {}
-        if self.cfg_spec.BN_POLICY == "freeze":
+    # -------------------------------------------------------------------------------------------------------- step
+    def _source_replay(self, batches_source, scale=1.0):
+        """Source replay with the BatchNorm policy of the config around it; returns the last batch's log entries."""
+        policy = self.cfg_spec.BN_POLICY
+        if policy == "freeze":
             switch_batch_statistics(self.model, False)
-        elif self.cfg_spec.BN_POLICY == "double":
+        elif policy == "double":
             self.bn.exchange()
-        for batch_source in batches_source:
+        log = {}
+        for batch in batches_source:
             if self.cfg.TRAINING.REPLAY_BUFFER > 0:
-                loss_seg_src_main = self.supervised_loss(batch_source)
-                loss_seg_src_main["buff_loss"].backward()
-        if self.cfg_spec.BN_POLICY == "freeze":
+                log = self.supervised_loss(batch)
+                (log["buff_loss"] if scale == 1.0 else log["buff_loss"] * scale).backward()
+        if policy == "freeze":
             switch_batch_statistics(self.model, True)
-        elif self.cfg_spec.BN_POLICY == "double":
+        elif policy == "double":
             self.bn.exchange()
-        pseudolabel_losses = self.pseudolabel_loss(batch_target)
-        pseudolabel_losses["Total target loss"].backward()
-        pseudolabel_losses["encoder_lr"] = self.optimizer.param_groups[0]["lr"]
-        pseudolabel_losses.update(loss_seg_src_main)
-        self._grad_sync.all_reduce()  # no-op on one GPU; one bucketed RCCL all-reduce otherwise
+        return log
+
+    def step(self, batches_source, batch_target):
+        """One adaptation step: source replay fwd+bwd (BN statistics frozen), teacher / static fwd, target fwd, (dynamic
+        fwd), pseudo-labels, target bwd, prototype EMA, optimizer step."""
+        return self.step_sharded([(batches_source, batch_target)])
+
+    def step_sharded(self, shards):
+        """`shards`: [(batches_source, batch_target), ...] -- micro-batches of ONE optimizer step, processed with the
+        arithmetic of len(shards) ranks (x the real ranks): every micro-batch normalises with its own batch
+        statistics, gradients are averaged, class statistics summed, monitor scalars averaged, the BatchNorm running
+        statistics averaged, one switch decision.  Returns the first micro-batch's log dict."""
+        n = len(shards)
+        scale = 1.0 / n
+        deferred, src_log, prepared = _Scalars(), {}, []
+        # source replay (gradients accumulate) and the no-grad teacher / static passes of every micro-batch; per
+        # micro-batch the Dropout2d masks are drawn in the reference's order: source student, target student, teacher
+        for i, (batches_source, batch_target) in enumerate(shards):
+            log = self._source_replay(batches_source, scale)
+            if i == 0:
+                src_log = log
+            prepared.append(self._target_prepare(batch_target))
+        fetch = self._switch_scalars(prepared)  # ONE decision per step, from the mean over micro-batches and ranks
+        run0 = None
+        if n > 1:  # every micro-batch starts from the same running statistics; their results are averaged
+            bufs = self._float_buffers()
+            run0 = [b.clone() for b in bufs]
+            run_sum = [torch.zeros_like(b) for b in bufs]
+        first_log = None
+        for i, ((_, batch_target), t) in enumerate(zip(shards, prepared)):
+            if run0 is not None:
+                torch._foreach_copy_(bufs, run0)
+            losses = self._target_finish(batch_target, t, deferred, fetch if i == 0 else None)
+            if i == n - 1:
+                self._grad_sync.arm()  # buckets go out as the last backward pass completes them
+            (losses["Total target loss"] if n == 1 else losses["Total target loss"] * scale).backward()
+            if i == 0:
+                first_log = losses
+            if run0 is not None:
+                torch._foreach_add_(run_sum, bufs)
+        self._img_cache = None
+        if run0 is not None:
+            torch._foreach_mul_(run_sum, scale)
+            torch._foreach_copy_(bufs, run_sum)
+            for b in bufs:
+                torch.autograd.graph.increment_version(b)
+        first_log = self._settle(first_log, prepared, deferred)
+        first_log["encoder_lr"] = self.optimizer.param_groups[0]["lr"]
+        first_log.update(src_log)
         self.optimizer.step()
         self.optimizer.zero_grad()
-        self._img_cache = None
-        return pseudolabel_losses
+        return first_log
+
+    def buffer_update(self, batch_target, probability, trainloader):
+        """With probability `probability` per target sample, put it (with its pseudo-label map at image resolution) into
+        the replay buffer (reference :452-464).  The reference upsamples inside its loop over the chosen samples, i.e.
+        a second chosen sample of the same batch would upsample the already-argmaxed map; here the map is built once."""
+        total_buffer_updates = 0
+        if probability > 0:
+            chosen = np.where(np.random.rand(len(batch_target["stored_predictions"])) < probability)[0]
+            if len(chosen):
+                stored = batch_target["stored_predictions"]
+                if stored.dim() == 4:
+                    batch_target["stored_predictions"] = ops.upsample_argmax(stored, self.interp.size).long()
+                for index in chosen:
+                    trainloader.add_from_batch(batch_target, index)
+                    total_buffer_updates += 1
+        return total_buffer_updates
 
     def train(self, trainloader, targetloader, validation_loaders, log_fn=None):
-        """The per-domain loop (reference :466-520); `log_fn(dict)` replaces wandb.log."""
-        if unset(self.cfg_spec.AUTO_DYNAMIC) or self.cfg_spec.AUTO_DYNAMIC is False:
+        """The per-domain loop (reference :466-520).  Log dictionaries go to ``wandb.log`` when wandb is importable and a
+        run is active -- as in the reference -- or to `log_fn` / onda_amd.logging.set_sink."""
+        emit = log_fn or olog.log
+        spec = self.cfg_spec
+        if unset(spec.AUTO_DYNAMIC) or spec.AUTO_DYNAMIC is False:
             self.update_dynamic()
-        if not self.cfg_spec.SKIP_CALC:
+        if not spec.SKIP_CALC:
             if not self.skip_proto:
                 switch_batch_statistics(self.model, False)
-                self.calculate_prototypes(targetloader if self.cfg_spec.STARTING_PROTO == "target" else trainloader)
+                self.calculate_prototypes(targetloader if spec.STARTING_PROTO == "target" else trainloader)
                 switch_batch_statistics(self.model, True)
                 self.skip_proto = True
-            if log_fn and validation_loaders:
-                log_fn(self.evaluate_all(validation_loaders))
-        steps = self.cfg_spec.EPOCHS * len(targetloader)
-        src_iter, trg_iter = iter(trainloader), iter(targetloader)
+            if validation_loaders:
+                emit(self.evaluate_all(validation_loaders))
+        steps = spec.EPOCHS * len(targetloader)
+        update_prob = self.probability_per_step / steps
+        sources, targets = _Cycle(trainloader), _Cycle(targetloader)
         self.optimizer.zero_grad()
         for i_iter in range(steps):
             self.adjust_learning_rate(i_iter, steps)
-            source_samples = []
-            for _ in range(self.cfg_spec.SOURCE_REPEAT):
-                try:
-                    sample = next(src_iter)
-                except StopIteration:
-                    src_iter = iter(trainloader)
-                    sample = next(src_iter)
-                source_samples.append(sample)
-            try:
-                target_sample = next(trg_iter)
-            except StopIteration:
-                trg_iter = iter(targetloader)
-                target_sample = next(trg_iter)
+            source_samples = [next(sources) for _ in range(spec.SOURCE_REPEAT)]
+            target_sample = next(targets)
             log = self.step(source_samples, target_sample)
             self.evaluate_update_dynamic()
             self.update_ema()
-            if (i_iter + 1) % len(targetloader) == 0 and validation_loaders:
-                log.update(self.evaluate_all(validation_loaders))
+            log["Total buffer updates"] = self.buffer_update(target_sample, update_prob, trainloader)
+            if (i_iter + 1) % len(targetloader) == 0:
+                if validation_loaders:
+                    log.update(self.evaluate_all(validation_loaders))
                 self.save_model()
-            if log_fn:
-                log_fn(log)
+            emit(log)
         self.save_model()
+
+
+class _Cycle:
+    """next() over a loader, restarted when it runs out (the reference's try / except StopIteration blocks)."""
+
+    def __init__(self, loader):
+        self.loader, self.it = loader, iter(loader)
+
+    def __next__(self):
+        try:
+            return next(self.it)
+        except StopIteration:
+            self.it = iter(self.loader)
+            return next(self.it)

@@ -1,11 +1,10 @@
-"""Drop-in for ``framework/domain_adaptation/methods/prototypes_vswitch.py``: ``vswitch_proDA``,
-the confidence-derivative switch (``configs/confidence_der_switch.yml``; reference :5-89)."""
-import torch
-
+"""Drop-in for ``framework/domain_adaptation/methods/prototypes_vswitch.py``: ``vswitch_proDA``, the
+confidence-derivative switch of ``configs/confidence_der_switch.yml`` (reference :5-89)."""
 from onda_amd.framework.domain_adaptation.methods.prototypes import online_proDA
 
 
 class model_select:
+    """The sign of the windowed derivative of the static prior's confidence picks the model."""
     static = 0
     dynamic = 1
 
@@ -21,13 +20,9 @@ class model_select:
         self.freeze = False
 
     def evaluate(self, dev_value):
-        if self.freeze:
+        if self.freeze or abs(dev_value) <= self.threshold:
             return
-        # the sign of the windowed derivative of the static prior's confidence picks the model
-        if dev_value > self.threshold:
-            self.current = self.static
-        elif dev_value < -self.threshold:
-            self.current = self.dynamic
+        self.current = self.static if dev_value > 0 else self.dynamic
 
 
 class vswitch_proDA(online_proDA):
@@ -35,13 +30,11 @@ class vswitch_proDA(online_proDA):
         super().__init__(model, cfg, cfg_spec)
         self.model_select = model_select(model_select.static, cfg_spec.SWITCH_PRIOR_THRESH)
 
-    def prototype_predictions(self, batch):
-        with torch.no_grad():
-            image, pred_ema, prior, cls_ema = self._teacher_and_static(batch)
-            self.model_select.evaluate(self.intensity_ma.dev_avg("prior static"))
-            if self.model_select.current == model_select.dynamic and self.cfg_spec.DYNAMIC_LAMBDA > 0:
-                prior = self.cfg_spec.DYNAMIC_LAMBDA * self._dynamic_prior(image)
-        return self._labels_from(pred_ema, prior, cls_ema)
+    def _prior_plan(self):
+        self.model_select.evaluate(self.intensity_ma.dev_avg("prior static"))
+        if self.model_select.current == model_select.dynamic and self.cfg_spec.DYNAMIC_LAMBDA > 0:
+            return 0.0, self.cfg_spec.DYNAMIC_LAMBDA
+        return 1.0, 0.0
 
     def models_eval(self):
         self.model_select.eval()

@@ -1,0 +1,107 @@
+"""Drop-in for ``framework/domain_adaptation/methods/segmentation.py`` (``train``, :18-138): plain supervised
+segmentation training -- BASELINE config 2: forward -> bilinear upsample (align_corners) to the label resolution ->
+cross-entropy -> backward -> SGD with the duplicated parameter groups -> poly learning rate.
+
+``train(model, train_loader, validation_loaders, cfg, cfg_spec)`` keeps the reference's signature and loop
+(:62-100); the unit of work lives in ``SegmentationTrainer.step`` so that bench.py can time exactly it.  Every
+forward/backward op is a HIP kernel; the loss is evaluated on the upsampled logits by the fused loss kernel;
+validation uses the fused upsample -> argmax -> confusion-matrix kernel (adaptation_model.da_model.evaluate).
+Not mirrored (outside SURVEY section 8): the DOMAIN_ANALYSIS branch, sample images, entropy logging, the
+per-phase timers (PytorchSpeedMeasure).
+"""
+import os
+
+import numpy as np
+import torch
+
+from onda_amd import logging as olog
+from onda_amd import ops
+from onda_amd.config import unset
+from onda_amd.framework.utils.func import lr_poly, per_class_iu
+from onda_amd.optim import ReplaySGD
+
+
+class SegmentationTrainer:
+    def __init__(self, model, cfg, cfg_spec):
+        if not unset(cfg.DOMAIN_ANALYSIS):
+            raise NotImplementedError("onda_amd: the DOMAIN_ANALYSIS variant of segmentation.train is outside the hot path")
+        self.model, self.cfg, self.spec = model, cfg, cfg_spec
+        self.device = cfg.OTHERS.DEVICE
+        width, height = cfg.SCHEME.RESOLUTION
+        self.size = (height, width)
+        self.base_lr = cfg_spec.LEARNING_RATE
+        self.optimizer = ReplaySGD(model.optim_parameters(self.base_lr), lr=self.base_lr, momentum=cfg_spec.MOMENTUM,
+                                   weight_decay=cfg_spec.WEIGHT_DECAY)
+        self.steps_done = 0
+
+    def loss(self, batch):
+        """loss_calc(interp(prediction), label) (+ 0.1 x the auxiliary head's when multi_level), segmentation.py:70-80."""
+        aux, pred = self.model(batch["image"].to(self.device))
+        label = batch["label"].to(self.device)
+        total = None
+        for weight, p in ((1.0, pred), (0.1, aux)):
+            if p is None:
+                continue
+            logits = p["out"] if isinstance(p, dict) else p
+            part = ops.seg_losses(ops.UpsampleFn.apply(logits, self.size), label, 1.0, 0.0, 0.0)[0]
+            total = weight * part if total is None else total + weight * part
+        return total
+
+    def adjust_learning_rate(self, total_steps):
+        """_adjust_learning_rate (func.py:50-58): poly schedule; the second group runs at 10x."""
+        lr = lr_poly(self.base_lr, self.steps_done, total_steps, self.spec.POWER)
+        self.optimizer.param_groups[0]["lr"] = lr
+        if len(self.optimizer.param_groups) > 1:
+            self.optimizer.param_groups[1]["lr"] = lr * 10
+
+    def step(self, batch, total_steps=None):
+        """One training step (segmentation.py:66-88); returns the loss as a device scalar."""
+        self.optimizer.zero_grad()
+        loss = self.loss(batch)
+        loss.backward()
+        self.optimizer.step()
+        if total_steps:
+            self.adjust_learning_rate(total_steps)
+        self.steps_done += 1
+        return loss.detach()
+
+    def evaluate(self, loader):
+        self.model.eval()
+        n = self.cfg.NUM_CLASSES
+        hist = torch.zeros(n, n, dtype=torch.int64, device=self.device)
+        with torch.no_grad():
+            for batch in loader:
+                out = self.model(batch["image"].to(self.device))[1]
+                ops.upsample_argmax_hist(out["out"] if isinstance(out, dict) else out, batch["label"], hist, n)
+        self.model.train()
+        return per_class_iu(hist.cpu().numpy())
+
+
+def save_model(model, epoch, cfg):
+    root = cfg.OTHERS.SNAPSHOT_DIR
+    if unset(root) or root == "NONE":
+        return
+    os.makedirs(root, exist_ok=True)
+    torch.save(model.state_dict(), os.path.join(root, f"model_{epoch}.pth"))
+
+
+def train(model, train_loader, validation_loaders, cfg, cfg_spec=None):
+    trainer = SegmentationTrainer(model, cfg, cfg_spec)
+    loader = next(iter(train_loader.values())) if isinstance(train_loader, dict) else train_loader
+    total = len(loader) * cfg_spec.EPOCHS
+    pending = []
+    for epoch in range(cfg_spec.EPOCHS):
+        model.train()
+        for batch in loader:
+            pending.append(trainer.step(batch, total))
+            if (trainer.steps_done - 1) % 10 == 0:  # the reference logs the running mean every 10 steps (:90-97)
+                olog.log({"Segmentation loss": torch.stack(pending).mean(), "learning_rate": trainer.optimizer.param_groups[0]["lr"]})
+                pending = []
+        log = {"epoch": epoch}
+        for name, val_loader in (validation_loaders or {}).items():
+            iou = trainer.evaluate(val_loader)
+            log[f"Val mIoU of {name}"] = np.nanmean(iou)
+            log[f"Val std IoU of {name}"] = np.nanstd(iou)
+        olog.log(log)
+        save_model(model, epoch, cfg)
+    return trainer

@@ -127,13 +127,42 @@ class SEBlock(nn.Module):
         return ops.SEScaleFn.apply(x, self.se[0].weight, self.se[0].bias, self.se[2].weight, self.se[2].bias)
 
 
+_rank_generators = {}
+
+
 def _default_drop_mask(batch, channels, p, device):
-    """What F.dropout2d draws: one Bernoulli(1-p) per (image, channel), scaled by 1/(1-p)."""
-    return torch.empty(batch, channels, 1, 1, device=device).bernoulli_(1 - p).div_(1 - p)
+    """What F.dropout2d draws: one Bernoulli(1-p) per (image, channel), scaled by 1/(1-p).  With several ranks every
+    rank draws from its own stream (seed + rank offset): the same seed everywhere would drop the same feature channels
+    of every rank's different micro-batch."""
+    from onda_amd import dist as odist
+    gen = None
+    if odist.is_on():
+        key = str(device)
+        gen = _rank_generators.get(key)
+        if gen is None:
+            gen = _rank_generators[key] = torch.Generator(device=device)
+            gen.manual_seed(torch.initial_seed() + odist.seed_offset())
+    return torch.empty(batch, channels, 1, 1, device=device).bernoulli_(1 - p, generator=gen).div_(1 - p)
 
 
 # tests replace this to inject the masks the CPU oracle used
 drop_mask_fn = _default_drop_mask
+
+# masks handed to the next forward passes explicitly (the adaptation step draws them in the reference's order and then
+# runs the passes in ITS order): consumed first-in first-out by Classifier_Module2.forward
+_forced_masks = []
+
+
+def force_mask(mask):
+    _forced_masks.append(mask)
+
+
+def draw_mask(model, batch, device):
+    """The Dropout2d mask the next training-mode forward of `model` would draw (None when dropout is inactive)."""
+    head = model.layer6.head[0]
+    if not (head.training and head.p > 0):
+        return None
+    return drop_mask_fn(batch, 256, head.p, device).reshape(batch, 256).contiguous()
 
 
 class Classifier_Module2(nn.Module):
@@ -187,7 +216,10 @@ class Classifier_Module2(nn.Module):
         drop = self.head[0]
         chmul = None
         if drop.training and drop.p > 0:
-            chmul = drop_mask_fn(y.shape[0], y.shape[3], drop.p, y.device).reshape(y.shape[0], y.shape[3]).contiguous()
+            if _forced_masks:
+                chmul = _forced_masks.pop(0)
+            else:
+                chmul = drop_mask_fn(y.shape[0], y.shape[3], drop.p, y.device).reshape(y.shape[0], y.shape[3]).contiguous()
         feat = ops.GNConcatFn.apply(False, chmul, y, rest[1].weight, rest[1].bias)
         out_pad, _ = self.head[1](feat, cout_pad=ops.HEAD_PAD)
         out = ops.ClassSliceFn.apply(out_pad, self.num_classes)

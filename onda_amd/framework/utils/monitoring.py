@@ -1,79 +1,120 @@
-"""Drop-in for the parts of ``framework/utils/monitoring.py`` on the hot path: ``Monitor``
-(:7-96), the windowed statistics that drive the static/dynamic switch.
+"""Drop-in for the hot-path part of ``framework/utils/monitoring.py``: ``Monitor`` (:7-96), the windowed statistics
+behind the static / dynamic switch.
 
-Same API and values as the reference; the difference is that samples are stored as Python
-floats (a device scalar is read back once, when it is added) instead of 0-dim device
-tensors whose every comparison inside ``statistics.median`` is a host sync.
+Same call surface and values as the reference (fixture G5): ``add({key: value})``, ``avg`` = median of the last
+``limit`` samples, ``exp`` = exponential moving average started at the first sample, ``dev_avg`` = weighted level of
+the window without its oldest sample minus that of the window without its newest one (zero until the window is
+full), ``eval()`` / ``train()`` freeze and unfreeze it.  Built differently: every key owns a fixed ring of float64
+slots (no list growth, no ``pop(0)``), samples are plain floats (a device scalar given to ``add`` is read back once,
+there), and several scalars that live on the device can be added with ONE transfer (``add_device``).
 """
-from statistics import median
-
 import numpy as np
 import torch
 
 
-def _scalar(v):
-    if isinstance(v, torch.Tensor):
-        return v.item()
-    return v
+class _Series:
+    """Ring buffer of one monitored quantity."""
+    __slots__ = ("ring", "count", "head", "ema")
+
+    def __init__(self, capacity, first):
+        self.ring = np.empty(capacity, dtype=np.float64)
+        self.ring[0] = first
+        self.count, self.head, self.ema = 1, 1 % capacity, first
+
+    def push(self, value, smoothing):
+        self.ring[self.head] = value
+        self.head = (self.head + 1) % self.ring.size
+        self.count = min(self.count + 1, self.ring.size)
+        self.ema = (1 - smoothing) * self.ema + smoothing * value
+
+    def ordered(self):
+        """Oldest -> newest."""
+        if self.count < self.ring.size:
+            return self.ring[: self.count]
+        return np.concatenate([self.ring[self.head:], self.ring[: self.head]])
+
+
+def _level_function(kind, span):
+    if kind == "median":
+        return lambda w: float(np.median(w))
+    if kind == "mean":
+        return lambda w: float(np.mean(w))
+    if kind == "hamming":
+        taps = np.hamming(span)
+        total = np.sum(taps)
+        return lambda w: np.sum(taps * w) / total
+    raise ValueError(f"unknown DEV_MONITOR_FUNC {kind!r}")
 
 
 class Monitor(object):
     def __init__(self, limit=None, exp_const=0.01, dev_func="hamming"):
-        self.current_dict = {}
         self.limit = limit
-        self.exp_dict = {}
         self.exp_const = exp_const
         self.freeze = False
-        self.signal = np.hamming(limit - 1)
-        self.signal_sum = np.sum(self.signal)
-        if dev_func == "median":
-            self.mean_func = median
-        elif dev_func == "mean":
-            self.mean_func = lambda x: np.mean(np.array(x))
-        elif dev_func == "hamming":
-            self.mean_func = lambda x: np.sum(self.signal * np.array(x)) / self.signal_sum
+        self._series = {}
+        self._level = _level_function(dev_func, limit - 1)
+        self._unbounded = 1 << 16  # limit None: the reference keeps every sample
 
+    # ---- mode ------------------------------------------------------------------------------------------------------
     def eval(self):
         self.freeze = True
 
     def train(self):
         self.freeze = False
 
+    def reset(self):
+        self._series = {}
+
+    # ---- samples ---------------------------------------------------------------------------------------------------
+    def _push(self, key, value, reset=False):
+        s = self._series.get(key)
+        if s is None or reset:
+            self._series[key] = _Series(self.limit or self._unbounded, value)
+        else:
+            s.push(value, self.exp_const)
+
     def add(self, values, reset=False):
         if self.freeze:
             return 0
-        for key, val in values.items():
-            val = _scalar(val)
-            window = self.current_dict.get(key)
-            if window is None or reset:
-                self.current_dict[key] = [val]
-                self.exp_dict[key] = val
-                continue
-            window.append(val)
-            if self.limit is not None and len(window) > self.limit:
-                window.pop(0)
-            self.exp_dict[key] = (1 - self.exp_const) * self.exp_dict[key] + self.exp_const * val
+        for key, value in values.items():
+            self._push(key, value.item() if isinstance(value, torch.Tensor) else value, reset)
 
-    def _dev_avg(self, item):
-        window = self.current_dict.get(item)
-        if window is None or len(window) < self.limit:
+    def add_device(self, keys, packed):
+        """keys[i] <- packed[i] for a 1-D device tensor `packed`: one read-back for all of them."""
+        if self.freeze:
             return 0
-        return self.mean_func(window[1:]) - self.mean_func(window[:-1])
+        for key, value in zip(keys, packed.tolist()):
+            self._push(key, value)
 
-    def dev_avg(self, item=None):
+    # ---- statistics ------------------------------------------------------------------------------------------------
+    def avg(self, item=None):
         if item is not None:
-            return self._dev_avg(item)
-        return {key: self._dev_avg(key) for key in self.current_dict}
+            s = self._series.get(item)
+            return float(np.median(s.ordered())) if s is not None else 1
+        return {key: float(np.median(s.ordered())) for key, s in self._series.items()}
 
     def exp(self, item=None):
         if item is not None:
-            return self.exp_dict.get(item, 1)
-        return self.exp_dict
+            s = self._series.get(item)
+            return s.ema if s is not None else 1
+        return {key: s.ema for key, s in self._series.items()}
 
-    def avg(self, item=None):
+    def _trend(self, s):
+        if s is None or self.limit is None or s.count < self.limit:
+            return 0
+        w = s.ordered()
+        return self._level(w[1:]) - self._level(w[:-1])
+
+    def dev_avg(self, item=None):
         if item is not None:
-            return median(self.current_dict[item]) if item in self.current_dict else 1
-        return {key: median(vals) for key, vals in self.current_dict.items()}
+            return self._trend(self._series.get(item))
+        return {key: self._trend(s) for key, s in self._series.items()}
 
-    def reset(self):
-        self.current_dict = {}
+    # the reference's attribute names, for code that peeks at them
+    @property
+    def current_dict(self):
+        return {key: list(s.ordered()) for key, s in self._series.items()}
+
+    @property
+    def exp_dict(self):
+        return {key: s.ema for key, s in self._series.items()}

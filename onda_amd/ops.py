@@ -38,6 +38,10 @@ CONV_MODE = os.environ.get("ONDA_CONV_MODE", "f16x2")
 #   "reg": inside the conv kernel, in registers between two barriers (csrc/conv_h2.hip).
 H2_PATH = os.environ.get("ONDA_H2_PATH", "dma")
 
+# the multi-GPU gradient exchange installs a callable here: called with the weight Parameter once its gradient of the
+# current backward pass has been accumulated in place (autograd's own hooks never fire for it: backward returns None)
+GRAD_READY = None
+
 # bench.py sets this to a list to collect (kernel family, algorithmic flops, start event, end event)
 # around every conv launch; the events are recorded on the launch stream (torch's current stream)
 PROFILE = None
@@ -534,8 +538,10 @@ class Conv2dFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = conv_dgrad(dy, ctx.cache.get_dgrad(weight, cout_pad), k, stride, dil, pad, cin, x.shape[1:3])
         if ctx.needs_input_grad[1]:
-            dw = conv_wgrad(x, dy, k, stride, dil, pad, cout, cin, into=_accumulate_target(ctx.weight_param), xscale=ctx.xscale,
-                            xlimbs=ctx.xlimbs)
+            into = _accumulate_target(ctx.weight_param)
+            dw = conv_wgrad(x, dy, k, stride, dil, pad, cout, cin, into=into, xscale=ctx.xscale, xlimbs=ctx.xlimbs)
+            if into is not None and GRAD_READY is not None:
+                GRAD_READY(ctx.weight_param)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = colsum(dy)[:cout]
         return dx, dw, db, None, None, None, None, None, None
@@ -572,7 +578,10 @@ class StemConvFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy, _dstats):
         (col,) = ctx.saved_tensors
-        dw = conv_wgrad(col, as_nhwc(dy), 1, 1, 1, 0, ctx.cout, 3, flat_k=49, into=_accumulate_target(ctx.weight))
+        into = _accumulate_target(ctx.weight)
+        dw = conv_wgrad(col, as_nhwc(dy), 1, 1, 1, 0, ctx.cout, 3, flat_k=49, into=into)
+        if into is not None and GRAD_READY is not None:
+            GRAD_READY(ctx.weight)
         return None, dw, None, None
 
 

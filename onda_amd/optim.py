@@ -23,6 +23,13 @@ class ReplaySGD(torch.optim.Optimizer):
             warnings.simplefilter("ignore")  # "parameter group contains duplicate parameters"
             super().__init__(params, dict(lr=lr, momentum=momentum, weight_decay=weight_decay))
 
+    flat_zero = None  # set by the multi-GPU gradient exchange: gradients are views of one flat buffer, zeroed in place
+
+    def zero_grad(self, set_to_none=True):
+        if self.flat_zero is not None:
+            return self.flat_zero()
+        return super().zero_grad(set_to_none)
+
     @torch.no_grad()
     def step(self, closure=None):
         by_cfg = {}
