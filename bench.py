@@ -1,22 +1,27 @@
 #!/usr/bin/env python3
-"""Headline benchmark: adaptation-step throughput (target images / second) of the
-hybrid-switch online adaptation step -- `hybrid_proDA.step([source], target)` +
-`update_ema()` = 2x (forward+backward) + 2-3 no-grad forwards of DeepLabV2/ResNet-50 +
-prototype pseudo-labelling + losses + SGD + teacher EMA -- on synthetic 512x1024 batches
-of 4 images per GPU (BASELINE.json configs[2]; configs[3] when launched on N GPUs).
+"""Headline benchmark: adaptation-step throughput (target images / second) of the hybrid-switch online adaptation
+step -- `hybrid_proDA.step([source], target)` + `update_ema()` = 2x (forward+backward) + 2-3 no-grad forwards of
+DeepLabV2/ResNet-50 + prototype pseudo-labelling + losses + SGD + teacher EMA -- on synthetic 512x1024 batches of 4
+images per GPU (BASELINE.json configs[2]; configs[3] when launched on N GPUs).
 
     python bench.py --gpus 1 --steps 10 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Rank 0 prints ONE JSON line.  `value` counts all ranks' target images over the max-over-ranks
-time of exactly K steps (inputs already resident in HBM).  Weak scaling: every rank adapts
-on its own micro-batch of 4; gradients, prototype statistics and the switch scalars are
-all-reduced over RCCL (onda_amd/dist.py).
+Rank 0 prints ONE JSON line.  `value` counts all ranks' target images over the max-over-ranks time of exactly K steps
+(inputs already resident in HBM).  Default = weak scaling: every rank adapts on its own micro-batch of 4; the
+exchange is onda_amd/dist.py (two collectives per step, the gradient buckets overlapped with the last backward).
+`--global-batch 32` = strong scaling: a fixed global batch processed by N GPUs, each running
+32 / (4 N) micro-batches per optimizer step with the arithmetic of that many more ranks (`step_sharded`).
+Other BASELINE configs: `--config 1` (forward-only evaluation of 8 frames), `--config 2` (supervised fwd+bwd+CE+SGD
+step), `--config 5` (the adaptation step at 1024x2048).
 
-`roofline` is measured live with HIP events on the launch stream in extra, instrumented
-steps after the timed region; `cpu_baseline` times the CPU oracle (oracle/step.py, the
-restatement of the reference pinned by the golden vectors) on the host cores, rank 0, N=1.
+The line carries its own context: `dtype` names the arithmetic the convolutions run in; `config.exact_f32` re-times 3
+steps with the exact fp32-MFMA kernels; `config.eager_rocm` times the same step on PyTorch-ROCm eager (MIOpen fp32,
+the reference's own cudnn flags) in this process; `roofline` is measured live with HIP events on the launch stream in
+extra, instrumented steps after the timed region; `cpu_baseline` times the CPU oracle (oracle/step.py, the restatement
+of the reference pinned by the golden vectors) on the host cores, rank 0, N=1; `config.library` ties the binary to the
+sources (hash compiled into libonda_hip.so vs hash of the sources on disk).
 """
 import argparse
 import glob
@@ -32,11 +37,10 @@ if ROOT not in sys.path:
 
 import torch  # noqa: E402
 
-# SURVEY 8d / BASELINE.md section 2: exact conv FLOPs per image at 512x1024
-FWD_GFLOP_PER_IMG = 781.05
-BWD_GFLOP_PER_IMG = 1559.64
+# SURVEY 8d / BASELINE.md section 2: exact conv FLOPs per image
+CONV_GFLOP = {(512, 1024): (781.05, 1559.64), (1024, 2048): (3088.60, 6167.33)}
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32 (the dtype's dense matrix peak)
-BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak: the pipe the split-precision kernels execute on
+F16_MFMA_PEAK_TFLOPS = 2500.0  # dense f16 / bf16 MFMA peak: the pipe the split-precision kernels execute on
 
 
 def parse():
@@ -44,17 +48,25 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--height", type=int, default=512)
-    ap.add_argument("--width", type=int, default=1024)
-    ap.add_argument("--batch", type=int, default=4, help="images per GPU per step")
+    ap.add_argument("--config", type=int, default=3, choices=[1, 2, 3, 5], help="BASELINE.json configs[N-1]")
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--batch", type=int, default=4, help="images per GPU per micro-batch")
+    ap.add_argument("--global-batch", type=int, default=0, help="strong scaling: fixed global batch per optimizer step")
     ap.add_argument("--branch", choices=["dynamic", "static"], default="dynamic",
                     help="which side of the hybrid switch the synthetic state sits on (pinned via the head scale)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    return ap.parse_args()
+    ap.add_argument("--no-eager", action="store_true")
+    ap.add_argument("--no-exact-f32", action="store_true")
+    args = ap.parse_args()
+    if args.height is None:
+        args.height, args.width = (1024, 2048) if args.config == 5 else (512, 1024)
+    return args
 
 
-def build_adapter(args, device, tmp):
+# ------------------------------------------------------------------------------------------------- workloads
+def build_adapter(args, device, tmp, shards=1):
     from onda_amd.config import hybrid_switch_cfg
     from onda_amd.framework.domain_adaptation.methods.adaptation_model import switch_batch_statistics
     from onda_amd.framework.handlers import get_adapt_method, get_model
@@ -71,34 +83,56 @@ def build_adapter(args, device, tmp):
         b = synth_batch(args.batch, args.height, args.width, seed=seed)
         return {k: v.to(device) for k, v in b.items()}
 
-    src = [dev_batch(1000 + 10 * rank + i) for i in range(2)]
-    trg = [dev_batch(2000 + 10 * rank + i) for i in range(2)]
+    n = 2 * shards
+    src = [dev_batch(1000 + 100 * rank + i) for i in range(n)]
+    trg = [dev_batch(2000 + 100 * rank + i) for i in range(n)]
     da.update_dynamic()
     switch_batch_statistics(da.model, False)
-    da.calculate_prototypes(src, save=False)  # the reference's `append` path over 2 source batches
+    da.calculate_prototypes(src[:2], save=False)  # the reference's `append` path over 2 source batches
     switch_batch_statistics(da.model, True)
     da.optimizer.zero_grad()
     return da, src, trg
 
 
-def one_step(da, src, trg, i, total):
+def one_step(da, src, trg, i, total, shards=1):
     da.adjust_learning_rate(i, total)
-    log = da.step([src[i % 2]], trg[i % 2])
+    if shards == 1:
+        log = da.step([src[i % 2]], trg[i % 2])
+    else:
+        base = (i % 2) * shards
+        log = da.step_sharded([([src[base + j]], trg[base + j]) for j in range(shards)])
     da.update_ema()
     return log
 
 
-def measure_roofline(da, src, trg, args, steps_done, record=True):
-    """Per-kernel-family time via events recorded around every conv launch on the launch
-    stream (torch's current stream).  Reported for the dominant family: the 128x128-tile
-    MFMA implicit-GEMM kernel that runs all forward and data-gradient convolutions.
-    Every rank runs the two instrumented steps (they contain the step's collectives); only the
-    recording rank keeps events."""
+def timed_loop(fn, warmup, steps, device):
+    from onda_amd import dist as odist
+    for i in range(warmup):
+        fn(i)
+    odist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = None
+    for i in range(steps):
+        out = fn(warmup + i)
+    torch.cuda.synchronize()
+    odist.barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+    odist.all_reduce_max(tmax)
+    return tmax.item(), out
+
+
+# ------------------------------------------------------------------------------------------------- roofline
+def measure_roofline(step_fn, steps_done, record=True):
+    """Per-kernel-family time via events recorded around every conv launch on the launch stream (torch's current
+    stream).  Reported for the dominant family.  Every rank runs the two instrumented steps (they contain the step's
+    collectives); only the recording rank keeps events."""
     from onda_amd import ops
     if record:
         ops.PROFILE = []
-    one_step(da, src, trg, steps_done, steps_done + 2)
-    one_step(da, src, trg, steps_done + 1, steps_done + 2)
+    step_fn(steps_done)
+    step_fn(steps_done + 1)
     torch.cuda.synchronize()
     if not record:
         return None
@@ -109,27 +143,28 @@ def measure_roofline(da, src, trg, args, steps_done, record=True):
         f[1] += e0.elapsed_time(e1) * 1e-3
         f[2] += 1
     ops.PROFILE = None
-    dom = max(fam.items(), key=lambda kv: kv[1][1])
-    name, (flops, secs, n) = dom
+    name, (flops, secs, n) = max(fam.items(), key=lambda kv: kv[1][1])
     achieved = flops / secs / 1e12
-    detail = {k: {"launches": v[2], "ms_total": round(v[1] * 1e3, 3), "tflops": round(v[0] / v[1] / 1e12, 2)}
-              for k, v in fam.items()}
-    # The roofline of the kernel is the matrix pipe it executes on: `peak` = that pipe's dense peak divided by
-    # the MFMA products the evaluation spends per fp32 product (f16x2: 3, bf16x3: 6, f32: the fp32 MFMA itself),
-    # so `frac` = executed MFMA flops / pipe peak.  The comparison with the fp32 matrix peak (what a kernel
-    # that did not split its operands could reach at most) is reported next to it.
-    if "h2" in name:
+    detail = {k: {"launches": v[2], "ms_total": round(v[1] * 1e3, 3), "tflops": round(v[0] / v[1] / 1e12, 2)} for k, v in fam.items()}
+    fwd = [v for k, v in fam.items() if "wgrad" not in k]
+    wg = [v for k, v in fam.items() if "wgrad" in k]
+    # The roofline of a kernel is the matrix pipe it executes on: `peak` = that pipe's dense peak divided by the MFMA
+    # products the evaluation spends per fp32 product (f16x2: 3, bf16x3: 6, f32: the fp32 MFMA itself), so `frac` =
+    # executed MFMA flops / pipe peak.  The fp32 matrix peak (what an unsplit fp32 kernel could reach at most) is
+    # reported next to it.
+    if "l2" in name or "h2" in name:
         products, what = 3, "f16 MFMA (v_mfma_f32_16x16x32_f16), 3 limb products per fp32 product, fp32 accumulate"
     elif "bf3" in name:
         products, what = 6, "bf16 MFMA (v_mfma_f32_16x16x32_bf16), 6 limb products per fp32 product, fp32 accumulate"
     else:
         products, what = 0, "fp32 MFMA (v_mfma_f32_32x32x2_f32)"
-    peak = BF16_MFMA_PEAK_TFLOPS / products if products else FP32_MFMA_PEAK_TFLOPS
-    roof = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": round(peak, 1),
-            "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
-            "launches_per_step": n // 2, "avg_launch_ms": round(secs / n * 1e3, 4),
-            "avg_launch_gflop": round(flops / n / 1e9, 3), "families": detail,
-            "pipe": {"what": what, "pipe_peak_tflops": BF16_MFMA_PEAK_TFLOPS if products else FP32_MFMA_PEAK_TFLOPS,
+    peak = F16_MFMA_PEAK_TFLOPS / products if products else FP32_MFMA_PEAK_TFLOPS
+    roof = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+            "frac": round(achieved / peak, 4), "traffic": None, "launches_per_step": n // 2,
+            "avg_launch_ms": round(secs / n * 1e3, 4), "avg_launch_gflop": round(flops / n / 1e9, 3), "families": detail,
+            "all_fwd_dgrad_tflops": round(sum(v[0] for v in fwd) / max(sum(v[1] for v in fwd), 1e-12) / 1e12, 2) if fwd else None,
+            "all_wgrad_tflops": round(sum(v[0] for v in wg) / max(sum(v[1] for v in wg), 1e-12) / 1e12, 2) if wg else None,
+            "pipe": {"what": what, "pipe_peak_tflops": F16_MFMA_PEAK_TFLOPS if products else FP32_MFMA_PEAK_TFLOPS,
                      "executed_tflops": round((products or 1) * achieved, 1)},
             "vs_fp32_matrix_peak": {"peak": FP32_MFMA_PEAK_TFLOPS, "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4)}}
     roof.update(committed_traffic(name))
@@ -137,55 +172,98 @@ def measure_roofline(da, src, trg, args, steps_done, record=True):
 
 
 def committed_traffic(kernel_family):
-    """HBM bytes per launch of the dominant kernel from the committed PMC summary (rocprofv3
-    FETCH_SIZE / WRITE_SIZE in separate passes over this same bench.py; tools/pmc_summary.py
-    applies the gfx950 corrections).  Counters cannot be read from inside the process, so the
-    number is the last profiled one and says which file it came from."""
+    """HBM bytes per launch of the dominant kernel from the committed PMC summary (rocprofv3 FETCH_SIZE / WRITE_SIZE in
+    separate passes over this same bench.py; tools/pmc_summary.py applies the gfx950 corrections).  Counters cannot be
+    read from inside the process, so the number is the last profiled one; the file says which source hash it was
+    taken on (`library_src`), to be compared with `config.library`."""
     best = None
+    stem = {"conv_l2_kernel<0>": "conv_l2_kernel<4, 2", "conv_l2_kernel<1>": "conv_l2_kernel<2, 2",
+            "conv_l2_kernel<2>": "conv_l2_kernel<4, 1"}.get(kernel_family, kernel_family.split("<")[0] + "<")
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json"))):
         try:
-            data = json.load(open(path))["kernels"]
+            blob = json.load(open(path))
+            data = blob["kernels"]
         except Exception:
             continue
-        stem = kernel_family.split("<")[0]
-        rows = [(k, v) for k, v in data.items() if stem + "<" in k]
+        rows = [(k, v) for k, v in data.items() if stem in k]
         if rows:
             tot = sum(v["hbm_bytes_per_launch"] * v["launches"] for _, v in rows)
             n = sum(v["launches"] for _, v in rows)
             best = {"traffic": round(tot / n), "traffic_unit": "bytes per launch (HBM + Infinity-Cache side of L2)",
-                    "traffic_source": os.path.relpath(path, ROOT)}
+                    "traffic_source": os.path.relpath(path, ROOT), "traffic_library_src": blob.get("library_src")}
     return best or {}
 
 
-def cpu_baseline(args):
-    """The CPU oracle on the host cores: one full step (+update_ema) on a bounded sample."""
-    from onda_amd.synthetic import synth_batch, synth_tensor
+# ------------------------------------------------------------------------------------------------- baselines
+def _oracle_adapter(args, device="cpu", batch=1):
+    from onda_amd.synthetic import synth_batch, synth_prototypes, synth_tensor
     from oracle import model as omodel
     from oracle.step import OracleAdapter
-    # torch's CPU convolutions stop scaling (and then collapse) far below the 256 hardware threads
-    # of the GPU node's host; 32 threads is about the best it does, and it is what is reported
+    hs = 40.0 if args.branch == "static" else 1.0
+    sd = {k: synth_tensor(k, torch.empty(shape, dtype=dt), 1, hs).to(dt).to(device) for k, shape, dt in omodel.state_spec()}
+    ad = OracleAdapter(sd, tuple(t.to(device) for t in synth_prototypes()))
+    ad.refresh_dynamic()
+    src = {k: v.to(device) for k, v in synth_batch(batch, args.height, args.width, seed=1000).items()}
+    trg = {k: v.to(device) for k, v in synth_batch(batch, args.height, args.width, seed=2000).items()}
+    return ad, src, trg, omodel
+
+
+def cpu_baseline(args):
+    """The CPU oracle on the host cores: full steps (+update_ema) on a bounded sample: one warm-up, one timed."""
+    # torch's CPU convolutions stop scaling (and then collapse) far below the 256 hardware threads of the GPU node's
+    # host; 32 threads is about the best it does, and it is what is reported
     cores = min(32, os.cpu_count() or 1)
     torch.set_num_threads(cores)
-    hs = 40.0 if args.branch == "static" else 1.0
-    sd = {k: synth_tensor(k, torch.empty(shape, dtype=dt), 1, hs).to(dt) for k, shape, dt in omodel.state_spec()}
-    b, h, w = 1, args.height, args.width
-    src, trg = synth_batch(b, h, w, seed=1000), synth_batch(b, h, w, seed=2000)
-    from onda_amd.synthetic import synth_prototypes
-    ad = OracleAdapter(sd, synth_prototypes())
-    ad.refresh_dynamic()
-    masks = tuple(omodel.draw_drop_mask(b) for _ in range(3))
-    t0 = time.perf_counter()
-    ad.step(src, trg, masks)
-    ad.update_ema()
-    dt = time.perf_counter() - t0
+    b = 1
+    ad, src, trg, omodel = _oracle_adapter(args, "cpu", b)
+    times = []
+    for _ in range(2):
+        masks = tuple(omodel.draw_drop_mask(b) for _ in range(3))
+        t0 = time.perf_counter()
+        ad.step(src, trg, masks)
+        ad.update_ema()
+        times.append(time.perf_counter() - t0)
+    dt = times[-1]
     return {"value": round(b / dt, 5), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"1 hybrid step (+update_ema) of the CPU oracle, B={b} at {w}x{h}, "
-                      f"branch={'dynamic' if ad.switch.current else 'static'}, {dt:.1f} s, torch CPU fp32, {cores} threads"}
+            "sample": f"hybrid step (+update_ema) of the CPU oracle on {b} image(s) per step at {args.width}x{args.height} "
+                      f"(the GPU line: {args.batch} per step), branch={'dynamic' if ad.switch.current else 'static'}; 1 warm-up "
+                      f"({times[0]:.1f} s) + 1 timed step ({dt:.1f} s), torch CPU fp32, {cores} threads"}
+
+
+def eager_rocm(args, device):
+    """The same step executed by PyTorch-ROCm eager kernels (MIOpen fp32 convolutions, torch's own BN / losses / SGD
+    for-loop) on this GPU: the oracle restatement moved to the device, with the cudnn flags the reference sets
+    (train_ouda.py:28-30: benchmark off, deterministic on)."""
+    import oracle.prototypes as op
+    torch.backends.cudnn.benchmark = False
+    torch.backends.cudnn.deterministic = True
+    ad, src, trg, omodel = _oracle_adapter(args, device, args.batch)
+    ones = torch.ones
+    op.torch.ones = lambda *a, **k: ones(*a, **{**k, "device": device})  # the oracle's distance scratch lives on the CPU
+    try:
+        def one():
+            masks = tuple(omodel.draw_drop_mask(args.batch, device=device) for _ in range(3))
+            ad.step(src, trg, masks)
+            ad.update_ema()
+        for _ in range(2):
+            one()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = 3
+        for _ in range(n):
+            one()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n
+    finally:
+        op.torch.ones = ones
+    return {"ms_per_step": round(dt * 1e3, 2), "images_per_s": round(args.batch / dt, 3),
+            "branch": "dynamic" if ad.switch.current else "static",
+            "what": "oracle step on PyTorch-ROCm eager (MIOpen fp32, cudnn.benchmark=False, deterministic=True as train_ouda.py:28-30)"}
 
 
 def conv_accuracy_probe(device):
-    """Evidence for the line's `dtype`: the conv path's error against fp64 on a sample (3x3 dilated conv,
-    forward + both gradients), next to the error of a plain fp32 conv (torch CPU) on the same data."""
+    """Evidence for the line's `dtype`: the conv path's error against fp64 on a sample (3x3 dilated conv, forward + both
+    gradients), next to the error of a plain fp32 conv (torch CPU) on the same data."""
     import torch.nn.functional as F
     from onda_amd import ops
     g = torch.Generator().manual_seed(3)
@@ -209,16 +287,140 @@ def conv_accuracy_probe(device):
             "torch_cpu_fp32_wgrad_rel_l2_vs_fp64": rel(w32.grad, w64.grad)}
 
 
-def conv_mode_note():
+def arithmetic():
+    """(dtype label, note) of the convolution arithmetic in force."""
     from onda_amd import ops
     if ops.CONV_MODE == "f16x2":
-        return ("f16x2: fp32 operands scaled by a per-tensor power of two and split into 2 f16 limbs, 3 limb products on "
-                "the f16 MFMA pipe, fp32 accumulation (3e-7 relative L2 against fp64, the accuracy of an fp32 FMA chain; "
-                "same parity tests as the exact-fp32 MFMA kernels)")
+        path = ("both operands pre-split into limb planes, LDS-DMA only (conv_l2.hip)" if ops.H2_PATH == "dma"
+                else "activations split in-kernel (conv_h2.hip)")
+        return ("f32 (f16x2 split emulation)",
+                "f16x2: fp32 operands scaled by a per-tensor power of two and split into 2 f16 limbs (22 significant bits), 3 limb "
+                "products on the f16 MFMA pipe, fp32 accumulation; 1-3e-7 relative L2 against fp64 = the accuracy of an fp32 FMA "
+                "chain, full accuracy for elements down to 2^-28 of a tensor's maximum; " + path)
     if ops.CONV_MODE == "bf16x3":
-        return ("bf16x3: fp32 operands split exactly into 3 bf16 limbs, 6 limb products on the bf16 MFMA pipe, "
-                "fp32 accumulation (2e-7 relative to the exact-fp32 MFMA kernels; same parity tests)")
-    return "f32: v_mfma_f32_32x32x2_f32 (exact fp32 fmaf chain)"
+        return ("f32 (bf16x3 split emulation)", "bf16x3: fp32 operands split exactly into 3 bf16 limbs, 6 limb products on the bf16 "
+                "MFMA pipe, fp32 accumulation (2e-7 relative to the exact-fp32 MFMA kernels)")
+    return ("f32", "f32: v_mfma_f32_32x32x2_f32 (exact fp32 fmaf chain)")
+
+
+def library_identity():
+    from onda_amd import _lib, build
+    built, src = build.check_fresh()
+    return {"onda_version": _lib.query("onda_version").decode(), "library_src": built, "sources_on_disk": src, "fresh": built == src}
+
+
+# ------------------------------------------------------------------------------------------------- configs
+def run_adaptation(args, device, rank, world):
+    from onda_amd import ops
+    shards = 1
+    if args.global_batch:
+        per_step = args.batch * world
+        if args.global_batch % per_step:
+            raise SystemExit(f"--global-batch {args.global_batch} is not a multiple of {args.batch} x {world} ranks")
+        shards = args.global_batch // per_step
+    with tempfile.TemporaryDirectory() as tmp:
+        da, src, trg = build_adapter(args, device, tmp, shards)
+        total = args.warmup + args.steps
+        step = lambda i: one_step(da, src, trg, i, total + 8, shards)  # noqa: E731
+        dt, log = timed_loop(step, args.warmup, args.steps, device)
+        branch = "dynamic" if da.model_select.current == 1 else "static"
+        roof = None if args.no_roofline else measure_roofline(step, total, record=(rank == 0))
+        loss = float(log["Total target loss"].detach())
+        exact = None
+        if not args.no_exact_f32 and rank == 0 and world == 1 and ops.CONV_MODE != "f32":
+            old, ops.CONV_MODE = ops.CONV_MODE, "f32"
+            try:
+                step(total + 2)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for i in range(3):
+                    step(total + 3 + i)
+                torch.cuda.synchronize()
+                e = (time.perf_counter() - t0) / 3
+                exact = {"ms_per_step": round(e * 1e3, 2), "images_per_s": round(args.batch * shards / e, 3),
+                         "what": "same step, exact fp32 MFMA kernels (ONDA_CONV_MODE=f32), 3 steps"}
+            finally:
+                ops.CONV_MODE = old
+    images = world * args.batch * shards
+    gf = CONV_GFLOP.get((args.height, args.width))
+    tflop_step = None
+    if gf:
+        n_fwd = 2 + (1 if branch == "dynamic" else 0)
+        tflop_step = args.batch * shards * (2 * (gf[0] + gf[1]) + n_fwd * gf[0]) / 1e3
+    cfg = {"workload": f"hybrid_switch adaptation step (step + update_ema), {args.width}x{args.height}, bs={args.batch} per "
+                       f"micro-batch, {shards} micro-batch(es) per GPU and optimizer step, {branch} branch, DeepLabV2-ResNet50 "
+                       f"ProDA head, random-init weights",
+           "baseline_config": 5 if (args.height, args.width) == (1024, 2048) else (4 if world > 1 else 3),
+           "global_batch": images, "parallelism": f"dp{world}", "branch": branch, "micro_batches_per_gpu": shards,
+           "conv_tflop_per_step_per_gpu": tflop_step, "final_loss": round(loss, 5), "exact_f32": exact}
+    if tflop_step:
+        cfg["step_conv_tflops_per_gpu"] = round(tflop_step / (dt / args.steps), 2)
+    return {"metric": f"adaptation-step images/sec (fwd+bwd+proto) {args.height}x{args.width} bs={args.batch}",
+            "value": round(images * args.steps / dt, 4), "unit": "images/s", "dt": dt,
+            "scaling": "strong" if args.global_batch else "weak", "config": cfg, "roofline": roof}
+
+
+def run_segmentation(args, device, rank, world):
+    """BASELINE config 2: `segmentation.train`'s step (segmentation.py:66-88) -- train-mode forward, bilinear upsample to
+    the label resolution, cross-entropy, backward, SGD -- on 4 synthetic images per GPU."""
+    from onda_amd.config import hybrid_switch_cfg
+    from onda_amd.framework.domain_adaptation.methods.segmentation import SegmentationTrainer
+    from onda_amd.framework.handlers import get_model
+    from onda_amd.synthetic import fill_state_dict, synth_batch
+    cfg, spec = hybrid_switch_cfg(args.width, args.height, device, "NONE", batch_size=args.batch)
+    spec.LEARNING_RATE, spec.POWER, spec.WEIGHT_DECAY = 2.5e-4, 0.9, 5e-4
+    torch.manual_seed(123)
+    model = get_model(cfg, 19)
+    fill_state_dict(model, 1, 3.0)
+    model.train()
+    tr = SegmentationTrainer(model, cfg, spec)
+    batches = [{k: v.to(device) for k, v in synth_batch(args.batch, args.height, args.width, seed=3000 + 10 * rank + i).items()}
+               for i in range(2)]
+    step = lambda i: tr.step(batches[i % 2], 1000)  # noqa: E731
+    dt, loss = timed_loop(step, args.warmup, args.steps, device)
+    roof = None if args.no_roofline else measure_roofline(step, args.warmup + args.steps, record=(rank == 0))
+    gf = CONV_GFLOP.get((args.height, args.width))
+    tf = args.batch * (gf[0] + gf[1]) / 1e3 if gf else None
+    cfg_out = {"workload": f"segmentation.train step (fwd -> bilinear upsample -> CE -> bwd -> SGD), {args.width}x{args.height}, "
+                           f"bs={args.batch} per GPU, DeepLabV2-ResNet50 ProDA head, random-init weights",
+               "baseline_config": 2, "global_batch": world * args.batch, "parallelism": f"dp{world} (replicas: no exchange)",
+               "conv_tflop_per_step_per_gpu": tf, "final_loss": round(float(loss), 5)}
+    if tf:
+        cfg_out["step_conv_tflops_per_gpu"] = round(tf / (dt / args.steps), 2)
+    return {"metric": f"supervised-step images/sec (fwd+bwd+CE+SGD) {args.height}x{args.width} bs={args.batch}",
+            "value": round(world * args.batch * args.steps / dt, 4), "unit": "images/s", "dt": dt, "scaling": "weak",
+            "config": cfg_out, "roofline": roof}
+
+
+def run_forward_only(args, device, rank, world):
+    """BASELINE config 1: the evaluation path (adaptation_model.py:127-166) -- eval-mode forward of 8 frames, fused
+    upsample -> argmax -> confusion matrix; one "step" = the 8 frames."""
+    from onda_amd import ops
+    from onda_amd.config import hybrid_switch_cfg
+    from onda_amd.framework.handlers import get_model
+    from onda_amd.synthetic import fill_state_dict, synth_batch
+    cfg, _ = hybrid_switch_cfg(args.width, args.height, device, "NONE", batch_size=1)
+    model = get_model(cfg, 19)
+    fill_state_dict(model, 1, 3.0)
+    model.eval()
+    frames = [{k: v.to(device) for k, v in synth_batch(1, args.height, args.width, seed=4000 + i).items()} for i in range(8)]
+    hist = torch.zeros(19, 19, dtype=torch.int64, device=device)
+
+    def step(_i):
+        with torch.no_grad():
+            for f in frames:
+                ops.upsample_argmax_hist(model(f["image"])[1]["out"], f["label"], hist, 19)
+        return hist
+
+    dt, _ = timed_loop(step, args.warmup, args.steps, device)
+    roof = None if args.no_roofline else measure_roofline(step, 0, record=(rank == 0))
+    gf = CONV_GFLOP.get((args.height, args.width))
+    cfg_out = {"workload": f"forward-only evaluation of 8 frames {args.width}x{args.height} (eval-mode forward + fused "
+                           f"upsample/argmax/confusion matrix), DeepLabV2-ResNet50 ProDA head, random-init weights",
+               "baseline_config": 1, "global_batch": 8 * world, "parallelism": f"dp{world} (replicas: no exchange)",
+               "conv_tflop_per_step_per_gpu": 8 * gf[0] / 1e3 if gf else None}
+    return {"metric": f"forward-only frames/sec {args.height}x{args.width}", "value": round(world * 8 * args.steps / dt, 4),
+            "unit": "images/s", "dt": dt, "scaling": "weak", "config": cfg_out, "roofline": roof}
 
 
 def main():
@@ -231,51 +433,29 @@ def main():
         raise SystemExit("bench.py needs an MI355X (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local)
     device = f"cuda:{local}"
-    with tempfile.TemporaryDirectory() as tmp:
-        da, src, trg = build_adapter(args, device, tmp)
-        total = args.warmup + args.steps
-        for i in range(args.warmup):
-            one_step(da, src, trg, i, total)
-        odist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(args.steps):
-            log = one_step(da, src, trg, args.warmup + i, total)
-        torch.cuda.synchronize()
-        odist.barrier()
-        dt = time.perf_counter() - t0
-        tmax = torch.tensor([dt], device=device, dtype=torch.float64)
-        odist.all_reduce_max(tmax)
-        dt = tmax.item()
-        branch = "dynamic" if da.model_select.current == 1 else "static"
-        roof = None
-        if not args.no_roofline:
-            roof = measure_roofline(da, src, trg, args, total, record=(rank == 0))
-        loss = float(log["Total target loss"].detach())
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(args)
+    lib = library_identity()
+    if not lib["fresh"]:
+        raise SystemExit(f"libonda_hip.so was not compiled from the sources beside it: {lib}; run `python -m onda_amd.build`")
+    run = {1: run_forward_only, 2: run_segmentation, 3: run_adaptation, 5: run_adaptation}[args.config]
+    res = run(args, device, rank, world)
+    dt = res.pop("dt")
+    cpu = eager = None
+    headline = args.config in (3, 5) and not args.global_batch
+    if rank == 0 and world == 1 and headline:
+        if not args.no_eager and (args.height, args.width) == (512, 1024):
+            eager = eager_rocm(args, device)
+        if not args.no_cpu_baseline:
+            cpu = cpu_baseline(args)
     if rank == 0:
-        n_fwd = 2 + (1 if branch == "dynamic" else 0)
-        tflop_step = args.batch * (2 * (FWD_GFLOP_PER_IMG + BWD_GFLOP_PER_IMG) + n_fwd * FWD_GFLOP_PER_IMG) / 1e3
-        if (args.height, args.width) != (512, 1024):
-            tflop_step = None
-        line = {
-            "metric": f"adaptation-step images/sec (fwd+bwd+proto) {args.height}x{args.width} bs={args.batch}",
-            "value": round(world * args.batch * args.steps / dt, 4), "unit": "images/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"hybrid_switch adaptation step (step + update_ema), {args.width}x{args.height}, "
-                                   f"bs={args.batch} per GPU, {branch} branch, DeepLabV2-ResNet50 ProDA head, "
-                                   f"random-init weights", "global_batch": world * args.batch,
-                       "parallelism": f"dp{world}", "branch": branch, "conv_mode": conv_mode_note(),
-                       "conv_tflop_per_step_per_gpu": tflop_step, "final_loss": round(loss, 5),
-                       "conv_accuracy": conv_accuracy_probe(device)},
-            "roofline": roof, "cpu_baseline": cpu,
-        }
-        if tflop_step:
-            line["config"]["step_conv_tflops_per_gpu"] = round(tflop_step / (dt / args.steps), 2)
+        dtype, note = arithmetic()
+        res["config"].update({"conv_mode": note, "conv_accuracy": conv_accuracy_probe(device), "library": lib})
+        if eager:
+            eager["speedup_of_this_repo"] = round(eager["ms_per_step"] / (dt / args.steps * 1e3), 3)
+            res["config"]["eager_rocm"] = eager
+        line = {"metric": res["metric"], "value": res["value"], "unit": res["unit"], "n_gpus": world, "steps": args.steps,
+                "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+                "scaling": res["scaling"], "vs_baseline": None, "dtype": dtype, "data": "synthetic", "config": res["config"],
+                "roofline": res["roofline"], "cpu_baseline": cpu}
         print(json.dumps(line), flush=True)
     if odist.is_on():
         torch.distributed.destroy_process_group()

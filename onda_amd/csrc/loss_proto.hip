@@ -479,6 +479,11 @@ int onda_ema_multi(const OndaEmaEntry* table, int n, int64_t max_n, onda_stream_
   return ONDA_LAUNCH_RESULT();
 }
 
-const char* onda_version(void) { return "onda_hip 0.1 (gfx950)"; }
+// ONDA_SRC_HASH: sha256 (first 16 hex digits) over csrc/*.hip, csrc/*.h and include/*.h at build time (onda_amd/build.py):
+// whoever loads the library can check that it was compiled from the sources beside it (onda_amd.build.source_hash()).
+#ifndef ONDA_SRC_HASH
+#define ONDA_SRC_HASH "unknown"
+#endif
+const char* onda_version(void) { return "onda_hip 0.2 (gfx950) src=" ONDA_SRC_HASH; }
 
 }  // extern "C"

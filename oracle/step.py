@@ -198,6 +198,99 @@ class OracleAdapter:
                                                           lr1, 1, c["MOMENTUM"], c["WEIGHT_DECAY"], self.first_step)
         return log
 
+    def step_sharded(self, shards, masks=None):
+        """The step of N data-parallel ranks, emulated sequentially: `shards` = [(batch_src, batch_trg)] one
+        per rank, `masks` = [(source, target-student, teacher) Dropout2d masks] per rank.  Every rank normalises with
+        the batch statistics of its own micro-batch and starts from the same running statistics (averaged afterwards);
+        gradients are averaged; the teacher/static confidences are averaged before the ONE switch decision; pseudo-labels
+        of every rank use the pre-step prototypes; the class statistics are summed before the prototype EMA; the
+        monitor sees rank-means.  Hybrid method only.  Returns rank 0's log dict."""
+        assert self.method == "hybrid"
+        c, n = self.cfg, len(shards)
+        masks = masks or [(None, None, None)] * n
+        grads, log = {}, {}
+        for r, ((src, _), m) in enumerate(zip(shards, masks)):
+            ce = losses.ce_hard(self._student_forward(src["image"], False, m[0])["out"], src["label_res"])
+            self._backward(c["BUFF_CE"] * ce / n, grads)
+            if r == 0:
+                log.update({"buff_ce_loss": ce.detach(), "buff_rce_loss": 0, "buff_loss": (c["BUFF_CE"] * ce).detach()})
+        teachers = []
+        with torch.no_grad():
+            for (_, trg), m in zip(shards, masks):
+                ema = model.forward(trg["image"], self.ema, model.BNMode(True, True, 0.1), m[2])[1]
+                st = model.forward(trg["image"], self.static, model.BNMode(False))[1]
+                teachers.append((ema, ema["out"].softmax(1), st["out"].softmax(1)))
+        self.stats.add({"prior EMA": sum(t[1].max(1)[0].mean().item() for t in teachers) / n})
+        self.stats.add({"prior static": sum(t[2].max(1)[0].mean().item() for t in teachers) / n})
+        self.switch.evaluate(self.stats.avg("prior static"), self.stats.dev_avg("prior static"))
+        use_dynamic = self.switch.current == self.switch.DYNAMIC and c["DYNAMIC_LAMBDA"] > 0
+        running = [k for k in self.student if "running_" in k]
+        start = {k: self.student[k].clone() for k in running}
+        tracked = {k: self.student[k].clone() for k in self.student if k.endswith("num_batches_tracked")}
+        mean_running = {k: torch.zeros_like(v) for k, v in start.items()}
+        seen = {key: 0.0 for key in ("model", "prior dynamic", "prior", "prototypes", "pseudolabel confidence")}
+        sums = None
+        for r, ((_, trg), m, (ema, p_ema, p_st)) in enumerate(zip(shards, masks, teachers)):
+            for k in running:
+                self.student[k] = start[k].clone()
+            for k, v in tracked.items():
+                self.student[k] = v.clone()
+            out_t = self._student_forward(trg["image"], True, m[1])["out"]
+            for k in running:
+                mean_running[k] += self.student[k].detach() / n
+            seen["model"] += out_t.detach().softmax(1).max(1)[0].mean().item() / n
+            with torch.no_grad():
+                prior = c["EMA_LAMBDA"] * p_ema + c["STATIC_LAMBDA"] * p_st
+                if use_dynamic:
+                    p_dy = model.forward(trg["image"], self.dynamic, model.BNMode(False))[1]["out"].softmax(1)
+                    seen["prior dynamic"] += p_dy.max(1)[0].mean().item() / n
+                    prior = c["DYNAMIC_LAMBDA"] * p_dy
+                seen["prior"] += prior.max(1)[0].mean().item() / n
+                labels, soft, conf = prototypes.assign(ema["feat"], prior, self.proto, self.tau, c["PSEUDO_THRESH"],
+                                                       c["DISTANCE_MEASURE"])
+                seen["prototypes"] += conf.item() / n
+                seen["pseudolabel confidence"] += soft.max(1)[0].mean().item() / n
+                s1, cnt = prototypes.class_sums(ema["feat"], ema["out"])
+                s2, _ = prototypes.class_sums(ema["feat"] ** 2, ema["out"])
+                sums = [s1, s2, cnt] if sums is None else [a + b for a, b in zip(sums, (s1, s2, cnt))]
+            b, k, h, w = out_t.shape
+            pseudo = labels.reshape(b, h, w)
+            parts = losses.target_loss(out_t, pseudo, c["RCE_ALPHA"], c["RCE_BETA"], c["REGULARIZER_WEIGHT"])
+            self._backward(parts["Total target loss"] / n, grads)
+            if r == 0:
+                log.update({name: v.detach() for name, v in parts.items()})
+                log["pseudolabel_pixel_num"] = ((labels >= 0) & (labels != 255)).float().sum()
+                log["output & prototype agreement"] = (pseudo == out_t.argmax(1)).float().mean()
+                self.last = {"soft": soft, "labels": labels}
+        with torch.no_grad():
+            for k_, t in self.student.items():
+                t.requires_grad_(False)
+            for k in running:
+                self.student[k] = mean_running[k]
+            # prototype EMA from the summed class statistics (prototype_handler.ma, :88-99)
+            proto, sqmean, counter = self.proto
+            s1, s2, cnt = sums
+            keep = c["MA_LAMBDA"] ** (cnt > 0).float()
+            safe = torch.where(cnt > 0, cnt, torch.ones_like(cnt))
+            self.proto = ((proto.T * keep).T + ((1 - keep) * (s1.T / safe)).T, (sqmean.T * keep).T + ((1 - keep) * (s2.T / safe)).T,
+                          counter)
+            for key, value in seen.items():
+                if key != "prior dynamic" or use_dynamic:
+                    self.stats.add({key: value})
+            log["mean_prototype_intensity_values"] = (self.proto[0] ** 2).mean()
+            for name, v in self.stats.avg().items():
+                log[f"{name} confidence ma"] = v
+            lr0, lr1 = (c["LEARNING_RATE"] * r_ for r_ in c["LR_RATIO"])
+            for name, times in self.g0:
+                if name in grads:
+                    self.momentum[name] = optim.sgd_apply(self.student[name], grads[name], self.momentum.get(name), lr0, times,
+                                                          c["MOMENTUM"], c["WEIGHT_DECAY"], self.first_step)
+            for name in self.g1:
+                if name in grads:
+                    self.momentum[name] = optim.sgd_apply(self.student[name], grads[name], self.momentum.get(name), lr1, 1,
+                                                          c["MOMENTUM"], c["WEIGHT_DECAY"], self.first_step)
+        return log
+
     @torch.no_grad()
     def update_ema(self):
         a = self.cfg["EMA_UPDATE"]

@@ -306,6 +306,68 @@ def test_full_size_step_golden(golden, tmp_path, conv_mode):
     assert (num / den) ** 0.5 <= 0.02, (num / den) ** 0.5  # post-step weights, as updates (see test_full_step_golden)
 
 
+def test_step_sharded_matches_the_oracle_emulation_of_two_ranks(tmp_path, conv_mode):
+    """``step_sharded`` with two micro-batches (= what two data-parallel ranks compute: rank-local batch statistics,
+    averaged gradients, one switch decision from averaged confidences, summed prototype statistics, averaged running
+    statistics) against the oracle's sequential emulation on the CPU (oracle/step.py step_sharded)."""
+    if conv_mode != "f16x2":
+        pytest.skip("default conv mode only")
+    from onda_amd.config import hybrid_switch_cfg
+    from onda_amd.framework.handlers import get_adapt_method, get_model
+    from onda_amd.framework.model import deeplabv2
+    from onda_amd.framework.domain_adaptation.methods.adaptation_model import switch_batch_statistics
+    from onda_amd.synthetic import fill_state_dict, synth_batch, synth_tensor
+    from oracle import model as omodel
+    from oracle.step import OracleAdapter
+    cfg, spec = hybrid_switch_cfg(128, 64, DEV, str(tmp_path), batch_size=2)
+    model = get_model(cfg, 19)
+    fill_state_dict(model, 1, 40.0)
+    da = get_adapt_method(cfg)(model, cfg, spec)
+    proto_src = [synth_batch(2, 64, 128, seed=100 + i) for i in range(2)]
+    shards = [({k: v for k, v in synth_batch(2, 64, 128, seed=300 + r).items()}, synth_batch(2, 64, 128, seed=400 + r)) for r in range(2)]
+    torch.manual_seed(123)
+    masks = [omodel.draw_drop_mask(2) for _ in range(2 + 6)]
+    it = iter(masks)
+    deeplabv2.drop_mask_fn = lambda B, C, p, dev: next(it).to(dev)
+    try:
+        da.update_dynamic()
+        switch_batch_statistics(da.model, False)
+        da.calculate_prototypes(proto_src, save=False)
+        switch_batch_statistics(da.model, True)
+        da.optimizer.zero_grad()
+        before = {k: v.detach().float().cpu().clone() for k, v in da.model.state_dict().items() if v.is_floating_point() and v.dim() > 0}
+        da.adjust_learning_rate(0, 6)
+        log = da.step_sharded([([s], t) for s, t in shards])
+    finally:
+        deeplabv2.drop_mask_fn = deeplabv2._default_drop_mask
+    # oracle: same state, same masks (prototype batches consumed masks 0,1; then per rank: source, target student, teacher)
+    sd = {k: synth_tensor(k, torch.empty(shape, dtype=dt), 1, 40.0).to(dt) for k, shape, dt in omodel.state_spec()}
+    from onda_amd.synthetic import synth_prototypes
+    ad = OracleAdapter(sd, synth_prototypes())
+    ad.refresh_dynamic()
+    torch.manual_seed(123)
+    ad.proto = ad.initial_prototypes(proto_src)  # draws the same two masks
+    rank_masks = [tuple(masks[2 + 3 * r: 5 + 3 * r]) for r in range(2)]
+    ref = ad.step_sharded(shards, rank_masks)
+    assert ad.switch.current == da.model_select.current
+    for key in ("buff_loss", "Total target loss", "ce_loss", "rce_loss", "regularization_loss", "pseudolabel_pixel_num",
+                "output & prototype agreement", "mean_prototype_intensity_values", "model confidence ma",
+                "prior static confidence ma", "prior EMA confidence ma", "prior confidence ma", "prototypes confidence ma",
+                "pseudolabel confidence confidence ma"):
+        mine, want = log[key], ref[key]
+        mine = mine.item() if isinstance(mine, torch.Tensor) else float(mine)
+        want = want.item() if isinstance(want, torch.Tensor) else float(want)
+        assert _log_close(mine, want, key, 0, 306), (key, mine, want)
+    np.testing.assert_allclose(da.prototypes.prototypes.cpu().numpy(), ad.proto[0].numpy(), rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(da.prototypes.squared_mean.cpu().numpy(), ad.proto[1].numpy(), rtol=1e-3, atol=1e-4)
+    num = den = 0.0
+    for k, b0 in before.items():
+        mine, want = da.model.state_dict()[k].detach().float().cpu(), ad.student[k].float()
+        num += float(((mine - want) ** 2).sum())
+        den += float(((want - b0) ** 2).sum())
+    assert (num / den) ** 0.5 <= 0.03, (num / den) ** 0.5  # post-step weights (running statistics included), as updates
+
+
 def test_eval_forward_1024x2048_golden(golden, conv_mode):
     """One frame at the resolution of BASELINE config 5: class map against the reference's (fixture G11)."""
     from onda_amd import ops
