@@ -88,6 +88,17 @@ int onda_absmax(const float* x, int64_t rows, int C, int ld, float* amax, onda_s
 /* OIHW fp32 weights -> dst[2][rows_pad][Kp] f16 limbs of w * 2^e(amax); other arguments as onda_pack_weight_bf3 */
 int onda_pack_weight_h2(const float* w_oihw, void* dst, int Cout, int Cin, int taps, int rows_pad, int Kp, int dgrad,
                         int Cout_pad, const float* amax, onda_stream_t s);
+/* All conv weights of a model at once: a device table of OIHW tensors -> per tensor max|w| into `amax` (zeroed) and the
+ * forward limb planes fwd[2][Cout][taps*Cin] (+ the data-gradient planes dgrad[2][Cin][taps*Cout], taps flipped, unless
+ * dgrad is NULL); two launches for the whole table instead of two or three per tensor. */
+typedef struct {
+  const float* w;
+  void* fwd;
+  void* dgrad;
+  float* amax;
+  int Cout, Cin, taps, pad_;
+} OndaPackEntry;
+int onda_pack_weights_h2_multi(const OndaPackEntry* table, int n, int64_t max_elems, onda_stream_t s);
 /* onda_conv2d_fwd with the activations split in-kernel (xamax = max|x|) and the weights pre-split (w2 / wamax
  * from onda_pack_weight_h2); same epilogue, workspace and schedule.  yamax (optional, zeroed): max|y| */
 int onda_conv2d_fwd_h2(const float* x, const float* xamax, const void* w2, const float* wamax, float* y,

@@ -23,6 +23,11 @@ class OndaSgdEntry(Structure):
                 ("times", c_int), ("fresh", c_int)]
 
 
+class OndaPackEntry(Structure):
+    _fields_ = [("w", c_void_p), ("fwd", c_void_p), ("dgrad", c_void_p), ("amax", c_void_p), ("Cout", c_int), ("Cin", c_int),
+                ("taps", c_int), ("pad_", c_int)]
+
+
 class OndaEmaEntry(Structure):
     _fields_ = [("k", c_void_p), ("q", c_void_p), ("n", c_int64), ("keep", c_float), ("blend", c_float)]
 
@@ -36,6 +41,7 @@ SIGNATURES = {
     "onda_conv2d_fwd_bf3": (I, [P, P, P, P, P, P, P, P, POINTER(OndaConv), P]),
     "onda_absmax": (I, [P, L, I, I, P, P]),
     "onda_pack_weight_h2": (I, [P, P, I, I, I, I, I, I, I, P, P]),
+    "onda_pack_weights_h2_multi": (I, [P, I, L, P]),
     "onda_conv2d_fwd_h2": (I, [P, P, P, P, P, P, P, P, P, P, P, POINTER(OndaConv), P]),
     "onda_conv2d_wgrad_h2": (I, [P, P, P, P, P, I, I, POINTER(OndaConv), P]),
     "onda_split_h2": (I, [P, L, I, I, P, I, L, P, P]),

@@ -133,6 +133,46 @@ __global__ void pack_h2_kernel(const float* __restrict__ w, _Float16* __restrict
   dst[plane + e] = (_Float16)((v - (float)a) * LIMB2_SCALE);
 }
 
+// ---- all conv weights of a model in two launches --------------------------------------------------
+// The student's weights change every step (SGD) and so do the teacher's (EMA): ~100 weight tensors to re-scale and
+// re-split, forward and data-gradient form.  One absmax + one pack launch per tensor cost 3 ms of launch overhead per
+// step; a table of tensors in device memory makes it one launch each.
+__global__ __launch_bounds__(256) void absmax_multi_kernel(const OndaPackEntry* __restrict__ table) {
+  const OndaPackEntry e = table[blockIdx.y];
+  const long long n = (long long)e.Cout * e.Cin * e.taps;
+  float m = 0.f;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) m = fmaxf(m, fabsf(e.w[i]));
+  __shared__ float red[4];
+  amax_update_block(e.amax, m, red);
+}
+
+__global__ __launch_bounds__(256) void pack_h2_multi_kernel(const OndaPackEntry* __restrict__ table) {
+  const OndaPackEntry e = table[blockIdx.y];
+  const size_t plane = (size_t)e.Cout * e.Cin * e.taps;  // both forms have Cout*taps*Cin elements per limb plane
+  const float s = scale_of(e.amax).s;
+  const int K = e.taps * e.Cin, Kd = e.taps * e.Cout;
+  _Float16* fwd = static_cast<_Float16*>(e.fwd);
+  _Float16* dg = static_cast<_Float16*>(e.dgrad);
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < plane; i += (size_t)gridDim.x * 256) {
+    {  // forward form: row n, k = tap*Cin + c
+      const int k = (int)(i % K), n = (int)(i / K);
+      const int tap = k / e.Cin, cc = k - tap * e.Cin;
+      const float v = e.w[((size_t)n * e.Cin + cc) * e.taps + tap] * s;
+      const _Float16 a = (_Float16)v;
+      fwd[i] = a;
+      fwd[plane + i] = (_Float16)((v - (float)a) * LIMB2_SCALE);
+    }
+    if (dg != nullptr) {  // data-gradient form: row c, k = tap'*Cout + n, taps flipped
+      const int k = (int)(i % Kd), c = (int)(i / Kd);
+      const int tap = k / e.Cout, n = k - tap * e.Cout;
+      const float v = e.w[((size_t)n * e.Cin + c) * e.taps + (e.taps - 1 - tap)] * s;
+      const _Float16 a = (_Float16)v;
+      dg[i] = a;
+      dg[plane + i] = (_Float16)((v - (float)a) * LIMB2_SCALE);
+    }
+  }
+}
+
 // ---- forward / data gradient ----------------------------------------------------------------------
 template <int BM, int BN, bool SK>
 __global__ __launch_bounds__(256, 2) void conv_fwd_h2_kernel(const ConvK a, unsigned limb_stride, unsigned x_bytes, unsigned w_bytes,
@@ -537,6 +577,14 @@ int onda_pack_weight_h2(const float* w_oihw, void* dst, int Cout, int Cin, int t
   const size_t plane = (size_t)rows_pad * Kp;
   hipLaunchKernelGGL(pack_h2_kernel, dim3((unsigned)((plane + 255) / 256)), dim3(256), 0, ONDA_STREAM(s), w_oihw,
                      static_cast<_Float16*>(dst), Cout, Cin, taps, rows_pad, Kp, dgrad, Cout_pad, amax);
+  return ONDA_LAUNCH_RESULT();
+}
+
+int onda_pack_weights_h2_multi(const OndaPackEntry* table, int n, int64_t max_elems, onda_stream_t s) {
+  ONDA_REQUIRE(table && n > 0 && max_elems > 0);
+  const int chunks = (int)(max_elems / (256 * 16) + 1 > 64 ? 64 : max_elems / (256 * 16) + 1);
+  hipLaunchKernelGGL(absmax_multi_kernel, dim3(chunks, n), dim3(256), 0, ONDA_STREAM(s), table);
+  hipLaunchKernelGGL(pack_h2_multi_kernel, dim3(chunks, n), dim3(256), 0, ONDA_STREAM(s), table);
   return ONDA_LAUNCH_RESULT();
 }
 

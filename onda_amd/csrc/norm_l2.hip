@@ -137,14 +137,14 @@ __global__ __launch_bounds__(256) void bn_apply_l2_kernel(const float* __restric
   const int col = (int)(e0 % c8) * 8;
   const f32x4 sc0 = LD4(invstd + col) * LD4(gamma + col), sc1 = LD4(invstd + col + 4) * LD4(gamma + col + 4);
   const f32x4 mu0 = LD4(mean + col), mu1 = LD4(mean + col + 4), be0 = LD4(beta + col), be1 = LD4(beta + col + 4);
-  for (size_t e = e0; e < total8; e += (size_t)gridDim.x * blockDim.x) {
-    f32x4 v0 = (LD4(x + e * 8) - mu0) * sc0 + be0;
-    f32x4 v1 = (LD4(x + e * 8 + 4) - mu1) * sc1 + be1;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  auto one = [&](size_t e, f32x4 x0, f32x4 x1, u32x4 r1, u32x4 r2) {
+    f32x4 v0 = (x0 - mu0) * sc0 + be0, v1 = (x1 - mu1) * sc1 + be1;
     if (res) {
-      f32x4 r0, r1;
-      join8(*reinterpret_cast<const u32x4*>(res + e * 8), *reinterpret_cast<const u32x4*>(res + res_plane + e * 8), r0, r1);
-      v0 += r0 * ri;
-      v1 += r1 * ri;
+      f32x4 q0, q1;
+      join8(r1, r2, q0, q1);
+      v0 += q0 * ri;
+      v1 += q1 * ri;
     }
     if (relu) {
 #pragma unroll
@@ -157,6 +157,29 @@ __global__ __launch_bounds__(256) void bn_apply_l2_kernel(const float* __restric
     split8(v0 * so, v1 * so, l1, l2);
     *reinterpret_cast<u32x4*>(out + e * 8) = l1;
     *reinterpret_cast<u32x4*>(out + out_plane + e * 8) = l2;
+  };
+  size_t e = e0;
+  // two independent items per iteration: all loads of both are issued before the first is used
+  for (; e + stride < total8; e += 2 * stride) {
+    const size_t f = e + stride;
+    const f32x4 a0 = LD4(x + e * 8), a1 = LD4(x + e * 8 + 4), b0 = LD4(x + f * 8), b1 = LD4(x + f * 8 + 4);
+    u32x4 ra1 = {}, ra2 = {}, rb1 = {}, rb2 = {};
+    if (res) {
+      ra1 = *reinterpret_cast<const u32x4*>(res + e * 8);
+      ra2 = *reinterpret_cast<const u32x4*>(res + res_plane + e * 8);
+      rb1 = *reinterpret_cast<const u32x4*>(res + f * 8);
+      rb2 = *reinterpret_cast<const u32x4*>(res + res_plane + f * 8);
+    }
+    one(e, a0, a1, ra1, ra2);
+    one(f, b0, b1, rb1, rb2);
+  }
+  if (e < total8) {
+    u32x4 r1 = {}, r2 = {};
+    if (res) {
+      r1 = *reinterpret_cast<const u32x4*>(res + e * 8);
+      r2 = *reinterpret_cast<const u32x4*>(res + res_plane + e * 8);
+    }
+    one(e, LD4(x + e * 8), LD4(x + e * 8 + 4), r1, r2);
   }
 }
 

@@ -276,6 +276,20 @@ class ResNetMulti(nn.Module):
             layers.append(block(self.inplanes, planes, dilation=dilation))
         return nn.Sequential(*layers)
 
+    def __deepcopy__(self, memo):
+        packer = self.__dict__.pop("_packer", None)  # buffers of the packed weights belong to one model instance
+        try:
+            cls = self.__class__
+            new = cls.__new__(cls)
+            memo[id(self)] = new
+            from copy import deepcopy
+            for k, v in self.__dict__.items():
+                new.__dict__[k] = deepcopy(v, memo)
+        finally:
+            if packer is not None:
+                self.__dict__["_packer"] = packer
+        return new
+
     def _stem(self, x):
         bn = self.bn1
         if bn.training:
@@ -291,6 +305,12 @@ class ResNetMulti(nn.Module):
             raise ValueError(f"expected an image batch f32[B,3,H,W], got {tuple(x.shape)}")
         ops._require_cuda(x, "image batch")
         x = x.to(torch.float32)
+        packer = self.__dict__.get("_packer")
+        if packer is None:
+            plain = [m for name, m in self.named_modules() if isinstance(m, HipConv2d) and m is not self.conv1
+                     and not name.endswith("head.1") and (self.multi_level or not name.startswith("layer5."))]
+            packer = self.__dict__["_packer"] = ops.ModelPacker(plain)
+        packer.refresh(need_dgrad=torch.is_grad_enabled() and self.training)
         y = self._stem(x)
         y = self.layer1(y)
         y = self.layer2(y)

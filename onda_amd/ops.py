@@ -508,6 +508,56 @@ class _PackCache:
         return _PackCache()
 
 
+class ModelPacker:
+    """Packed "f16x2" weights of ALL plain convolutions of a model, refreshed with two launches (csrc/conv_h2.hip
+    pack_h2_multi_kernel) when parameters have changed -- every step for the student (SGD) and the teacher (EMA).  The
+    limb planes are persistent buffers rewritten in place (stream order protects their readers); every refresh takes
+    fresh zeroed max|w| slots.  Convolutions with padded layouts (stem, class head) keep their own _PackCache path."""
+
+    def __init__(self, convs):
+        self.convs = [c for c in convs if c.weight.numel() % 4 == 0]
+        self.bufs = {}
+
+    def refresh(self, need_dgrad):
+        if CONV_MODE != "f16x2" or not self.convs:
+            return
+        stale = []
+        for c in self.convs:
+            w, cache = c.weight, c._pack
+            key = _PackCache._key(w)
+            if cache.key_f != key or (need_dgrad and cache.key_d != key):
+                stale.append((c, key))
+        if not stale:
+            return
+        dev = stale[0][0].weight.device
+        ents, biggest = [], 0
+        for c, key in stale:
+            w = c.weight.detach()
+            if not w.is_contiguous():
+                w = w.contiguous()
+            cout, cin, kh, kw = w.shape
+            buf = self.bufs.get(id(c))
+            if buf is None or buf[0].device != w.device:
+                buf = self.bufs[id(c)] = (torch.empty(2, cout, kh * kw * cin, device=w.device, dtype=torch.float16),
+                                          torch.empty(2, cin, kh * kw * cout, device=w.device, dtype=torch.float16))
+            slot = amax_slot(w.device)
+            tag_amax(c.weight, slot)
+            cache = c._pack
+            cache.fwd, cache.key_f = H2Weight(buf[0], slot), key
+            if need_dgrad:
+                cache.dgrad, cache.key_d = H2Weight(buf[1], slot), key
+            else:
+                cache.key_d = None
+            ents.append(_lib.OndaPackEntry(w.data_ptr(), buf[0].data_ptr(), buf[1].data_ptr() if need_dgrad else None, slot.data_ptr(),
+                                           cout, cin, kh * kw, 0))
+            biggest = max(biggest, w.numel())
+            self._keep = getattr(self, "_keep", [])
+            self._keep.append(w)
+        table = _table(ents, _lib.OndaPackEntry).to(dev, non_blocking=False)
+        call("onda_pack_weights_h2_multi", _p(table), len(ents), biggest, _stream())
+        self._keep = []
+
+
 class Conv2dFn(torch.autograd.Function):
     """NHWC convolution (+bias) with optional BatchNorm statistic partials from the epilogue."""
 
