@@ -582,7 +582,8 @@ int onda_pack_weight_h2(const float* w_oihw, void* dst, int Cout, int Cin, int t
 
 int onda_pack_weights_h2_multi(const OndaPackEntry* table, int n, int64_t max_elems, onda_stream_t s) {
   ONDA_REQUIRE(table && n > 0 && max_elems > 0);
-  const int chunks = (int)(max_elems / (256 * 16) + 1 > 64 ? 64 : max_elems / (256 * 16) + 1);
+  // enough workgroups for the largest tensor to run at memory speed (small tensors' surplus workgroups exit at once)
+  const int chunks = (int)(max_elems / (256 * 8) + 1 > 1024 ? 1024 : max_elems / (256 * 8) + 1);
   hipLaunchKernelGGL(absmax_multi_kernel, dim3(chunks, n), dim3(256), 0, ONDA_STREAM(s), table);
   hipLaunchKernelGGL(pack_h2_multi_kernel, dim3(chunks, n), dim3(256), 0, ONDA_STREAM(s), table);
   return ONDA_LAUNCH_RESULT();

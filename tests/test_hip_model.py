@@ -388,6 +388,82 @@ def test_eval_forward_1024x2048_golden(golden, conv_mode):
                                atol=1e-3 * np.abs(g["feat_digest"][2:]).max())
 
 
+def test_f16x2_per_layer_against_exact_f32_on_a_pretrained_like_state(conv_mode):
+    """What random-init weights and N(0,1) images do not exercise: a state with the dynamic ranges of a trained network --
+    per-layer weight scales spread log-uniformly over four decades, BatchNorm gains in [0.05, 4] and offsets of either
+    sign, a confident head (so that most per-pixel loss gradients are ~1e-8 next to a few ~1).  One train-mode pass runs
+    on the EXACT fp32 MFMA kernels while every convolution's input, weight, output gradient are captured; each layer is
+    then re-evaluated by the two-limb f16 kernels on exactly those tensors (so nothing is amplified through the
+    network) and held to the exact result: forward, data gradient and weight gradient to 3e-6 relative L2 (two fp32
+    accumulations in different orders; each is ~3e-7 from fp64) and 1e-5 of the largest value."""
+    if conv_mode != "f16x2":
+        pytest.skip("runs once: it switches the conv mode itself")
+    from onda_amd import ops
+    from onda_amd.framework.model import deeplabv2
+    from onda_amd.synthetic import synth_batch
+    old_mode = ops.CONV_MODE
+    ops.CONV_MODE = "f32"
+    try:
+        m = build_model(7, 1.0).train()
+        g = torch.Generator().manual_seed(77)
+        with torch.no_grad():
+            for name, p in m.named_parameters():
+                if p.dim() == 4:
+                    p.mul_(10.0 ** float(torch.empty(1).uniform_(-2, 2, generator=g)))
+                elif ".bn" in name or name.startswith("bn1") or "downsample.1" in name:
+                    if name.endswith("weight"):
+                        p.copy_(torch.exp(torch.empty(p.shape).uniform_(-3.0, 1.4, generator=g)).to(p.device))
+                    else:
+                        p.copy_((torch.randn(p.shape, generator=g) * 0.5).to(p.device))
+            m.layer6.head[1].weight.mul_(3000.0)  # confident head: per-pixel CE gradients from ~1e-8 to ~1
+        captured = []
+
+        def hook(mod, inputs, output):
+            x, y = inputs[0], output[0]
+            rec = {"mod": mod, "x": x.detach(), "w": mod.weight.detach().clone()}
+            if y.requires_grad:
+                y.register_hook(lambda gr, rec=rec: rec.__setitem__("dy", gr.detach().clone()))
+            captured.append(rec)
+
+        handles = [mod.register_forward_hook(hook) for mod in m.modules() if isinstance(mod, deeplabv2.HipConv2d) and mod is not m.conv1]
+        b = synth_batch(2, 64, 128, seed=70)
+        _, o = m(b["image"].to(DEV))
+        ops.seg_losses(o["out"], b["label_res"].to(DEV), 1.0, 0.0, 0.0)[0].backward()
+        for h in handles:
+            h.remove()
+        probs = o["out"].detach().softmax(1).max(1)[0]
+        assert probs.median() > 0.99  # the head is confident
+        assert len(captured) >= 50
+        spans = []
+        for rec in captured:
+            mod, x, w, dy = rec["mod"], rec["x"], rec["w"], rec.get("dy")
+            k, stride, dil, pad = mod.geom()
+            pad_to = ops.HEAD_PAD if w.shape[0] == 19 else None
+            ref, test = {}, {}
+            for mode, dst in (("f32", ref), ("f16x2", test)):
+                ops.CONV_MODE = mode
+                xi, wi = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+                y, _ = ops.Conv2dFn.apply(xi, wi, None, ops._PackCache(), stride, dil, pad, False, pad_to)
+                dst["y"] = y.detach()
+                if dy is not None:
+                    y.backward(dy)
+                    dst["dx"], dst["dw"] = xi.grad, wi.grad
+            for key in ref:
+                a, r = test[key].double(), ref[key].double()
+                scale = r.abs().max()
+                if scale == 0:
+                    assert a.abs().max() == 0
+                    continue
+                assert (a - r).norm() <= 3e-6 * r.norm(), (key, tuple(w.shape), float((a - r).norm() / r.norm()))
+                assert (a - r).abs().max() <= 1e-5 * scale, (key, tuple(w.shape), float((a - r).abs().max() / scale))
+            if dy is not None:
+                nz = dy[dy != 0].abs()
+                spans.append(float(nz.max() / nz.min()) if nz.numel() else 1.0)
+        assert max(spans) > 1e6  # the gradients really span many decades
+    finally:
+        ops.CONV_MODE = old_mode
+
+
 def test_eval_after_train_step_uses_fresh_running_statistics():
     """eval forward -> one train-mode forward that moves the running statistics -> eval forward again: the folded
     BatchNorm of the second eval pass must be rebuilt (the kernel writes the buffers behind torch's back)."""
