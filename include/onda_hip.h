@@ -115,7 +115,7 @@ int onda_conv2d_fwd_h2(const float* x, const float* xamax, const void* w2, const
 int onda_split_h2(const float* x, int64_t rows, int C, int ldx, void* dst, int ldo, int64_t plane, const float* amax,
                   onda_stream_t s);
 int onda_conv_l2_variant(int64_t M, int Cout);  /* tile shape used for an (M, Cout) problem: 0 256x128, 1 128x128, 2 256x64 */
-int onda_conv_l2_tiles_m(int64_t M, int Cout);  /* rows of the `stats` partials for that tile shape */
+int onda_conv_l2_tiles_m(int64_t M, int Cout, int taps, int Cin);  /* rows of the `stats` partials the conv writes for this problem */
 /* stats_rows: 2 = stats[tile][sum, sumsq][Cout] as onda_conv2d_fwd; 4 = also the per-channel min and max of the raw
  * output tile, from which onda_bn_finalize_l2 bounds max|BatchNorm output| before the apply pass writes limb planes */
 int onda_conv2d_fwd_l2(const void* xl, int64_t xplane, const float* xamax, const void* w2, const float* wamax, float* y,

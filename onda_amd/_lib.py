@@ -46,7 +46,7 @@ SIGNATURES = {
     "onda_conv2d_wgrad_h2": (I, [P, P, P, P, P, I, I, POINTER(OndaConv), P]),
     "onda_split_h2": (I, [P, L, I, I, P, I, L, P, P]),
     "onda_conv_l2_variant": (I, [L, I]),
-    "onda_conv_l2_tiles_m": (I, [L, I]),
+    "onda_conv_l2_tiles_m": (I, [L, I, I, I]),
     "onda_conv_wgrad_l2_variant": (I, [I, I]),
     "onda_conv2d_wgrad_l2": (I, [P, L, P, P, L, P, P, I, I, POINTER(OndaConv), P]),
     "onda_conv2d_fwd_l2": (I, [P, L, P, P, P, P, P, P, P, P, I, P, P, POINTER(OndaConv), P]),

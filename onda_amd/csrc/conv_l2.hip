@@ -448,6 +448,115 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_l2_kernel(const ConvK 
 }
 
 
+// ---- stream-K remainder: partial tiles -> output, in ONE wide launch ---------------------------------------------------
+// A remainder tile was cut into pieces by the workgroups of conv_l2_kernel<.., SK = true> (raw accumulators in `ws`).
+// One workgroup per 8 rows of a remainder tile sums that tile's pieces in ascending-workgroup order (fixed order:
+// deterministic) and runs the epilogue on them; its statistics partial goes to a row of its own (sub-block 0: the tile's
+// own row, the others: extra rows behind the regular ones -- bn_finalize sums over all rows anyway), so no second stage
+// and no cross-workgroup reduction is needed.  Replaces the two-launch piece_sum + fixup of the older kernels
+// (measured there: 31 us per convolution, 5.4 ms per adaptation step).
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void conv_l2_fixup_kernel(const ConvK a, int G, int rows_regular) {
+  constexpr int C4 = BN / 4;      // float4 columns of a tile row
+  constexpr int RG = 256 / C4;    // rows covered by the workgroup (one element group per thread)
+  constexpr int SUB = BM / RG;    // sub-blocks per tile
+  __shared__ f32x4 red[4][256];
+  __shared__ int piece[1024];
+  const OndaConv& c = a.c;
+  const int KT = a.taps * a.kcper;
+  const long long U = (long long)(a.tilesM * a.tilesN - a.tiles_dp) * KT;
+  // grid.x walks every tile of the tile ROWS that hold remainder tiles (a statistic row spans all channel tiles of a tile
+  // row, so the extra rows must be complete): tiles of the first such row that ran one-per-workgroup only fill identities
+  const int sub = blockIdx.y;
+  const int first_m = a.tiles_dp / a.tilesN;
+  const int tile = first_m * a.tilesN + blockIdx.x;
+  const int lt = tile - a.tiles_dp;  // remainder-local tile (negative: not a remainder tile)
+  const long long t0 = (long long)lt * KT, t1 = t0 + KT;
+  const int vs = lt < 0 ? 0 : (int)(((t0 + 1) * G + U - 1) / U - 1), ve = lt < 0 ? 0 : (int)((t1 * G + U - 1) / U - 1);
+  const int tile_n = tile % a.tilesN, tile_m = tile / a.tilesN;
+  const int t = threadIdx.x, col = (t % C4) * 4, rg = t / C4;
+  const int n = tile_n * BN + col;
+  const bool vn = n < c.Cout;
+  const int SR = a.stats_rows;
+  float* srow = a.stats ? a.stats + (size_t)(sub == 0 ? tile_m : rows_regular + (tile_m - first_m) * (SUB - 1) + sub - 1) * SR * c.Cout + n
+                        : nullptr;
+  if (vs == ve) {  // computed whole by one workgroup: its own epilogue ran; the extra statistic rows are identities
+    if (srow && sub != 0 && rg == 0 && vn) {
+      *reinterpret_cast<f32x4*>(srow) = f32x4{0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<f32x4*>(srow + c.Cout) = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (SR == 4) {
+        *reinterpret_cast<f32x4*>(srow + 2 * c.Cout) = f32x4{3.0e38f, 3.0e38f, 3.0e38f, 3.0e38f};
+        *reinterpret_cast<f32x4*>(srow + 3 * c.Cout) = f32x4{-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
+      }
+    }
+    return;
+  }
+  const int npieces = ve - vs + 1;
+  for (int p = t; p < npieces; p += 256) {
+    const int vb = vs + p;
+    const long long b0 = (long long)vb * U / G, b1 = (long long)(vb + 1) * U / G;
+    const long long g0 = max(b0, t0), g1 = min(b1, t1);
+    piece[p] = g1 > g0 ? vb * 2 + (g0 == b0 ? 0 : 1) : -1;
+  }
+  __syncthreads();
+  const int row = sub * RG + rg;
+  const int eo = row * BN + col;
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+  for (int p = 0; p < npieces; ++p) {
+    const int pc = piece[p];
+    if (pc >= 0) v += *reinterpret_cast<const f32x4*>(a.ws + (size_t)pc * (BM * BN) + eo);
+  }
+  const int m = tile_m * BM + row;
+  float mx = 0.f;
+  if (m < a.M && vn) {
+    f32x4 o = v;
+    if (a.scale) o *= *reinterpret_cast<const f32x4*>(a.scale + n);
+    if (a.shift) o += *reinterpret_cast<const f32x4*>(a.shift + n);
+    if (a.res) o += *reinterpret_cast<const f32x4*>(a.res + (size_t)m * c.ldr + n);
+    if (c.relu) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = fmaxf(o[j], 0.f);
+    }
+    size_t orow = m;
+    if (!(c.out_os == 1 && c.Hf == c.Ho && c.Wf == c.Wo)) {
+      const int wo = m % c.Wo, tq = m / c.Wo;
+      const int ho = tq % c.Ho, b = tq / c.Ho;
+      orow = ((size_t)b * c.Hf + (size_t)ho * c.out_os) * c.Wf + (size_t)wo * c.out_os;
+    }
+    *reinterpret_cast<f32x4*>(a.y + orow * c.ldy + n) = o;
+    mx = fmaxf(fmaxf(mx, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
+  }
+  if (a.amax != nullptr) amax_update_block(a.amax, mx, reinterpret_cast<float*>(&red[0][0]));
+  if (a.stats != nullptr) {
+    __syncthreads();
+    red[0][t] = v;
+    red[1][t] = v * v;
+    red[2][t] = v;
+    red[3][t] = v;
+    __syncthreads();
+    if (rg == 0 && vn) {
+      f32x4 s1 = red[0][t], s2 = red[1][t], mn = v, mxv = v;
+      for (int g = 1; g < RG; ++g) {
+        s1 += red[0][g * C4 + t];
+        s2 += red[1][g * C4 + t];
+        const f32x4 o = red[2][g * C4 + t];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          mn[j] = fminf(mn[j], o[j]);
+          mxv[j] = fmaxf(mxv[j], o[j]);
+        }
+      }
+      *reinterpret_cast<f32x4*>(srow) = s1;
+      *reinterpret_cast<f32x4*>(srow + c.Cout) = s2;
+      if (SR == 4) {
+        *reinterpret_cast<f32x4*>(srow + 2 * c.Cout) = mn;
+        *reinterpret_cast<f32x4*>(srow + 3 * c.Cout) = mxv;
+      }
+    }
+  }
+}
+
 // ---- weight gradient ----------------------------------------------------------------------------------------------------
 // dw[n][tap][c] = sum over pixels m of dy[m][n] * x[pix(m, tap)][c]: the contraction index (pixels) is the SLOW memory axis
 // of both operands.  Both arrive as they lie in HBM -- [pixel][channel] rows of their limb planes, by LDS-DMA, 4 pixels x 128
@@ -777,15 +886,50 @@ int onda_conv_l2_variant(int64_t M, int Cout) {
   const long long t256 = ((M + 255) / 256) * ((Cout + 127) / 128);
   return t256 >= 200 ? 0 : 1;
 }
-int onda_conv_l2_tiles_m(int64_t M, int Cout) {
-  const int v = onda_conv_l2_variant(M, Cout);
-  return (int)(v == 1 ? (M + 127) / 128 : (M + 255) / 256);
+
+}  // extern "C"
+
+namespace {
+// How an (M, Cout, K) problem is scheduled: whole rounds of one tile per workgroup; a remainder of tiles (tiles mod the
+// resident workgroups) is cut into equal K ranges over all workgroups when that pays (hybrid stream-K).
+struct L2Schedule {
+  int variant, BM, BN, tilesM, tilesN, G, rem, sub;
+  bool balanced;
+  int rem_rows() const { return tilesM - (tilesM * tilesN - rem) / tilesN; }  // tile rows that hold remainder tiles
+  int stats_rows_total() const { return tilesM + (balanced ? rem_rows() * (sub - 1) : 0); }
+};
+L2Schedule l2_schedule(long long M, int Cout, int taps, int Cin, bool have_ws) {
+  L2Schedule q;
+  q.variant = onda_conv_l2_variant(M, Cout);
+  q.BM = q.variant == 1 ? 128 : 256;
+  q.BN = q.variant == 2 ? 64 : 128;
+  q.tilesM = (int)((M + q.BM - 1) / q.BM);
+  q.tilesN = (Cout + q.BN - 1) / q.BN;
+  q.G = conv_resident_workgroups() / 2;  // one workgroup per CU (144 / 96 / 120 KB of LDS)
+  q.sub = q.BM / (256 / (q.BN / 4));
+  const int tiles = q.tilesM * q.tilesN, KT = taps * (Cin / 32);
+  q.rem = tiles % q.G;
+  const double t_tile_us = 2.0 * q.BM * q.BN * taps * Cin / 1.4e6;  // one tile on one CU at ~360 TF/s chip-wide
+  const double fix_us = 6.0 + (q.G + 2.0 * q.rem) * (q.BM * q.BN / 16384.0) * 0.02;  // partial tiles written + read
+  q.balanced = have_ws && q.rem != 0 && KT >= 4 && t_tile_us * (1.0 - (double)q.rem / q.G) > fix_us &&
+               (size_t)q.G * 2 * q.BM * q.BN <= (size_t)onda_conv_ws_floats() && q.G <= 1024;
+  if (const int force = conv_sched_override()) {  // ONDA_CONV_SCHED: 1 tile-per-workgroup, 2 hybrid
+    if (force == 1 || !have_ws) q.balanced = false;
+    else if (force == 2) q.balanced = q.rem != 0;
+  }
+  return q;
 }
+}  // namespace
+
+extern "C" {
+
+/* rows of the `stats` partials the conv will write for this problem (tile rows + the extra rows of a stream-K remainder) */
+int onda_conv_l2_tiles_m(int64_t M, int Cout, int taps, int Cin) { return l2_schedule(M, Cout, taps, Cin, true).stats_rows_total(); }
 
 int onda_conv2d_fwd_l2(const void* xl, int64_t xplane, const float* xamax, const void* w2, const float* wamax, float* y,
                        const float* scale, const float* shift, const float* residual, float* stats, int stats_rows, float* ws,
                        float* yamax, const OndaConv* c, onda_stream_t s) {
-  ONDA_REQUIRE(xl && xamax && w2 && wamax && y && c && (stats_rows == 2 || stats_rows == 4));
+  ONDA_REQUIRE(xl && xamax && w2 && wamax && y && c && ws && (stats_rows == 2 || stats_rows == 4));
   ONDA_REQUIRE(c->Cin > 0 && c->Cin % 32 == 0 && c->Cout > 0 && c->Cout % 4 == 0 && c->ldx % 8 == 0 && c->ldx >= c->Cin);
   ONDA_REQUIRE(c->kh >= 1 && c->kw >= 1 && c->stride >= 1 && c->dil >= 1 && c->out_os >= 1 && xplane > 0 && xplane % 8 == 0);
   if (!ONDA_ALIGNED16(xl) || !ONDA_ALIGNED16(w2)) return ONDA_EALIGN;
@@ -805,72 +949,32 @@ int onda_conv2d_fwd_l2(const void* xl, int64_t xplane, const float* xamax, const
   k.M = (int)M;
   k.taps = c->kh * c->kw;
   k.kcper = c->Cin / 32;
-  const int variant = onda_conv_l2_variant(M, c->Cout);
-  const int BM = variant == 1 ? 128 : 256, BN = variant == 2 ? 64 : 128;
-  k.tilesM = (k.M + BM - 1) / BM;
-  k.tilesN = (c->Cout + BN - 1) / BN;
+  const L2Schedule q = l2_schedule(M, c->Cout, k.taps, c->Cin, true);
+  k.tilesM = q.tilesM;
+  k.tilesN = q.tilesN;
   const size_t limb_elems = (size_t)c->Cout * k.taps * c->Cin;  // weight planes are [Cout][taps*Cin]
   ONDA_REQUIRE(limb_elems * 4 < (1ull << 31));
   const unsigned x_bytes = (unsigned)x_total, w_bytes = (unsigned)(limb_elems * 4);
   const unsigned xpl = (unsigned)(xplane * 2), wpl = (unsigned)(limb_elems * 2);
-  const int cus = conv_resident_workgroups() / 2;
-  const int G = variant == 1 ? cus : cus;  // one workgroup per CU (144 / 96 / 120 KB of LDS)
-  const int tiles = k.tilesM * k.tilesN, KT = k.taps * k.kcper;
-  const int rem = tiles % G;
-  k.tiles_dp = tiles - rem;
-  const double t_tile_us = 2.0 * BM * BN * k.taps * c->Cin / 1.4e6;  // one tile on one CU at ~360 TF/s chip-wide
-  const double fix_us = 8.0 + (G + 2.0 * rem) * (BM * BN / 16384.0) * 0.03;  // partial tiles written + read
-  bool balanced = ws != nullptr && rem != 0 && KT >= 4 && t_tile_us * (1.0 - (double)rem / G) > fix_us &&
-                  (size_t)G * 2 * BM * BN + (size_t)(rem * 4 < G ? rem : 0) * BM * BN <= (size_t)onda_conv_ws_floats();
-  if (const int force = conv_sched_override()) {  // ONDA_CONV_SCHED: 1 tile-per-workgroup, 2 hybrid
-    if (force == 1 || ws == nullptr) balanced = false;
-    else if (force == 2) balanced = rem != 0;
-  }
+  const int tiles = k.tilesM * k.tilesN;
+  k.tiles_dp = tiles - q.rem;
   hipStream_t st = ONDA_STREAM(s);
 #define L2_LAUNCH(WM_, WN_, ST_, OCC_)                                                                                       \
   do {                                                                                                                       \
-    if (balanced)                                                                                                            \
-      hipLaunchKernelGGL((conv_l2_kernel<WM_, WN_, ST_, OCC_, true>), dim3(G), dim3(WM_ * WN_ * 64), 0, st, k, xpl, wpl, x_bytes, \
+    if (q.balanced) {                                                                                                        \
+      hipLaunchKernelGGL((conv_l2_kernel<WM_, WN_, ST_, OCC_, true>), dim3(q.G), dim3(WM_ * WN_ * 64), 0, st, k, xpl, wpl, x_bytes, \
                          w_bytes, xamax, wamax);                                                                            \
-    else                                                                                                                     \
+      hipLaunchKernelGGL((conv_l2_fixup_kernel<64 * WM_, 64 * WN_>), dim3(q.rem_rows() * q.tilesN, q.sub), dim3(256), 0, st, k, q.G, \
+                         q.tilesM);                                                                                           \
+    } else {                                                                                                                 \
       hipLaunchKernelGGL((conv_l2_kernel<WM_, WN_, ST_, OCC_, false>), dim3(tiles), dim3(WM_ * WN_ * 64), 0, st, k, xpl, wpl,    \
                          x_bytes, w_bytes, xamax, wamax);                                                                   \
+    }                                                                                                                        \
   } while (0)
-  static const int dbg = getenv("ONDA_L2_DEBUG") ? atoi(getenv("ONDA_L2_DEBUG")) : 0;
-  if (dbg == 1 && variant == 0) {
-    hipLaunchKernelGGL((conv_l2_kernel<4, 2, 3, 2, false, 1>), dim3(tiles), dim3(512), 0, st, k, xpl, wpl, x_bytes, w_bytes, xamax, wamax);
-    return ONDA_LAUNCH_RESULT();
-  }
-  if (dbg == 2 && variant == 0) {
-    hipLaunchKernelGGL((conv_l2_kernel<4, 2, 3, 2, false, 2>), dim3(tiles), dim3(512), 0, st, k, xpl, wpl, x_bytes, w_bytes, xamax, wamax);
-    return ONDA_LAUNCH_RESULT();
-  }
-  if (dbg == 3 && variant == 0) {  // 128 x 128, five stages, one workgroup per CU
-    k.tilesM = (k.M + 127) / 128;
-    hipLaunchKernelGGL((conv_l2_kernel<2, 2, 5, 1, false>), dim3(k.tilesM * k.tilesN), dim3(256), 0, st, k, xpl, wpl, x_bytes, w_bytes, xamax, wamax);
-    return ONDA_LAUNCH_RESULT();
-  }
-  if (dbg == 5 && variant == 0) {  // persistent grid, whole tiles only (the remainder is dropped), phase stamps into ws
-    k.tiles_dp = tiles - rem;
-    k.tilesM = k.tiles_dp / k.tilesN;  // (not exact for every shape: diagnostic only)
-    hipLaunchKernelGGL((conv_l2_kernel<4, 2, 3, 2, true, 5>), dim3(G), dim3(512), 0, st, k, xpl, wpl, x_bytes, w_bytes, xamax, wamax);
-    return ONDA_LAUNCH_RESULT();
-  }
-  if (dbg == 6 && variant == 0) {  // no stagger
-    if (balanced) hipLaunchKernelGGL((conv_l2_kernel<4, 2, 3, 2, true, 6>), dim3(G), dim3(512), 0, st, k, xpl, wpl, x_bytes, w_bytes, xamax, wamax);
-    else hipLaunchKernelGGL((conv_l2_kernel<4, 2, 3, 2, false, 6>), dim3(tiles), dim3(512), 0, st, k, xpl, wpl, x_bytes, w_bytes, xamax, wamax);
-    if (balanced) return conv_launch_fixup_tile(k, G, BM, BN, st);
-    return ONDA_LAUNCH_RESULT();
-  }
-  if (dbg == 4 && variant == 0) {  // plain one tile per workgroup
-    hipLaunchKernelGGL((conv_l2_kernel<4, 2, 3, 2, false>), dim3(tiles), dim3(512), 0, st, k, xpl, wpl, x_bytes, w_bytes, xamax, wamax);
-    return ONDA_LAUNCH_RESULT();
-  }
-  if (variant == 0) L2_LAUNCH(4, 2, 3, 2);
-  else if (variant == 1) L2_LAUNCH(2, 2, 3, 1);
+  if (q.variant == 0) L2_LAUNCH(4, 2, 3, 2);
+  else if (q.variant == 1) L2_LAUNCH(2, 2, 3, 1);
   else L2_LAUNCH(4, 1, 3, 1);
 #undef L2_LAUNCH
-  if (balanced) return conv_launch_fixup_tile(k, G, BM, BN, st);
   return ONDA_LAUNCH_RESULT();
 }
 

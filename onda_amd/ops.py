@@ -310,7 +310,7 @@ def conv_forward(x, wp, k, stride, dil, pad, cout, out=None, scale=None, shift=N
         raise RuntimeError("onda_amd: a limb-only activation reached a conv that does not take limb planes")
     stats_rows = 4 if (l2 and want_stats == 4) else 2  # 4: + per-channel min / max, for the limb-writing BatchNorm
     if want_stats:
-        tiles = query("onda_conv_l2_tiles_m", B * Ho * Wo, cout) if l2 else query("onda_conv_tiles_m", B * Ho * Wo)
+        tiles = query("onda_conv_l2_tiles_m", B * Ho * Wo, cout, k * k, Cin) if l2 else query("onda_conv_tiles_m", B * Ho * Wo)
         stats = torch.empty(tiles, stats_rows, cout, device=x.device, dtype=torch.float32)
     d = _desc(B, Hi, Wi, Cin, Ho, Wo, cout, k, stride, dil, pad, ldx, ldy, ldr, relu=relu)
     if l2:
