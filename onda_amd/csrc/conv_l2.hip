@@ -93,9 +93,11 @@ __global__ __launch_bounds__(256) void split_h2_kernel(const float* __restrict__
 // channels).  So each wave transposes its 64 x 64 sub-tile through LDS, 16 rows at a time, and stores whole
 // 256-byte row segments as 16-byte vectors: 16 stores per lane, scale / shift loaded once per lane.
 // `scratch`: LDS nobody else touches during the epilogue: 4 KiB per wave, then WM*BN*4 + WM*WN floats of statistics.
-template <int WM, int WN>
+// COUNTED: every wave issues exactly 16 output stores (buffer stores; rows past M / channels past Cout get an
+// out-of-range offset and are dropped by the hardware) -- conv_l2x_kernel counts them in its vmcnt waits.
+template <int WM, int WN, bool COUNTED = false>
 __device__ __forceinline__ void l2_epilogue(const ConvK& a, const f32x4 (&acc)[4][4], unsigned char* scratch, int tile_m, int m0,
-                                            int n0, int wm, int wn, int lane) {
+                                            int n0, int wm, int wn, int lane, unsigned y_bytes = 0) {
   constexpr int BN = 64 * WN, NW = WM * WN, NT = NW * 64;
   const OndaConv& c = a.c;
   const int t = threadIdx.x, wave = t >> 6;
@@ -159,20 +161,30 @@ __device__ __forceinline__ void l2_epilogue(const ConvK& a, const f32x4 (&acc)[4
       const int row = 4 * r + rl;
       f32x4 v = *reinterpret_cast<const f32x4*>(tr + row * 64 + cl);
       const int m = m0 + (wm * 4 + i) * 16 + row;
-      if (m >= a.M || !vn) continue;
+      const bool live = m < a.M && vn;
+      if (!COUNTED && !live) continue;
+      const int mm = live ? m : 0;
       v = v * sc + sh;
-      if (a.res) v += *reinterpret_cast<const f32x4*>(a.res + (size_t)m * c.ldr + n);
+      if (a.res && live) v += *reinterpret_cast<const f32x4*>(a.res + (size_t)mm * c.ldr + n);
       if (c.relu) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
       }
-      size_t orow = m;
+      size_t orow = mm;
       if (!plain) {
-        const int wo = m % c.Wo, tq = m / c.Wo;
+        const int wo = mm % c.Wo, tq = mm / c.Wo;
         const int ho = tq % c.Ho, b = tq / c.Ho;
         orow = ((size_t)b * c.Hf + (size_t)ho * c.out_os) * c.Wf + (size_t)wo * c.out_os;
       }
-      *reinterpret_cast<f32x4*>(a.y + orow * c.ldy + n) = v;
+      if constexpr (COUNTED) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const unsigned off = live ? (unsigned)((orow * c.ldy + n) * 4) : OOB;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), make_rsrc(a.y, y_bytes), off, 0, 0);
+#endif
+        if (!live) continue;
+      } else {
+        *reinterpret_cast<f32x4*>(a.y + orow * c.ldy + n) = v;
+      }
       mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
     }
     __builtin_amdgcn_wave_barrier();
@@ -447,6 +459,224 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_l2_kernel(const ConvK 
   }
 }
 
+
+// ---- the same kernel as ONE continuous K-step stream over all of a workgroup's tiles ------------------------------------
+// conv_l2_kernel starts every tile cold: row decomposition, two DMA round trips before the first MFMA, and it ends it with
+// an epilogue during which nothing is in flight -- 3 500-7 700 + ~6 000 cycles per tile, as much as the K loop itself for
+// a 1 x 1 convolution with 256 input channels (8 K-steps of ~2 300 cycles).  Here the DMA issue runs ahead ACROSS tile
+// boundaries: while the last two K-steps of a tile are being multiplied the first two stages of the workgroup's next tile
+// are already on their way, the epilogue's stores are issued behind them, and the next tile's first MFMA waits for
+// neither (s_waitcnt vmcnt counts in issue order: the two waits after an epilogue leave its 16 stores per wave -- buffer
+// stores, out-of-range lanes dropped by the hardware, so that the count is exact -- and the younger DMAs in flight).
+// The epilogue transposes through the ring stage that was read last (free until the next DMA issue, one barrier later).
+// Work items of a workgroup: its whole tiles, then its one or two stream-K segments of remainder tiles.
+template <int WM, int WN, int STAGES, int OCC>
+__global__ __launch_bounds__(WM * WN * 64, OCC) void conv_l2x_kernel(const ConvK a, unsigned xplane, unsigned wplane, unsigned x_bytes,
+                                                                    unsigned w_bytes, unsigned y_bytes, const float* __restrict__ xamax,
+                                                                    const float* __restrict__ wamax) {
+  constexpr int NW = WM * WN;
+  constexpr int BM = 64 * WM, BN = 64 * WN;
+  constexpr int PLANE_A = BM * 64, PLANE_B = BN * 64;
+  constexpr int A_BYTES = 2 * PLANE_A, STAGE = A_BYTES + 2 * PLANE_B;
+  constexpr int APW = (BM / 16) / NW, BPW = (BN / 16) / NW;
+  static_assert((BM / 16) % NW == 0 && (BN / 16) % NW == 0, "whole blocks per wave");
+  constexpr int DPW = 2 * (APW + BPW);
+  constexpr int EST = 16;  // buffer stores every wave issues per epilogue (l2_epilogue<.., true>)
+  static_assert(STAGES == 3 && DPW + EST <= 63, "ring of three; vmcnt holds 6 bits");
+  __shared__ __attribute__((aligned(16))) unsigned char lds[STAGES * STAGE];
+
+  const OndaConv& c = a.c;
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int nblk = gridDim.x, bid = blockIdx.x;
+  const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
+  const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  const int KT = a.taps * a.kcper;
+  const int tiles_all = a.tilesM * a.tilesN, tiles_dp = a.tiles_dp;
+  const long long U = (long long)(tiles_all - tiles_dp) * KT;
+  const long long u_begin = swz * U / nblk, u_end = (swz + 1) * U / nblk;
+  const int wstride = a.taps * c.Cin;
+  const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, x_bytes), rw = make_rsrc(a.w, w_bytes);
+  const Scale2 sx = scale_of(xamax), sw = scale_of(wamax);
+  const float unscale_a = sx.inv, unscale_b = sw.inv;
+  const int lrow = lane >> 2;
+  const unsigned cq16 = (unsigned)(((lane & 3) ^ swz_row(lrow)) << 4);
+  const int frag = (lane & 15) * 64 + (((lane >> 4) ^ swz_row(lane & 15)) << 4);
+
+  // ---- work items: (tile, k_begin, k_end); a cursor is (whole tile index, stream-K unit) ------------------------------
+  struct Cursor {
+    int dp_tile;
+    long long u;
+  };
+  auto item_valid = [&](const Cursor& cu) { return cu.dp_tile < tiles_dp || cu.u < u_end; };
+  auto item_of = [&](const Cursor& cu, int& tile, int& k_begin, int& k_end) {
+    if (cu.dp_tile < tiles_dp) {
+      tile = cu.dp_tile;
+      k_begin = 0;
+      k_end = KT;
+    } else {
+      tile = tiles_dp + (int)(cu.u / KT);
+      k_begin = (int)(cu.u - (long long)(tile - tiles_dp) * KT);
+      k_end = (int)min((long long)KT, k_begin + (u_end - cu.u));
+    }
+  };
+  auto item_next = [&](Cursor& cu, int k_begin, int k_end) {
+    if (cu.dp_tile < tiles_dp) cu.dp_tile += nblk; else cu.u += k_end - k_begin;
+  };
+
+  // ---- issue side ------------------------------------------------------------------------------------------------------
+  Cursor ci{swz, u_begin};
+  int i_left = 0;  // K-steps of the issue item still to be issued
+  int hi0[APW], wi0[APW], bH[APW], tap_i = 0, c0_i = 0;
+  unsigned bofs[BPW], aofs[APW];
+  int st_issue = 0, st_read = 0, in_flight = 0;  // in_flight: issued steps whose DMAs have not been waited for
+  auto set_tap = [&](int tp) {
+    const int rr = tp / c.kw, ss = tp - rr * c.kw;
+#pragma unroll
+    for (int d = 0; d < APW; ++d) {
+      const int hi = hi0[d] + rr * c.dil, wi = wi0[d] + ss * c.dil;
+      const bool ok = (unsigned)hi < (unsigned)c.Hi && (unsigned)wi < (unsigned)c.Wi;
+      aofs[d] = ok ? (unsigned)(((bH[d] + hi) * c.Wi + wi) * c.ldx) * 2u + cq16 : OOB;
+    }
+  };
+  auto open_issue_item = [&]() {  // row decomposition of the item at `ci` (the VALU work that used to start every tile)
+    int tile, k_begin, k_end;
+    item_of(ci, tile, k_begin, k_end);
+    i_left = k_end - k_begin;
+    const int m0 = (tile / a.tilesN) * BM, n0 = (tile % a.tilesN) * BN;
+#pragma unroll
+    for (int d = 0; d < APW; ++d) {
+      const int m = m0 + (wave * APW + d) * 16 + lrow;
+      const bool vm = m < a.M;
+      const int mm = vm ? m : 0;
+      const int wo = mm % c.Wo, tq = mm / c.Wo;
+      const int ho = tq % c.Ho, b = tq / c.Ho;
+      hi0[d] = vm ? ho * c.stride - c.pad : -(1 << 28);
+      wi0[d] = wo * c.stride - c.pad;
+      bH[d] = b * c.Hi;
+    }
+#pragma unroll
+    for (int d = 0; d < BPW; ++d) {
+      const int n = n0 + (wave * BPW + d) * 16 + lrow;
+      bofs[d] = n < c.Cout ? (unsigned)n * wstride * 2u + cq16 : OOB;
+    }
+    tap_i = k_begin / a.kcper;
+    c0_i = (k_begin - tap_i * a.kcper) * BK;
+    set_tap(tap_i);
+    item_next(ci, k_begin, k_end);
+  };
+  auto issue_step = [&]() {  // the next K-step of the stream, if there is one
+    if (i_left == 0) {
+      if (!item_valid(ci)) return;
+      open_issue_item();
+    }
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int sa = c0_i * 2, sb = (tap_i * c.Cin + c0_i) * 2;
+#pragma unroll
+    for (int l = 0; l < 2; ++l) {
+#pragma unroll
+      for (int d = 0; d < APW; ++d) {
+        unsigned char* dst = lds + st_issue + l * PLANE_A + (wave * APW + d) * 1024;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)dst, 16, aofs[d], sa + l * xplane, 0, 0);
+      }
+#pragma unroll
+      for (int d = 0; d < BPW; ++d) {
+        unsigned char* dst = lds + st_issue + A_BYTES + l * PLANE_B + (wave * BPW + d) * 1024;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)dst, 16, bofs[d], sb + l * wplane, 0, 0);
+      }
+    }
+#endif
+    st_issue = st_issue + STAGE == STAGES * STAGE ? 0 : st_issue + STAGE;
+    ++in_flight;
+    --i_left;
+    c0_i += BK;
+    if (c0_i == c.Cin) {
+      c0_i = 0;
+      ++tap_i;
+      if (i_left > 0) set_tap(tap_i);
+    }
+  };
+
+  // ---- compute side ----------------------------------------------------------------------------------------------------
+  f16x8 af[4][2], bf[4];
+  const unsigned char *Ab, *Bb;
+  auto prepare = [&]() {
+    Ab = lds + st_read + wm * 64 * 64 + frag;
+    Bb = lds + st_read + A_BYTES + wn * 64 * 64 + frag;
+    st_read = st_read + STAGE == STAGES * STAGE ? 0 : st_read + STAGE;
+#pragma unroll
+    for (int l = 0; l < 2; ++l)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i][l] = *reinterpret_cast<const f16x8*>(Ab + l * PLANE_A + i * 1024);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bf[j] = *reinterpret_cast<const f16x8*>(Bb + PLANE_B + j * 1024);
+  };
+  int stores_young = 0;  // waits during which an epilogue's stores are still younger than the DMAs waited for
+  auto wait_step = [&]() {  // the DMAs of the oldest step in flight have landed
+    // outstanding, oldest first: [that step] [the step after it, if issued] [an epilogue's stores, for two waits]
+    if (in_flight > 1) {
+      if (stores_young) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPW + EST) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPW) : "memory");
+    } else {
+      if (stores_young) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(EST) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    if (stores_young) --stores_young;
+    --in_flight;
+  };
+
+  Cursor cc{swz, u_begin};
+  issue_step();
+  issue_step();
+  while (item_valid(cc)) {
+    int tile, k_begin, k_end;
+    item_of(cc, tile, k_begin, k_end);
+    const bool whole = k_begin == 0 && k_end == KT;
+    const bool first_piece = cc.dp_tile >= tiles_dp && cc.u == u_begin;
+    item_next(cc, k_begin, k_end);
+    f32x4 acc[4][4], accx[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[i][j][e] = accx[i][j][e] = 0.f;
+    for (int kt = k_begin; kt < k_end; ++kt) {
+      wait_step();
+      __builtin_amdgcn_s_barrier();  // everybody's DMAs of this step have landed; the stage read one step ago is free
+      issue_step();                  // two steps ahead in the stream, whatever tile that is
+      prepare();
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) accx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][0], bf[j], accx[i][j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bf[j] = *reinterpret_cast<const f16x8*>(Bb + j * 1024);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) accx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][1], bf[j], accx[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][0], bf[j], acc[i][j], 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = ((acc[i][j] + accx[i][j] * LIMB2_UNSCALE) * unscale_a) * unscale_b;
+    if (!whole) {  // stream-K piece: raw accumulators to this workgroup's slot (64 unconditional stores per lane)
+      float* slot = a.ws + ((size_t)swz * 2 + (first_piece ? 0 : 1)) * (BM * BN);
+      conv_store_partial<BN, 4, 4, 16>(slot, acc, wm, wn, lane);
+      stores_young = 2;
+      continue;
+    }
+    __syncthreads();  // every wave has its fragments of the last step: that stage is scratch now
+    const int scratch = st_read == 0 ? (STAGES - 1) * STAGE : st_read - STAGE;  // the stage read last
+    l2_epilogue<WM, WN, true>(a, acc, lds + scratch, tile / a.tilesN, (tile / a.tilesN) * BM, (tile % a.tilesN) * BN, wm, wn, lane, y_bytes);
+    stores_young = 2;
+  }
+}
 
 // ---- stream-K remainder: partial tiles -> output, in ONE wide launch ---------------------------------------------------
 // A remainder tile was cut into pieces by the workgroups of conv_l2_kernel<.., SK = true> (raw accumulators in `ws`).
@@ -971,6 +1201,22 @@ int onda_conv2d_fwd_l2(const void* xl, int64_t xplane, const float* xamax, const
                          x_bytes, w_bytes, xamax, wamax);                                                                   \
     }                                                                                                                        \
   } while (0)
+  static const int xt = getenv("ONDA_L2_XT") ? atoi(getenv("ONDA_L2_XT")) : 1;  // 0: one cold start per tile (conv_l2_kernel)
+  // the output as a buffer: last byte any tile can store (dense rows of ldy floats; scattered stride-2 gradients included)
+  const long long y_rows = (long long)c->B * (c->out_os == 1 && c->Hf == c->Ho && c->Wf == c->Wo ? (long long)c->Ho * c->Wo : (long long)c->Hf * c->Wf);
+  const long long y_total = ((y_rows - 1) * c->ldy + c->Cout) * 4;
+  // short K loops (1 x 1 convolutions up to 1024 input channels) gain 6-17 % from the continuous stream; long ones lose
+  // ~4 % against the slot-staggered kernel, whose per-tile start / end they amortise anyway (measured per shape, one process)
+  const bool short_k = k.taps * k.kcper <= 32 || xt == 2;
+  if (xt && short_k && q.variant == 0 && y_total < 0x7FFFF000ll) {
+    if (!q.balanced) k.tiles_dp = tiles;  // persistent either way: whole tiles only
+    const int grid = tiles < q.G ? tiles : q.G;
+    hipLaunchKernelGGL((conv_l2x_kernel<4, 2, 3, 2>), dim3(q.balanced ? q.G : grid), dim3(512), 0, st, k, xpl, wpl, x_bytes, w_bytes,
+                       (unsigned)y_total, xamax, wamax);
+    if (q.balanced)
+      hipLaunchKernelGGL((conv_l2_fixup_kernel<256, 128>), dim3(q.rem_rows() * q.tilesN, q.sub), dim3(256), 0, st, k, q.G, q.tilesM);
+    return ONDA_LAUNCH_RESULT();
+  }
   if (q.variant == 0) L2_LAUNCH(4, 2, 3, 2);
   else if (q.variant == 1) L2_LAUNCH(2, 2, 3, 1);
   else L2_LAUNCH(4, 1, 3, 1);
