@@ -302,8 +302,33 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_l2_kernel(const ConvK 
       bofs[d] = n < c.Cout ? (unsigned)n * wstride * 2u + cq16 : OOB;
     }
 
+    // Filter taps whose input rows all lie outside the image for EVERY output row of this tile (whole image rows of a
+    // dilated tap: a quarter of the K-steps of the dilation-24 ASPP branch) contribute exact zeros: a whole tile skips
+    // them -- no DMA, no MFMA.  (Stream-K pieces keep the full K range their unit arithmetic is written in.)
+    unsigned live = 0xFFFFFFFFu;
+    if (dp && a.taps > 1 && a.skip_dead_taps) {
+      live = 0;
+      const int m_last = min(a.M, m0 + BM) - 1;
+      const int r0 = m0 / c.Wo, r1 = m_last / c.Wo;  // global output rows (b*Ho + ho) the tile touches
+      const int ho0 = r0 % c.Ho;
+      for (int tp = 0; tp < a.taps; ++tp) {
+        const int dh = (tp / c.kw) * c.dil - c.pad;
+        bool alive = false;
+        for (int r = r0, ho = ho0; r <= r1; ++r) {
+          alive |= (unsigned)(ho * c.stride + dh) < (unsigned)c.Hi;
+          if (++ho == c.Ho) ho = 0;
+        }
+        live |= (alive ? 1u : 0u) << tp;
+      }
+      if (live == 0) live = 1;  // (cannot happen for a tile with a valid row and pad < kernel reach; keeps the loop non-empty)
+    }
+    auto next_live_tap = [&](int tp) {
+      while (tp < a.taps && !((live >> tp) & 1u)) ++tp;
+      return tp;
+    };
     unsigned aofs[APW];
-    int tap_i = k_begin / a.kcper, c0_i = (k_begin - tap_i * a.kcper) * BK;  // the K-step the next issue() fetches
+    int tap_i = dp ? next_live_tap(0) : k_begin / a.kcper;
+    int c0_i = dp ? 0 : (k_begin - tap_i * a.kcper) * BK;  // the K-step the next issue() fetches
     auto set_tap = [&](int tp) {
       const int rr = tp / c.kw, ss = tp - rr * c.kw;
 #pragma unroll
@@ -336,7 +361,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_l2_kernel(const ConvK 
       c0_i += BK;
       if (c0_i == c.Cin) {
         c0_i = 0;
-        ++tap_i;
+        tap_i = next_live_tap(tap_i + 1);
         if (tap_i < a.taps) set_tap(tap_i);
       }
     };
@@ -352,7 +377,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_l2_kernel(const ConvK 
     __syncthreads();  // the previous tile's readers (fragments, epilogue scratch) are done with every LDS region
     set_tap(tap_i);
     int st_issue = 0, st_read = 0;  // byte offsets of the ring stages
-    const int nsteps = k_end - k_begin;
+    const int nsteps = dp && a.taps > 1 && a.skip_dead_taps ? __builtin_popcount(live & ((1u << a.taps) - 1u)) * a.kcper : k_end - k_begin;
     issue(st_issue);
     st_issue += STAGE;
     if (nsteps > 1) {
@@ -1171,6 +1196,8 @@ int onda_conv2d_fwd_l2(const void* xl, int64_t xplane, const float* xamax, const
   k.x = static_cast<const float*>(xl); k.w = w2; k.y = y; k.scale = scale; k.shift = shift; k.res = residual; k.stats = stats; k.ws = ws;
   k.amax = yamax;
   k.stats_rows = stats_rows;
+  static const int noskip = getenv("ONDA_L2_NOSKIP") ? atoi(getenv("ONDA_L2_NOSKIP")) : 0;
+  k.skip_dead_taps = !noskip;
   k.c = *c;
   const long long M = (long long)c->B * c->Ho * c->Wo;
   ONDA_REQUIRE(M > 0 && M < (1ll << 31));

@@ -1,2 +1,1 @@
-timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -4
-timeout 400 python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-exact-f32 2>&1 | tail -1 | cut -c1-200
+for x in 1 0; do echo "== ONDA_L2_NOSKIP=$x"; ONDA_L2_NOSKIP=$x QUICK=1 timeout 300 python tools/conv_l2_bench.py 2>&1 | grep Cin | cut -c1-120; done

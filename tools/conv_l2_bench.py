@@ -9,7 +9,7 @@ import torch
 from onda_amd import ops
 
 SHAPES = [  # (B,H,W,Cin,Cout,k,dil)
-    (4, 65, 129, 2048, 256, 3, 12), (4, 65, 129, 256, 2048, 3, 12), (4, 65, 129, 512, 512, 3, 4),
+    (4, 65, 129, 2048, 256, 3, 12), (4, 65, 129, 256, 2048, 3, 12), (4, 65, 129, 2048, 256, 3, 24), (4, 65, 129, 256, 2048, 3, 24), (4, 65, 129, 512, 512, 3, 4),
     (4, 65, 129, 256, 256, 3, 2), (4, 65, 129, 1280, 256, 3, 1),
     (4, 65, 129, 1024, 256, 1, 1), (4, 65, 129, 256, 1024, 1, 1), (4, 65, 129, 512, 2048, 1, 1), (4, 65, 129, 2048, 512, 1, 1),
     (4, 65, 129, 128, 128, 3, 1), (4, 65, 129, 128, 512, 1, 1), (4, 129, 257, 64, 256, 1, 1), (4, 129, 257, 64, 64, 3, 1),
