@@ -11,6 +11,7 @@ _MODULES = [
     "framework.domain_adaptation.methods.adaptation_model", "framework.domain_adaptation.methods.prototype_handler",
     "framework.domain_adaptation.methods.prototypes", "framework.domain_adaptation.methods.prototypes_hybrid_switch",
     "framework.domain_adaptation.methods.prototypes_hswitch", "framework.domain_adaptation.methods.prototypes_vswitch",
+    "framework.domain_adaptation.methods.segmentation", "framework.dataset", "framework.dataset.buffer_db",
 ]
 
 

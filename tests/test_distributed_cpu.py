@@ -56,3 +56,50 @@ def test_single_process_is_a_noop():
     t = torch.ones(3)
     assert od.all_reduce_sum(t) is t and od.all_reduce_mean(t) is t
     assert od.GradSync(torch.nn.Linear(2, 2)).all_reduce() == 0
+
+
+def _flat_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from onda_amd import dist as od
+    od.init_from_env("gloo")
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(64, 32), torch.nn.ReLU(), torch.nn.Linear(32, 8), torch.nn.Linear(8, 4))
+    net[3].weight.requires_grad_(False)  # a parameter that stays out
+    sync = od.GradSync(net, tail_floats=6, bucket_floats=1000, skip=lambda name: name == "2.bias")
+    assert sync.active and len(sync.buckets) >= 2
+    views = {n: p.grad for n, p in net.named_parameters() if p.grad is not None}
+    assert "2.bias" not in views and "3.weight" not in views
+    for step in range(2):
+        sync.zero()
+        x = torch.randn(16, 64) * (rank + 1)
+        net(x).sum().backward()                 # first backward of the step: no exchange yet
+        launched_before = len(sync._pending)
+        sync.arm()
+        net(x * 0.5).pow(2).sum().backward()    # last backward: buckets go out from the hooks
+        launched_in_backward = len(sync._pending)
+        sync.tail.copy_(torch.arange(6.0) * (rank + 1))
+        local = {n: p.grad.clone() for n, p in net.named_parameters() if n in views}
+        n = sync.finish()
+        for name, p in net.named_parameters():  # gradients are still views of the flat buffer
+            if name in views:
+                assert p.grad.data_ptr() == views[name].data_ptr()
+    out[rank] = (n, local, {k: v.grad.clone() for k, v in net.named_parameters() if k in views}, sync.tail.clone(), launched_before,
+                 launched_in_backward, net[2].bias.grad.clone())
+    dist.destroy_process_group()
+
+
+def test_flat_bucketed_gradient_exchange_with_tail():
+    """GradSync: .grad are views of one flat buffer, buckets are all-reduced from the hooks of the LAST backward pass,
+    the tail rides with the last bucket (rank-SUM), gradients come back as the rank-MEAN, skipped parameters stay local."""
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_flat_worker, args=(2, port, out), nprocs=2, join=True)
+    (n0, local0, avg0, tail0, before0, during0, skipped0), (n1, local1, avg1, tail1, _, _, skipped1) = out[0], out[1]
+    assert n0 == n1 == 64 * 32 + 32 + 32 * 8 + 4 + 6  # 2.bias (skipped) and 3.weight (frozen) are not in the buffer
+    assert before0 == 0 and during0 >= 1              # nothing before arm(); at least one bucket out during the backward
+    for k in local0:
+        assert torch.allclose(avg0[k], (local0[k] + local1[k]) / 2, rtol=1e-6, atol=1e-7), k
+        assert torch.equal(avg0[k], avg1[k])
+    assert torch.equal(tail0, torch.arange(6.0) * 3) and torch.equal(tail0, tail1)
+    assert not torch.equal(skipped0, skipped1)

@@ -157,3 +157,127 @@ def test_amax_constants_match_header():
     floats = int(re.search(r"#define ONDA_AMAX_FLOATS (\d+)", hdr).group(1))
     slots = int(re.search(r"#define ONDA_AMAX_SLOTS (\d+)", hdr).group(1))
     assert ops.AMAX_SLOTS == floats and floats % slots == 0 and (floats // slots) * 4 == 128 and slots == 64
+
+
+def test_library_carries_the_hash_of_its_sources():
+    """onda_version() ends in the sha256 of the sources the library was compiled from: a stale or foreign .so is detected."""
+    from onda_amd import _lib, build
+    built, src = build.check_fresh()
+    assert built == src and len(src) == 16
+    assert _lib.load().onda_version().decode().endswith("src=" + src)
+    assert ctypes_sizeof_pack_entry() == 48
+
+
+def ctypes_sizeof_pack_entry():
+    import ctypes
+    from onda_amd import _lib
+    return ctypes.sizeof(_lib.OndaPackEntry)
+
+
+def test_monitor_ring_buffer_and_packed_adds():
+    """Monitor on a ring: the window rolls over, packed device adds equal single adds, freeze ignores everything."""
+    from onda_amd.framework.utils.monitoring import Monitor
+    a, b = Monitor(5, 0.1, "hamming"), Monitor(5, 0.1, "hamming")
+    vals = [0.1 * i * (-1) ** i for i in range(13)]
+    for i, v in enumerate(vals):
+        a.add({"x": v, "y": 2 * v})
+        b.add_device(["x", "y"], torch.tensor([v, 2 * v], dtype=torch.float64))
+        window = vals[max(0, i - 4): i + 1]
+        assert a.avg("x") == pytest.approx(float(np.median(window)))
+        assert a.avg("x") == b.avg("x") and a.exp("y") == pytest.approx(b.exp("y")) and a.dev_avg("x") == pytest.approx(b.dev_avg("x"))
+        assert a.current_dict["x"] == pytest.approx(window)
+    assert a.dev_avg("x") != 0 and a.dev_avg("missing") == 0 and a.avg("missing") == 1 and a.exp("missing") == 1
+    a.eval()
+    before = a.avg("x")
+    a.add({"x": 100.0})
+    a.add_device(["x"], torch.tensor([100.0]))
+    assert a.avg("x") == before
+    a.train()
+    a.add({"x": 1.0}, reset=True)
+    assert a.avg("x") == 1.0 and a.exp("x") == 1.0
+
+
+def test_replay_buffer_mirror():
+    """Buffer_db: batches of consecutive samples, queue / random replacement, add_from_batch, and the nearest-neighbour
+    label resize with OpenCV's index rule (floor(dst * src / dst_size))."""
+    from onda_amd.framework.dataset.buffer_db import Buffer_db, label_to_outputs
+    rng = np.random.default_rng(0)
+    db = [{"image": torch.full((3, 8, 16), float(i)), "label": rng.integers(0, 19, (8, 16)).astype(np.uint8), "name": f"s{i}"}
+          for i in range(5)]
+    buf = Buffer_db(db, batch_size=2)
+    assert len(buf) == 5 and buf.type_dict["image"] is torch.Tensor and buf.buffer[0]["domain"] == "source"
+    batch = next(buf)
+    assert batch["image"].shape == (2, 3, 8, 16) and batch["stored_predictions"].shape == (2, 8, 16)
+    assert [float(batch["image"][i, 0, 0, 0]) for i in range(2)] == [0.0, 1.0]
+    seen = [float(b["image"][0, 0, 0, 0]) for b in buf.sequential()]
+    assert sorted(seen) == [0.0, 1.0, 2.0, 3.0, 4.0]
+    target = {"image": torch.full((2, 3, 8, 16), 9.0), "label": torch.zeros(2, 8, 16, dtype=torch.uint8),
+              "stored_predictions": torch.ones(2, 8, 16, dtype=torch.int64), "name": ["t0", "t1"]}
+    buf.add_from_batch(target, 1)
+    assert len(buf) == 5 and float(buf.buffer[-1]["image"][0, 0, 0]) == 9.0 and buf.buffer[-1]["domain"] == "target"
+    assert float(buf.buffer[0]["image"][0, 0, 0]) == 1.0  # the oldest sample left the queue
+    assert isinstance(buf.buffer[-1]["label"], np.ndarray) and buf.buffer[-1]["name"] == "t1"
+    with pytest.raises(NotImplementedError):
+        buf.add({}, policy="lifo")
+    lab = rng.integers(0, 19, (64, 128)).astype(np.uint8)
+    small = label_to_outputs(lab)
+    assert small.shape == (9, 17)
+    for r in (0, 3, 8):
+        for c in (0, 5, 16):
+            assert small[r, c] == lab[int(np.floor(r * 64 / 9)), int(np.floor(c * 128 / 17))]
+
+
+def test_logging_sink_reads_device_scalars_once():
+    from onda_amd import logging as olog
+    got = []
+    olog.set_sink(got.append)
+    try:
+        olog.log({"a": torch.tensor(1.5), "b": 2, "c": torch.tensor([3.0])})
+    finally:
+        olog.set_sink(None)
+    assert got == [{"a": 1.5, "b": 2, "c": 3.0}]
+
+
+def test_switch_plans_of_the_prototype_methods():
+    """_prior_plan of every method (how teacher/static and dynamic priors are mixed) against the reference's rules
+    (prototypes.py:232-255, prototypes_hybrid_switch.py:57-75, prototypes_hswitch.py:27-84, prototypes_vswitch.py:20-89),
+    evaluated on stub objects: no model, no GPU."""
+    from types import SimpleNamespace
+    from onda_amd.config import Cfg
+    from onda_amd.framework.domain_adaptation.methods import prototypes, prototypes_hswitch, prototypes_hybrid_switch, prototypes_vswitch
+    from onda_amd.framework.utils.monitoring import Monitor
+
+    def stub(cls, conf, **spec):
+        mon = Monitor(200, 0.003, "hamming")
+        mon.add({"prior static": conf})
+        obj = SimpleNamespace(cfg_spec=Cfg.from_dict(spec), intensity_ma=mon)
+        return obj, (lambda: cls._prior_plan(obj))
+
+    _, plan = stub(prototypes.online_proDA, 0.7, SWITCH_PRIOR_THRESH=0.8, DYNAMIC_LAMBDA=1)
+    assert plan() == (0.0, 1)  # low static confidence: the dynamic prior replaces
+    _, plan = stub(prototypes.online_proDA, 0.9, SWITCH_PRIOR_THRESH=0.8, DYNAMIC_LAMBDA=1)
+    assert plan() == (1.0, 0.0)
+    _, plan = stub(prototypes.online_proDA, 0.9, SWITCH_PRIOR_THRESH=0, DYNAMIC_LAMBDA=0.5)
+    assert plan() == (1.0, 0.5)  # no threshold: both priors add up
+    _, plan = stub(prototypes.online_proDA, 0.9, SWITCH_PRIOR_THRESH=0, DYNAMIC_LAMBDA=0)
+    assert plan() == (1.0, 0.0)
+    sel = prototypes_hybrid_switch.model_select(0, [0.83, 0.9], 2e-4)
+    obj, plan = stub(prototypes_hybrid_switch.hybrid_proDA, 0.5, DYNAMIC_LAMBDA=1)
+    obj.model_select = sel
+    assert plan() == (0.0, 1) and sel.current == sel.dynamic
+    obj, plan = stub(prototypes_hybrid_switch.hybrid_proDA, 0.95, DYNAMIC_LAMBDA=1)
+    obj.model_select = sel
+    assert plan() == (1.0, 0.0) and sel.current == sel.static
+    obj, plan = stub(prototypes_hswitch.hswitch_proDA, 0.88, SOFT_TRANS=True, DYNAMIC_LAMBDA=1)
+    share = 0.88 * 25.0 / 3 - 41.0 / 6
+    assert plan() == pytest.approx((share, 1 - share)) and obj.intensity_ma.avg("percentage_static") == pytest.approx(share)
+    _, plan = stub(prototypes_hswitch.hswitch_proDA, 0.99, SOFT_TRANS=True, DYNAMIC_LAMBDA=1)
+    assert plan() == (1, 0.0)
+    _, plan = stub(prototypes_hswitch.hswitch_proDA, 0.5, SOFT_TRANS=False, SWITCH_PRIOR_THRESH=0.86, DYNAMIC_LAMBDA=2)
+    assert plan() == (0, 2)
+    vsel = prototypes_vswitch.model_select(0, 2e-4)
+    obj, plan = stub(prototypes_vswitch.vswitch_proDA, 0.9, DYNAMIC_LAMBDA=1)
+    obj.model_select = vsel
+    assert plan() == (1.0, 0.0)
+    vsel.evaluate(-1e-3)
+    assert plan() == (0.0, 1)
