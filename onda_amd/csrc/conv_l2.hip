@@ -148,6 +148,20 @@ __device__ __forceinline__ void l2_epilogue(const ConvK& a, const f32x4 (&acc)[4
   if (vn && a.shift) sh = *reinterpret_cast<const f32x4*>(a.shift + n);
   float* tr = reinterpret_cast<float*>(scratch + wave * 4096);
   float mx = 0.f;
+  // the residual (a shortcut in eval mode; the running gradient sum of a shared activation, ops.GradSink) is fetched
+  // up front -- 16 independent 16-byte loads per lane into the registers the second accumulator set just vacated --
+  // instead of one round trip per 16-row chunk in the store loop
+  f32x4 rv[4][4];
+  if (a.res) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + (wm * 4 + i) * 16 + 4 * r + rl;
+        const bool live = m < a.M && vn;
+        rv[i][r] = live ? *reinterpret_cast<const f32x4*>(a.res + (size_t)m * c.ldr + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+  }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     // this wave's own 4 KiB: only its own earlier reads have to be out of the way
@@ -165,7 +179,7 @@ __device__ __forceinline__ void l2_epilogue(const ConvK& a, const f32x4 (&acc)[4
       if (!COUNTED && !live) continue;
       const int mm = live ? m : 0;
       v = v * sc + sh;
-      if (a.res && live) v += *reinterpret_cast<const f32x4*>(a.res + (size_t)mm * c.ldr + n);
+      if (a.res) v += rv[i][r];
       if (c.relu) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
@@ -397,9 +411,9 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_l2_kernel(const ConvK 
       st_issue = st_issue + STAGE == STAGES * STAGE ? 0 : st_issue + STAGE;
     };
     // fragments: A limbs stay in registers; B limbs stream 2 -> 1 (smaller products first): a1*b2, a2*b1, a1*b1
-    f16x8 af[4][2], bf[4];
+    f16x8 af[4][2], bf[4], b1[4];
     const unsigned char *Ab, *Bb;
-    auto prepare = [&]() {  // "P": first fragments of the stage at st_read
+    auto prepare = [&]() {  // "P": first fragments of the stage at st_read (ALL of them when the halves are staggered)
       Ab = lds + st_read + wm * 64 * 64 + frag;
       Bb = lds + st_read + A_BYTES + wn * 64 * 64 + frag;
       st_read = st_read + STAGE == STAGES * STAGE ? 0 : st_read + STAGE;
@@ -409,22 +423,28 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_l2_kernel(const ConvK 
         for (int i = 0; i < 4; ++i) af[i][l] = *reinterpret_cast<const f16x8*>(Ab + l * PLANE_A + i * 1024);
 #pragma unroll
       for (int j = 0; j < 4; ++j) bf[j] = *reinterpret_cast<const f16x8*>(Bb + PLANE_B + j * 1024);
+      if constexpr (STAGGER) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b1[j] = *reinterpret_cast<const f16x8*>(Bb + j * 1024);
+      }
     };
-    auto compute = [&]() {  // "C": 48 MFMAs; the b1 fragments are fetched behind the first 16
+    auto compute = [&]() {  // "C": 48 MFMAs (one wave per SIMD: the b1 fragments are fetched behind the first 16)
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) accx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][0], bf[j], accx[i][j], 0, 0, 0);
+      if constexpr (!STAGGER) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) bf[j] = *reinterpret_cast<const f16x8*>(Bb + j * 1024);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) accx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][1], bf[j], accx[i][j], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) b1[j] = *reinterpret_cast<const f16x8*>(Bb + j * 1024);
+      }
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][0], bf[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) accx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][1], b1[j], accx[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][0], b1[j], acc[i][j], 0, 0, 0);
     };
     if constexpr (!STAGGER) {
       for (int kt = 0; kt < nsteps; ++kt) {
@@ -441,8 +461,12 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_l2_kernel(const ConvK 
       // with a barrier between slots, and the second half of the workgroup runs ONE SLOT LATE: in every slot one wave
       // of each SIMD computes while the other prepares.  Same code for both halves; only the places of the DMA issue
       // and of the vmcnt wait differ (each sits where that half's stage is free / has to be published).
+      // The compute slot reads nothing from LDS (all fragments are fetched in the prepare slot), so the stage of step
+      // k-1 is last read in slot 2k-1 (late P) and BOTH halves issue the DMAs of step k+2 in their own PREPARE slot --
+      // early in slot 2k, late in slot 2k+1: the ~60 cycles an LDS-DMA instruction costs its wave (6 per step) fall
+      // beside the other half's MFMAs instead of in front of the wave's own (measured before: slot pairs of ~1 170 + 800
+      // cycles against 2 x 768 of MFMA).
       //   barrier #2k   : early half has waited for its DMAs of step k;  late half for its DMAs of step k (before #2k)
-      //   stage of step k-1 is last read in slot 2k (late C) -> both halves issue the DMAs of step k+2 in slot 2k+1
       if (late) {
         wait_landed(nsteps > 1);
         __builtin_amdgcn_s_barrier();
@@ -450,11 +474,10 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_l2_kernel(const ConvK 
       for (int kt = 0; kt < nsteps; ++kt) {
         if (!late) wait_landed(kt + 1 < nsteps);
         __builtin_amdgcn_s_barrier();
-        if (late && DBG != 2 && kt + 2 < nsteps) issue_next();
+        if (DBG != 2 && kt + 2 < nsteps) issue_next();
         prepare();
         if (late && kt + 1 < nsteps) wait_landed(kt + 2 < nsteps);
         __builtin_amdgcn_s_barrier();
-        if (!late && DBG != 2 && kt + 2 < nsteps) issue_next();
         compute();
       }
       if (!late) __builtin_amdgcn_s_barrier();

@@ -107,6 +107,9 @@ class Bottleneck(nn.Module):
         self.stride = stride
 
     def forward(self, x):
+        # x feeds conv1 and the shortcut (identity into bn3's residual add, or the downsample conv): their gradients meet
+        # in one buffer instead of an elementwise add (ops.GradSink)
+        ops.share_grad(x)
         y = conv_bn(self.conv1, self.bn1, x, True)
         y = conv_bn(self.conv2, self.bn2, y, True)
         if self.downsample is not None:
@@ -202,6 +205,7 @@ class Classifier_Module2(nn.Module):
 
     def forward(self, x, get_feat=False):
         ys, gammas, betas = [], [], []
+        ops.share_grad(x)  # five convs read x: their data gradients accumulate in place (ops.GradSink)
         for seq in self.conv2d_list:
             y, _ = seq[0](x)
             ys.append(y)

@@ -289,6 +289,57 @@ def pack_weight_dgrad(weight, cout_pad=None):
     return dst
 
 
+class GradSink:
+    """One accumulation buffer for the gradient of an activation with several consumers (a bottleneck block's input:
+    first 1x1 conv + identity shortcut or downsample conv; the ASPP input: five convs).  Autograd would add the consumers'
+    gradients with one elementwise pass per extra consumer (3 x 4 B per element each); here the first consumer to run
+    backward hands ITS gradient tensor to autograd and keeps it as `buf`, every later consumer adds into it in place --
+    a conv's data-gradient kernel takes it as the epilogue residual (one extra 4 B read per element) -- and returns None.
+    Valid only when EVERY consumer of the tensor follows this protocol (Conv2dFn and the BatchNorm functions' residual
+    input): a foreign consumer's gradient would be summed by the engine while later in-place updates are still coming."""
+    __slots__ = ("buf", "pending")
+
+    def __init__(self):
+        self.buf, self.pending = None, 0
+
+
+SHARE_GRADS = True  # tests turn this off to compare with autograd's own accumulation
+
+
+def share_grad(x):
+    """Mark `x` (about to be consumed by several of this module's Functions, and by nothing else) for GradSink."""
+    if SHARE_GRADS and torch.is_grad_enabled() and x.requires_grad and getattr(x, "_onda_sink", None) is None:
+        x._onda_sink = GradSink()  # (marked twice -- an activation read by two modules -- all consumers share one sink)
+    return x
+
+
+def _sink_of(x):
+    sink = getattr(x, "_onda_sink", None) if x is not None else None
+    if sink is not None:
+        sink.pending += 1
+    return sink
+
+
+def _sink_done(sink):
+    sink.pending -= 1
+    if sink.pending <= 0:
+        sink.buf = None  # the engine holds its own reference; a second backward through the graph starts clean
+
+
+def _sink_give(sink, grad, owned):
+    """A consumer's gradient `grad` for the shared tensor (owned: a buffer nobody else references).  Returns what the
+    Function hands to autograd."""
+    if sink is None:
+        return grad
+    out = None
+    if sink.buf is None:
+        out = sink.buf = grad if owned else grad.clone()
+    else:
+        sink.buf.add_(grad)
+    _sink_done(sink)
+    return out
+
+
 def conv_forward(x, wp, k, stride, dil, pad, cout, out=None, scale=None, shift=None, residual=None, relu=False,
                  want_stats=False):
     """x NHWC view, wp packed [cout][k*k*Cin].  Returns (y, stats partials or None, tiles)."""
@@ -342,11 +393,27 @@ def conv_forward(x, wp, k, stride, dil, pad, cout, out=None, scale=None, shift=N
     return out, stats, tiles
 
 
-def conv_dgrad(dy, wpd, k, stride, dil, pad, cin, in_hw):
-    """Data gradient.  dy NHWC [B,Ho,Wo,Cout(_pad)], wpd = pack_weight_dgrad(weight)."""
+def conv_dgrad(dy, wpd, k, stride, dil, pad, cin, in_hw, accumulate=None):
+    """Data gradient.  dy NHWC [B,Ho,Wo,Cout(_pad)], wpd = pack_weight_dgrad(weight).
+    `accumulate`: a dense fp32 [B,Hi,Wi,cin] buffer the gradient is ADDED to (GradSink); returns it."""
     B, Ho, Wo, Co = dy.shape
     Hi, Wi = in_hw
     ldy = 0 if is_limb_only(dy) else nhwc_ld(dy)
+    if accumulate is not None:
+        fused = (stride == 1 and _use_l2(wpd, Co) and accumulate.is_contiguous() and accumulate.dtype == torch.float32
+                 and tuple(accumulate.shape) == (B, Hi, Wi, cin) and not is_limb_only(accumulate))
+        if not fused:
+            accumulate.add_(conv_dgrad(dy, wpd, k, stride, dil, pad, cin, in_hw))
+            return accumulate
+        # the epilogue reads the running sum as its residual and stores over it (same thread, same 16 bytes)
+        d = _desc(B, Ho, Wo, Co, Hi, Wi, cin, k, 1, dil, dil * (k - 1) - pad, ldy, cin, cin)
+        dyl = limbs_of(dy)
+        d.ldx = dyl.ld
+        _launch("conv_l2_kernel<%d>" % query("onda_conv_l2_variant", B * Hi * Wi, cin), 2.0 * B * Ho * Wo * cin * k * k * Co,
+                "onda_conv2d_fwd_l2", _p(dyl.planes), dyl.plane, _p(dyl.amax), _p(wpd.limbs), _p(wpd.amax), _p(accumulate), None,
+                None, _p(accumulate), None, 2, _p(_conv_ws(dy.device)), None, byref(d), _stream(),
+                tag=("dgrad", B * Hi * Wi, cin, Co, k, stride, dil))
+        return accumulate
     if stride == 1:
         dx = torch.empty(B, Hi, Wi, cin, device=dy.device, dtype=torch.float32)
         d = _desc(B, Ho, Wo, Co, Hi, Wi, cin, k, 1, dil, dil * (k - 1) - pad, ldy, cin)
@@ -572,6 +639,7 @@ class Conv2dFn(torch.autograd.Function):
         hit = getattr(x, "_onda_limbs", None)
         ctx.xlimbs = hit[1] if hit is not None and hit[0] == x._version else None  # ... and its limb planes
         ctx.weight_param = weight  # the Parameter itself: its .grad is the accumulation target
+        ctx.sink = _sink_of(x) if ctx.needs_input_grad[0] else None
         ctx.cache, ctx.geom, ctx.has_bias = cache, (k, stride, dil, pad, cout, cin, cout_pad), bias is not None
         if want_stats:
             ctx.mark_non_differentiable(stats)
@@ -586,7 +654,13 @@ class Conv2dFn(torch.autograd.Function):
             dy = as_nhwc(dy)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = conv_dgrad(dy, ctx.cache.get_dgrad(weight, cout_pad), k, stride, dil, pad, cin, x.shape[1:3])
+            sink = ctx.sink
+            wpd = ctx.cache.get_dgrad(weight, cout_pad)
+            if sink is not None and sink.buf is not None:
+                conv_dgrad(dy, wpd, k, stride, dil, pad, cin, x.shape[1:3], accumulate=sink.buf)
+                _sink_done(sink)
+            else:
+                dx = _sink_give(sink, conv_dgrad(dy, wpd, k, stride, dil, pad, cin, x.shape[1:3]), True)
         if ctx.needs_input_grad[1]:
             into = _accumulate_target(ctx.weight_param)
             dw = conv_wgrad(x, dy, k, stride, dil, pad, cout, cin, into=into, xscale=ctx.xscale, xlimbs=ctx.xlimbs)
@@ -678,6 +752,7 @@ class BNTrainFn(torch.autograd.Function):
             tag_amax(out, amax)
         ctx.save_for_backward(y, out if relu else None, mean, invstd, gamma)
         ctx.relu, ctx.has_res = relu, residual is not None
+        ctx.res_sink = _sink_of(residual) if (residual is not None and ctx.needs_input_grad[4]) else None
         return out
 
     @staticmethod
@@ -697,6 +772,8 @@ class BNTrainFn(torch.autograd.Function):
              _p(dres) if (need_res and ctx.relu) else None, _p(ws), M, C, int(ctx.relu), _p(amax), _stream())
         if amax is not None:
             tag_amax(dx, amax)  # dx is the dy of the conv below: data gradient and weight gradient read it
+        if need_res:
+            dres = _sink_give(ctx.res_sink, dres, ctx.relu)
         return dx, None, None, None, dres, None, None, None
 
 
@@ -735,6 +812,7 @@ class BNTrainLimbFn(torch.autograd.Function):
         ctx.save_for_backward(y, mean, invstd, gamma, xhat_amax)
         ctx.out_limbs = lb if relu else None
         ctx.relu, ctx.has_res = relu, residual is not None
+        ctx.res_sink = _sink_of(residual) if (residual is not None and ctx.needs_input_grad[4]) else None
         return limb_only((B, H, W, C), dev, lb)
 
     @staticmethod
@@ -758,6 +836,8 @@ class BNTrainLimbFn(torch.autograd.Function):
              _p(mean), _p(invstd), _p(gamma), _p(xhat_amax), _p(planes), M * C, _p(dx_amax),
              _p(dres) if (need_res and ctx.relu) else None, _p(ws), M, C, int(ctx.relu), _stream())
         dx = limb_only((B, H, W, C), dev, Limbs(planes, dx_amax, C, M * C))
+        if need_res:
+            dres = _sink_give(ctx.res_sink, dres, ctx.relu)
         return dx, None, None, None, dres, None, None, None
 
 

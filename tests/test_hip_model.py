@@ -179,6 +179,44 @@ def test_model_invariants_on_device():
         m.cpu()(x.cpu())  # no CPU fallback
 
 
+@pytest.mark.parametrize("multi_level", [False, True])
+def test_shared_gradient_buffers_match_autograd_accumulation(multi_level):
+    """ops.GradSink (gradients of a block input / of the ASPP input accumulated in place by the data-gradient kernels)
+    against autograd's own sum of the consumers' gradients: same parameter gradients, same input-side gradients, on a
+    ragged size, and a second backward pass through a fresh graph starts from a clean buffer."""
+    from onda_amd import ops
+    m = build_model(4, 3.0).train()
+    m.multi_level = multi_level
+    torch.manual_seed(3)
+    x = torch.randn(2, 3, 97, 161, device=DEV)
+    lab = torch.randint(0, 19, (2, 13, 21), device=DEV)
+
+    def grads(share):
+        old, ops.SHARE_GRADS = ops.SHARE_GRADS, share
+        try:
+            m.zero_grad(set_to_none=True)
+            from onda_amd.framework.model import deeplabv2
+            deeplabv2.force_mask(torch.ones(2, 256, device=DEV))
+            if multi_level:
+                deeplabv2.force_mask(torch.ones(2, 256, device=DEV))
+            o1, o2 = m(x)
+            loss = ops.seg_losses(o2["out"], lab, 1.0, 0.0, 0.0)[0]
+            if multi_level:
+                loss = loss + 0.1 * ops.seg_losses(o1["out"], lab, 1.0, 0.0, 0.0)[0]
+            loss.backward()
+            return {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+        finally:
+            ops.SHARE_GRADS = old
+
+    ref = grads(False)
+    for _ in range(2):
+        got = grads(True)
+        assert got.keys() == ref.keys() and len(ref) > 50
+        for n in ref:
+            scale = ref[n].abs().max().item() + 1e-30
+            assert (got[n] - ref[n]).abs().max().item() <= 2e-5 * scale, n
+
+
 @pytest.mark.parametrize("tag,head_scale", [("static", 40.0), ("dynamic", 3.0)])
 def test_full_step_golden(golden, tmp_path, tag, head_scale):
     """Two complete hybrid_proDA steps (+update_ema) at 128x64, B=2 against the reference's log
