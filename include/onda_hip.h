@@ -81,7 +81,8 @@ int onda_conv2d_fwd_bf3(const float* x, const void* w3, float* y, const float* s
  * their atomicMax over ONDA_AMAX_SLOTS slots, one cache line apart); every consumer derives 2^e (max * 2^e in
  * [2^14, 2^15)) from it in-kernel.  amax buffers must be ZERO before their producer runs; producers are
  * onda_absmax below, or -- fused, no extra pass -- onda_bn_apply / onda_bn_bwd / onda_conv2d_fwd_h2 (their
- * `amax` / `yamax` argument, may be NULL). */
+ * `amax` / `yamax` argument, may be NULL).  onda_absmax: x[rows][ld] with C valid channels, C and ld multiples of
+ * 4; a flat tensor (rows == 1) may have any length. */
 #define ONDA_AMAX_SLOTS 64     /* slots, one 128-byte line apart */
 #define ONDA_AMAX_FLOATS 2048  /* floats per amax buffer */
 int onda_absmax(const float* x, int64_t rows, int C, int ld, float* amax, onda_stream_t s);
@@ -114,6 +115,11 @@ int onda_conv2d_fwd_h2(const float* x, const float* xamax, const void* w2, const
  * elements of a plane row, xplane the f16 elements between the two planes. */
 int onda_split_h2(const float* x, int64_t rows, int C, int ldx, void* dst, int ldo, int64_t plane, const float* amax,
                   onda_stream_t s);
+/* Stem patches (onda_stem_im2col) written directly as limb planes dst[2][B*Ho*Wo][Kp] f16 (plane = f16 elements between
+ * the two planes): the patch matrix holds image values and zeros, so its max|x| is the image's (xamax, from onda_absmax
+ * over the image).  Replaces the stem's F.conv2d input side (deeplabv2.py:283) in "f16x2" pre-split mode. */
+int onda_stem_im2col_l2(const float* x_nchw, const float* xamax, void* dst, int64_t plane, int B, int H, int W, int Ho, int Wo,
+                        int Kp, onda_stream_t s);
 int onda_conv_l2_variant(int64_t M, int Cout);  /* tile shape used for an (M, Cout) problem: 0 256x128, 1 128x128, 2 256x64 */
 int onda_conv_l2_tiles_m(int64_t M, int Cout, int taps, int Cin);  /* rows of the `stats` partials the conv writes for this problem */
 /* stats_rows: 2 = stats[tile][sum, sumsq][Cout] as onda_conv2d_fwd; 4 = also the per-channel min and max of the raw

@@ -45,6 +45,7 @@ SIGNATURES = {
     "onda_conv2d_fwd_h2": (I, [P, P, P, P, P, P, P, P, P, P, P, POINTER(OndaConv), P]),
     "onda_conv2d_wgrad_h2": (I, [P, P, P, P, P, I, I, POINTER(OndaConv), P]),
     "onda_split_h2": (I, [P, L, I, I, P, I, L, P, P]),
+    "onda_stem_im2col_l2": (I, [P, P, P, L, I, I, I, I, I, I, P]),
     "onda_conv_l2_variant": (I, [L, I]),
     "onda_conv_l2_tiles_m": (I, [L, I, I, I]),
     "onda_conv_wgrad_l2_variant": (I, [I, I]),

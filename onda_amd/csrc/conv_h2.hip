@@ -105,6 +105,8 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x
     const f32x4 v = *reinterpret_cast<const f32x4*>(x + row * ld + ch);
     m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
   }
+  // a flat tensor (rows == 1) whose length is not a multiple of 4: the last 1-3 values
+  if (rows == 1 && blockIdx.x == 0 && threadIdx.x < (C & 3)) m = fmaxf(m, fabsf(x[(C & ~3) + threadIdx.x]));
   __shared__ float red[4];
   amax_update_block(amax, m, red);
 }
@@ -563,7 +565,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_h2_kernel(const WgradK a, u
 extern "C" {
 
 int onda_absmax(const float* x, int64_t rows, int C, int ld, float* amax, onda_stream_t s) {
-  ONDA_REQUIRE(x && amax && rows > 0 && C > 0 && C % 4 == 0 && ld >= C && ld % 4 == 0);
+  ONDA_REQUIRE(x && amax && rows > 0 && C > 0 && ld >= C && (rows == 1 || (C % 4 == 0 && ld % 4 == 0)));
   if (!ONDA_ALIGNED16(x)) return ONDA_EALIGN;
   const long long n = rows * (C / 4);
   const int blocks = (int)(n / 256 / 8 + 1 > 1024 ? 1024 : n / 256 / 8 + 1);

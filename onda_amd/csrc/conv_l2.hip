@@ -86,6 +86,47 @@ __global__ __launch_bounds__(256) void split_h2_kernel(const float* __restrict__
   }
 }
 
+// Stem patches (7 x 7, stride 2, pad 3 on the NCHW image) written as limb planes: col[2][M][Kp], row m = output pixel,
+// k = (r*7 + s)*3 + c, zero padded to Kp.  A patch matrix holds copies of image values and zeros, so max|col| is the
+// image's max|x| (known before this kernel runs): no fp32 patch matrix, no max pass, no split pass.
+__global__ __launch_bounds__(256) void stem_im2col_l2_kernel(const float* __restrict__ x, _Float16* __restrict__ dst,
+                                                             long long plane, int B, int H, int W, int Ho, int Wo, int Kp,
+                                                             const float* __restrict__ amax) {
+  const float sc = scale_of(amax).s;
+  const int k8 = Kp >> 3;
+  const long long n = (long long)B * Ho * Wo * k8;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256) {
+    const long long m = e / k8;
+    const int k0 = (int)(e - m * k8) * 8;
+    const int wo = (int)(m % Wo);
+    const long long tq = m / Wo;
+    const int ho = (int)(tq % Ho), b = (int)(tq / Ho);
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = k0 + j;
+      float val = 0.f;
+      if (k < 147) {
+        const int tap = k / 3, cc = k - tap * 3;
+        const int r = tap / 7, t7 = tap - r * 7;
+        const int hi = ho * 2 - 3 + r, wi = wo * 2 - 3 + t7;
+        if ((unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W) val = x[(((size_t)b * 3 + cc) * H + hi) * W + wi];
+      }
+      v[j] = val * sc;
+    }
+    u32x4 l1, l2;
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      const unsigned pk = cvt2h(v[2 * h], v[2 * h + 1]);
+      const f32x2 f = unpack2h(pk);
+      l1[h] = pk;
+      l2[h] = cvt2h((v[2 * h] - f[0]) * LIMB2_SCALE, (v[2 * h + 1] - f[1]) * LIMB2_SCALE);
+    }
+    *reinterpret_cast<u32x4*>(dst + m * Kp + k0) = l1;
+    *reinterpret_cast<u32x4*>(dst + plane + m * Kp + k0) = l2;
+  }
+}
+
 // ---- epilogue of a (64*WM) x (64*WN) tile held as 4 x 4 MFMA tiles of 16 x 16 per wave ----------------------------
 // The accumulator layout has a lane's 16 values of one MFMA column 4 rows apart: stored as they stand that is 64
 // four-byte stores per lane in 64-byte runs, and the store ISSUE (not bandwidth) is what a tile then waits for
@@ -1154,6 +1195,17 @@ int onda_split_h2(const float* x, int64_t rows, int C, int ldx, void* dst, int l
   const int blocks = (int)(n / 256 / 4 + 1 > 2048 ? 2048 : n / 256 / 4 + 1);
   hipLaunchKernelGGL(split_h2_kernel, dim3(blocks), dim3(256), 0, ONDA_STREAM(s), x, (long long)rows, C, ldx,
                      static_cast<_Float16*>(dst), ldo, (long long)plane, amax);
+  return ONDA_LAUNCH_RESULT();
+}
+
+int onda_stem_im2col_l2(const float* x_nchw, const float* xamax, void* dst, int64_t plane, int B, int H, int W, int Ho, int Wo,
+                        int Kp, onda_stream_t s) {
+  ONDA_REQUIRE(x_nchw && xamax && dst && Kp % 8 == 0 && Kp >= 147 && plane % 8 == 0 && B > 0 && Ho > 0 && Wo > 0);
+  if (!ONDA_ALIGNED16(dst)) return ONDA_EALIGN;
+  const long long n = (long long)B * Ho * Wo * (Kp / 8);
+  const int blocks = (int)(n / 256 / 2 + 1 > 4096 ? 4096 : n / 256 / 2 + 1);
+  hipLaunchKernelGGL(stem_im2col_l2_kernel, dim3(blocks), dim3(256), 0, ONDA_STREAM(s), x_nchw, static_cast<_Float16*>(dst),
+                     (long long)plane, B, H, W, Ho, Wo, Kp, xamax);
   return ONDA_LAUNCH_RESULT();
 }
 

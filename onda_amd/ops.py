@@ -679,6 +679,33 @@ def _pad_vec(v, n):
     return out
 
 
+def stem_patches(x_nchw, Ho, Wo, l2):
+    """The stem's patch matrix [B,Ho,Wo,STEM_K] of an image batch.  In pre-split "f16x2" mode it exists as limb planes
+    only, written by the patch kernel itself (max|patches| = max|image|, one small pass over the image).  The matrix is
+    remembered on the image tensor: the teacher, the static model and the student all read the same target batch."""
+    hit = getattr(x_nchw, "_onda_patches", None)
+    key = (x_nchw._version, bool(l2), Ho, Wo)
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    B, _, H, W = x_nchw.shape
+    dev = x_nchw.device
+    if l2:
+        amax = amax_slot(dev)
+        call("onda_absmax", _p(x_nchw), 1, x_nchw.numel(), x_nchw.numel(), _p(amax), _stream())
+        M = B * Ho * Wo
+        planes = torch.empty(2, M, STEM_K, device=dev, dtype=torch.float16)
+        call("onda_stem_im2col_l2", _p(x_nchw), _p(amax), _p(planes), M * STEM_K, B, H, W, Ho, Wo, STEM_K, _stream())
+        col = limb_only((B, Ho, Wo, STEM_K), dev, Limbs(planes, amax, STEM_K, M * STEM_K))
+    else:
+        col = torch.empty(B, Ho, Wo, STEM_K, device=dev, dtype=torch.float32)
+        call("onda_stem_im2col", _p(x_nchw), _p(col), B, H, W, Ho, Wo, STEM_K, _stream())
+    try:
+        x_nchw._onda_patches = (key, col)
+    except AttributeError:
+        pass
+    return col
+
+
 class StemConvFn(torch.autograd.Function):
     """7x7 / stride 2 / pad 3 stem on the NCHW image: im2col patches + the same MFMA GEMM."""
 
@@ -688,11 +715,11 @@ class StemConvFn(torch.autograd.Function):
         x_nchw = x_nchw.contiguous()
         B, _, H, W = x_nchw.shape
         Ho, Wo = conv_out_size(H, 7, 2, 1, 3), conv_out_size(W, 7, 2, 1, 3)
-        col = torch.empty(B, Ho, Wo, STEM_K, device=x_nchw.device, dtype=torch.float32)
-        call("onda_stem_im2col", _p(x_nchw), _p(col), B, H, W, Ho, Wo, STEM_K, _stream())
         wp = cache.get_fwd(weight, None, STEM_K)
+        col = stem_patches(x_nchw, Ho, Wo, _use_l2(wp, STEM_K))
         y, stats, _ = conv_forward(col, wp, 1, 1, 1, 0, weight.shape[0], want_stats=want_stats)
         ctx.save_for_backward(col)  # dropped again by autograd when no graph is being recorded
+        ctx.col_limbs = limbs_of(col) if is_limb_only(col) else None
         ctx.cout, ctx.weight = weight.shape[0], weight
         if want_stats:
             ctx.mark_non_differentiable(stats)
@@ -703,7 +730,7 @@ class StemConvFn(torch.autograd.Function):
     def backward(ctx, dy, _dstats):
         (col,) = ctx.saved_tensors
         into = _accumulate_target(ctx.weight)
-        dw = conv_wgrad(col, as_nhwc(dy), 1, 1, 1, 0, ctx.cout, 3, flat_k=49, into=into)
+        dw = conv_wgrad(col, as_nhwc(dy), 1, 1, 1, 0, ctx.cout, 3, flat_k=49, into=into, xlimbs=ctx.col_limbs)
         if into is not None and GRAD_READY is not None:
             GRAD_READY(ctx.weight)
         return None, dw, None, None
@@ -716,10 +743,9 @@ def stem_eval(x_nchw, weight, cache, scale, shift):
         x_nchw = x_nchw.contiguous()
         B, _, H, W = x_nchw.shape
         Ho, Wo = conv_out_size(H, 7, 2, 1, 3), conv_out_size(W, 7, 2, 1, 3)
-        col = torch.empty(B, Ho, Wo, STEM_K, device=x_nchw.device, dtype=torch.float32)
-        call("onda_stem_im2col", _p(x_nchw), _p(col), B, H, W, Ho, Wo, STEM_K, _stream())
-        y, _, _ = conv_forward(col, cache.get_fwd(weight, None, STEM_K), 1, 1, 1, 0, weight.shape[0], scale=scale,
-                               shift=shift, relu=True)
+        wp = cache.get_fwd(weight, None, STEM_K)
+        col = stem_patches(x_nchw, Ho, Wo, _use_l2(wp, STEM_K))
+        y, _, _ = conv_forward(col, wp, 1, 1, 1, 0, weight.shape[0], scale=scale, shift=shift, relu=True)
     return y
 
 

@@ -171,6 +171,28 @@ def test_head_and_stem(conv_mode):
     close(wd.grad, wr.grad, 5e-5, "stem wgrad")
 
 
+def test_stem_patches_as_limb_planes():
+    """Pre-split "f16x2": the stem's patch kernel writes limb planes directly (scale from max|image|); rebuilt, they are
+    the fp32 patch matrix to 2^-22 of each value, ragged image size, and the matrix is shared by every pass that reads
+    the same image tensor (teacher / static / student) until the image changes."""
+    from onda_amd import ops
+    g = torch.Generator().manual_seed(16)
+    x = (torch.randn(2, 3, 75, 141, generator=g) * 3.0).to(DEV)
+    Ho, Wo = ops.conv_out_size(75, 7, 2, 1, 3), ops.conv_out_size(141, 7, 2, 1, 3)
+    ref = ops.stem_patches(x, Ho, Wo, False)
+    assert not ops.is_limb_only(ref) and ref[..., 147:].abs().max().item() == 0
+    col = ops.stem_patches(x, Ho, Wo, True)
+    assert ops.is_limb_only(col) and ops.stem_patches(x, Ho, Wo, True) is col
+    got = ops.materialize(col)
+    assert (got - ref).abs().max().item() <= 2.0 ** -21 * ref.abs().max().item()
+    rel = ((got - ref).abs() / ref.abs().clamp_min(1e-3)).max().item()
+    assert rel <= 2.0 ** -20, rel
+    x.mul_(0.5)  # in-place change of the image: the remembered matrix is stale
+    again = ops.stem_patches(x, Ho, Wo, True)
+    assert again is not col
+    assert (ops.materialize(again) - 0.5 * ref).abs().max().item() <= 2.0 ** -21 * ref.abs().max().item()
+
+
 @pytest.mark.parametrize("C,H,W,relu,res,track", [(64, 17, 33, True, False, True), (256, 9, 17, True, True, False),
                                                     (512, 9, 17, False, False, True), (2048, 5, 9, True, True, True)])
 def test_batchnorm_train(C, H, W, relu, res, track):
