@@ -291,8 +291,10 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_l2_kernel(const ConvK 
   constexpr int APW = (BM / 16) / NW, BPW = (BN / 16) / NW;  // 16-row blocks (2 limbs x 1 KiB) per wave and stage
   static_assert((BM / 16) % NW == 0 && (BN / 16) % NW == 0, "whole blocks per wave");
   constexpr int DPW = 2 * (APW + BPW);  // LDS-DMA instructions per wave per K-step
-  static_assert(STAGES >= 3, "ring: one stage being read, two in flight");
+  static_assert(STAGES >= 2, "ring: one stage being read, STAGES - 1 in flight");
+  constexpr int AHEAD = STAGES >= 3 ? 2 : 1;     // K-steps in flight beyond the one being read
   constexpr bool STAGGER = NW == 8 && DBG != 6;  // two waves per SIMD: the second half of the workgroup runs half a step late
+  static_assert(!STAGGER || STAGES >= 3, "the staggered halves need two steps in flight");
   __shared__ __attribute__((aligned(16))) unsigned char lds[STAGES * STAGE];
 
   const OndaConv& c = a.c;
@@ -435,10 +437,11 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_l2_kernel(const ConvK 
     const int nsteps = dp && a.taps > 1 && a.skip_dead_taps ? __builtin_popcount(live & ((1u << a.taps) - 1u)) * a.kcper : k_end - k_begin;
     issue(st_issue);
     st_issue += STAGE;
-    if (nsteps > 1) {
+    if (AHEAD == 2 && nsteps > 1) {
       issue(st_issue);
       st_issue += STAGE;
     }
+    if (st_issue == STAGES * STAGE) st_issue = 0;
     stamp(tk_setup);
     auto wait_landed = [&](bool more_in_flight) {  // this wave's DMAs of a step have landed; those of the step after may still fly
       if (DBG == 1) return;
@@ -488,10 +491,11 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_l2_kernel(const ConvK 
         for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][0], b1[j], acc[i][j], 0, 0, 0);
     };
     if constexpr (!STAGGER) {
+      // (a two-stage ring -- half the LDS, two workgroups per CU hide each other's waits -- has one step in flight)
       for (int kt = 0; kt < nsteps; ++kt) {
-        wait_landed(kt + 1 < nsteps);
+        wait_landed(AHEAD == 2 && kt + 1 < nsteps);
         __builtin_amdgcn_s_barrier();  // everybody's DMAs of step kt have landed; the stage read in step kt-1 is free
-        if (DBG != 2 && kt + 2 < nsteps) issue_next();
+        if (DBG != 2 && kt + AHEAD < nsteps) issue_next();
         prepare();
         compute();
       }
@@ -1228,6 +1232,11 @@ struct L2Schedule {
   int rem_rows() const { return tilesM - (tilesM * tilesN - rem) / tilesN; }  // tile rows that hold remainder tiles
   int stats_rows_total() const { return tilesM + (balanced ? rem_rows() * (sub - 1) : 0); }
 };
+bool l2_small_ring2() {
+  static const int on = getenv("ONDA_L2_RING2") ? atoi(getenv("ONDA_L2_RING2")) : 1;
+  return on != 0;
+}
+
 L2Schedule l2_schedule(long long M, int Cout, int taps, int Cin, bool have_ws) {
   L2Schedule q;
   q.variant = onda_conv_l2_variant(M, Cout);
@@ -1235,7 +1244,9 @@ L2Schedule l2_schedule(long long M, int Cout, int taps, int Cin, bool have_ws) {
   q.BN = q.variant == 2 ? 64 : 128;
   q.tilesM = (int)((M + q.BM - 1) / q.BM);
   q.tilesN = (Cout + q.BN - 1) / q.BN;
-  q.G = conv_resident_workgroups() / 2;  // one workgroup per CU (144 / 96 / 120 KB of LDS)
+  // 256 x 128 tiles: one workgroup per CU (144 KB of LDS, 3-stage ring).  The four-wave tiles (128 x 128, 256 x 64) run a
+  // 2-stage ring (64 / 80 KB): two workgroups per CU, each covering the other's DMA waits, prologue and epilogue
+  q.G = q.variant == 0 || !l2_small_ring2() ? conv_resident_workgroups() / 2 : conv_resident_workgroups();
   q.sub = q.BM / (256 / (q.BN / 4));
   const int tiles = q.tilesM * q.tilesN, KT = taps * (Cin / 32);
   q.rem = tiles % q.G;
@@ -1320,7 +1331,9 @@ int onda_conv2d_fwd_l2(const void* xl, int64_t xplane, const float* xamax, const
     return ONDA_LAUNCH_RESULT();
   }
   if (q.variant == 0) L2_LAUNCH(4, 2, 3, 2);
+  else if (q.variant == 1 && l2_small_ring2()) L2_LAUNCH(2, 2, 2, 2);
   else if (q.variant == 1) L2_LAUNCH(2, 2, 3, 1);
+  else if (l2_small_ring2()) L2_LAUNCH(4, 1, 2, 2);
   else L2_LAUNCH(4, 1, 3, 1);
 #undef L2_LAUNCH
   return ONDA_LAUNCH_RESULT();

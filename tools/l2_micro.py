@@ -11,7 +11,10 @@ SHAPES = [  # (B,H,W,Cin,Cout,k,dil)
     (4, 65, 129, 1024, 256, 1, 1), (4, 64, 128, 1024, 256, 1, 1), (4, 65, 129, 256, 1024, 1, 1), (4, 64, 128, 256, 1024, 1, 1),
     (4, 65, 129, 512, 2048, 1, 1), (4, 65, 129, 2048, 512, 1, 1), (4, 65, 129, 256, 256, 3, 2), (4, 65, 129, 512, 512, 3, 4),
     (4, 65, 129, 128, 512, 1, 1), (4, 65, 129, 512, 128, 1, 1), (4, 129, 257, 64, 256, 1, 1), (4, 129, 257, 256, 64, 1, 1),
+    (4, 65, 129, 128, 128, 3, 1), (4, 129, 257, 64, 64, 3, 1), (4, 129, 257, 64, 64, 1, 1), (4, 256, 512, 160, 64, 1, 1),
 ]
+if os.environ.get("SMALL"):
+    SHAPES = SHAPES[8:]
 N = 20
 stats = int(os.environ.get("STATS", "4"))
 ops.H2_PATH = "dma"
