@@ -1092,8 +1092,10 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_wgrad_l2_kernel(const 
     else
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   };
+  constexpr int AHEAD = STAGES >= 3 ? 2 : 1;  // (two-stage ring: two workgroups per CU cover each other's waits)
+  static_assert(!STAGGER || STAGES >= 3, "the staggered halves need two steps in flight");
   if (i_iss < nlive) issue_next();
-  if (i_iss < nlive) issue_next();
+  if (AHEAD == 2 && i_iss < nlive) issue_next();
   f16x8 af[4][2], bf[4], b1[4];
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
   unsigned base;
@@ -1106,21 +1108,28 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_wgrad_l2_kernel(const 
       for (int i = 0; i < 4; ++i) af[i][l] = tr_read8(base + l * A_LIMB + fa[i][0], base + l * A_LIMB + fa[i][1]);
 #pragma unroll
     for (int j = 0; j < 4; ++j) bf[j] = tr_read8(base + B_LIMB + fb[j][0], base + B_LIMB + fb[j][1]);
+    if constexpr (STAGGER) {  // staggered halves: the compute slot reads nothing from LDS (see conv_l2_kernel)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b1[j] = tr_read8(base + fb[j][0], base + fb[j][1]);
+    }
   };
   auto prepared = [&]() {  // ... and wait for them (before the barrier that lets the stage be refilled / before the MFMAs)
     lds_wait(af[0][0], af[1][0], af[2][0], af[3][0]);
     lds_wait(af[0][1], af[1][1], af[2][1], af[3][1]);
     lds_wait(bf[0], bf[1], bf[2], bf[3]);
+    if constexpr (STAGGER) lds_wait(b1[0], b1[1], b1[2], b1[3]);
     __builtin_amdgcn_sched_barrier(0);
   };
-  auto compute = [&]() {  // "C": the b1 fragments arrive behind the first 16 MFMAs
+  auto compute = [&]() {  // "C" (one wave per SIMD: the b1 fragments arrive behind the first 16 MFMAs)
+    if constexpr (!STAGGER) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) b1[j] = tr_read8(base + fb[j][0], base + fb[j][1]);
+      for (int j = 0; j < 4; ++j) b1[j] = tr_read8(base + fb[j][0], base + fb[j][1]);
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) accx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][0], bf[j], accx[i][j], 0, 0, 0);
-    lds_wait(b1[0], b1[1], b1[2], b1[3]);
+    if constexpr (!STAGGER) lds_wait(b1[0], b1[1], b1[2], b1[3]);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -1133,7 +1142,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_wgrad_l2_kernel(const 
   };
   if constexpr (!STAGGER) {
     for (; i_cur < nlive; ++i_cur) {
-      wait_landed(i_cur + 1 < nlive);
+      wait_landed(AHEAD == 2 && i_cur + 1 < nlive);
       __builtin_amdgcn_s_barrier();
       if (i_iss < nlive) issue_next();
       prepare();
@@ -1148,12 +1157,11 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_wgrad_l2_kernel(const 
     for (; i_cur < nlive; ++i_cur) {
       if (!late) wait_landed(i_cur + 1 < nlive);
       __builtin_amdgcn_s_barrier();
-      if (late && i_iss < nlive) issue_next();
+      if (i_iss < nlive) issue_next();  // both halves in their own prepare slot, beside the other half's MFMAs
       prepare();
       prepared();
       if (late && i_cur + 1 < nlive) wait_landed(i_cur + 2 < nlive);
       __builtin_amdgcn_s_barrier();
-      if (!late && i_iss < nlive) issue_next();
       compute();
     }
     if (!late && nlive > 0) __builtin_amdgcn_s_barrier();
@@ -1375,7 +1383,7 @@ int onda_conv2d_wgrad_l2(const void* xl, int64_t xplane, const float* xamax, con
     hipLaunchKernelGGL((conv_wgrad_l2_kernel<4, 2, 3, 2>), dim3(grid), dim3(512), 0, ONDA_STREAM(s), k, xpl, dypl, (unsigned)x_total,
                        (unsigned)dy_total, xamax, dyamax);
   else
-    hipLaunchKernelGGL((conv_wgrad_l2_kernel<2, 2, 3, 1>), dim3(grid), dim3(256), 0, ONDA_STREAM(s), k, xpl, dypl, (unsigned)x_total,
+    hipLaunchKernelGGL((conv_wgrad_l2_kernel<2, 2, 2, 2>), dim3(grid), dim3(256), 0, ONDA_STREAM(s), k, xpl, dypl, (unsigned)x_total,
                        (unsigned)dy_total, xamax, dyamax);
   return ONDA_LAUNCH_RESULT();
 }

@@ -450,10 +450,10 @@ def conv_dgrad(dy, wpd, k, stride, dil, pad, cin, in_hw, accumulate=None):
 def _wgrad_splitk(M, cout, cin, taps, l2=False):
     """Split count over the pixel (K) range: pick the one whose workgroup count best fills whole
     rounds of the resident workgroups (tail effect) net of the slab write+read it costs."""
-    if l2:  # pre-split kernel: 256 x 128 or 128 x 128 tiles, one workgroup per CU
+    if l2:  # pre-split kernel: 256 x 128 tiles, one workgroup per CU; 128 x 128 (two-stage ring), two per CU
         tn = 256 if query("onda_conv_wgrad_l2_variant", cout, cin) == 0 else 128
         tiles = -(-cout // tn) * -(-cin // 128) * taps
-        G = query("onda_conv_ws_floats") // (3 * 128 * 128) // 2
+        G = query("onda_conv_ws_floats") // (3 * 128 * 128) // (2 if tn == 256 else 1)
         # (the kernel lists a workgroup's K-steps in LDS: at most 2048 steps of 32 pixels per split)
         return max(_best_splitk(M, cout, cin, taps, tiles, G, 3.2e14 if tn == 256 else 2.0e14), -(-M // 65536))
     t = 128 if (cout > 64 and cin > 64) else 64
