@@ -17,7 +17,8 @@ struct ConvK {
   float* ws;     // stream-K partial tiles [grid][2][BM*BN]
   int tiles_dp;  // tiles done one-per-workgroup before the stream-K remainder (multiple of the grid)
   float* amax = nullptr;  // optional: running max|y| of the stored output (amax_update, common.h)
-  int skip_dead_taps = 1;  // whole tiles skip filter taps that only see padding (conv_l2.hip)
+  int skip_dead_taps = 1;
+  int late_issue = 1;  // conv_l2x_kernel: second half of the waves issues its DMAs behind its MFMAs  // whole tiles skip filter taps that only see padding (conv_l2.hip)
   int stats_rows = 2;     // 2: stats[tile][sum, sumsq][Cout]; 4: also the per-channel min and max of the raw tile (conv_l2.hip)
 };
 

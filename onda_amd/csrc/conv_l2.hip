@@ -718,6 +718,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_l2x_kernel(const ConvK
     --in_flight;
   };
 
+  const bool late = a.late_issue && wave >= NW / 2;
   Cursor cc{swz, u_begin};
   issue_step();
   issue_step();
@@ -737,7 +738,12 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_l2x_kernel(const ConvK
     for (int kt = k_begin; kt < k_end; ++kt) {
       wait_step();
       __builtin_amdgcn_s_barrier();  // everybody's DMAs of this step have landed; the stage read one step ago is free
-      issue_step();                  // two steps ahead in the stream, whatever tile that is
+      // two steps ahead in the stream, whatever tile that is.  The two waves of a SIMD leave the barrier together: one
+      // (first half of the workgroup) issues its DMAs now, the other goes straight to its fragments and MFMAs and issues
+      // behind them -- the matrix pipe starts ~360 cycles earlier and the second wave's issue overlaps the first one's
+      // MFMAs (the stage it fills was read one step ago either way; same order of DMAs and epilogue stores per wave, so
+      // the vmcnt arithmetic of wait_step is unchanged)
+      if (!late) issue_step();
       prepare();
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -753,6 +759,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_l2x_kernel(const ConvK
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][0], bf[j], acc[i][j], 0, 0, 0);
+      if (late) issue_step();
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -1292,6 +1299,8 @@ int onda_conv2d_fwd_l2(const void* xl, int64_t xplane, const float* xamax, const
   k.stats_rows = stats_rows;
   static const int noskip = getenv("ONDA_L2_NOSKIP") ? atoi(getenv("ONDA_L2_NOSKIP")) : 0;
   k.skip_dead_taps = !noskip;
+  static const int late_issue = getenv("ONDA_L2X_LATE") ? atoi(getenv("ONDA_L2X_LATE")) : 1;
+  k.late_issue = late_issue;
   k.c = *c;
   const long long M = (long long)c->B * c->Ho * c->Wo;
   ONDA_REQUIRE(M > 0 && M < (1ll << 31));
