@@ -136,13 +136,45 @@ __global__ __launch_bounds__(256) void stem_im2col_l2_kernel(const float* __rest
 // `scratch`: LDS nobody else touches during the epilogue: 4 KiB per wave, then WM*BN*4 + WM*WN floats of statistics.
 // COUNTED: every wave issues exactly 16 output stores (buffer stores; rows past M / channels past Cout get an
 // out-of-range offset and are dropped by the hardware) -- conv_l2x_kernel counts them in its vmcnt waits.
-template <int WM, int WN, bool COUNTED = false>
+// x[lane] (+, min, max) x[lane ^ 16] and x[lane ^ 32] on the VALU (v_permlane16/32_swap: gfx950), four values per call.
+// (Inline assembly: this compiler folds the builtin's two results into one when both inputs are the same value.)
+#define ONDA_SWAP4(INSN, A, B)                                                                                          \
+  asm volatile("s_nop 1\n\t" INSN " %0, %4\n\t" INSN " %1, %5\n\t" INSN " %2, %6\n\t" INSN " %3, %7\n\ts_nop 0"         \
+               : "+v"(A[0]), "+v"(A[1]), "+v"(A[2]), "+v"(A[3]), "+v"(B[0]), "+v"(B[1]), "+v"(B[2]), "+v"(B[3]))
+__device__ __forceinline__ void rows_reduce4(float& s1, float& s2, float& mn, float& mx) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  float A[4] = {s1, s2, mn, mx}, B[4] = {s1, s2, mn, mx};
+  ONDA_SWAP4("v_permlane16_swap_b32", A, B);
+  float C[4] = {A[0] + B[0], A[1] + B[1], fminf(A[2], B[2]), fmaxf(A[3], B[3])};
+  float D[4] = {C[0], C[1], C[2], C[3]};
+  ONDA_SWAP4("v_permlane32_swap_b32", C, D);
+  s1 = C[0] + D[0];
+  s2 = C[1] + D[1];
+  mn = fminf(C[2], D[2]);
+  mx = fmaxf(C[3], D[3]);
+#endif
+}
+
+// AFFINE = false: no per-channel scale / shift, residual or ReLU (train-mode convolutions, plain data gradients): the
+// epilogue then issues no global LOAD at all.  That matters in the continuous stream (COUNTED): vmcnt counts in issue
+// order, so waiting for any load issued here means waiting for the next tile's DMAs that are already in flight, and
+// the compiler has to place such a wait (vmcnt(0)) as soon as a load MAY have been issued.  For the same reason the
+// barriers of the COUNTED path are bare s_barrier + lgkmcnt waits, not __syncthreads() (whose release fence is a
+// vmcnt(0)): measured 4 000 of the epilogue's 13 000 cycles.
+template <int WM, int WN, bool COUNTED = false, bool AFFINE = true>
 __device__ __forceinline__ void l2_epilogue(const ConvK& a, const f32x4 (&acc)[4][4], unsigned char* scratch, int tile_m, int m0,
-                                            int n0, int wm, int wn, int lane, unsigned y_bytes = 0) {
+                                            int n0, int wm, int wn, int lane, float ua, float ub, unsigned y_bytes = 0) {
+  // `acc` holds RAW sums (operand units: value * 2^ea * 2^eb); ua = 2^-ea, ub = 2^-eb (exact) are applied to the four
+  // statistics of a column and folded into the per-channel scale of the output instead of to all 64 accumulators
   constexpr int BN = 64 * WN, NW = WM * WN, NT = NW * 64;
+  constexpr int TRS = 68;  // floats per row of the transposition buffer: rows 4 apart land 16 banks apart (ds_write_b32
+                           // banks are (a/4) % 32 per 32-lane half; 64 would put lanes l and l+16 on one bank)
   const OndaConv& c = a.c;
   const int t = threadIdx.x, wave = t >> 6;
-  float* red = reinterpret_cast<float*>(scratch + NW * 4096);
+  // diagnostics: the phases of the workgroup's LAST tile (overwritten per tile: no load here, see AFFINE)
+  unsigned long long* est = a.stamps != nullptr && t == 0 ? a.stamps + (size_t)blockIdx.x * 32 + 24 : nullptr;
+  if (est) est[0] = __builtin_amdgcn_s_memtime();
+  float* red = reinterpret_cast<float*>(scratch + NW * (16 * TRS * 4));
   const int SR = a.stats_rows;  // 2, or 4 with the per-channel min / max of the raw tile (rows past M count as zeros:
                                 // the extrema only have to BOUND the tensor's, norm_l2.hip)
   if (a.stats != nullptr) {
@@ -159,41 +191,36 @@ __device__ __forceinline__ void l2_epilogue(const ConvK& a, const f32x4 (&acc)[4
           mn = fminf(mn, v);
           mxv = fmaxf(mxv, v);
         }
-      s1 += __shfl_xor(s1, 16, 64);
-      s2 += __shfl_xor(s2, 16, 64);
-      s1 += __shfl_xor(s1, 32, 64);
-      s2 += __shfl_xor(s2, 32, 64);
-      if (SR == 4) {
-        mn = fminf(mn, __shfl_xor(mn, 16, 64));
-        mxv = fmaxf(mxv, __shfl_xor(mxv, 16, 64));
-        mn = fminf(mn, __shfl_xor(mn, 32, 64));
-        mxv = fmaxf(mxv, __shfl_xor(mxv, 32, 64));
-      }
+      rows_reduce4(s1, s2, mn, mxv);
       if (lane < 16) {
         const int col = (wn * 4 + jn) * 16 + lane;
-        red[(wm * BN + col) * 4 + 0] = s1;
-        red[(wm * BN + col) * 4 + 1] = s2;
-        red[(wm * BN + col) * 4 + 2] = mn;
-        red[(wm * BN + col) * 4 + 3] = mxv;
+        red[(wm * BN + col) * 4 + 0] = (s1 * ua) * ub;
+        red[(wm * BN + col) * 4 + 1] = (((s2 * ua) * ub) * ua) * ub;
+        red[(wm * BN + col) * 4 + 2] = (mn * ua) * ub;
+        red[(wm * BN + col) * 4 + 3] = (mxv * ua) * ub;
       }
     }
   }
 
+  if (est) est[1] = __builtin_amdgcn_s_memtime();
   const bool plain = (c.out_os == 1 && c.Hf == c.Ho && c.Wf == c.Wo);
   // after the transposition: lane -> row 4*r + (lane >> 4) of a 16-row chunk (r = 0..3), columns 4*(lane & 15) .. +3
   const int cl = (lane & 15) * 4, rl = lane >> 4;
   const int n = n0 + wn * 64 + cl;
   const bool vn = n < c.Cout;  // Cout is a multiple of 4
   f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-  if (vn && a.scale) sc = *reinterpret_cast<const f32x4*>(a.scale + n);
-  if (vn && a.shift) sh = *reinterpret_cast<const f32x4*>(a.shift + n);
-  float* tr = reinterpret_cast<float*>(scratch + wave * 4096);
+  if constexpr (AFFINE) {
+    if (vn && a.scale) sc = *reinterpret_cast<const f32x4*>(a.scale + n);
+    if (vn && a.shift) sh = *reinterpret_cast<const f32x4*>(a.shift + n);
+  }
+  sc = (sc * ua) * ub;
+  float* tr = reinterpret_cast<float*>(scratch + wave * (16 * TRS * 4));
   float mx = 0.f;
   // the residual (a shortcut in eval mode; the running gradient sum of a shared activation, ops.GradSink) is fetched
   // up front -- 16 independent 16-byte loads per lane into the registers the second accumulator set just vacated --
   // instead of one round trip per 16-row chunk in the store loop
   f32x4 rv[4][4];
-  if (a.res) {
+  if (AFFINE && a.res) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -203,53 +230,83 @@ __device__ __forceinline__ void l2_epilogue(const ConvK& a, const f32x4 (&acc)[4
         rv[i][r] = live ? *reinterpret_cast<const f32x4*>(a.res + (size_t)m * c.ldr + n) : f32x4{0.f, 0.f, 0.f, 0.f};
       }
   }
+  // Dense output (row m of the GEMM is row m of y: every convolution but the strided data gradient): the address of
+  // (i, r) is a per-lane base plus a workgroup-uniform term -- one VALU add per store instead of the 64-bit index
+  // arithmetic; with buffer stores (COUNTED) the rows past M lie past the end of the buffer (y_bytes covers M dense
+  // rows) and the columns past Cout carry an out-of-range base: the hardware drops both, no per-row test.
+  const bool track = a.amax != nullptr;
+  const bool full_rows = m0 + 64 * WM <= a.M;
+  const int mw = m0 + wm * 64 + rl;  // this lane's output row for (i, r) = (0, 0)
+  const unsigned vbase = vn ? (unsigned)(((size_t)mw * c.ldy + n) * 4) : OOB;
+  float* const ybase = a.y + (size_t)mw * c.ldy + n;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    // this wave's own 4 KiB: only its own earlier reads have to be out of the way
+    // this wave's own rows of the buffer: only its own earlier reads have to be out of the way
 #pragma unroll
     for (int jn = 0; jn < 4; ++jn)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) tr[(4 * (lane >> 4) + e) * 64 + jn * 16 + (lane & 15)] = acc[i][jn][e];
+      for (int e = 0; e < 4; ++e)
+        if (!(a.dbg & 2)) tr[(4 * (lane >> 4) + e) * TRS + jn * 16 + (lane & 15)] = acc[i][jn][e];
     __builtin_amdgcn_wave_barrier();  // one wave, and the LDS executes a wave's instructions in order: no wait, no s_barrier
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = 4 * r + rl;
-      f32x4 v = *reinterpret_cast<const f32x4*>(tr + row * 64 + cl);
-      const int m = m0 + (wm * 4 + i) * 16 + row;
-      const bool live = m < a.M && vn;
-      if (!COUNTED && !live) continue;
-      const int mm = live ? m : 0;
-      v = v * sc + sh;
-      if (a.res) v += rv[i][r];
-      if (c.relu) {
+      f32x4 v = acc[i][r];
+      if (!(a.dbg & 4)) v = *reinterpret_cast<const f32x4*>(tr + row * TRS + cl);
+      const int m = mw + i * 16 + 4 * r;
+      const bool live = (full_rows || m < a.M) && vn;
+      if constexpr (AFFINE) {
+        v = v * sc + sh;
+        if (a.res) v += rv[i][r];
+        if (c.relu) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
+          for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
+        }
+      } else {
+        v = v * sc;
       }
-      size_t orow = mm;
-      if (!plain) {
+      if (plain) {
+        if constexpr (COUNTED) {
+#if defined(__HIP_DEVICE_COMPILE__)
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), make_rsrc(a.y, y_bytes),
+                                                 (a.dbg & 1) ? OOB : vbase + (unsigned)((i * 16 + 4 * r) * c.ldy * 4), 0, 0);
+#endif
+        } else if (live) {
+          *reinterpret_cast<f32x4*>(ybase + (size_t)((i * 16 + 4 * r) * c.ldy)) = v;
+        }
+      } else {  // scattered rows (stride-2 data gradient)
+        const int mm = live ? m : 0;
         const int wo = mm % c.Wo, tq = mm / c.Wo;
         const int ho = tq % c.Ho, b = tq / c.Ho;
-        orow = ((size_t)b * c.Hf + (size_t)ho * c.out_os) * c.Wf + (size_t)wo * c.out_os;
-      }
-      if constexpr (COUNTED) {
+        const size_t orow = ((size_t)b * c.Hf + (size_t)ho * c.out_os) * c.Wf + (size_t)wo * c.out_os;
+        if constexpr (COUNTED) {
 #if defined(__HIP_DEVICE_COMPILE__)
-        const unsigned off = live ? (unsigned)((orow * c.ldy + n) * 4) : OOB;
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), make_rsrc(a.y, y_bytes), off, 0, 0);
+          const unsigned off = live ? (unsigned)((orow * c.ldy + n) * 4) : OOB;
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), make_rsrc(a.y, y_bytes), off, 0, 0);
 #endif
-        if (!live) continue;
-      } else {
-        *reinterpret_cast<f32x4*>(a.y + orow * c.ldy + n) = v;
+        } else if (live) {
+          *reinterpret_cast<f32x4*>(a.y + orow * c.ldy + n) = v;
+        }
       }
-      mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+      if (track && live) mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
     }
     __builtin_amdgcn_wave_barrier();
   }
+  if (est) est[2] = __builtin_amdgcn_s_memtime();
   float* ar = red + WM * BN * 4;
   if (a.amax != nullptr) {
     mx = wave_max(mx);
     if (lane == 0) ar[wave] = mx;
   }
-  if (a.stats != nullptr || a.amax != nullptr) __syncthreads();
+  if (a.stats != nullptr || a.amax != nullptr) {
+    if constexpr (COUNTED) {  // the partial statistics in LDS are all the barrier has to publish
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    } else {
+      __syncthreads();
+    }
+  }
+  if (est) est[3] = __builtin_amdgcn_s_memtime();
   if (a.stats != nullptr) {
     for (int col = t; col < BN; col += NT) {
       if (n0 + col >= c.Cout) continue;
@@ -277,6 +334,7 @@ __device__ __forceinline__ void l2_epilogue(const ConvK& a, const f32x4 (&acc)[4
     if (m > 0.f)
       atomicMax(reinterpret_cast<unsigned*>(a.amax) + (blockIdx.x & (ONDA_AMAX_SLOTS - 1)) * AMAX_STRIDE, __float_as_uint(m));
   }
+  if (est) est[4] = __builtin_amdgcn_s_memtime();
 }
 
 // ---- forward / data gradient ------------------------------------------------------------------------------------------
@@ -532,15 +590,30 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_l2_kernel(const ConvK 
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = ((acc[i][j] + accx[i][j] * LIMB2_UNSCALE) * unscale_a) * unscale_b;
+      for (int j = 0; j < 4; ++j) acc[i][j] = acc[i][j] + accx[i][j] * LIMB2_UNSCALE;
     if (dp) dp_tile += nblk; else u += k_end - k_begin;
     if (SK && (k_begin != 0 || k_end != KT)) {
+      // a piece goes to the workspace in the operands' own units (exact: powers of two, one after the other)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (acc[i][j] * unscale_a) * unscale_b;
       float* slot = a.ws + ((size_t)swz * 2 + (u - (k_end - k_begin) == u_begin ? 0 : 1)) * (BM * BN);
       conv_store_partial<BN, 4, 4, 16>(slot, acc, wm, wn, lane);
       continue;
     }
+    // (the epilogue folds the two exact unscale factors into its per-column constants; if their PRODUCT left the normal
+    //  range -- tensors with max|x| around 2^-50 and less -- apply them here, one after the other, as the pieces do)
+    float ua = unscale_a, ub = unscale_b;
+    if (const float u = ua * ub; !(u >= 0x1p-100f && u <= 0x1p100f)) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (acc[i][j] * ua) * ub;
+      ua = ub = 1.f;
+    }
     __syncthreads();
-    l2_epilogue<WM, WN>(a, acc, lds, tile_m, m0, n0, wm, wn, lane);
+    l2_epilogue<WM, WN>(a, acc, lds, tile_m, m0, n0, wm, wn, lane, ua, ub);
     if (DBG == 5) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       stamp(tk_epi);
@@ -720,6 +793,14 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_l2x_kernel(const ConvK
 
   const bool late = a.late_issue && wave >= NW / 2;
   Cursor cc{swz, u_begin};
+  int n_stamp = 0;
+  auto stamp = [&]() {
+    if (a.stamps != nullptr && t == 0 && n_stamp < 32) a.stamps[(size_t)bid * 32 + n_stamp++] = __builtin_amdgcn_s_memtime();
+  };
+  stamp();
+  if (a.skew_cycles > 0 && (xcd & 1)) {
+    for (int w_ = a.skew_cycles; w_ > 0; w_ -= 64 * 100) __builtin_amdgcn_s_sleep(100);
+  }
   issue_step();
   issue_step();
   while (item_valid(cc)) {
@@ -761,20 +842,44 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_l2x_kernel(const ConvK
         for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][0], bf[j], acc[i][j], 0, 0, 0);
       if (late) issue_step();
     }
+    stamp();
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = ((acc[i][j] + accx[i][j] * LIMB2_UNSCALE) * unscale_a) * unscale_b;
+      for (int j = 0; j < 4; ++j) acc[i][j] = acc[i][j] + accx[i][j] * LIMB2_UNSCALE;
     if (!whole) {  // stream-K piece: raw accumulators to this workgroup's slot (64 unconditional stores per lane)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (acc[i][j] * unscale_a) * unscale_b;
       float* slot = a.ws + ((size_t)swz * 2 + (first_piece ? 0 : 1)) * (BM * BN);
       conv_store_partial<BN, 4, 4, 16>(slot, acc, wm, wn, lane);
       stores_young = 2;
+      stamp();
       continue;
     }
-    __syncthreads();  // every wave has its fragments of the last step: that stage is scratch now
+    // (the epilogue folds the two exact unscale factors into its per-column constants; if their PRODUCT left the normal
+    //  range -- tensors with max|x| around 2^-50 and less -- apply them here, one after the other, as the pieces do)
+    float ua = unscale_a, ub = unscale_b;
+    if (const float u = ua * ub; !(u >= 0x1p-100f && u <= 0x1p100f)) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (acc[i][j] * ua) * ub;
+      ua = ub = 1.f;
+    }
+    // every wave has its fragments of the last step (they fed its MFMAs): that stage is scratch now.  A bare barrier:
+    // the DMAs of the next two steps stay in flight (see l2_epilogue)
+    __builtin_amdgcn_s_barrier();
     const int scratch = st_read == 0 ? (STAGES - 1) * STAGE : st_read - STAGE;  // the stage read last
-    l2_epilogue<WM, WN, true>(a, acc, lds + scratch, tile / a.tilesN, (tile / a.tilesN) * BM, (tile % a.tilesN) * BN, wm, wn, lane, y_bytes);
+    if (a.scale != nullptr || a.shift != nullptr || a.res != nullptr || c.relu)
+      l2_epilogue<WM, WN, true, true>(a, acc, lds + scratch, tile / a.tilesN, (tile / a.tilesN) * BM, (tile % a.tilesN) * BN, wm, wn,
+                                      lane, ua, ub, y_bytes);
+    else
+      l2_epilogue<WM, WN, true, false>(a, acc, lds + scratch, tile / a.tilesN, (tile / a.tilesN) * BM, (tile % a.tilesN) * BN, wm, wn,
+                                       lane, ua, ub, y_bytes);
     stores_young = 2;
+    stamp();
   }
 }
 
@@ -1301,6 +1406,13 @@ int onda_conv2d_fwd_l2(const void* xl, int64_t xplane, const float* xamax, const
   k.skip_dead_taps = !noskip;
   static const int late_issue = getenv("ONDA_L2X_LATE") ? atoi(getenv("ONDA_L2X_LATE")) : 1;
   k.late_issue = late_issue;
+  static const int epi_dbg = getenv("ONDA_L2_EPI_DBG") ? atoi(getenv("ONDA_L2_EPI_DBG")) : 0;
+  k.dbg = epi_dbg;
+  static const int skew = getenv("ONDA_L2X_SKEW") ? atoi(getenv("ONDA_L2X_SKEW")) : 0;
+  k.skew_cycles = skew;
+  static const int stamp_on = getenv("ONDA_L2X_STAMP") ? atoi(getenv("ONDA_L2X_STAMP")) : 0;
+  if (stamp_on)  // the last 64 KiB of the workspace (beyond anything the schedules use: checked below)
+    k.stamps = reinterpret_cast<unsigned long long*>(ws + onda_conv_ws_floats()) - 1024 * 32;
   k.c = *c;
   const long long M = (long long)c->B * c->Ho * c->Wo;
   ONDA_REQUIRE(M > 0 && M < (1ll << 31));
