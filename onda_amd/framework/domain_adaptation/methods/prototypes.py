@@ -49,6 +49,66 @@ def _positive(v):
     return v if v > 0 else 0.0
 
 
+class _StepLog(dict):
+    """A log dictionary whose monitor entries are computed on first access (any read of the mapping).  They describe
+    the monitor as it is at that moment: read the log before the next step, as the reference's loop does, and they are
+    the reference's values."""
+
+    def __init__(self, eager, lazy):
+        super().__init__(eager)
+        self._lazy = lazy
+
+    def _resolve(self):
+        lazy, self._lazy = self._lazy, None
+        if lazy is not None:
+            for key, value in lazy().items():
+                dict.__setitem__(self, key, value)
+
+    def __getitem__(self, key):
+        if not dict.__contains__(self, key):
+            self._resolve()
+        return dict.__getitem__(self, key)
+
+    def get(self, key, default=None):
+        if not dict.__contains__(self, key):
+            self._resolve()
+        return dict.get(self, key, default)
+
+    def __contains__(self, key):
+        if dict.__contains__(self, key):
+            return True
+        self._resolve()
+        return dict.__contains__(self, key)
+
+    def __iter__(self):
+        self._resolve()
+        return dict.__iter__(self)
+
+    def __len__(self):
+        self._resolve()
+        return dict.__len__(self)
+
+    def keys(self):
+        self._resolve()
+        return dict.keys(self)
+
+    def values(self):
+        self._resolve()
+        return dict.values(self)
+
+    def items(self):
+        self._resolve()
+        return dict.items(self)
+
+    def __repr__(self):
+        self._resolve()
+        return dict.__repr__(self)
+
+    def copy(self):
+        self._resolve()
+        return dict(self)
+
+
 class _Scalars:
     """Device scalars waiting for ONE transfer to the host (optionally averaged over ranks first)."""
 
@@ -301,13 +361,21 @@ class online_proDA(da_model):
         }
 
     def _monitor_log(self, losses):
+        """The step's log entries.  The monitor's statistics need this step's device scalars on the host; they are filled
+        in when the log is first LOOKED AT (_StepLog), so a loop that logs every n-th step -- or the benchmark, which reads
+        the last one -- never stops the host behind the backward pass it has just launched."""
         losses["mean_prototype_intensity_values"] = (self.prototypes.prototypes ** 2).mean()
-        for name, value in self.intensity_ma.avg().items():
-            losses[f"{name} confidence ma"] = value
-        for name, value in self.intensity_ma.exp().items():
-            losses[f"{name} exp confidence ma"] = value
-        losses["dev avg prior static"] = self.intensity_ma.dev_avg("prior static")
-        return losses
+        monitor = self.intensity_ma
+
+        def entries():
+            out = {}
+            for name, value in monitor.avg().items():
+                out[f"{name} confidence ma"] = value
+            for name, value in monitor.exp().items():
+                out[f"{name} exp confidence ma"] = value
+            out["dev avg prior static"] = monitor.dev_avg("prior static")
+            return out
+        return _StepLog(losses, entries)
 
     def _target_prepare(self, batch):
         """First half of the target side: Dropout2d masks (in the reference's order of draws: the student's target pass,
