@@ -10,8 +10,12 @@ there), and several scalars that live on the device can be added with ONE transf
 stop the host: the copy to pinned memory is enqueued and the samples enter their rings when the monitor is next
 looked at or written to (by then, normally, the copy has long finished).
 """
+import os
+
 import numpy as np
 import torch
+
+_SYNC_TRANSFERS = os.environ.get("ONDA_MONITOR_SYNC", "0") == "1"  # measurement knob: wait for every transfer at once
 
 
 class _Series:
@@ -114,6 +118,8 @@ class Monitor(object):
         event = torch.cuda.Event()
         event.record()
         self._pending = (list(keys), host, event)
+        if _SYNC_TRANSFERS:
+            self._flush()
 
     # ---- statistics ------------------------------------------------------------------------------------------------
     def avg(self, item=None):
