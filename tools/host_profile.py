@@ -23,3 +23,5 @@ with tempfile.TemporaryDirectory() as tmp:
     print(f"issue time per step {t_issue/3*1e3:.1f} ms, wall per step {t_all/3*1e3:.1f} ms (with cProfile overhead)")
     st = pstats.Stats(pr)
     st.sort_stats("tottime").print_stats(28)
+    st.print_callers("method 'to' of")
+    st.print_callers("Event.synchronize")
