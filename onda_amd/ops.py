@@ -641,6 +641,8 @@ class Conv2dFn(torch.autograd.Function):
         ctx.weight_param = weight  # the Parameter itself: its .grad is the accumulation target
         ctx.sink = _sink_of(x) if ctx.needs_input_grad[0] else None
         ctx.cache, ctx.geom, ctx.has_bias = cache, (k, stride, dil, pad, cout, cin, cout_pad), bias is not None
+        # the statistics output never has a gradient: do not let autograd build a zero tensor of its shape for backward
+        ctx.set_materialize_grads(False)
         if want_stats:
             ctx.mark_non_differentiable(stats)
             return y, stats
@@ -648,6 +650,8 @@ class Conv2dFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy, _dstats):
+        if dy is None:
+            return (None,) * 9
         x, weight = ctx.saved_tensors
         k, stride, dil, pad, cout, cin, cout_pad = ctx.geom
         if not is_limb_only(dy):
@@ -721,6 +725,7 @@ class StemConvFn(torch.autograd.Function):
         ctx.save_for_backward(col)  # dropped again by autograd when no graph is being recorded
         ctx.col_limbs = limbs_of(col) if is_limb_only(col) else None
         ctx.cout, ctx.weight = weight.shape[0], weight
+        ctx.set_materialize_grads(False)
         if want_stats:
             ctx.mark_non_differentiable(stats)
             return y, stats
@@ -728,6 +733,8 @@ class StemConvFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy, _dstats):
+        if dy is None:
+            return None, None, None, None
         (col,) = ctx.saved_tensors
         into = _accumulate_target(ctx.weight)
         dw = conv_wgrad(col, as_nhwc(dy), 1, 1, 1, 0, ctx.cout, 3, flat_k=49, into=into, xlimbs=ctx.col_limbs)
@@ -1032,10 +1039,13 @@ class SegLossFn(torch.autograd.Function):
         ce, rce, reg = result[0], result[1], result[2]
         total = w_ce * ce + w_rce * rce + w_reg * reg
         ctx.mark_non_differentiable(ce, rce, reg)
+        ctx.set_materialize_grads(False)
         return total, ce, rce, reg
 
     @staticmethod
     def backward(ctx, gtotal, _a, _b, _c):
+        if gtotal is None:
+            return None, None, None, None, None
         rows, labels, result = ctx.saved_tensors
         ld, N, K, w_ce, w_rce, w_reg, shape = ctx.meta
         B, _, H, W = shape
