@@ -19,8 +19,6 @@ struct ConvK {
   float* amax = nullptr;  // optional: running max|y| of the stored output (amax_update, common.h)
   int skip_dead_taps = 1;  // whole tiles skip filter taps that only see padding (conv_l2.hip)
   int late_issue = 1;      // conv_l2x_kernel: second half of the waves issues its DMAs behind its MFMAs
-  int dbg = 0;             // diagnostics only (ONDA_L2_EPI_DBG): 1 = no output stores, 2 = no transposition writes, 4 = no reads
-  int skew_cycles = 0;     // conv_l2x_kernel: workgroups of odd XCDs start this many cycles late (see the kernel)
   unsigned long long* stamps = nullptr;  // diagnostics (ONDA_L2X_STAMP=1, tools/l2x_stamps.py): s_memtime per workgroup,
                                          // [32] each: start, then (end of K loop, end of epilogue) per work item
   int stats_rows = 2;     // 2: stats[tile][sum, sumsq][Cout]; 4: also the per-channel min and max of the raw tile (conv_l2.hip)

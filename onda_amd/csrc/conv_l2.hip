@@ -245,14 +245,12 @@ __device__ __forceinline__ void l2_epilogue(const ConvK& a, const f32x4 (&acc)[4
 #pragma unroll
     for (int jn = 0; jn < 4; ++jn)
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
-        if (!(a.dbg & 2)) tr[(4 * (lane >> 4) + e) * TRS + jn * 16 + (lane & 15)] = acc[i][jn][e];
+      for (int e = 0; e < 4; ++e) tr[(4 * (lane >> 4) + e) * TRS + jn * 16 + (lane & 15)] = acc[i][jn][e];
     __builtin_amdgcn_wave_barrier();  // one wave, and the LDS executes a wave's instructions in order: no wait, no s_barrier
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = 4 * r + rl;
-      f32x4 v = acc[i][r];
-      if (!(a.dbg & 4)) v = *reinterpret_cast<const f32x4*>(tr + row * TRS + cl);
+      f32x4 v = *reinterpret_cast<const f32x4*>(tr + row * TRS + cl);
       const int m = mw + i * 16 + 4 * r;
       const bool live = (full_rows || m < a.M) && vn;
       if constexpr (AFFINE) {
@@ -269,7 +267,7 @@ __device__ __forceinline__ void l2_epilogue(const ConvK& a, const f32x4 (&acc)[4
         if constexpr (COUNTED) {
 #if defined(__HIP_DEVICE_COMPILE__)
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), make_rsrc(a.y, y_bytes),
-                                                 (a.dbg & 1) ? OOB : vbase + (unsigned)((i * 16 + 4 * r) * c.ldy * 4), 0, 0);
+                                                 vbase + (unsigned)((i * 16 + 4 * r) * c.ldy * 4), 0, 0);
 #endif
         } else if (live) {
           *reinterpret_cast<f32x4*>(ybase + (size_t)((i * 16 + 4 * r) * c.ldy)) = v;
@@ -798,9 +796,6 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_l2x_kernel(const ConvK
     if (a.stamps != nullptr && t == 0 && n_stamp < 32) a.stamps[(size_t)bid * 32 + n_stamp++] = __builtin_amdgcn_s_memtime();
   };
   stamp();
-  if (a.skew_cycles > 0 && (xcd & 1)) {
-    for (int w_ = a.skew_cycles; w_ > 0; w_ -= 64 * 100) __builtin_amdgcn_s_sleep(100);
-  }
   issue_step();
   issue_step();
   while (item_valid(cc)) {
@@ -1406,10 +1401,6 @@ int onda_conv2d_fwd_l2(const void* xl, int64_t xplane, const float* xamax, const
   k.skip_dead_taps = !noskip;
   static const int late_issue = getenv("ONDA_L2X_LATE") ? atoi(getenv("ONDA_L2X_LATE")) : 1;
   k.late_issue = late_issue;
-  static const int epi_dbg = getenv("ONDA_L2_EPI_DBG") ? atoi(getenv("ONDA_L2_EPI_DBG")) : 0;
-  k.dbg = epi_dbg;
-  static const int skew = getenv("ONDA_L2X_SKEW") ? atoi(getenv("ONDA_L2X_SKEW")) : 0;
-  k.skew_cycles = skew;
   static const int stamp_on = getenv("ONDA_L2X_STAMP") ? atoi(getenv("ONDA_L2X_STAMP")) : 0;
   if (stamp_on)  // the last 64 KiB of the workspace (beyond anything the schedules use: checked below)
     k.stamps = reinterpret_cast<unsigned long long*>(ws + onda_conv_ws_floats()) - 1024 * 32;
