@@ -171,6 +171,40 @@ def test_head_and_stem(conv_mode):
     close(wd.grad, wr.grad, 5e-5, "stem wgrad")
 
 
+def test_host_never_waits_for_tables_or_monitor_scalars():
+    """Multi-tensor entry tables and the monitor's device scalars reach their destination through pinned staging
+    buffers (asynchronous copies): same values as the direct path, staging buffers reused only after their copy's event
+    has completed, and neither call waits for work queued in front of it."""
+    import time
+    from onda_amd import ops, _lib
+    from onda_amd.framework.utils.monitoring import Monitor
+    # tables: round trip of the bytes, ring reuse
+    ents = [_lib.OndaEmaEntry(1000 + i, 2000 + i, 10 + i, 0.5, 0.5) for i in range(300)]
+    want = bytes((_lib.OndaEmaEntry * len(ents))(*ents))
+    for _ in range(6):
+        dev = ops._table(ents, _lib.OndaEmaEntry, torch.device(DEV))
+        assert bytes(dev.cpu().numpy().tobytes()) == want
+    assert 1 <= len(ops._TABLE_STAGES[DEV]) <= 16
+    # neither path blocks behind a long-running queue (steady state: the pinned buffers exist -- allocating page-locked
+    # memory is slow and may synchronise, it happens once)
+    mon = Monitor(5, 0.1, "hamming")
+    big = torch.randn(8192, 8192, device=DEV)
+    for rep in range(2):  # (the first round loads the kernels of the torch ops used here and sets hipBLASLt up)
+        mon.reset()
+        torch.cuda.synchronize()
+        for _ in range(6):
+            big = big @ big * 1e-4
+        t0 = time.perf_counter()
+        dev = ops._table(ents, _lib.OndaEmaEntry, torch.device(DEV))
+        mon.add_device(["a", "b"], torch.stack([big[0, 0] * 0 + 0.25, big[0, 0] * 0 + 0.75]))
+        issued = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        drained = time.perf_counter() - t0
+    assert issued < 0.25 * drained, (issued, drained)
+    assert bytes(dev.cpu().numpy().tobytes()) == want
+    assert mon.avg("a") == 0.25 and mon.avg("b") == 0.75
+
+
 def test_stem_patches_as_limb_planes():
     """Pre-split "f16x2": the stem's patch kernel writes limb planes directly (scale from max|image|); rebuilt, they are
     the fp32 patch matrix to 2^-22 of each value, ragged image size, and the matrix is shared by every pass that reads

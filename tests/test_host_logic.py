@@ -197,6 +197,60 @@ def test_monitor_ring_buffer_and_packed_adds():
     assert a.avg("x") == 1.0 and a.exp("x") == 1.0
 
 
+def test_step_log_resolves_its_monitor_entries_on_first_read():
+    """_StepLog: eager entries are there at once and can be extended without touching the lazy part; any read of the
+    mapping (lookup of a missing key, iteration, len, `in`, items, copy) fills the monitor entries in exactly once."""
+    from onda_amd.framework.domain_adaptation.methods.prototypes import _StepLog
+    calls = []
+
+    def lazy():
+        calls.append(1)
+        return {"x confidence ma": 0.25, "dev avg prior static": 0.0}
+
+    def fresh():
+        del calls[:]
+        log = _StepLog({"Total target loss": 1.5}, lazy)
+        log["encoder_lr"] = 1e-4
+        log.update({"buff_loss": 2.0})
+        assert log["Total target loss"] == 1.5 and log["buff_loss"] == 2.0 and not calls
+        return log
+    log = fresh()
+    assert log["x confidence ma"] == 0.25 and len(calls) == 1
+    assert log["dev avg prior static"] == 0.0 and len(calls) == 1
+    for read in (lambda m: len(m), lambda m: list(m), lambda m: "x confidence ma" in m, lambda m: dict(m.items()),
+                 lambda m: m.get("x confidence ma"), lambda m: m.copy(), lambda m: list(m.keys()), lambda m: list(m.values())):
+        log = fresh()
+        read(log)
+        assert len(calls) == 1 and dict.__len__(log) == 5
+        read(log)
+        assert len(calls) == 1
+    log = fresh()
+    assert log.get("missing", 7) == 7 and len(calls) == 1
+
+
+def test_monitor_pending_transfer_is_selective(monkeypatch):
+    """A query for a series the pending device transfer does not feed leaves the transfer alone (the switch decision
+    reads "prior static" in the middle of a step while the previous step's scalars may still be in flight); any query
+    that involves a pending series, and any later add, drains it first (sample order per series is kept)."""
+    from onda_amd.framework.utils import monitoring
+    m = monitoring.Monitor(5, 0.1, "hamming")
+    m.add({"prior static": 0.5, "model": 0.1})
+
+    class _Event:
+        waited = 0
+
+        def synchronize(self):
+            _Event.waited += 1
+    host = torch.tensor([0.2, 0.3])
+    m._pending = (["model", "prior"], host, _Event())
+    assert m.avg("prior static") == 0.5 and m.dev_avg("prior static") == 0 and _Event.waited == 0 and m._pending is not None
+    assert m.avg("model") == pytest.approx(0.15) and _Event.waited == 1 and m._pending is None
+    assert m.current_dict["model"] == pytest.approx([0.1, 0.2]) and m.avg("prior") == pytest.approx(0.3)
+    m._pending = (["model"], torch.tensor([0.4]), _Event())
+    m.add({"model": 0.5})  # the pending sample enters its ring BEFORE the new one
+    assert m.current_dict["model"] == pytest.approx([0.1, 0.2, 0.4, 0.5]) and _Event.waited == 2
+
+
 def test_replay_buffer_mirror():
     """Buffer_db: batches of consecutive samples, queue / random replacement, add_from_batch, and the nearest-neighbour
     label resize with OpenCV's index rule (floor(dst * src / dst_size))."""
