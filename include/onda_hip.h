@@ -115,6 +115,32 @@ int onda_conv2d_fwd_h2(const float* x, const float* xamax, const void* w2, const
  * elements of a plane row, xplane the f16 elements between the two planes. */
 int onda_split_h2(const float* x, int64_t rows, int C, int ldx, void* dst, int ldo, int64_t plane, const float* amax,
                   onda_stream_t s);
+/* onda_conv2d_fwd_l2 whose OUTPUT is limb planes as well: eval-mode conv + folded BatchNorm (scale, shift) [+ residual
+ * given as limb planes] [+ ReLU, c->relu] -> out[2][M][c->ldy] f16, the operand format of the next convolution -- no fp32
+ * tensor and no split pass in between (deeplabv2.py:53-68 in eval mode: static / dynamic model, evaluation).
+ * The planes' scale must exist before the first element is stored, so it comes from an a-priori bound
+ *   max|y| <= max|x| * kb[0] + kb[1] (+ max|residual|),  kb[0] = max_c |scale_c| * sum_k |w_ck|,  kb[1] = max_c |shift_c|
+ * (device floats, computed once per weight version by the caller).  The kernel writes the bound to out_bound (an amax
+ * buffer: it defines the scale of `out` for every consumer) and the TRUE max|y| to out_amax (zeroed amax buffer): the
+ * next layer's bound starts from the true maximum (`xtrue` of its own call), so bounds do not compound.  `xtrue` = the
+ * amax buffer holding the true max|x| of the input (= xamax for planes whose scale comes from their true maximum).
+ * The output is dense ([B,Ho,Wo] rows of c->ldy f16); c->ldr is the residual planes' row length. */
+typedef struct OndaLimbOut {
+  void* out;
+  int64_t out_plane;      /* f16 elements between the two output planes */
+  float* out_bound;       /* amax buffer, receives the bound (scale of `out`) */
+  float* out_amax;        /* amax buffer, zeroed: true max|y| (may be NULL) */
+  const float* kb;        /* {kb[0], kb[1]} */
+  const float* xtrue;     /* true max|x| of the input */
+  const void* res;        /* residual limb planes or NULL */
+  int64_t res_plane;
+  const float* res_amax;  /* the residual planes' scale-defining amax buffer */
+  const float* res_true;  /* true max|residual| (NULL: res_amax) */
+} OndaLimbOut;
+int onda_conv2d_fwd_l2_limbs(const void* xl, int64_t xplane, const float* xamax, const void* w2, const float* wamax,
+                             const float* scale, const float* shift, const OndaLimbOut* lo, float* ws, const OndaConv* c,
+                             onda_stream_t s);
+
 /* Stem patches (onda_stem_im2col) written directly as limb planes dst[2][B*Ho*Wo][Kp] f16 (plane = f16 elements between
  * the two planes): the patch matrix holds image values and zeros, so its max|x| is the image's (xamax, from onda_absmax
  * over the image).  Replaces the stem's F.conv2d input side (deeplabv2.py:283) in "f16x2" pre-split mode. */

@@ -18,6 +18,11 @@ class OndaConv(Structure):
     _fields_ = [(n, c_int) for n in ("B Hi Wi Cin Ho Wo Cout kh kw stride dil pad ldx ldy ldr out_os Hf Wf relu").split()]
 
 
+class OndaLimbOut(Structure):
+    _fields_ = [("out", c_void_p), ("out_plane", c_int64), ("out_bound", c_void_p), ("out_amax", c_void_p), ("kb", c_void_p),
+                ("xtrue", c_void_p), ("res", c_void_p), ("res_plane", c_int64), ("res_amax", c_void_p), ("res_true", c_void_p)]
+
+
 class OndaSgdEntry(Structure):
     _fields_ = [("p", c_void_p), ("g", c_void_p), ("buf", c_void_p), ("n", c_int64), ("lr", c_float),
                 ("times", c_int), ("fresh", c_int)]
@@ -46,6 +51,7 @@ SIGNATURES = {
     "onda_conv2d_wgrad_h2": (I, [P, P, P, P, P, I, I, POINTER(OndaConv), P]),
     "onda_split_h2": (I, [P, L, I, I, P, I, L, P, P]),
     "onda_stem_im2col_l2": (I, [P, P, P, L, I, I, I, I, I, I, P]),
+    "onda_conv2d_fwd_l2_limbs": (I, [P, L, P, P, P, P, P, P, P, P, P]),
     "onda_conv_l2_variant": (I, [L, I]),
     "onda_conv_l2_tiles_m": (I, [L, I, I, I]),
     "onda_conv_wgrad_l2_variant": (I, [I, I]),

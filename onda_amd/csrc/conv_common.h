@@ -19,6 +19,16 @@ struct ConvK {
   float* amax = nullptr;  // optional: running max|y| of the stored output (amax_update, common.h)
   int skip_dead_taps = 1;  // whole tiles skip filter taps that only see padding (conv_l2.hip)
   int late_issue = 1;      // conv_l2x_kernel: second half of the waves issues its DMAs behind its MFMAs
+  // ---- limb-plane OUTPUT (eval-mode conv + folded BatchNorm whose result feeds other convs; conv_l2.hip) ----------------
+  _Float16* yl = nullptr;           // out planes [2][M][ldy] f16 (dense rows); when set, `y` is not written
+  long long yplane = 0;             // f16 elements between the two planes
+  float* ybound = nullptr;          // amax buffer that DEFINES the planes' scale: receives the a-priori bound
+  const float* kb = nullptr;        // {max_c |scale_c| * sum_k |w_ck|, max_c |shift_c|}
+  const float* xtrue = nullptr;     // amax buffer with the TRUE max|x| of the input (its planes may be scaled by a bound)
+  const _Float16* resl = nullptr;   // residual as limb planes [2][M][ldr]
+  long long resplane = 0;
+  const float* res_amax = nullptr;  // scale-defining amax of the residual planes
+  const float* res_true = nullptr;  // true max|residual|
   unsigned long long* stamps = nullptr;  // diagnostics (ONDA_L2X_STAMP=1, tools/l2x_stamps.py): s_memtime per workgroup,
                                          // [32] each: start, then (end of K loop, end of epilogue) per work item
   int stats_rows = 2;     // 2: stats[tile][sum, sumsq][Cout]; 4: also the per-channel min and max of the raw tile (conv_l2.hip)

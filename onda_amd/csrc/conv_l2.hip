@@ -41,8 +41,9 @@ __device__ __forceinline__ int swz_row(int row) {
 struct Scale2 {
   float s, inv;
 };
-__device__ __forceinline__ Scale2 scale_of(const float* __restrict__ amax) {
-  const float m = amax_read(amax);
+__device__ __forceinline__ Scale2 scale_from(float m);
+__device__ __forceinline__ Scale2 scale_of(const float* __restrict__ amax) { return scale_from(amax_read(amax)); }
+__device__ __forceinline__ Scale2 scale_from(const float m) {
   int e = 0;
   if (m > 0.f && m < 3.0e38f) {
     int ex;
@@ -335,6 +336,129 @@ __device__ __forceinline__ void l2_epilogue(const ConvK& a, const f32x4 (&acc)[4
   if (est) est[4] = __builtin_amdgcn_s_memtime();
 }
 
+// ---- epilogue that writes LIMB PLANES (eval mode: conv + folded BatchNorm [+ residual limbs] [+ ReLU] -> the next conv's
+// operand format, no fp32 tensor and no split pass in between).  The planes' scale has to exist before the first element
+// is stored: it comes from an a-priori bound
+//     max|y| <= max|x| * max_c(|scale_c| * sum_k |w_ck|) + max_c |shift_c| + max|residual|
+// (every workgroup computes it from three device scalars and writes it to its slot of `ybound`: same value everywhere).
+// The bound is 2^7..2^10 above the true maximum for these layers; a scale 2^k too small costs k of the 28 bits of range
+// the format has below the maximum, nothing else.  The TRUE maximum of the stored values still goes to `amax` (one atomic
+// per tile), because it is what bounds the NEXT layer: bounds do not compound.
+__device__ __forceinline__ float limb_out_bound(const ConvK& a) {
+  float b = amax_read(a.xtrue) * a.kb[0] + a.kb[1];
+  if (a.resl != nullptr) b += amax_read(a.res_true);
+  return b * 1.0001f;  // (fp32 rounding of the sums and of the bound itself)
+}
+
+template <int WM, int WN, bool COUNTED>
+__device__ __forceinline__ void l2_epilogue_limbs(const ConvK& a, const f32x4 (&acc)[4][4], unsigned char* scratch, int m0, int n0,
+                                                  int wm, int wn, int lane, float ua, float ub) {
+  constexpr int BN = 64 * WN, NW = WM * WN;
+  constexpr int TRS = 68;
+  const OndaConv& c = a.c;
+  if constexpr (COUNTED) asm volatile("" : "+v"(lane));
+  int t = threadIdx.x;
+  if constexpr (COUNTED) asm volatile("" : "+v"(t));
+  const int wave = t >> 6;
+  const float bound = limb_out_bound(a);
+  const float so = scale_from(bound).s;
+  if (t == 0) a.ybound[(blockIdx.x & (ONDA_AMAX_SLOTS - 1)) * AMAX_STRIDE] = bound;
+  const float ri = a.resl != nullptr ? scale_of(a.res_amax).inv : 0.f;
+  const int cl = (lane & 15) * 4, rl = lane >> 4;
+  const int n = n0 + wn * 64 + cl;
+  const bool vn = n < c.Cout;
+  f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+  if (vn && a.scale) sc = *reinterpret_cast<const f32x4*>(a.scale + n);
+  if (vn && a.shift) sh = *reinterpret_cast<const f32x4*>(a.shift + n);
+  sc = (sc * ua) * ub;
+  float* tr = reinterpret_cast<float*>(scratch + wave * (16 * TRS * 4));
+  float* ar = reinterpret_cast<float*>(scratch + NW * (16 * TRS * 4));
+  const int mw = m0 + wm * 64 + rl;
+  // residual limbs, all 16 row positions of this lane up front (8 bytes per plane each)
+  u32x2 r1[4][4], r2[4][4];
+  if (a.resl != nullptr) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = mw + i * 16 + 4 * r;
+        const bool live = m < a.M && vn;
+        const _Float16* p = a.resl + (size_t)(live ? m : 0) * c.ldr + (live ? n : 0);
+        r1[i][r] = live ? *reinterpret_cast<const u32x2*>(p) : u32x2{0u, 0u};
+        r2[i][r] = live ? *reinterpret_cast<const u32x2*>(p + a.resplane) : u32x2{0u, 0u};
+      }
+  }
+  float mx = 0.f;
+  const size_t plane_bytes = (size_t)a.M * c.ldy * 2;  // one plane as a buffer: rows past M fall outside
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int jn = 0; jn < 4; ++jn)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) tr[(4 * (lane >> 4) + e) * TRS + jn * 16 + (lane & 15)] = acc[i][jn][e];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 4 * r + rl;
+      f32x4 v = *reinterpret_cast<const f32x4*>(tr + row * TRS + cl);
+      const int m = mw + i * 16 + 4 * r;
+      const bool live = m < a.M && vn;
+      v = v * sc + sh;
+      if (a.resl != nullptr) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const f32x2 p1 = unpack2h(r1[i][r][h]), p2 = unpack2h(r2[i][r][h]);
+          v[2 * h] += (p1[0] + p2[0] * LIMB2_UNSCALE) * ri;
+          v[2 * h + 1] += (p1[1] + p2[1] * LIMB2_UNSCALE) * ri;
+        }
+      }
+      if (c.relu) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
+      }
+      if (live) mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+      const f32x4 w = v * so;
+      u32x2 l1, l2;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const unsigned pk = cvt2h(w[2 * h], w[2 * h + 1]);
+        const f32x2 f = unpack2h(pk);
+        l1[h] = pk;
+        l2[h] = cvt2h((w[2 * h] - f[0]) * LIMB2_SCALE, (w[2 * h + 1] - f[1]) * LIMB2_SCALE);
+      }
+      if constexpr (COUNTED) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const unsigned off = vn ? (unsigned)(((size_t)m * c.ldy + n) * 2) : OOB;  // rows past M: past the plane's end
+        __builtin_amdgcn_raw_buffer_store_b64(l1, make_rsrc(a.yl, (unsigned)plane_bytes), off, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(l2, make_rsrc(a.yl + a.yplane, (unsigned)plane_bytes), off, 0, 0);
+#endif
+      } else if (live) {
+        _Float16* dst = a.yl + (size_t)m * c.ldy + n;
+        *reinterpret_cast<u32x2*>(dst) = l1;
+        *reinterpret_cast<u32x2*>(dst + a.yplane) = l2;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (a.amax != nullptr) {  // the true maximum of what was stored (bounds the next layer)
+    mx = wave_max(mx);
+    if (lane == 0) ar[wave] = mx;
+    if constexpr (COUNTED) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    } else {
+      __syncthreads();
+    }
+    if (t == 0) {
+      float mm = ar[0];
+#pragma unroll
+      for (int w_ = 1; w_ < NW; ++w_) mm = fmaxf(mm, ar[w_]);
+      if (mm > 0.f)
+        atomicMax(reinterpret_cast<unsigned*>(a.amax) + (blockIdx.x & (ONDA_AMAX_SLOTS - 1)) * AMAX_STRIDE, __float_as_uint(mm));
+    }
+  }
+}
+
 // ---- forward / data gradient ------------------------------------------------------------------------------------------
 template <int WM, int WN, int STAGES, int OCC, bool SK, int DBG = 0>
 __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_l2_kernel(const ConvK a, unsigned xplane, unsigned wplane, unsigned x_bytes,
@@ -611,7 +735,8 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_l2_kernel(const ConvK 
       ua = ub = 1.f;
     }
     __syncthreads();
-    l2_epilogue<WM, WN>(a, acc, lds, tile_m, m0, n0, wm, wn, lane, ua, ub);
+    if (a.yl != nullptr) l2_epilogue_limbs<WM, WN, false>(a, acc, lds, m0, n0, wm, wn, lane, ua, ub);
+    else l2_epilogue<WM, WN>(a, acc, lds, tile_m, m0, n0, wm, wn, lane, ua, ub);
     if (DBG == 5) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       stamp(tk_epi);
@@ -776,13 +901,17 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_l2x_kernel(const ConvK
     for (int j = 0; j < 4; ++j) bf[j] = *reinterpret_cast<const f16x8*>(Bb + PLANE_B + j * 1024);
   };
   int stores_young = 0;  // waits during which an epilogue's stores are still younger than the DMAs waited for
+  const bool limb_out = a.yl != nullptr;  // limb-plane output: two 8-byte stores where the fp32 output has one of 16 bytes
+  static_assert(DPW + 2 * EST <= 63, "vmcnt holds 6 bits");
   auto wait_step = [&]() {  // the DMAs of the oldest step in flight have landed
     // outstanding, oldest first: [that step] [the step after it, if issued] [an epilogue's stores, for two waits]
     if (in_flight > 1) {
-      if (stores_young) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPW + EST) : "memory");
+      if (stores_young && limb_out) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPW + 2 * EST) : "memory");
+      else if (stores_young) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPW + EST) : "memory");
       else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPW) : "memory");
     } else {
-      if (stores_young) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(EST) : "memory");
+      if (stores_young && limb_out) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * EST) : "memory");
+      else if (stores_young) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(EST) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     if (stores_young) --stores_young;
@@ -867,7 +996,9 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_l2x_kernel(const ConvK
     // the DMAs of the next two steps stay in flight (see l2_epilogue)
     __builtin_amdgcn_s_barrier();
     const int scratch = st_read == 0 ? (STAGES - 1) * STAGE : st_read - STAGE;  // the stage read last
-    if (a.scale != nullptr || a.shift != nullptr || a.res != nullptr || c.relu)
+    if (limb_out)
+      l2_epilogue_limbs<WM, WN, true>(a, acc, lds + scratch, (tile / a.tilesN) * BM, (tile % a.tilesN) * BN, wm, wn, lane, ua, ub);
+    else if (a.scale != nullptr || a.shift != nullptr || a.res != nullptr || c.relu)
       l2_epilogue<WM, WN, true, true>(a, acc, lds + scratch, tile / a.tilesN, (tile / a.tilesN) * BM, (tile % a.tilesN) * BN, wm, wn,
                                       lane, ua, ub, y_bytes);
     else
@@ -939,6 +1070,46 @@ __global__ __launch_bounds__(256) void conv_l2_fixup_kernel(const ConvK a, int G
   }
   const int m = tile_m * BM + row;
   float mx = 0.f;
+  if (a.yl != nullptr) {  // limb-plane output (l2_epilogue_limbs): same bound, same scale, same arithmetic
+    const float bound = limb_out_bound(a);
+    const float so = scale_from(bound).s;
+    if (t == 0) a.ybound[(blockIdx.x & (ONDA_AMAX_SLOTS - 1)) * AMAX_STRIDE] = bound;
+    const float ri = a.resl != nullptr ? scale_of(a.res_amax).inv : 0.f;
+    if (m < a.M && vn) {
+      f32x4 o = v;
+      if (a.scale) o *= *reinterpret_cast<const f32x4*>(a.scale + n);
+      if (a.shift) o += *reinterpret_cast<const f32x4*>(a.shift + n);
+      if (a.resl != nullptr) {
+        const _Float16* p = a.resl + (size_t)m * c.ldr + n;
+        const u32x2 q1 = *reinterpret_cast<const u32x2*>(p), q2 = *reinterpret_cast<const u32x2*>(p + a.resplane);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const f32x2 p1 = unpack2h(q1[h]), p2 = unpack2h(q2[h]);
+          o[2 * h] += (p1[0] + p2[0] * LIMB2_UNSCALE) * ri;
+          o[2 * h + 1] += (p1[1] + p2[1] * LIMB2_UNSCALE) * ri;
+        }
+      }
+      if (c.relu) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = fmaxf(o[j], 0.f);
+      }
+      mx = fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3])));
+      const f32x4 w = o * so;
+      u32x2 l1, l2;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const unsigned pk = cvt2h(w[2 * h], w[2 * h + 1]);
+        const f32x2 f = unpack2h(pk);
+        l1[h] = pk;
+        l2[h] = cvt2h((w[2 * h] - f[0]) * LIMB2_SCALE, (w[2 * h + 1] - f[1]) * LIMB2_SCALE);
+      }
+      _Float16* dst = a.yl + (size_t)m * c.ldy + n;
+      *reinterpret_cast<u32x2*>(dst) = l1;
+      *reinterpret_cast<u32x2*>(dst + a.yplane) = l2;
+    }
+    if (a.amax != nullptr) amax_update_block(a.amax, mx, reinterpret_cast<float*>(&red[0][0]));
+    return;
+  }
   if (m < a.M && vn) {
     f32x4 o = v;
     if (a.scale) o *= *reinterpret_cast<const f32x4*>(a.scale + n);
@@ -1382,21 +1553,40 @@ extern "C" {
 /* rows of the `stats` partials the conv will write for this problem (tile rows + the extra rows of a stream-K remainder) */
 int onda_conv_l2_tiles_m(int64_t M, int Cout, int taps, int Cin) { return l2_schedule(M, Cout, taps, Cin, true).stats_rows_total(); }
 
-int onda_conv2d_fwd_l2(const void* xl, int64_t xplane, const float* xamax, const void* w2, const float* wamax, float* y,
+static int l2_fwd_impl(const void* xl, int64_t xplane, const float* xamax, const void* w2, const float* wamax, float* y,
                        const float* scale, const float* shift, const float* residual, float* stats, int stats_rows, float* ws,
-                       float* yamax, const OndaConv* c, onda_stream_t s) {
-  ONDA_REQUIRE(xl && xamax && w2 && wamax && y && c && ws && (stats_rows == 2 || stats_rows == 4));
+                       float* yamax, const OndaConv* c, onda_stream_t s, const OndaLimbOut* lo) {
+  ONDA_REQUIRE(xl && xamax && w2 && wamax && (y || lo) && c && ws && (stats_rows == 2 || stats_rows == 4));
+  if (lo != nullptr) {  // limb-plane output: dense [M][ldy] planes, no statistics, residual (if any) as limb planes
+    ONDA_REQUIRE(lo->out && lo->out_bound && lo->kb && lo->xtrue && lo->out_plane > 0 && lo->out_plane % 8 == 0 && !stats && !residual);
+    ONDA_REQUIRE(c->out_os == 1 && c->Hf == c->Ho && c->Wf == c->Wo && c->ldy % 4 == 0 && c->ldy >= c->Cout);
+    ONDA_REQUIRE(!lo->res || (lo->res_amax && lo->res_plane > 0 && lo->res_plane % 8 == 0 && c->ldr % 4 == 0 && c->ldr >= c->Cout));
+    ONDA_REQUIRE((long long)c->B * c->Ho * c->Wo * c->ldy * 2 < 0x7FFFF000ll);
+    if (!ONDA_ALIGNED16(lo->out) || (lo->res && !ONDA_ALIGNED16(lo->res))) return ONDA_EALIGN;
+  }
   ONDA_REQUIRE(c->Cin > 0 && c->Cin % 32 == 0 && c->Cout > 0 && c->Cout % 4 == 0 && c->ldx % 8 == 0 && c->ldx >= c->Cin);
   ONDA_REQUIRE(c->kh >= 1 && c->kw >= 1 && c->stride >= 1 && c->dil >= 1 && c->out_os >= 1 && xplane > 0 && xplane % 8 == 0);
   if (!ONDA_ALIGNED16(xl) || !ONDA_ALIGNED16(w2)) return ONDA_EALIGN;
   // the epilogue stores (and reads the residual in) 16-byte vectors
-  if (c->ldy % 4 != 0 || !ONDA_ALIGNED16(y) || (residual && (c->ldr % 4 != 0 || !ONDA_ALIGNED16(residual)))) return ONDA_EALIGN;
+  if (c->ldy % 4 != 0 || (y && !ONDA_ALIGNED16(y)) || (residual && (c->ldr % 4 != 0 || !ONDA_ALIGNED16(residual)))) return ONDA_EALIGN;
   if (scale && !ONDA_ALIGNED16(scale)) return ONDA_EALIGN;
   if (shift && !ONDA_ALIGNED16(shift)) return ONDA_EALIGN;
   ConvK k;
   k.x = static_cast<const float*>(xl); k.w = w2; k.y = y; k.scale = scale; k.shift = shift; k.res = residual; k.stats = stats; k.ws = ws;
   k.amax = yamax;
   k.stats_rows = stats_rows;
+  if (lo != nullptr) {
+    k.yl = static_cast<_Float16*>(lo->out);
+    k.yplane = lo->out_plane;
+    k.ybound = lo->out_bound;
+    k.amax = lo->out_amax;
+    k.kb = lo->kb;
+    k.xtrue = lo->xtrue;
+    k.resl = static_cast<const _Float16*>(lo->res);
+    k.resplane = lo->res_plane;
+    k.res_amax = lo->res_amax;
+    k.res_true = lo->res_true ? lo->res_true : lo->res_amax;
+  }
   static const int noskip = getenv("ONDA_L2_NOSKIP") ? atoi(getenv("ONDA_L2_NOSKIP")) : 0;
   k.skip_dead_taps = !noskip;
   static const int late_issue = getenv("ONDA_L2X_LATE") ? atoi(getenv("ONDA_L2X_LATE")) : 1;
@@ -1457,6 +1647,19 @@ int onda_conv2d_fwd_l2(const void* xl, int64_t xplane, const float* xamax, const
   else L2_LAUNCH(4, 1, 3, 1);
 #undef L2_LAUNCH
   return ONDA_LAUNCH_RESULT();
+}
+
+int onda_conv2d_fwd_l2(const void* xl, int64_t xplane, const float* xamax, const void* w2, const float* wamax, float* y,
+                       const float* scale, const float* shift, const float* residual, float* stats, int stats_rows, float* ws,
+                       float* yamax, const OndaConv* c, onda_stream_t s) {
+  return l2_fwd_impl(xl, xplane, xamax, w2, wamax, y, scale, shift, residual, stats, stats_rows, ws, yamax, c, s, nullptr);
+}
+
+int onda_conv2d_fwd_l2_limbs(const void* xl, int64_t xplane, const float* xamax, const void* w2, const float* wamax,
+                             const float* scale, const float* shift, const OndaLimbOut* lo, float* ws, const OndaConv* c,
+                             onda_stream_t s) {
+  ONDA_REQUIRE(lo != nullptr);
+  return l2_fwd_impl(xl, xplane, xamax, w2, wamax, nullptr, scale, shift, nullptr, nullptr, 2, ws, nullptr, c, s, lo);
 }
 
 // weight-gradient tile of the pre-split kernel for a (Cout, Cin) problem: 0 = 256 output x 128 input channels (8 waves),

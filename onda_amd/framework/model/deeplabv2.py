@@ -14,6 +14,8 @@ What is different: inside ``forward`` activations are NHWC and every op is a HIP
 `feat` / `out` come back as NCHW-shaped views of pixel-major buffers (no copy), which is
 also the layout ``prototype_handler.transform`` wants.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -48,6 +50,7 @@ class HipBatchNorm2d(nn.BatchNorm2d):
         return self._fold
 
     def __deepcopy__(self, memo):
+        self.__dict__.pop("_bound_cache", None)
         fold = self.__dict__.pop("_fold", None), self.__dict__.pop("_fold_key", None)
         cls = self.__class__
         new = cls.__new__(cls)
@@ -58,6 +61,9 @@ class HipBatchNorm2d(nn.BatchNorm2d):
         if fold[0] is not None:
             self._fold, self._fold_key = fold
         return new
+
+
+EVAL_LIMBS = os.environ.get("ONDA_EVAL_LIMBS", "1") != "0"  # measurement knob: 0 = fp32 eval outputs + split passes
 
 
 def conv_bn(conv, bn, x, relu, residual=None):
@@ -79,8 +85,19 @@ def conv_bn(conv, bn, x, relu, residual=None):
         return fn.apply(y, stats, bn.weight, bn.bias, residual, relu, running, bn.momentum)
     scale, shift = bn.folded()
     with torch.no_grad():
-        y, _, _ = ops.conv_forward(x, conv._pack.get_fwd(conv.weight), k, stride, dil, pad, conv.out_channels,
-                                   scale=scale, shift=shift, residual=residual, relu=relu)
+        wp = conv._pack.get_fwd(conv.weight)
+        limb_out = None
+        if EVAL_LIMBS and ops.limb_mode(conv.out_channels) and ops._use_l2(wp, x.shape[3]):
+            # the result feeds convolutions (and residual adds) only: written as limb planes by the conv epilogue itself,
+            # scaled by an a-priori bound (ops.fold_bounds; cached per weight / statistics version)
+            w = conv.weight
+            key = (w.data_ptr(), w._version, id(scale), id(shift))
+            hit = getattr(bn, "_bound_cache", None)
+            if hit is None or hit[0] != key:
+                hit = bn._bound_cache = (key, ops.fold_bounds(w, scale, shift), scale, shift)
+            limb_out = hit[1]
+        y, _, _ = ops.conv_forward(x, wp, k, stride, dil, pad, conv.out_channels, scale=scale, shift=shift, residual=residual,
+                                   relu=relu, limb_out=limb_out)
     return y
 
 

@@ -15,7 +15,7 @@ from ctypes import byref
 import torch
 
 from . import _lib
-from ._lib import OndaConv, call, query
+from ._lib import OndaConv, OndaLimbOut, call, query
 
 BN_EPS = 1e-5
 GN_EPS = 1e-5
@@ -169,10 +169,13 @@ def activation_scale(x):
 class Limbs:
     """An activation as the two f16 limb planes of x * 2^e (include/onda_hip.h, pre-split section):
     planes f16[2, rows, ld], `amax` the device floats that define e."""
-    __slots__ = ("planes", "amax", "ld", "plane")
+    __slots__ = ("planes", "amax", "ld", "plane", "true_amax")
 
-    def __init__(self, planes, amax, ld, plane):
+    def __init__(self, planes, amax, ld, plane, true_amax=None):
         self.planes, self.amax, self.ld, self.plane = planes, amax, ld, plane
+        # planes whose scale comes from an a-priori BOUND (eval-mode conv outputs) also carry their true max|x|: it is
+        # what bounds the next layer's output, so that bounds do not compound
+        self.true_amax = true_amax if true_amax is not None else amax
 
 
 def activation_limbs(x):
@@ -341,12 +344,32 @@ def _sink_give(sink, grad, owned):
 
 
 def conv_forward(x, wp, k, stride, dil, pad, cout, out=None, scale=None, shift=None, residual=None, relu=False,
-                 want_stats=False):
-    """x NHWC view, wp packed [cout][k*k*Cin].  Returns (y, stats partials or None, tiles)."""
+                 want_stats=False, limb_out=None):
+    """x NHWC view, wp packed [cout][k*k*Cin].  Returns (y, stats partials or None, tiles).
+    limb_out: the two device floats of `fold_bounds` -- the result (conv + folded BatchNorm [+ residual] [+ ReLU]) is
+    written as limb planes only, scaled by an a-priori bound (include/onda_hip.h, onda_conv2d_fwd_l2_limbs)."""
     _require_cuda(x, "conv input")
     B, Hi, Wi, Cin = x.shape
     ldx = 0 if is_limb_only(x) else nhwc_ld(x)
     Ho, Wo = conv_out_size(Hi, k, stride, dil, pad), conv_out_size(Wi, k, stride, dil, pad)
+    if limb_out is not None:
+        if out is not None or want_stats or not _use_l2(wp, Cin) or cout % 8 != 0:
+            raise RuntimeError("onda_amd: limb-plane conv output needs the pre-split path, a dense result and no statistics")
+        dev, M = x.device, B * Ho * Wo
+        xl = limbs_of(x)
+        res = limbs_of(residual) if residual is not None else None
+        if res is not None and tuple(residual.shape) != (B, Ho, Wo, cout):
+            raise RuntimeError("onda_amd: residual of a limb-plane conv output must be a dense [B,H,W,C] activation")
+        planes = torch.empty(2, M, cout, device=dev, dtype=torch.float16)
+        bound, true = amax_slot(dev), amax_slot(dev)
+        d = _desc(B, Hi, Wi, Cin, Ho, Wo, cout, k, stride, dil, pad, xl.ld, cout, res.ld if res is not None else 0, relu=relu)
+        lo = OndaLimbOut(_p(planes), M * cout, _p(bound), _p(true), _p(limb_out), _p(xl.true_amax),
+                         _p(res.planes) if res is not None else None, res.plane if res is not None else 0,
+                         _p(res.amax) if res is not None else None, _p(res.true_amax) if res is not None else None)
+        _launch("conv_l2_kernel<%d>" % query("onda_conv_l2_variant", M, cout), 2.0 * M * cout * k * k * Cin,
+                "onda_conv2d_fwd_l2_limbs", _p(xl.planes), xl.plane, _p(xl.amax), _p(wp.limbs), _p(wp.amax), _p(scale), _p(shift),
+                byref(lo), _p(_conv_ws(dev)), byref(d), _stream(), tag=("fwd", M, cout, Cin, k, stride, dil))
+        return limb_only((B, Ho, Wo, cout), dev, Limbs(planes, bound, cout, M * cout, true_amax=true)), None, 0
     if out is None:
         out = torch.empty(B, Ho, Wo, cout, device=x.device, dtype=torch.float32)
     else:  # a caller's buffer is rewritten behind torch's version counter: forget its old max|x| / limb planes
@@ -872,6 +895,14 @@ class BNTrainLimbFn(torch.autograd.Function):
         if need_res:
             dres = _sink_give(ctx.res_sink, dres, ctx.relu)
         return dx, None, None, None, dres, None, None, None
+
+
+def fold_bounds(weight, scale, shift):
+    """{max_c |scale_c| * sum_k |w_ck|, max_c |shift_c|} as two device floats: the a-priori bound of an eval-mode
+    conv + folded BatchNorm output is max|x| * [0] + [1] (once per weight / statistics version; plain torch plumbing)."""
+    with torch.no_grad():
+        l1 = weight.detach().abs().sum(dim=(1, 2, 3))
+        return torch.stack([(scale.abs() * l1).max(), shift.abs().max()]).float().contiguous()
 
 
 def bn_eval_fold(gamma, beta, rm, rv):

@@ -171,6 +171,47 @@ def test_head_and_stem(conv_mode):
     close(wd.grad, wr.grad, 5e-5, "stem wgrad")
 
 
+@pytest.mark.parametrize("cin,cout,k,dil,H,W,res", [(64, 256, 1, 1, 33, 65, True), (256, 64, 1, 1, 33, 65, False),
+                                                     (128, 128, 3, 2, 19, 37, False), (512, 2048, 1, 1, 65, 129, True),
+                                                     (512, 512, 3, 4, 65, 129, False)])
+def test_eval_conv_writes_limb_planes(cin, cout, k, dil, H, W, res):
+    """Eval-mode conv + folded BatchNorm [+ residual limbs] + ReLU with the result written as limb planes by the conv
+    epilogue itself (a-priori bound as the scale): values against fp32 torch on the CPU, the bound really bounds, the
+    true maximum is reported exactly, and a second such conv on top (bounds must not compound) is as accurate as the
+    first; small and full-size grids, every tile variant, stream-K remainders."""
+    from onda_amd import ops
+    g = torch.Generator().manual_seed(cin + cout + k)
+    B, pad = 2, dil * (k - 1) // 2
+    x = torch.relu(torch.randn(B, cin, H, W, generator=g)) * 3.0
+    w = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    sc, sh = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g)
+    r = torch.randn(B, cout, H, W, generator=g) if res else None
+    ref = F.conv2d(x, w, None, 1, pad, dil) * sc[None, :, None, None] + sh[None, :, None, None]
+    if res:
+        ref = ref + r
+    ref = F.relu(ref)
+    xd = nhwc(x).to(DEV)
+    ops.activation_limbs(xd)
+    rd = nhwc(r).to(DEV) if res else None
+    kb = ops.fold_bounds(w.to(DEV), sc.to(DEV), sh.to(DEV))
+    y, _, _ = ops.conv_forward(xd, ops.pack_weight_fwd(w.to(DEV)), k, 1, dil, pad, cout, scale=sc.to(DEV), shift=sh.to(DEV),
+                               residual=rd, relu=True, limb_out=kb)
+    assert ops.is_limb_only(y)
+    lb = ops.limbs_of(y)
+    close(nchw(ops.materialize(y)), ref, 2e-5, "limb-plane conv output")
+    true_max, bound = lb.true_amax.max().item(), lb.amax.max().item()
+    assert true_max == pytest.approx(ref.max().item(), rel=2e-5) and true_max <= bound <= true_max * 2.0 ** 13, (true_max, bound)
+    # a second conv of the same kind on top, the first one's output as its residual too
+    w2 = torch.randn(cout, cout, 1, 1, generator=g) / cout ** 0.5
+    ref2 = F.relu(F.conv2d(ref, w2) * sc[None, :, None, None] + sh[None, :, None, None] + ref)
+    kb2 = ops.fold_bounds(w2.to(DEV), sc.to(DEV), sh.to(DEV))
+    y2, _, _ = ops.conv_forward(y, ops.pack_weight_fwd(w2.to(DEV)), 1, 1, 1, 0, cout, scale=sc.to(DEV), shift=sh.to(DEV),
+                                residual=y, relu=True, limb_out=kb2)
+    close(nchw(ops.materialize(y2)), ref2, 3e-5, "second limb-plane conv")
+    lb2 = ops.limbs_of(y2)
+    assert lb2.true_amax.max().item() <= lb2.amax.max().item() <= lb2.true_amax.max().item() * 2.0 ** 13
+
+
 def test_host_never_waits_for_tables_or_monitor_scalars():
     """Multi-tensor entry tables and the monitor's device scalars reach their destination through pinned staging
     buffers (asynchronous copies): same values as the direct path, staging buffers reused only after their copy's event
