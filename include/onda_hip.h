@@ -141,6 +141,10 @@ int onda_conv2d_fwd_l2_limbs(const void* xl, int64_t xplane, const float* xamax,
                              const float* scale, const float* shift, const OndaLimbOut* lo, float* ws, const OndaConv* c,
                              onda_stream_t s);
 
+/* Diagnostics: a device buffer of 4096 x 8 uint64 into which onda_conv2d_wgrad_l2's workgroups write s_memtime at the
+ * start, after their set-up, after the K loop and after the slab store (slot 5: live K-steps).  NULL switches it off. */
+void onda_debug_stamps(void* buffer);
+
 /* Stem patches (onda_stem_im2col) written directly as limb planes dst[2][B*Ho*Wo][Kp] f16 (plane = f16 elements between
  * the two planes): the patch matrix holds image values and zeros, so its max|x| is the image's (xamax, from onda_absmax
  * over the image).  Replaces the stem's F.conv2d input side (deeplabv2.py:283) in "f16x2" pre-split mode. */

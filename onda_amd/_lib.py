@@ -51,6 +51,7 @@ SIGNATURES = {
     "onda_conv2d_wgrad_h2": (I, [P, P, P, P, P, I, I, POINTER(OndaConv), P]),
     "onda_split_h2": (I, [P, L, I, I, P, I, L, P, P]),
     "onda_stem_im2col_l2": (I, [P, P, P, L, I, I, I, I, I, I, P]),
+    "onda_debug_stamps": (None, [P]),
     "onda_conv2d_fwd_l2_limbs": (I, [P, L, P, P, P, P, P, P, P, P, P]),
     "onda_conv_l2_variant": (I, [L, I]),
     "onda_conv_l2_tiles_m": (I, [L, I, I, I]),

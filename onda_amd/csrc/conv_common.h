@@ -40,6 +40,7 @@ struct WgradK {
   float* slabs;
   OndaConv c;
   int M, lddy, splitk, mchunk, tilesN, tilesC, taps;
+  unsigned long long* stamps = nullptr;  // diagnostics (onda_debug_stamps, tools/wgrad_stamps.py): [8] s_memtime per workgroup
 };
 
 constexpr int BK = 32;

@@ -1225,6 +1225,8 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_wgrad_l2_kernel(const 
   const int KT = mend > mbeg ? (mend - mbeg + 31) / 32 : 0;
   const int rr = tap / c.kw, ss = tap - rr * c.kw;
   const int dh = rr * c.dil - c.pad, dw = ss * c.dil - c.pad;
+  unsigned long long* stp = a.stamps != nullptr && t == 0 && blockIdx.x < 4096 ? a.stamps + (size_t)blockIdx.x * 8 : nullptr;
+  if (stp) stp[0] = __builtin_amdgcn_s_memtime();
   const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, x_bytes), rdy = make_rsrc(a.dy, dy_bytes);
   const Scale2 sx = scale_of(xamax), sd = scale_of(dyamax);
   const float unscale_a = sx.inv, unscale_b = sd.inv;
@@ -1285,13 +1287,43 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_wgrad_l2_kernel(const 
     p_b[d] = tq / c.Ho;
   }
   int k_decoded = 0;  // the K-step p_* stand at
-  auto issue = [&](int kt, int stage_off) {
+  // A step's DMAs in two parts -- first limb planes, second limb planes -- so that the staggered kernel can issue one
+  // part in the prepare slot and the other behind the first MFMAs of the compute slot.  Stamps (tools/wgrad_stamps.py):
+  // 2 650 cycles per K-step with every workgroup within 10 of that; the first half's prepare slot = 620 (live-list
+  // lookup, pixel offsets, DMA issue) + 640 (32 transposed fragment reads: LDS bandwidth of four waves) + 140 at the
+  // barrier, its compute slot 768 of MFMA.  With the split: 2 550.  Tried and slower: reads issued before the DMAs
+  // (2 950: the read issue itself blocks for 780 cycles and the DMAs behind it for 1 000), next step's offsets worked
+  // out in the compute slot (3 190: branchy VALU code and an LDS lookup break the MFMA stream).
+  unsigned pdy_s[GPW], px_s[GPW];
+  int stage_s = 0;
+  auto issue_part = [&](int l) {
 #if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+    for (int d = 0; d < GPW; ++d) {
+      const int grp = wave * GPW + d;
+#pragma unroll
+      for (int sI = 0; sI < SA; ++sI) {
+        unsigned char* dst = lds + stage_s + l * A_LIMB + sI * SUB + grp * 1024;
+        const unsigned vo = pdy_s[d] + ch_dy[d][sI];  // OOB (2^31) + anything below 2^31 stays out of range, no wrap
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rdy, (__attribute__((address_space(3))) void*)dst, 16, vo, l * dyplane, 0, 0);
+      }
+#pragma unroll
+      for (int sI = 0; sI < SB; ++sI) {
+        unsigned char* dst = lds + stage_s + A_BYTES + l * B_LIMB + sI * SUB + grp * 1024;
+        const unsigned vo = px_s[d] + ch_x[d][sI];
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)dst, 16, vo, l * xplane, 0, 0);
+      }
+    }
+#else
+    (void)l;
+#endif
+  };
+  auto issue_addr = [&](int kt, int stage_off) {  // the step's pixel offsets (kept for both parts)
+    stage_s = stage_off;
     const int adv = (kt - k_decoded) * 32;
     k_decoded = kt;
 #pragma unroll
     for (int d = 0; d < GPW; ++d) {
-      const int grp = wave * GPW + d;
       p_m[d] += adv;
       p_wo[d] += adv;
       while (p_wo[d] >= c.Wo) {
@@ -1308,26 +1340,14 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_wgrad_l2_kernel(const 
         const int hi = p_ho[d] * c.stride + dh, wi = p_wo[d] * c.stride + dw;
         if ((unsigned)hi < (unsigned)c.Hi && (unsigned)wi < (unsigned)c.Wi) px = (unsigned)(((p_b[d] * c.Hi + hi) * c.Wi + wi) * c.ldx) * 2u;
       }
-#pragma unroll
-      for (int l = 0; l < 2; ++l) {
-#pragma unroll
-        for (int sI = 0; sI < SA; ++sI) {
-          unsigned char* dst = lds + stage_off + l * A_LIMB + sI * SUB + grp * 1024;
-          const unsigned vo = pdy + ch_dy[d][sI];  // OOB (2^31) + anything below 2^31 stays out of range, no wrap
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rdy, (__attribute__((address_space(3))) void*)dst, 16, vo, l * dyplane, 0, 0);
-        }
-#pragma unroll
-        for (int sI = 0; sI < SB; ++sI) {
-          unsigned char* dst = lds + stage_off + A_BYTES + l * B_LIMB + sI * SUB + grp * 1024;
-          const unsigned vo = px + ch_x[d][sI];
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)dst, 16, vo, l * xplane, 0, 0);
-        }
-      }
+      pdy_s[d] = pdy;
+      px_s[d] = px;
     }
-#else
-    (void)kt;
-    (void)stage_off;
-#endif
+  };
+  auto issue = [&](int kt, int stage_off) {
+    issue_addr(kt, stage_off);
+    issue_part(0);
+    issue_part(1);
   };
 
   // transposed fragment reads: 16-lane group g = k-group (pixels 8g .. 8g+7), lane 4q+p of the group addresses row q,
@@ -1356,6 +1376,10 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_wgrad_l2_kernel(const 
 #pragma unroll
       for (int e = 0; e < 4; ++e) acc[i][j][e] = accx[i][j][e] = 0.f;
 
+  if (stp) {
+    stp[1] = __builtin_amdgcn_s_memtime();
+    stp[5] = (unsigned long long)nlive;
+  }
   // the live K-steps, fetched two ahead
   int i_cur = 0, i_iss = 0;
   int st_issue = 0, st_read = 0;
@@ -1363,6 +1387,26 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_wgrad_l2_kernel(const 
     issue(live_at(i_iss), st_issue);
     st_issue = st_issue + STAGE == STAGES * STAGE ? 0 : st_issue + STAGE;
     ++i_iss;
+  };
+  bool second_part_due = false;
+  auto issue_first_part = [&]() {   // prepare slot
+    second_part_due = i_iss < nlive;
+    if (second_part_due) {
+      issue_addr(live_at(i_iss), st_issue);
+      issue_part(0);
+      st_issue = st_issue + STAGE == STAGES * STAGE ? 0 : st_issue + STAGE;
+      ++i_iss;
+    }
+  };
+  auto issue_second_part = [&]() {  // compute slot, behind the first 16 MFMAs
+    if (second_part_due) issue_part(1);
+    second_part_due = false;
+  };
+  auto wait_landed_half = [&](bool first_part_in_flight) {  // (second half of the workgroup: only the first part of the
+    if (first_part_in_flight)                               //  younger step has been issued when it waits)
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPW / 2) : "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   };
   auto wait_landed = [&](bool more_in_flight) {
     if (more_in_flight)
@@ -1408,6 +1452,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_wgrad_l2_kernel(const 
 #pragma unroll
       for (int j = 0; j < 4; ++j) accx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][0], bf[j], accx[i][j], 0, 0, 0);
     if constexpr (!STAGGER) lds_wait(b1[0], b1[1], b1[2], b1[3]);
+    if constexpr (STAGGER) issue_second_part();
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -1435,12 +1480,22 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_wgrad_l2_kernel(const 
     for (; i_cur < nlive; ++i_cur) {
       if (!late) wait_landed(i_cur + 1 < nlive);
       __builtin_amdgcn_s_barrier();
-      if (i_iss < nlive) issue_next();  // both halves in their own prepare slot, beside the other half's MFMAs
+      unsigned long long tk0 = 0, tk1 = 0, tk2 = 0;
+      if (stp) tk0 = __builtin_amdgcn_s_memtime();
+      issue_first_part();  // both halves: first limb planes here, second ones behind the first MFMAs of the compute slot
+      if (stp) tk1 = __builtin_amdgcn_s_memtime();
       prepare();
       prepared();
-      if (late && i_cur + 1 < nlive) wait_landed(i_cur + 2 < nlive);
+      if (stp) tk2 = __builtin_amdgcn_s_memtime();
+      if (late && i_cur + 1 < nlive) wait_landed_half(i_cur + 2 < nlive);
       __builtin_amdgcn_s_barrier();
+      if (stp && i_cur == nlive / 2) {  // one step in the middle: DMA issue | fragment reads | wait at the barrier
+        const unsigned long long tk3 = __builtin_amdgcn_s_memtime();
+        stp[4] = ((tk1 - tk0) << 40) | ((tk2 - tk1) << 20) | (tk3 - tk2);
+        stp[6] = tk3;
+      }
       compute();
+      if (stp && i_cur == nlive / 2) stp[7] = __builtin_amdgcn_s_memtime() - stp[6];
     }
     if (!late && nlive > 0) __builtin_amdgcn_s_barrier();
   }
@@ -1449,6 +1504,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_wgrad_l2_kernel(const 
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = ((acc[i][j] + accx[i][j] * LIMB2_UNSCALE) * unscale_a) * unscale_b;
+  if (stp) stp[2] = __builtin_amdgcn_s_memtime();
   __syncthreads();
   // slab store through the wave's own 4 KiB of LDS: 16 rows (output channels) x 64 input channels at a time, 16-byte stores
   float* tr = reinterpret_cast<float*>(lds + (t >> 6) * 4096);
@@ -1470,6 +1526,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_wgrad_l2_kernel(const 
     }
     __builtin_amdgcn_wave_barrier();
   }
+  if (stp) stp[3] = __builtin_amdgcn_s_memtime();
 }
 
 }  // namespace
@@ -1664,6 +1721,10 @@ int onda_conv2d_fwd_l2_limbs(const void* xl, int64_t xplane, const float* xamax,
 
 // weight-gradient tile of the pre-split kernel for a (Cout, Cin) problem: 0 = 256 output x 128 input channels (8 waves),
 // 1 = 128 x 128 (4 waves)
+static unsigned long long* g_debug_stamps = nullptr;
+/* diagnostics: device buffer of 4096 x 8 uint64 the weight-gradient kernel timestamps its phases into (NULL: off) */
+void onda_debug_stamps(void* p) { g_debug_stamps = static_cast<unsigned long long*>(p); }
+
 int onda_conv_wgrad_l2_variant(int Cout, int Cin) {
   (void)Cin;
   if (const char* e = getenv("ONDA_WGRAD_L2_VARIANT")) return atoi(e);
@@ -1685,6 +1746,7 @@ int onda_conv2d_wgrad_l2(const void* xl, int64_t xplane, const float* xamax, con
   k.M = (int)M;
   k.lddy = lddy;
   k.splitk = splitk;
+  k.stamps = g_debug_stamps;
   k.mchunk = (int)(((M + splitk - 1) / splitk + 31) / 32 * 32);
   ONDA_REQUIRE(k.mchunk / 32 <= 2048);  // the kernel lists a workgroup's live K-steps in LDS (MAX_KT); raise splitk beyond that
   k.taps = c->kh * c->kw;
