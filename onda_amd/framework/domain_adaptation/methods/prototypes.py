@@ -562,6 +562,11 @@ class online_proDA(da_model):
         first_log = self._settle(first_log, prepared, deferred)
         first_log["encoder_lr"] = self.optimizer.param_groups[0]["lr"]
         first_log.update(src_log)
+        # the backward passes are done: the entries leave as plain values -- a caller that keeps log dictionaries must not
+        # keep the step's autograd graph (and the ~7 GB of limb planes its nodes reference) alive with them
+        for key, value in dict.items(first_log):
+            if torch.is_tensor(value) and value.requires_grad:
+                dict.__setitem__(first_log, key, value.detach())
         self.optimizer.step()
         self.optimizer.zero_grad()
         return first_log

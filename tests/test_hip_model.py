@@ -252,6 +252,8 @@ def test_full_step_golden(golden, tmp_path, tag, head_scale):
             da.adjust_learning_rate(s, 6)
             log = da.step([src[s]], trg[s])
             da.update_ema()
+            # the log leaves the step as plain values: keeping it must not keep the step's autograd graph alive
+            assert not any(torch.is_tensor(v) and (v.requires_grad or v.grad_fn is not None) for v in log.values())
             assert int(g[f"branch{s}"]) == da.model_select.current
             soft = trg[s]["stored_predictions"]
             assert (soft.cpu() - torch.from_numpy(g[f"soft{s}"])).abs().max() < 2e-3
