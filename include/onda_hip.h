@@ -307,7 +307,10 @@ int onda_seg_loss_bwd(const float* logits, int ldl, const int64_t* labels, const
  * (mahalanobis=1) or || f - p_k ||, minus its minimum; P = softmax(-D/tau); P *= prior;
  * P /= sum P; label = argmax P, 255 if max P < thresh.  One pass emits the hard labels, the
  * soft map and the three monitor sums result[0..2] = mean max softmax(-D/tau), mean max P,
- * mean max prior.  prior may be NULL.  ws: 3*onda_proto_assign_blocks(N) floats.  C == 256. */
+ * mean max prior.  prior may be NULL.  ws: 3*onda_proto_assign_blocks(N) floats.  C == 256.
+ * The feature <-> prototype contraction runs on the matrix cores (v_mfma_f32_32x32x2_f32, fp32 operands):
+ * D^2 = |f/s|^2 - 2 (f/s).(p/s) + |p/s|^2; pixels whose decision is closer than 1e-3 (two largest P, or max P
+ * against thresh) are redone in the direct form above, so labels are those of the direct form. */
 int onda_proto_assign_blocks(int64_t N);
 int onda_proto_sigma(const float* proto, const float* sqmean, const float* counter, float* sigma, int K, int C,
                      onda_stream_t s);

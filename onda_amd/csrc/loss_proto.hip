@@ -2,6 +2,7 @@
 // gradient, prototype distances / pseudo-labels, prototype statistics and EMA, plus the
 // multi-tensor SGD and teacher-EMA updates.  All HBM-bound; reductions are two-stage with a
 // fixed order (bitwise reproducible).
+#include <cstdlib>
 #include "common.h"
 
 namespace {
@@ -9,13 +10,16 @@ namespace {
 constexpr int KMAX = 32;              // class vectors are kept in registers, K <= 32
 constexpr float LOG_CLAMP = -9.21034037f;  // log(1e-4): loss.py:104-106 clamps the one-hot to [1e-4, 1]
 
+// result[j] = scale * sum over blocks of ws[block][j]; one workgroup of 64 * nvals threads: a wave per value, lanes strided
+// over the blocks, fixed order (lane-local sums in block order, then the wave tree): bitwise reproducible
 __global__ void sum_partials_kernel(const float* __restrict__ ws, int nblocks, int nvals, float scale,
                                     float* __restrict__ result) {
-  const int j = threadIdx.x;
+  const int j = threadIdx.x >> 6, lane = threadIdx.x & 63;
   if (j >= nvals) return;
   double s = 0.0;
-  for (int b = 0; b < nblocks; ++b) s += (double)ws[(size_t)b * nvals + j];
-  result[j] = (float)(s * (double)scale);
+  for (int b = lane; b < nblocks; b += 64) s += (double)ws[(size_t)b * nvals + j];
+  s = wave_sum_d(s);
+  if (lane == 0) result[j] = (float)(s * (double)scale);
 }
 
 // ---- softmax statistics ----------------------------------------------------------------------
@@ -199,7 +203,9 @@ __global__ __launch_bounds__(256) void proto_assign_kernel(const float* __restri
                                                            const float* __restrict__ sigma, int mahalanobis,
                                                            float tau, float thresh, int64_t* __restrict__ labels,
                                                            float* __restrict__ soft, float* __restrict__ ws, int64_t N,
-                                                           int K) {
+                                                           int K, const int* __restrict__ list = nullptr,
+                                                           const int* __restrict__ list_len = nullptr) {
+  // (list != nullptr: only the pixels list[0 .. *list_len) -- the close decisions of proto_assign_mfma_kernel)
   __shared__ __attribute__((aligned(16))) float sp[KMAX * 256];
   __shared__ float red[3][4];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -209,7 +215,9 @@ __global__ __launch_bounds__(256) void proto_assign_kernel(const float* __restri
   if (mahalanobis) sg = *reinterpret_cast<const f32x4*>(sigma + lane * 4);
   float a_conf = 0.f, a_soft = 0.f, a_prior = 0.f;
   const int64_t wstride = (int64_t)gridDim.x * 4;
-  for (int64_t n = (int64_t)blockIdx.x * 4 + wave; n < N; n += wstride) {
+  const int64_t count = list ? (int64_t)*list_len : N;
+  for (int64_t i_ = (int64_t)blockIdx.x * 4 + wave; i_ < count; i_ += wstride) {
+    const int64_t n = list ? (int64_t)list[i_] : i_;
     const f32x4 f = *reinterpret_cast<const f32x4*>(feat + (size_t)n * ldf + lane * 4);
     float d[KMAX];
     float dmin = INFINITY;
@@ -274,6 +282,193 @@ __global__ __launch_bounds__(256) void proto_assign_kernel(const float* __restri
   }
   __syncthreads();
   if (t < 3) ws[(size_t)blockIdx.x * 3 + t] = red[t][0] + red[t][1] + red[t][2] + red[t][3];
+}
+
+// ---- the same assignment with the feature <-> prototype contraction on the matrix cores -------------------------------------
+//   D^2[n][k] = |f_n/s|^2 - 2 (f_n/s).(p_k/s) + |p_k/s|^2,   the [N x 256] x [256 x K<=32] product on v_mfma_f32_32x32x2_f32
+// (fp32 operands, fp32 accumulate: exact products).  A wave takes 32 pixels: their scaled features are staged through LDS
+// in two 128-channel halves (coalesced 16-byte loads, rows padded to 129 floats: conflict-free operand reads), the scaled
+// prototypes live in LDS for the whole workgroup (rows of 257 floats).  K order: MFMA step s of a half multiplies channel
+// s (lanes 0-31) and channel 64+s (lanes 32-63) -- any order is a valid order of the sum.  The accumulator tile goes
+// through LDS once more so that lane p < 32 holds pixel p's K products and runs the softmax / prior / argmax / threshold
+// exactly like the direct kernel above.
+// The expanded form cancels where the direct form (what the reference computes, prototype_handler.py:111-138) does
+// not: its distances carry an absolute error of ~1e-5.  Decisions that close are not trusted: a pixel whose two largest
+// posteriors, or whose largest posterior and the threshold, lie within `margin` goes on a list and is redone by the
+// direct kernel (proto_assign_list_kernel); everything else -- labels, soft map, monitor sums -- is final here.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int PA_TS = 129, PA_PS = 257, PA_GS = 33;
+constexpr int PA_WAVES = 6;  // 33 KB of prototypes + 6 x 16.6 KB of feature tiles = 133 KB: one workgroup per CU; 1 536 waves
+                             // take the 1 049 pixel blocks of a 65 x 129 x 4 grid in ONE round (four waves per CU: two)
+constexpr int PA_WAVE_FLOATS = 32 * PA_TS + 32;  // a wave's half-tile + its 32 squared feature norms
+
+__global__ __launch_bounds__(64 * PA_WAVES) void proto_assign_mfma_kernel(const float* __restrict__ feat, int ldf,
+                                                                const float* __restrict__ prior, int ldp,
+                                                                const float* __restrict__ proto,
+                                                                const float* __restrict__ sigma, int mahalanobis, float tau,
+                                                                float thresh, float margin, int64_t* __restrict__ labels,
+                                                                float* __restrict__ soft, float* __restrict__ ws,
+                                                                int* __restrict__ flagged, int* __restrict__ nflagged,
+                                                                int64_t N, int K) {
+  __shared__ float sm[32 * PA_PS + 32 + PA_WAVES * PA_WAVE_FLOATS];
+  __shared__ float red[3][PA_WAVES];
+  float* ph = sm;                // [32][PA_PS]: prototypes / sigma, rows >= K zero
+  float* pn = sm + 32 * PA_PS;   // [32]: their squared norms
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  float* tile = pn + 32 + wave * PA_WAVE_FLOATS;  // [32][PA_TS], later the product tile [32][PA_GS]
+  for (int i = t; i < 32 * 256; i += 64 * PA_WAVES) {
+    const int k = i >> 8, ch = i & 255;
+    float v = 0.f;
+    if (k < K) v = mahalanobis ? proto[k * 256 + ch] / sigma[ch] : proto[k * 256 + ch];
+    ph[k * PA_PS + ch] = v;
+  }
+  __syncthreads();
+  if (t < 256) {  // squared norms: 8 threads per class, 32 channels each, fixed order
+    const int k = t >> 3, part = t & 7;
+    float a = 0.f;
+#pragma unroll 8
+    for (int ch = part * 32; ch < part * 32 + 32; ++ch) a += ph[k * PA_PS + ch] * ph[k * PA_PS + ch];
+    a += __shfl_xor(a, 1, 64);
+    a += __shfl_xor(a, 2, 64);
+    a += __shfl_xor(a, 4, 64);
+    if (part == 0) pn[k] = a;
+  }
+  __syncthreads();
+  const int half_lane = lane >> 5, l32 = lane & 31;
+  float a_conf = 0.f, a_soft = 0.f, a_prior = 0.f;
+  const int64_t nblocks = (N + 31) / 32;
+  for (int64_t blk = (int64_t)blockIdx.x * PA_WAVES + wave; blk < nblocks; blk += (int64_t)gridDim.x * PA_WAVES) {
+    const int64_t n0 = blk * 32;
+    float f2 = 0.f;  // lanes 0-31: squared norm of pixel l32's scaled features
+    f32x16 acc;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[v] = 0.f;
+    // this lane's pixel's priors, requested now, used after the contraction
+    float pr_[KMAX];
+    {
+      const int64_t n = n0 + l32;
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k) pr_[k] = (prior != nullptr && k < K && n < N && half_lane == 0) ? prior[(size_t)n * ldp + k] : 1.f;
+    }
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
+      f32x4 sg = {1.f, 1.f, 1.f, 1.f};  // 1 / sigma (a reciprocal, not the direct kernel's division: close decisions are redone there)
+      if (mahalanobis) sg = f32x4{1.f, 1.f, 1.f, 1.f} / *reinterpret_cast<const f32x4*>(sigma + half * 128 + l32 * 4);
+      // stage 32 pixels x 128 channels: a 16-byte load per lane covers two pixel rows per instruction; all 16 loads of
+      // the half go out before the first is used (a wave has about one block: nothing else hides the latency)
+      f32x4 fv[16];
+#pragma unroll
+      for (int it = 0; it < 16; ++it) {
+        const int64_t n = n0 + 2 * it + half_lane;
+        fv[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (n < N) fv[it] = *reinterpret_cast<const f32x4*>(feat + (size_t)n * ldf + half * 128 + l32 * 4);
+      }
+#pragma unroll
+      for (int it = 0; it < 16; ++it) {
+        const int row = 2 * it + half_lane;
+        const f32x4 v = fv[it] * sg;
+        float* dst = tile + row * PA_TS + l32 * 4;
+        dst[0] = v[0];
+        dst[1] = v[1];
+        dst[2] = v[2];
+        dst[3] = v[3];
+      }
+      __builtin_amdgcn_wave_barrier();  // one wave: its LDS instructions execute in order
+      if (half_lane == 0) {  // the pixel's squared norm from its staged row (conflict-free reads, no cross-lane traffic)
+        float a0 = 0.f, a1 = 0.f;
+#pragma unroll 8
+        for (int ch = 0; ch < 128; ch += 2) {
+          const float x0 = tile[l32 * PA_TS + ch], x1 = tile[l32 * PA_TS + ch + 1];
+          a0 += x0 * x0;
+          a1 += x1 * x1;
+        }
+        f2 += a0 + a1;
+      }
+      const float* ap = tile + l32 * PA_TS + half_lane * 64;
+      const float* bp = ph + l32 * PA_PS + half * 128 + half_lane * 64;
+#pragma unroll 8
+      for (int s_ = 0; s_ < 64; ++s_) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[s_], bp[s_], acc, 0, 0, 0);
+      __builtin_amdgcn_wave_barrier();
+    }
+    // accumulator (row 8*(v/4) + 4*(lane/32) + v%4, column lane%32) -> [pixel][class] in LDS
+#pragma unroll
+    for (int v = 0; v < 16; ++v) tile[(8 * (v >> 2) + 4 * half_lane + (v & 3)) * PA_GS + l32] = acc[v];
+    __builtin_amdgcn_wave_barrier();
+    const int64_t n = n0 + l32;
+    if (half_lane == 0 && n < N) {
+      float d[KMAX];
+      float dmin = INFINITY;
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k)
+        if (k < K) {
+          d[k] = sqrtf(fmaxf(f2 + pn[k] - 2.f * tile[l32 * PA_GS + k], 0.f));
+          dmin = fminf(dmin, d[k]);
+        }
+      float sum = 0.f;
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k)
+        if (k < K) {
+          d[k] = expf(-(d[k] - dmin) / tau);
+          sum += d[k];
+        }
+      float conf = 0.f, psum = 0.f, prmax = 0.f;
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k)
+        if (k < K) {
+          float pp = d[k] / sum;
+          conf = fmaxf(conf, pp);
+          if (prior) {
+            prmax = fmaxf(prmax, pr_[k]);
+            pp *= pr_[k];
+          }
+          d[k] = pp;
+          psum += pp;
+        }
+      float best = -INFINITY, second = -INFINITY;
+      int arg = 0;
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k)
+        if (k < K) {
+          d[k] = d[k] / psum;
+          if (d[k] > best) {
+            second = best;
+            best = d[k];
+            arg = k;
+          } else if (d[k] > second) {
+            second = d[k];
+          }
+        }
+      if (best - second < margin || fabsf(best - thresh) < margin || !(best == best)) {
+        flagged[atomicAdd(nflagged, 1)] = (int)n;  // redone in the direct form
+      } else {
+        labels[n] = best < thresh ? 255 : arg;
+        if (soft) {
+#pragma unroll
+          for (int k = 0; k < KMAX; ++k)
+            if (k < K) soft[(size_t)n * K + k] = d[k];
+        }
+        a_conf += conf;
+        a_soft += best;
+        a_prior += prmax;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  a_conf = wave_sum(a_conf);
+  a_soft = wave_sum(a_soft);
+  a_prior = wave_sum(a_prior);
+  if (lane == 0) {
+    red[0][wave] = a_conf;
+    red[1][wave] = a_soft;
+    red[2][wave] = a_prior;
+  }
+  __syncthreads();
+  if (t < 3) {
+    float a = 0.f;
+#pragma unroll
+    for (int w_ = 0; w_ < PA_WAVES; ++w_) a += red[t][w_];
+    ws[(size_t)blockIdx.x * 3 + t] = a;
+  }
 }
 
 constexpr int SUMS_BLOCKS = 256;
@@ -408,10 +603,18 @@ int onda_proto_sigma(const float* proto, const float* sqmean, const float* count
   return ONDA_LAUNCH_RESULT();
 }
 
+// workspace of onda_proto_assign in units of 3 floats: partial sums of the MFMA pass (PA_GRID workgroups) and of the direct
+// pass over the close decisions (PA_LIST_GRID), the list itself (N ints) and its length
+constexpr int PA_GRID = 256, PA_LIST_GRID = 256;
+static bool proto_direct_only() {
+  static const int on = getenv("ONDA_PROTO_DIRECT") ? atoi(getenv("ONDA_PROTO_DIRECT")) : 0;
+  return on != 0;
+}
 int onda_proto_assign_blocks(int64_t N) {
   int64_t nb = (N + 3) / 4;
   if (nb > 2048) nb = 2048;
-  return (int)nb;
+  const int64_t mfma = PA_GRID + PA_LIST_GRID + (N + 4 + 2) / 3;
+  return (int)(nb > mfma ? nb : mfma);
 }
 
 int onda_proto_assign(const float* feat, int ldf, const float* prior, int ldp, const float* proto, const float* sigma,
@@ -420,11 +623,25 @@ int onda_proto_assign(const float* feat, int ldf, const float* prior, int ldp, c
   ONDA_REQUIRE(feat && proto && labels && result && ws && C == 256 && K >= 1 && K <= KMAX && N >= 1 && ldf % 4 == 0);
   ONDA_REQUIRE(!mahalanobis || sigma);
   if (!ONDA_ALIGNED16(feat) || !ONDA_ALIGNED16(proto)) return ONDA_EALIGN;
-  const int nb = onda_proto_assign_blocks(N);
-  hipLaunchKernelGGL(proto_assign_kernel, dim3(nb), dim3(256), 0, ONDA_STREAM(s), feat, ldf, prior, ldp, proto, sigma,
-                     mahalanobis, tau, thresh, labels, soft, ws, N, K);
-  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(64), 0, ONDA_STREAM(s), ws, nb, 3, (float)(1.0 / (double)N),
-                     result);
+  if (proto_direct_only() || N >= (1ll << 31)) {  // the direct form everywhere (measurement / fallback for huge N)
+    int64_t nb = (N + 3) / 4;
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(proto_assign_kernel, dim3((unsigned)nb), dim3(256), 0, ONDA_STREAM(s), feat, ldf, prior, ldp, proto, sigma,
+                       mahalanobis, tau, thresh, labels, soft, ws, N, K, nullptr, nullptr);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(192), 0, ONDA_STREAM(s), ws, (int)nb, 3, (float)(1.0 / (double)N),
+                       result);
+    return ONDA_LAUNCH_RESULT();
+  }
+  int* list = reinterpret_cast<int*>(ws + 3 * (PA_GRID + PA_LIST_GRID));
+  int* list_len = list + N;
+  hipError_t e = hipMemsetAsync(list_len, 0, sizeof(int), ONDA_STREAM(s));
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(proto_assign_mfma_kernel, dim3(PA_GRID), dim3(64 * PA_WAVES), 0, ONDA_STREAM(s), feat, ldf, prior, ldp, proto, sigma,
+                     mahalanobis, tau, thresh, 1.0e-3f, labels, soft, ws, list, list_len, N, K);
+  hipLaunchKernelGGL(proto_assign_kernel, dim3(PA_LIST_GRID), dim3(256), 0, ONDA_STREAM(s), feat, ldf, prior, ldp, proto, sigma,
+                     mahalanobis, tau, thresh, labels, soft, ws + 3 * PA_GRID, N, K, list, list_len);
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(192), 0, ONDA_STREAM(s), ws, PA_GRID + PA_LIST_GRID, 3,
+                     (float)(1.0 / (double)N), result);
   return ONDA_LAUNCH_RESULT();
 }
 
