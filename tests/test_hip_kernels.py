@@ -212,6 +212,32 @@ def test_eval_conv_writes_limb_planes(cin, cout, k, dil, H, W, res):
     assert lb2.true_amax.max().item() <= lb2.amax.max().item() <= lb2.true_amax.max().item() * 2.0 ** 13
 
 
+def test_model_packer_matches_the_single_weight_packer():
+    """All conv weights of a model packed in two launches (LDS-blocked transposition) against the one-weight packer:
+    bit-identical limb planes in the forward and the data-gradient layout, same max|w|; 1 x 1 and 3 x 3 filters, channel
+    counts that are and are not multiples of the 32-channel block (the latter take the element-per-thread path)."""
+    from onda_amd import ops
+    from onda_amd.framework.model.deeplabv2 import HipConv2d
+    old, ops.CONV_MODE = ops.CONV_MODE, "f16x2"
+    try:
+        g = torch.Generator().manual_seed(21)
+        shapes = [(64, 256, 1), (256, 64, 3), (128, 128, 3), (2048, 512, 1), (96, 40, 3), (32, 1280, 3)]
+        convs = []
+        for cin, cout, k in shapes:
+            c = HipConv2d(cin, cout, kernel_size=k, padding=k // 2, bias=False).to(DEV)
+            c.weight.data = (torch.randn(cout, cin, k, k, generator=g) * 10.0 ** float(torch.randn((), generator=g))).to(DEV)
+            convs.append(c)
+        ops.ModelPacker(convs).refresh(need_dgrad=True)
+        for c in convs:
+            f, d = c._pack.get_fwd(c.weight), c._pack.get_dgrad(c.weight)
+            rf, rd = ops.pack_weight_fwd(c.weight.detach().clone()), ops.pack_weight_dgrad(c.weight.detach().clone())
+            assert f.amax.max().item() == rf.amax.max().item() == c.weight.abs().max().item()
+            assert torch.equal(f.limbs.reshape(-1), rf.limbs.reshape(-1)), tuple(c.weight.shape)
+            assert torch.equal(d.limbs.reshape(-1), rd.limbs.reshape(-1)), tuple(c.weight.shape)
+    finally:
+        ops.CONV_MODE = old
+
+
 def test_host_never_waits_for_tables_or_monitor_scalars():
     """Multi-tensor entry tables and the monitor's device scalars reach their destination through pinned staging
     buffers (asynchronous copies): same values as the direct path, staging buffers reused only after their copy's event
