@@ -97,9 +97,11 @@ typedef struct {
   void* fwd;
   void* dgrad;
   float* amax;
-  int Cout, Cin, taps, pad_;
+  int Cout, Cin, taps;
+  int first_block; /* sum of onda_pack_blocks() of the entries before this one */
 } OndaPackEntry;
-int onda_pack_weights_h2_multi(const OndaPackEntry* table, int n, int64_t max_elems, onda_stream_t s);
+int onda_pack_blocks(int Cout, int Cin, int taps); /* workgroups one entry takes in the two launches */
+int onda_pack_weights_h2_multi(const OndaPackEntry* table, int n, int64_t total_blocks, onda_stream_t s);
 /* onda_conv2d_fwd with the activations split in-kernel (xamax = max|x|) and the weights pre-split (w2 / wamax
  * from onda_pack_weight_h2); same epilogue, workspace and schedule.  yamax (optional, zeroed): max|y| */
 int onda_conv2d_fwd_h2(const float* x, const float* xamax, const void* w2, const float* wamax, float* y,

@@ -30,7 +30,7 @@ class OndaSgdEntry(Structure):
 
 class OndaPackEntry(Structure):
     _fields_ = [("w", c_void_p), ("fwd", c_void_p), ("dgrad", c_void_p), ("amax", c_void_p), ("Cout", c_int), ("Cin", c_int),
-                ("taps", c_int), ("pad_", c_int)]
+                ("taps", c_int), ("first_block", c_int)]
 
 
 class OndaEmaEntry(Structure):
@@ -47,6 +47,7 @@ SIGNATURES = {
     "onda_absmax": (I, [P, L, I, I, P, P]),
     "onda_pack_weight_h2": (I, [P, P, I, I, I, I, I, I, I, P, P]),
     "onda_pack_weights_h2_multi": (I, [P, I, L, P]),
+    "onda_pack_blocks": (I, [I, I, I]),
     "onda_conv2d_fwd_h2": (I, [P, P, P, P, P, P, P, P, P, P, P, POINTER(OndaConv), P]),
     "onda_conv2d_wgrad_h2": (I, [P, P, P, P, P, I, I, POINTER(OndaConv), P]),
     "onda_split_h2": (I, [P, L, I, I, P, I, L, P, P]),

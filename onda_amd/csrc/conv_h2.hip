@@ -139,11 +139,39 @@ __global__ void pack_h2_kernel(const float* __restrict__ w, _Float16* __restrict
 // The student's weights change every step (SGD) and so do the teacher's (EMA): ~100 weight tensors to re-scale and
 // re-split, forward and data-gradient form.  One absmax + one pack launch per tensor cost 3 ms of launch overhead per
 // step; a table of tensors in device memory makes it one launch each.
-__global__ __launch_bounds__(256) void absmax_multi_kernel(const OndaPackEntry* __restrict__ table) {
-  const OndaPackEntry e = table[blockIdx.y];
-  const long long n = (long long)e.Cout * e.Cin * e.taps;
+// The launches are FLAT: an entry owns the blocks [first_block, first_block + onda_pack_blocks(entry)) of one 1-D grid
+// (a (largest tensor) x (entries) grid dispatched 106 000 workgroups for a ResNet-50, nine in ten of them empty: the
+// dispatch alone took longer than the copy).  A workgroup finds its entry by bisection over the table.
+constexpr int PK_BLOCK_ELEMS = 9216;   // weights per block: one 32 x 32 x 9 unit, or nine 32 x 32 x 1 units (loaded together)
+constexpr int PK_T = 32;               // channels per side of a unit
+constexpr int PK_MAXTAPS = 9;          // 3 x 3 (other filters take the element-per-thread path)
+__host__ __device__ inline bool pack_fast(int Cout, int Cin, int taps) {
+  return (taps == 1 || taps == 9) && Cin % PK_T == 0 && Cout % PK_T == 0;
+}
+__host__ __device__ inline int pack_blocks_of(int Cout, int Cin, int taps) {
+  if (pack_fast(Cout, Cin, taps)) {
+    const int units = (Cout / PK_T) * (Cin / PK_T), upb = PK_BLOCK_ELEMS / (PK_T * PK_T * taps);
+    return (units + upb - 1) / upb;
+  }
+  const long long elems = (long long)Cout * Cin * taps;
+  return (int)((elems + PK_BLOCK_ELEMS - 1) / PK_BLOCK_ELEMS);
+}
+__device__ __forceinline__ int pack_entry_of(const OndaPackEntry* __restrict__ table, int n, int block) {
+  int lo = 0, hi = n - 1;  // largest i with table[i].first_block <= block
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (table[mid].first_block <= block) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+
+__global__ __launch_bounds__(256) void absmax_multi_kernel(const OndaPackEntry* __restrict__ table, int n_entries) {
+  const OndaPackEntry e = table[pack_entry_of(table, n_entries, blockIdx.x)];
+  const int lb = blockIdx.x - e.first_block, nb = pack_blocks_of(e.Cout, e.Cin, e.taps);
+  const long long n = (long long)e.Cout * e.Cin * e.taps, per = (n + nb - 1) / nb;
+  const long long i0 = lb * per, i1 = i0 + per < n ? i0 + per : n;
   float m = 0.f;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) m = fmaxf(m, fabsf(e.w[i]));
+  for (long long i = i0 + threadIdx.x; i < i1; i += 256) m = fmaxf(m, fabsf(e.w[i]));
   __shared__ float red[4];
   amax_update_block(e.amax, m, red);
 }
@@ -153,63 +181,69 @@ __global__ __launch_bounds__(256) void absmax_multi_kernel(const OndaPackEntry* 
 // read below is conflict-free) and writes the forward rows [n][tap][c] and the data-gradient rows [c][tap'][n] (taps
 // flipped) in runs of 32 f16 per limb plane.  (The element-per-thread version gathered with a stride of `taps` floats
 // and scattered 2-byte stores: 280 us for a ResNet-50's weights, 5 x the time this traffic takes at HBM rate.)
-constexpr int PK_T = 32;          // channels per side of a block
-constexpr int PK_MAXTAPS = 9;     // 3 x 3 (larger filters take the element-per-thread path below)
-
 template <int TAPS>
-__device__ __forceinline__ void pack_blocks(const OndaPackEntry& e, float s, float* tile) {
+__device__ __forceinline__ void pack_blocks(const OndaPackEntry& e, float s, float* tile, int lb) {
   constexpr int ROW = PK_T * TAPS + 1, PER_N = PK_T * TAPS, TOTAL = PK_T * PER_N;
+  constexpr int UPB = PK_BLOCK_ELEMS / (PK_T * PK_T * TAPS), SLOT = PK_T * ROW;  // units per block, floats per unit in LDS
   const size_t plane = (size_t)e.Cout * e.Cin * TAPS;
   const int K = TAPS * e.Cin, Kd = TAPS * e.Cout;
   _Float16* fwd = static_cast<_Float16*>(e.fwd);
   _Float16* dg = static_cast<_Float16*>(e.dgrad);
   const int cblocks = e.Cin / PK_T, units = (e.Cout / PK_T) * cblocks;
-  for (int u = blockIdx.x; u < units; u += gridDim.x) {
-    const int n0 = (u / cblocks) * PK_T, c0 = (u % cblocks) * PK_T;
-    __syncthreads();  // the previous unit's readers are done
-    for (int i = threadIdx.x; i < TOTAL; i += 256) {
-      const int nl = i / PER_N, r = i - nl * PER_N;  // r = c_l * TAPS + tap: contiguous in memory
-      tile[nl * ROW + r] = e.w[((size_t)(n0 + nl) * e.Cin + c0) * TAPS + r] * s;
-    }
-    __syncthreads();
-    // two neighbouring elements per thread: 4-byte stores, runs of 32 f16 per limb plane
-    for (int j = threadIdx.x; j < TOTAL / 2; j += 256) {  // forward form: (n_l, tap, c_l), c_l fastest
-      const int cl = (j % (PK_T / 2)) * 2, q = j / (PK_T / 2), tap = q % TAPS, nl = q / TAPS;
-      const float v0 = tile[nl * ROW + cl * TAPS + tap], v1 = tile[nl * ROW + (cl + 1) * TAPS + tap];
+  const int u0 = lb * UPB, nu = units - u0 < UPB ? units - u0 : UPB;
+  // all of the block's units are loaded before the one barrier (a 1 x 1 unit alone is 4 KB: nine load / barrier / store
+  // round trips in a row were latency, not bandwidth)
+  for (int i = threadIdx.x; i < nu * TOTAL; i += 256) {
+    const int us = i / TOTAL, k = i - us * TOTAL, nl = k / PER_N, r = k - nl * PER_N;  // r = c_l * TAPS + tap: contiguous
+    const int u = u0 + us, n0 = (u / cblocks) * PK_T, c0 = (u % cblocks) * PK_T;
+    tile[us * SLOT + nl * ROW + r] = e.w[((size_t)(n0 + nl) * e.Cin + c0) * TAPS + r] * s;
+  }
+  __syncthreads();
+  // two neighbouring elements per thread: 4-byte stores, runs of 32 f16 per limb plane
+  for (int i = threadIdx.x; i < nu * (TOTAL / 2); i += 256) {  // forward form: (n_l, tap, c_l), c_l fastest
+    const int us = i / (TOTAL / 2), j = i - us * (TOTAL / 2);
+    const int u = u0 + us, n0 = (u / cblocks) * PK_T, c0 = (u % cblocks) * PK_T;
+    const int cl = (j % (PK_T / 2)) * 2, q = j / (PK_T / 2), tap = q % TAPS, nl = q / TAPS;
+    const float* tl = tile + us * SLOT;
+    const float v0 = tl[nl * ROW + cl * TAPS + tap], v1 = tl[nl * ROW + (cl + 1) * TAPS + tap];
+    const unsigned p1 = cvt2h(v0, v1);
+    const f32x2 f = unpack2h(p1);
+    const size_t o = (size_t)(n0 + nl) * K + (size_t)tap * e.Cin + c0 + cl;
+    *reinterpret_cast<unsigned*>(fwd + o) = p1;
+    *reinterpret_cast<unsigned*>(fwd + plane + o) = cvt2h((v0 - f[0]) * LIMB2_SCALE, (v1 - f[1]) * LIMB2_SCALE);
+  }
+  if (dg != nullptr) {
+    for (int i = threadIdx.x; i < nu * (TOTAL / 2); i += 256) {  // data-gradient form: (c_l, tap', n_l), n_l fastest
+      const int us = i / (TOTAL / 2), j = i - us * (TOTAL / 2);
+      const int u = u0 + us, n0 = (u / cblocks) * PK_T, c0 = (u % cblocks) * PK_T;
+      const int nl = (j % (PK_T / 2)) * 2, q = j / (PK_T / 2), tapd = q % TAPS, cl = q / TAPS;
+      const float* tl = tile + us * SLOT;
+      const float v0 = tl[nl * ROW + cl * TAPS + (TAPS - 1 - tapd)], v1 = tl[(nl + 1) * ROW + cl * TAPS + (TAPS - 1 - tapd)];
       const unsigned p1 = cvt2h(v0, v1);
       const f32x2 f = unpack2h(p1);
-      const size_t o = (size_t)(n0 + nl) * K + (size_t)tap * e.Cin + c0 + cl;
-      *reinterpret_cast<unsigned*>(fwd + o) = p1;
-      *reinterpret_cast<unsigned*>(fwd + plane + o) = cvt2h((v0 - f[0]) * LIMB2_SCALE, (v1 - f[1]) * LIMB2_SCALE);
-    }
-    if (dg != nullptr) {
-      for (int j = threadIdx.x; j < TOTAL / 2; j += 256) {  // data-gradient form: (c_l, tap', n_l), n_l fastest
-        const int nl = (j % (PK_T / 2)) * 2, q = j / (PK_T / 2), tapd = q % TAPS, cl = q / TAPS;
-        const float v0 = tile[nl * ROW + cl * TAPS + (TAPS - 1 - tapd)], v1 = tile[(nl + 1) * ROW + cl * TAPS + (TAPS - 1 - tapd)];
-        const unsigned p1 = cvt2h(v0, v1);
-        const f32x2 f = unpack2h(p1);
-        const size_t o = (size_t)(c0 + cl) * Kd + (size_t)tapd * e.Cout + n0 + nl;
-        *reinterpret_cast<unsigned*>(dg + o) = p1;
-        *reinterpret_cast<unsigned*>(dg + plane + o) = cvt2h((v0 - f[0]) * LIMB2_SCALE, (v1 - f[1]) * LIMB2_SCALE);
-      }
+      const size_t o = (size_t)(c0 + cl) * Kd + (size_t)tapd * e.Cout + n0 + nl;
+      *reinterpret_cast<unsigned*>(dg + o) = p1;
+      *reinterpret_cast<unsigned*>(dg + plane + o) = cvt2h((v0 - f[0]) * LIMB2_SCALE, (v1 - f[1]) * LIMB2_SCALE);
     }
   }
 }
 
-__global__ __launch_bounds__(256) void pack_h2_multi_kernel(const OndaPackEntry* __restrict__ table) {
-  const OndaPackEntry e = table[blockIdx.y];
+__global__ __launch_bounds__(256) void pack_h2_multi_kernel(const OndaPackEntry* __restrict__ table, int n_entries) {
+  const OndaPackEntry e = table[pack_entry_of(table, n_entries, blockIdx.x)];
+  const int lb = blockIdx.x - e.first_block;
   const size_t plane = (size_t)e.Cout * e.Cin * e.taps;  // both forms have Cout*taps*Cin elements per limb plane
   const float s = scale_of(e.amax).s;
   const int K = e.taps * e.Cin, Kd = e.taps * e.Cout;
   _Float16* fwd = static_cast<_Float16*>(e.fwd);
   _Float16* dg = static_cast<_Float16*>(e.dgrad);
-  if ((e.taps == 1 || e.taps == 9) && e.Cin % PK_T == 0 && e.Cout % PK_T == 0) {
-    __shared__ float tile[PK_T * (PK_T * PK_MAXTAPS + 1)];
-    if (e.taps == 1) pack_blocks<1>(e, s, tile);
-    else pack_blocks<9>(e, s, tile);
+  if (pack_fast(e.Cout, e.Cin, e.taps)) {
+    __shared__ float tile[9 * PK_T * (PK_T + 1) > PK_T * (PK_T * PK_MAXTAPS + 1) ? 9 * PK_T * (PK_T + 1) : PK_T * (PK_T * PK_MAXTAPS + 1)];
+    if (e.taps == 1) pack_blocks<1>(e, s, tile, lb);
+    else pack_blocks<9>(e, s, tile, lb);
     return;
   }
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < plane; i += (size_t)gridDim.x * 256) {
+  const size_t i_end = (size_t)(lb + 1) * PK_BLOCK_ELEMS < plane ? (size_t)(lb + 1) * PK_BLOCK_ELEMS : plane;
+  for (size_t i = (size_t)lb * PK_BLOCK_ELEMS + threadIdx.x; i < i_end; i += 256) {
     {  // forward form: row n, k = tap*Cin + c
       const int k = (int)(i % K), n = (int)(i / K);
       const int tap = k / e.Cin, cc = k - tap * e.Cin;
@@ -636,12 +670,12 @@ int onda_pack_weight_h2(const float* w_oihw, void* dst, int Cout, int Cin, int t
   return ONDA_LAUNCH_RESULT();
 }
 
-int onda_pack_weights_h2_multi(const OndaPackEntry* table, int n, int64_t max_elems, onda_stream_t s) {
-  ONDA_REQUIRE(table && n > 0 && max_elems > 0);
-  // enough workgroups for the largest tensor to run at memory speed (small tensors' surplus workgroups exit at once)
-  const int chunks = (int)(max_elems / (256 * 8) + 1 > 1024 ? 1024 : max_elems / (256 * 8) + 1);
-  hipLaunchKernelGGL(absmax_multi_kernel, dim3(chunks, n), dim3(256), 0, ONDA_STREAM(s), table);
-  hipLaunchKernelGGL(pack_h2_multi_kernel, dim3(chunks, n), dim3(256), 0, ONDA_STREAM(s), table);
+int onda_pack_blocks(int Cout, int Cin, int taps) { return Cout > 0 && Cin > 0 && taps > 0 ? pack_blocks_of(Cout, Cin, taps) : 0; }
+
+int onda_pack_weights_h2_multi(const OndaPackEntry* table, int n, int64_t total_blocks, onda_stream_t s) {
+  ONDA_REQUIRE(table && n > 0 && total_blocks > 0 && total_blocks < (1ll << 31));
+  hipLaunchKernelGGL(absmax_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, ONDA_STREAM(s), table, n);
+  hipLaunchKernelGGL(pack_h2_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, ONDA_STREAM(s), table, n);
   return ONDA_LAUNCH_RESULT();
 }
 

@@ -620,7 +620,7 @@ class ModelPacker:
         if not stale:
             return
         dev = stale[0][0].weight.device
-        ents, biggest = [], 0
+        ents, biggest = [], 0  # biggest: running total of blocks
         for c, key in stale:
             w = c.weight.detach()
             if not w.is_contiguous():
@@ -639,8 +639,8 @@ class ModelPacker:
             else:
                 cache.key_d = None
             ents.append(_lib.OndaPackEntry(w.data_ptr(), buf[0].data_ptr(), buf[1].data_ptr() if need_dgrad else None, slot.data_ptr(),
-                                           cout, cin, kh * kw, 0))
-            biggest = max(biggest, w.numel())
+                                           cout, cin, kh * kw, biggest))
+            biggest += query("onda_pack_blocks", cout, cin, kh * kw)  # running total: the next entry's first block
             self._keep = getattr(self, "_keep", [])
             self._keep.append(w)
         table = _table(ents, _lib.OndaPackEntry, dev)
