@@ -335,12 +335,14 @@ int onda_proto_append(float* proto, float* sqmean, float* counter, const float* 
  * prototypes.py:407-416 EMA teacher).  Tables are device arrays of n entries. ---------------- */
 typedef struct OndaSgdEntry {
   float* p; const float* g; float* buf; int64_t n; float lr; int times; int fresh;
+  int first_block; /* flat launch: blocks of the entries before this one, ceil(n / onda_multi_tensor_block()) each */
 } OndaSgdEntry;
-int onda_sgd_multi(const OndaSgdEntry* table, int n, float momentum, float weight_decay, int64_t max_n,
+int onda_multi_tensor_block(void); /* elements per workgroup of the multi-tensor launches */
+int onda_sgd_multi(const OndaSgdEntry* table, int n, float momentum, float weight_decay, int64_t total_blocks,
                    onda_stream_t s);
 /* k = k*keep + q*blend  (keep=0, blend=1 copies a buffer, prototypes.py:415-416) */
-typedef struct OndaEmaEntry { float* k; const float* q; int64_t n; float keep; float blend; } OndaEmaEntry;
-int onda_ema_multi(const OndaEmaEntry* table, int n, int64_t max_n, onda_stream_t s);
+typedef struct OndaEmaEntry { float* k; const float* q; int64_t n; float keep; float blend; int first_block; } OndaEmaEntry;
+int onda_ema_multi(const OndaEmaEntry* table, int n, int64_t total_blocks, onda_stream_t s);
 
 /* ---- input pipeline -----------------------------------------------------------
  * Replaces the per-sample CPU work of framework/dataset/segmentation_db.py:56-99 (`__getitem__`,

@@ -25,7 +25,7 @@ class OndaLimbOut(Structure):
 
 class OndaSgdEntry(Structure):
     _fields_ = [("p", c_void_p), ("g", c_void_p), ("buf", c_void_p), ("n", c_int64), ("lr", c_float),
-                ("times", c_int), ("fresh", c_int)]
+                ("times", c_int), ("fresh", c_int), ("first_block", c_int)]
 
 
 class OndaPackEntry(Structure):
@@ -34,7 +34,7 @@ class OndaPackEntry(Structure):
 
 
 class OndaEmaEntry(Structure):
-    _fields_ = [("k", c_void_p), ("q", c_void_p), ("n", c_int64), ("keep", c_float), ("blend", c_float)]
+    _fields_ = [("k", c_void_p), ("q", c_void_p), ("n", c_int64), ("keep", c_float), ("blend", c_float), ("first_block", c_int)]
 
 
 # name -> (restype, argtypes); mirrors include/onda_hip.h one to one
@@ -101,6 +101,7 @@ SIGNATURES = {
     "onda_proto_append": (I, [P, P, P, P, P, I, I, P]),
     "onda_sgd_multi": (I, [P, I, F, F, L, P]),
     "onda_ema_multi": (I, [P, I, L, P]),
+    "onda_multi_tensor_block": (I, []),
     "onda_resample_h_u8": (I, [P, P, I, I, I, P, P, I, P]),
     "onda_resample_v_norm": (I, [P, P, I, I, I, P, P, I, POINTER(c_float), POINTER(c_float), I, P]),
     "onda_resize_nearest_lut": (I, [P, P, I, I, I, P, P, P, P]),

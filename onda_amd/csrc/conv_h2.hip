@@ -157,10 +157,16 @@ __host__ __device__ inline int pack_blocks_of(int Cout, int Cin, int taps) {
   return (int)((elems + PK_BLOCK_ELEMS - 1) / PK_BLOCK_ELEMS);
 }
 __device__ __forceinline__ int pack_entry_of(const OndaPackEntry* __restrict__ table, int n, int block) {
+  __shared__ int starts[1024];  // block starts in LDS: the bisection's dependent loads stay off the memory system
+  const bool in_lds = n <= 1024;
+  if (in_lds) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) starts[i] = table[i].first_block;
+    __syncthreads();
+  }
   int lo = 0, hi = n - 1;  // largest i with table[i].first_block <= block
   while (lo < hi) {
     const int mid = (lo + hi + 1) >> 1;
-    if (table[mid].first_block <= block) lo = mid; else hi = mid - 1;
+    if ((in_lds ? starts[mid] : table[mid].first_block) <= block) lo = mid; else hi = mid - 1;
   }
   return lo;
 }

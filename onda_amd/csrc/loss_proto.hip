@@ -540,26 +540,80 @@ __global__ void proto_append_counter_kernel(float* __restrict__ counter, const f
 }
 
 // ---- multi-tensor optimizer / teacher ---------------------------------------------------------
-__global__ __launch_bounds__(256) void sgd_multi_kernel(const OndaSgdEntry* __restrict__ table, float momentum,
+// FLAT launches (see pack_h2_multi_kernel): an entry owns the blocks [first_block, first_block + ceil(n / MT_BLOCK)) of a 1-D
+// grid and is found by bisection -- a (largest tensor) x (217 tensors) grid is nine tenths empty workgroups.
+constexpr int MT_BLOCK = 4096;  // elements per workgroup: four 16-byte vectors per thread
+template <class E>
+__device__ __forceinline__ int mt_entry_of(const E* __restrict__ table, int n, int block) {
+  // the block starts go to LDS first (one load per thread): ten dependent global loads per workgroup were most of a
+  // 16 KB workgroup's life
+  __shared__ int starts[1024];
+  const bool in_lds = n <= 1024;
+  if (in_lds) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) starts[i] = table[i].first_block;
+    __syncthreads();
+  }
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if ((in_lds ? starts[mid] : table[mid].first_block) <= block) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+
+__device__ __forceinline__ void sgd_one(float& p, float& b, float g, float lr, float momentum, float wd, int times, int fresh) {
+  if (fresh) b = 0.f;
+  for (int r = 0; r < times; ++r) {
+    const float d = g + wd * p;
+    b = fresh ? d : b * momentum + d;
+    p = p - lr * b;
+  }
+}
+
+__global__ __launch_bounds__(256) void sgd_multi_kernel(const OndaSgdEntry* __restrict__ table, int n_entries, float momentum,
                                                         float wd) {
-  const OndaSgdEntry e = table[blockIdx.y];
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < e.n; i += (int64_t)gridDim.x * 256) {
-    float p = e.p[i], b = e.fresh ? 0.f : e.buf[i];
-    const float g = e.g[i];
-    for (int r = 0; r < e.times; ++r) {
-      const float d = g + wd * p;
-      b = e.fresh ? d : b * momentum + d;
-      p = p - e.lr * b;
+  const OndaSgdEntry e = table[mt_entry_of(table, n_entries, blockIdx.x)];
+  const int64_t i0 = (int64_t)(blockIdx.x - e.first_block) * MT_BLOCK, i1 = i0 + MT_BLOCK < e.n ? i0 + MT_BLOCK : e.n;
+  const bool vec = ((reinterpret_cast<size_t>(e.p) | reinterpret_cast<size_t>(e.g) | reinterpret_cast<size_t>(e.buf)) & 15) == 0;
+  if (vec && i1 - i0 == MT_BLOCK) {
+#pragma unroll
+    for (int k = 0; k < MT_BLOCK / 1024; ++k) {
+      const int64_t i = i0 + (k * 256 + threadIdx.x) * 4;
+      f32x4 p = *reinterpret_cast<const f32x4*>(e.p + i), b = e.fresh ? f32x4{0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4*>(e.buf + i);
+      const f32x4 g = *reinterpret_cast<const f32x4*>(e.g + i);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float pj = p[j], bj = b[j];
+        sgd_one(pj, bj, g[j], e.lr, momentum, wd, e.times, e.fresh);
+        p[j] = pj;
+        b[j] = bj;
+      }
+      *reinterpret_cast<f32x4*>(e.p + i) = p;
+      *reinterpret_cast<f32x4*>(e.buf + i) = b;
     }
+    return;
+  }
+  for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
+    float p = e.p[i], b = e.fresh ? 0.f : e.buf[i];
+    sgd_one(p, b, e.g[i], e.lr, momentum, wd, e.times, e.fresh);
     e.p[i] = p;
     e.buf[i] = b;
   }
 }
 
-__global__ __launch_bounds__(256) void ema_multi_kernel(const OndaEmaEntry* __restrict__ table) {
-  const OndaEmaEntry e = table[blockIdx.y];
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < e.n; i += (int64_t)gridDim.x * 256)
-    e.k[i] = e.k[i] * e.keep + e.q[i] * e.blend;
+__global__ __launch_bounds__(256) void ema_multi_kernel(const OndaEmaEntry* __restrict__ table, int n_entries) {
+  const OndaEmaEntry e = table[mt_entry_of(table, n_entries, blockIdx.x)];
+  const int64_t i0 = (int64_t)(blockIdx.x - e.first_block) * MT_BLOCK, i1 = i0 + MT_BLOCK < e.n ? i0 + MT_BLOCK : e.n;
+  const bool vec = ((reinterpret_cast<size_t>(e.k) | reinterpret_cast<size_t>(e.q)) & 15) == 0;
+  if (vec && i1 - i0 == MT_BLOCK) {
+#pragma unroll
+    for (int k = 0; k < MT_BLOCK / 1024; ++k) {
+      const int64_t i = i0 + (k * 256 + threadIdx.x) * 4;
+      *reinterpret_cast<f32x4*>(e.k + i) = *reinterpret_cast<const f32x4*>(e.k + i) * e.keep + *reinterpret_cast<const f32x4*>(e.q + i) * e.blend;
+    }
+    return;
+  }
+  for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) e.k[i] = e.k[i] * e.keep + e.q[i] * e.blend;
 }
 
 }  // namespace
@@ -680,19 +734,16 @@ int onda_proto_append(float* proto, float* sqmean, float* counter, const float* 
 
 int onda_sgd_multi(const OndaSgdEntry* table, int n, float momentum, float weight_decay, int64_t max_n,
                    onda_stream_t s) {
-  ONDA_REQUIRE(table && n >= 1 && max_n >= 1);
-  int64_t gx = (max_n + 1023) / 1024;
-  if (gx > 128) gx = 128;
-  hipLaunchKernelGGL(sgd_multi_kernel, dim3((unsigned)gx, n), dim3(256), 0, ONDA_STREAM(s), table, momentum,
-                     weight_decay);
+  ONDA_REQUIRE(table && n >= 1 && max_n >= 1 && max_n < (1ll << 31));  // max_n: total blocks (flat launch)
+  hipLaunchKernelGGL(sgd_multi_kernel, dim3((unsigned)max_n), dim3(256), 0, ONDA_STREAM(s), table, n, momentum, weight_decay);
   return ONDA_LAUNCH_RESULT();
 }
 
+int onda_multi_tensor_block(void) { return MT_BLOCK; }
+
 int onda_ema_multi(const OndaEmaEntry* table, int n, int64_t max_n, onda_stream_t s) {
-  ONDA_REQUIRE(table && n >= 1 && max_n >= 1);
-  int64_t gx = (max_n + 1023) / 1024;
-  if (gx > 128) gx = 128;
-  hipLaunchKernelGGL(ema_multi_kernel, dim3((unsigned)gx, n), dim3(256), 0, ONDA_STREAM(s), table);
+  ONDA_REQUIRE(table && n >= 1 && max_n >= 1 && max_n < (1ll << 31));  // max_n: total blocks (flat launch)
+  hipLaunchKernelGGL(ema_multi_kernel, dim3((unsigned)max_n), dim3(256), 0, ONDA_STREAM(s), table, n);
   return ONDA_LAUNCH_RESULT();
 }
 

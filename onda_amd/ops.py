@@ -1185,20 +1185,25 @@ def _table(entries, struct, device):
 
 def sgd_multi(items, momentum, weight_decay):
     """items: list of (param, grad, buf, lr, times, fresh).  One launch for all tensors."""
-    ents = [_lib.OndaSgdEntry(p.data_ptr(), g.data_ptr(), b.data_ptr(), p.numel(), float(lr), int(times), int(fresh))
-            for p, g, b, lr, times, fresh in items]
+    blk, ents, first = query("onda_multi_tensor_block"), [], 0
+    for p, g, b, lr, times, fresh in items:
+        ents.append(_lib.OndaSgdEntry(p.data_ptr(), g.data_ptr(), b.data_ptr(), p.numel(), float(lr), int(times), int(fresh), first))
+        first += -(-p.numel() // blk)
     dev = items[0][0].device
     table = _table(ents, _lib.OndaSgdEntry, dev)
-    call("onda_sgd_multi", _p(table), len(ents), float(momentum), float(weight_decay), max(e.n for e in ents), _stream())
+    call("onda_sgd_multi", _p(table), len(ents), float(momentum), float(weight_decay), first, _stream())
     for p, *_ in items:
         torch.autograd.graph.increment_version(p)
 
 
 def ema_multi(items):
     """items: list of (k, q, keep, blend): k = k*keep + q*blend, one launch."""
-    ents = [_lib.OndaEmaEntry(k.data_ptr(), q.data_ptr(), k.numel(), float(keep), float(blend)) for k, q, keep, blend in items]
+    blk, ents, first = query("onda_multi_tensor_block"), [], 0
+    for k, q, keep, blend in items:
+        ents.append(_lib.OndaEmaEntry(k.data_ptr(), q.data_ptr(), k.numel(), float(keep), float(blend), first))
+        first += -(-k.numel() // blk)
     dev = items[0][0].device
     table = _table(ents, _lib.OndaEmaEntry, dev)
-    call("onda_ema_multi", _p(table), len(ents), max(e.n for e in ents), _stream())
+    call("onda_ema_multi", _p(table), len(ents), first, _stream())
     for k, *_ in items:
         torch.autograd.graph.increment_version(k)

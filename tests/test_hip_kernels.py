@@ -246,7 +246,7 @@ def test_host_never_waits_for_tables_or_monitor_scalars():
     from onda_amd import ops, _lib
     from onda_amd.framework.utils.monitoring import Monitor
     # tables: round trip of the bytes, ring reuse
-    ents = [_lib.OndaEmaEntry(1000 + i, 2000 + i, 10 + i, 0.5, 0.5) for i in range(300)]
+    ents = [_lib.OndaEmaEntry(1000 + i, 2000 + i, 10 + i, 0.5, 0.5, i) for i in range(300)]
     want = bytes((_lib.OndaEmaEntry * len(ents))(*ents))
     for _ in range(6):
         dev = ops._table(ents, _lib.OndaEmaEntry, torch.device(DEV))
