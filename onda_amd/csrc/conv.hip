@@ -435,27 +435,115 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK a) {
   }
 }
 
-__global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw, int splitk, int Cout,
-                                    int taps, int Cin, int Cout_real, int Cin_real, int flat_k, int accumulate) {
+// slabs k0 .. k1-1 of one 16-byte element group, summed in ascending order; eight loads in flight (a tail is padded with
+// zeros, which add exactly)
+__device__ __forceinline__ f32x4 slab_sum(const float* __restrict__ src, size_t total, int k0, int k1) {
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  f32x4 s = zero;
+  for (int k = k0; k < k1; k += 8) {
+    f32x4 v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = k + j < k1 ? *reinterpret_cast<const f32x4*>(src + (size_t)(k + j) * total) : zero;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += v[j];
+  }
+  return s;
+}
+
+// Filters with taps: slabs are [n][tap][cc], the gradient is [n][cc][tap].  A workgroup owns dw[n][cc0 .. cc0+128)[all taps]
+// -- 128 * taps contiguous floats -- transposes through LDS and stores them as 16-byte vectors (a thread-per-element store
+// leaves 4 of every 36 bytes, and the rest of each line to workgroups on other XCDs: partial-line writes all the way to HBM).
+__global__ __launch_bounds__(256) void wgrad_reduce_taps_kernel(const float* __restrict__ slabs, float* __restrict__ dw, int splitk,
+                                                                int Cout, int taps, int Cin, int Cout_real, int accumulate) {
+  __shared__ __attribute__((aligned(16))) float tile[128 * 9];
+  const int cbs = Cin / 128;
+  const int n = blockIdx.x / cbs, cc0 = (blockIdx.x % cbs) * 128;
+  if (n >= Cout_real) return;
   const size_t total = (size_t)Cout * taps * Cin;
-  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int items = 32 * taps, t = threadIdx.x;
+  // items t and t + 256 (taps <= 9: at most 288 items); both sums in flight together
+  const int i1 = t + 256;
+  const float* src0 = slabs + ((size_t)n * taps + (t >> 5)) * Cin + cc0 + 4 * (t & 31);
+  const float* src1 = slabs + ((size_t)n * taps + (i1 >> 5)) * Cin + cc0 + 4 * (i1 & 31);
+  const bool has0 = t < items, has1 = i1 < items;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  f32x4 s0 = zero, s1 = zero;
+  for (int k = 0; k < splitk; k += 8) {
+    f32x4 v[8], u[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      v[j] = has0 && k + j < splitk ? *reinterpret_cast<const f32x4*>(src0 + (size_t)(k + j) * total) : zero;
+      u[j] = has1 && k + j < splitk ? *reinterpret_cast<const f32x4*>(src1 + (size_t)(k + j) * total) : zero;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      s0 += v[j];
+      s1 += u[j];
+    }
+  }
+  if (has0)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) tile[(4 * (t & 31) + j) * taps + (t >> 5)] = s0[j];
+  if (has1)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) tile[(4 * (i1 & 31) + j) * taps + (i1 >> 5)] = s1[j];
+  __syncthreads();
+  f32x4* d = reinterpret_cast<f32x4*>(dw + ((size_t)n * Cin + cc0) * taps);
+  for (int i = t; i < items; i += 256) {
+    const f32x4 val = *reinterpret_cast<const f32x4*>(tile + 4 * i);
+    d[i] = accumulate ? d[i] + val : val;
+  }
+}
+
+// Sum of the split-K slabs [splitk][Cout][taps][Cin] into dw (OIHW).  A thread owns 4 consecutive elements (one 16-byte
+// load per slab); P groups of threads share the slabs of those elements -- group p sums the contiguous slab range
+// [p*S/P, (p+1)*S/P) in ascending order, the groups are added in ascending order through LDS: deterministic, and a 64 x 64
+// filter with 128 slabs is no longer a chain of 128 dependent loads on 16 workgroups (31 us -> the launch floor).
+template <int P>
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw, int splitk, int Cout,
+                                                           int taps, int Cin, int Cout_real, int Cin_real, int flat_k, int accumulate) {
+  constexpr int TX = 256 / P;
+  __shared__ f32x4 part[P > 1 ? P : 1][TX];
+  const size_t total = (size_t)Cout * taps * Cin;
+  const int tx = threadIdx.x % TX, p = threadIdx.x / TX;
+  const size_t e = ((size_t)blockIdx.x * TX + tx) * 4;
+  const int k0 = (int)((long long)splitk * p / P), k1 = (int)((long long)splitk * (p + 1) / P);
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  if (e < total) s = slab_sum(slabs + e, total, k0, k1);
+  if (P > 1) {
+    part[p][tx] = s;
+    __syncthreads();
+    if (p != 0) return;
+#pragma unroll
+    for (int i = 1; i < P; ++i) s += part[i][tx];
+  }
   if (e >= total) return;
-  float s = 0.f;
-  for (int k = 0; k < splitk; ++k) s += slabs[(size_t)k * total + e];
-  const int cc = (int)(e % Cin);
+  const int cc = (int)(e % Cin);  // Cin % 4 == 0: the four elements share (n, tap)
   const size_t q = e / Cin;
   const int tap = (int)(q % taps);
   const int n = (int)(q / taps);
   if (n >= Cout_real) return;
   if (flat_k > 0) {  // stem: packed K index = tap7*Cin_real + c3, OIHW = [n][c3][tap7]
-    const int tap7 = cc / Cin_real, c3 = cc - tap7 * Cin_real;
-    if (tap7 < flat_k) {
-      float* d = dw + ((size_t)n * Cin_real + c3) * flat_k + tap7;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int tap7 = (cc + j) / Cin_real, c3 = (cc + j) - tap7 * Cin_real;
+      if (tap7 < flat_k) {
+        float* d = dw + ((size_t)n * Cin_real + c3) * flat_k + tap7;
+        *d = accumulate ? *d + s[j] : s[j];
+      }
+    }
+  } else if (taps == 1 && Cin_real % 4 == 0) {
+    if (cc < Cin_real) {
+      f32x4* d = reinterpret_cast<f32x4*>(dw + (size_t)n * Cin_real + cc);
       *d = accumulate ? *d + s : s;
     }
-  } else if (cc < Cin_real) {
-    float* d = dw + ((size_t)n * Cin_real + cc) * taps + tap;
-    *d = accumulate ? *d + s : s;
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (cc + j < Cin_real) {
+        float* d = dw + ((size_t)n * Cin_real + cc + j) * taps + tap;
+        *d = accumulate ? *d + s[j] : s[j];
+      }
   }
 }
 
@@ -654,10 +742,23 @@ int onda_conv2d_wgrad(const float* x, const float* dy, float* slabs, int lddy, i
 
 int onda_wgrad_reduce(const float* slabs, float* dw, int splitk, int Cout, int taps, int Cin, int Cout_real,
                       int Cin_real, int flat_k, int accumulate, onda_stream_t s) {
-  ONDA_REQUIRE(slabs && dw && splitk >= 1);
+  ONDA_REQUIRE(slabs && dw && splitk >= 1 && Cin % 4 == 0);
+  if (!ONDA_ALIGNED16(slabs) || (taps == 1 && flat_k == 0 && Cin_real % 4 == 0 && !ONDA_ALIGNED16(dw))) return ONDA_EALIGN;
   const size_t total = (size_t)Cout * taps * Cin;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ONDA_STREAM(s), slabs,
-                     dw, splitk, Cout, taps, Cin, Cout_real, Cin_real, flat_k, accumulate);
+  // slab groups per element: enough workgroups to fill the chip, at least two slabs per group
+  int P = 1;
+  while (P < 16 && total * P / 1024 < 1024 && splitk >= 8 * P) P *= 4;
+#define WGRAD_REDUCE(P_)                                                                                                    \
+  hipLaunchKernelGGL(wgrad_reduce_kernel<P_>, dim3((unsigned)((total / 4 + 256 / P_ - 1) / (256 / P_))), dim3(256), 0,      \
+                     ONDA_STREAM(s), slabs, dw, splitk, Cout, taps, Cin, Cout_real, Cin_real, flat_k, accumulate)
+  if (taps > 1 && taps <= 9 && flat_k == 0 && Cin % 128 == 0 && Cin_real == Cin && ONDA_ALIGNED16(dw) &&
+      (P == 1 || (long long)Cout_real * (Cin / 128) >= 512)) {
+    hipLaunchKernelGGL(wgrad_reduce_taps_kernel, dim3((unsigned)(Cout_real * (Cin / 128))), dim3(256), 0, ONDA_STREAM(s), slabs, dw,
+                       splitk, Cout, taps, Cin, Cout_real, accumulate);
+  } else if (P == 1) WGRAD_REDUCE(1);
+  else if (P == 4) WGRAD_REDUCE(4);
+  else WGRAD_REDUCE(16);
+#undef WGRAD_REDUCE
   return ONDA_LAUNCH_RESULT();
 }
 

@@ -1023,6 +1023,7 @@ __global__ __launch_bounds__(256) void conv_l2_fixup_kernel(const ConvK a, int G
   constexpr int SUB = BM / RG;    // sub-blocks per tile
   __shared__ f32x4 red[4][256];
   __shared__ int piece[1024];
+  __shared__ int wave_count[4];
   const OndaConv& c = a.c;
   const int KT = a.taps * a.kcper;
   const long long U = (long long)(a.tilesM * a.tilesN - a.tiles_dp) * KT;
@@ -1052,21 +1053,42 @@ __global__ __launch_bounds__(256) void conv_l2_fixup_kernel(const ConvK a, int G
     }
     return;
   }
+  // the workgroups whose K range meets this tile, compacted in ascending order (with fewer remainder K-steps than
+  // workgroups some ranges are empty); entry = workgroup * 2 + (0: its first piece, 1: its second)
   const int npieces = ve - vs + 1;
-  for (int p = t; p < npieces; p += 256) {
-    const int vb = vs + p;
-    const long long b0 = (long long)vb * U / G, b1 = (long long)(vb + 1) * U / G;
-    const long long g0 = max(b0, t0), g1 = min(b1, t1);
-    piece[p] = g1 > g0 ? vb * 2 + (g0 == b0 ? 0 : 1) : -1;
+  int nvalid = 0;
+  for (int p0 = 0; p0 < npieces; p0 += 256) {
+    const int p = p0 + t;
+    int val = -1;
+    if (p < npieces) {
+      const int vb = vs + p;
+      const long long b0 = (long long)vb * U / G, b1 = (long long)(vb + 1) * U / G;
+      const long long g0 = max(b0, t0), g1 = min(b1, t1);
+      if (g1 > g0) val = vb * 2 + (g0 == b0 ? 0 : 1);
+    }
+    const unsigned long long mask = __ballot(val >= 0);
+    if ((t & 63) == 0) wave_count[t >> 6] = __popcll(mask);
+    __syncthreads();
+    int off = nvalid;
+    for (int w = 0; w < (t >> 6); ++w) off += wave_count[w];
+    if (val >= 0) piece[off + __popcll(mask & ((1ull << (t & 63)) - 1ull))] = val;
+    nvalid += wave_count[0] + wave_count[1] + wave_count[2] + wave_count[3];
+    __syncthreads();
   }
-  __syncthreads();
   const int row = sub * RG + rg;
   const int eo = row * BN + col;
-  f32x4 v = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 8
-  for (int p = 0; p < npieces; ++p) {
-    const int pc = piece[p];
-    if (pc >= 0) v += *reinterpret_cast<const f32x4*>(a.ws + (size_t)pc * (BM * BN) + eo);
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  f32x4 v = zero;
+  // eight pieces in flight (a chain of dependent loads was most of this kernel's 10-14 us); added in ascending order
+  for (int p = 0; p < nvalid; p += 8) {
+    f32x4 part[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int pc = piece[min(p + j, nvalid - 1)];
+      part[j] = *reinterpret_cast<const f32x4*>(a.ws + (size_t)pc * (BM * BN) + eo);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v += p + j < nvalid ? part[j] : zero;
   }
   const int m = tile_m * BM + row;
   float mx = 0.f;
