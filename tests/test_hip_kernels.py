@@ -666,6 +666,41 @@ def test_ema_multi():
     assert torch.equal(kd[2].cpu(), qs[2])
 
 
+@pytest.mark.parametrize("sk,Co,taps,Cin,co_real,ci_real,flat_k", [
+    (128, 64, 1, 64, 64, 64, 0),      # 16 slab groups per element, vector store
+    (32, 256, 1, 1024, 256, 1024, 0),  # 4 slab groups
+    (3, 128, 1, 256, 100, 250, 0),     # one group; padded rows / columns dropped, scalar store (250 % 4 != 0)
+    (14, 256, 9, 256, 256, 256, 0),    # taps: workgroup per 128 channels x 9 taps, transposed through LDS
+    (7, 64, 9, 128, 64, 128, 0),       # taps kernel, one slab batch with a zero-padded tail
+    (56, 64, 9, 64, 64, 64, 0),        # taps with Cin < 128: generic kernel, strided stores
+    (128, 64, 1, 160, 64, 3, 49),      # stem: packed K = tap7 * 3 + c3 -> OIHW [n][c3][7 x 7]
+])
+def test_slab_reduction_variants(sk, Co, taps, Cin, co_real, ci_real, flat_k):
+    """onda_wgrad_reduce (split-K slabs [sk][Cout][taps][Cin] -> OIHW gradient): every launch variant against a float64
+    sum; overwrite and accumulate; bit-reproducible (fixed order inside and across the slab groups)."""
+    from onda_amd import ops
+    from onda_amd._lib import call
+    g = torch.Generator().manual_seed(sk * 31 + Cin)
+    slabs = torch.randn(sk, Co, taps, Cin, generator=g)
+    ref = slabs.double().sum(0)  # [Co][taps][Cin]
+    if flat_k:
+        kk = flat_k * ci_real
+        want = ref[:co_real, 0, :kk].reshape(co_real, flat_k, ci_real).permute(0, 2, 1)  # [n][c3][tap7]
+        shape = (co_real, ci_real, flat_k)
+    else:
+        want = ref[:co_real, :, :ci_real].permute(0, 2, 1)  # [n][c][tap]
+        shape = (co_real, ci_real, taps)
+    sd = slabs.to(DEV)
+    prev = torch.randn(shape, generator=g)
+    outs = []
+    for acc in (0, 1, 1):
+        dw = prev.to(DEV).contiguous()
+        call("onda_wgrad_reduce", ops._p(sd), ops._p(dw), sk, Co, taps, Cin, co_real, ci_real, flat_k, acc, ops._stream())
+        outs.append(dw.cpu())
+        close(dw.reshape(shape), want + (prev.double() if acc else 0.0), 2e-6, f"slab sum acc={acc}")
+    assert torch.equal(outs[1], outs[2])
+
+
 def test_bad_arguments_raise():
     from onda_amd import ops
     with pytest.raises(RuntimeError):
