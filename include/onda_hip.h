@@ -165,18 +165,20 @@ int onda_conv2d_fwd_l2(const void* xl, int64_t xplane, const float* xamax, const
  * finalize: partials[tiles][4][C] (sum, sumsq, min, max) -> mean, invstd, running statistics, xhat_amax[C] =
  *   max|(x-mean)*invstd| per channel, and an upper bound of max|out| folded into out_amax (zeroed; res_amax = the amax
  *   of the residual operand or NULL).  apply: out[2][M][C] limb planes of [relu]((x-mean)*invstd*gamma+beta [+res]),
- *   the residual read from ITS limb planes.  bwd: g = dout*[out>0] (sign from out's limbs), dres = g (fp32, optional),
+ *   the residual read from ITS limb planes; relu_mask (optional, M*C/8 bytes): bit (m*C+c) & 7 of byte (m*C+c) >> 3 =
+ *   [out > 0], read by the backward passes instead of out's first limb (1/8 byte per element instead of 2).
+ *   bwd: g = dout*[out>0] (relu_mask, or the sign of out's first limb when relu_mask is NULL), dres = g (fp32, optional),
  *   dx[2][M][C] limb planes of gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)), scaled by a bound folded into dx_amax. */
 int onda_bn_finalize_l2(const float* partials, int tiles, int C, int64_t count, float eps, float* mean, float* invstd,
                         float* running_mean, float* running_var, int64_t* nbt, float momentum, const float* gamma,
                         const float* beta, const float* res_amax, int relu, float* xhat_amax, float* out_amax, onda_stream_t s);
 int onda_bn_apply_l2(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
                      const void* res, int64_t res_plane, const float* res_amax, void* out, int64_t out_plane,
-                     const float* out_amax, int64_t M, int C, int relu, onda_stream_t s);
+                     const float* out_amax, int64_t M, int C, int relu, uint8_t* relu_mask, onda_stream_t s);
 int64_t onda_bn_bwd_l2_ws(int64_t M, int C);
 int onda_bn_bwd_l2(const float* dout, const void* out, int64_t out_plane, const float* x, const float* mean, const float* invstd,
                    const float* gamma, const float* xhat_amax, void* dx, int64_t dx_plane, float* dx_amax, float* dres, float* ws,
-                   int64_t M, int C, int relu, onda_stream_t s);
+                   int64_t M, int C, int relu, const uint8_t* relu_mask, onda_stream_t s);
 
 /* onda_conv2d_wgrad slabs with both operands pre-split: [pixel][channel] limb planes in, LDS-DMA + transposed LDS reads
  * (ds_read_b64_tr_b16), tiles of 256 x 128 or 128 x 128 (output x input channels) per tap and pixel range */

@@ -60,9 +60,9 @@ SIGNATURES = {
     "onda_conv2d_wgrad_l2": (I, [P, L, P, P, L, P, P, I, I, POINTER(OndaConv), P]),
     "onda_conv2d_fwd_l2": (I, [P, L, P, P, P, P, P, P, P, P, I, P, P, POINTER(OndaConv), P]),
     "onda_bn_finalize_l2": (I, [P, I, I, L, F, P, P, P, P, P, F, P, P, P, I, P, P, P]),
-    "onda_bn_apply_l2": (I, [P, P, P, P, P, P, L, P, P, L, P, L, I, I, P]),
+    "onda_bn_apply_l2": (I, [P, P, P, P, P, P, L, P, P, L, P, L, I, I, P, P]),
     "onda_bn_bwd_l2_ws": (L, [L, I]),
-    "onda_bn_bwd_l2": (I, [P, P, L, P, P, P, P, P, P, L, P, P, P, L, I, I, P]),
+    "onda_bn_bwd_l2": (I, [P, P, L, P, P, P, P, P, P, L, P, P, P, L, I, I, P, P]),
     "onda_conv2d_wgrad": (I, [P, P, P, I, I, POINTER(OndaConv), P]),
     "onda_conv2d_wgrad_bf3": (I, [P, P, P, I, I, POINTER(OndaConv), P]),
     "onda_wgrad_reduce": (I, [P, P, I, I, I, I, I, I, I, I, P]),

@@ -192,7 +192,8 @@ __global__ __launch_bounds__(256) void bn_apply_l2_kernel(const float* __restric
                                                           const float* __restrict__ beta, const _Float16* __restrict__ res,
                                                           size_t res_plane, const float* __restrict__ res_amax,
                                                           _Float16* __restrict__ out, size_t out_plane,
-                                                          const float* __restrict__ out_amax, size_t total8, int C, int relu) {
+                                                          const float* __restrict__ out_amax, size_t total8, int C, int relu,
+                                                          unsigned char* __restrict__ mask) {
   const int c8 = C / 8;
   const float so = scale_of(out_amax).s;
   const float ri = res ? scale_of(res_amax).inv : 0.f;
@@ -210,6 +211,12 @@ __global__ __launch_bounds__(256) void bn_apply_l2_kernel(const float* __restric
       join8(r1, r2, q0, q1);
       v0 += q0 * ri;
       v1 += q1 * ri;
+    }
+    if (mask) {  // [out > 0], one bit per element (byte e = the 8 channels of this item): what the backward passes read
+      unsigned bits = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bits |= (v0[j] > 0.f ? 1u << j : 0u) | (v1[j] > 0.f ? 16u << j : 0u);
+      mask[e] = (unsigned char)bits;
     }
     if (relu) {
 #pragma unroll
@@ -275,7 +282,13 @@ static inline ColPlan3 col_plan3(int64_t M, int C) {
 // g * [out > 0] from the FIRST limb of out (2 bytes per element).  The first limb of a positive element is zero only below
 // 2^-40 of the tensor maximum (f16 subnormals reach 2^-24, the scale puts the maximum at 2^15): there the gradient is
 // dropped, at the kink of the ReLU.
-__device__ __forceinline__ f32x4 relu_mask4(const _Float16* __restrict__ out, size_t o, f32x4 g) {
+__device__ __forceinline__ f32x4 relu_mask4(const _Float16* __restrict__ out, const unsigned char* __restrict__ mask, size_t o, f32x4 g) {
+  if (mask != nullptr) {  // the bit mask of the apply pass: 1/8 byte per element instead of the 2 bytes of the first limb
+    const unsigned bits = (unsigned)mask[o >> 3] >> ((o & 4) ? 4 : 0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) g[j] = (bits >> j) & 1u ? g[j] : 0.f;
+    return g;
+  }
   const u32x2 h1 = *reinterpret_cast<const u32x2*>(out + o);
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
@@ -290,7 +303,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_l2_kernel(const float* __re
                                                                size_t out_plane, const float* __restrict__ x,
                                                                const float* __restrict__ mean, const float* __restrict__ invstd,
                                                                float* __restrict__ dres, int64_t M, int C, int relu, int cx,
-                                                               int64_t rows_per_chunk, float* __restrict__ partials) {
+                                                               int64_t rows_per_chunk, float* __restrict__ partials,
+                                                               const unsigned char* __restrict__ mask) {
   __shared__ f32x4 red[3][256];
   const int t = threadIdx.x;
   const int ry_n = 256 / cx;
@@ -305,7 +319,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_l2_kernel(const float* __re
     for (int64_t r = r0 + ty; r < r1; r += ry_n) {
       const size_t o = (size_t)r * C + col;
       f32x4 g = LD4(dout + o);
-      if (relu) g = relu_mask4(out, o, g);
+      if (relu) g = relu_mask4(out, mask, o, g);
       if (dres) *reinterpret_cast<f32x4*>(dres + o) = g;
       const f32x4 xh = (LD4(x + o) - mu) * is;
       s1 += g;
@@ -360,7 +374,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_l2_kernel(const float* __res
                                                               const float* __restrict__ gamma, const float* __restrict__ sums,
                                                               _Float16* __restrict__ dx, size_t dx_plane,
                                                               const float* __restrict__ dx_amax, size_t total8, int C, float inv_m,
-                                                              int relu) {
+                                                              int relu, const unsigned char* __restrict__ mask) {
   const int c8 = C / 8;
   const float sd = scale_of(dx_amax).s;
   const size_t e0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -381,7 +395,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_l2_kernel(const float* __res
     for (int h = 0; h < 2; ++h) {
       const size_t o = e * 8 + 4 * h;
       f32x4 g = LD4(dout + o);
-      if (relu) g = relu_mask4(out, o, g);
+      if (relu) g = relu_mask4(out, mask, o, g);
       const f32x4 xh = (LD4(x + o) - mu[h]) * is[h];
       v[h] = gi[h] * (g - m1[h] - xh * m2[h]);
     }
@@ -415,14 +429,14 @@ int onda_bn_finalize_l2(const float* partials, int tiles, int C, int64_t count, 
 
 int onda_bn_apply_l2(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
                      const void* res, int64_t res_plane, const float* res_amax, void* out, int64_t out_plane,
-                     const float* out_amax, int64_t M, int C, int relu, onda_stream_t s) {
+                     const float* out_amax, int64_t M, int C, int relu, uint8_t* relu_mask, onda_stream_t s) {
   ONDA_REQUIRE(x && mean && invstd && gamma && beta && out && out_amax && C % 8 == 0 && out_plane % 8 == 0 && (!res || res_amax));
   ONDA_REQUIRE(256 % (C / 8) == 0 || (C / 8) % 256 == 0);  // a thread keeps its channel group across the grid stride
   if (!ONDA_ALIGNED16(x) || !ONDA_ALIGNED16(out) || (res && !ONDA_ALIGNED16(res))) return ONDA_EALIGN;
   const size_t total8 = (size_t)M * C / 8;
   hipLaunchKernelGGL(bn_apply_l2_kernel, dim3(ew_grid(total8)), dim3(256), 0, ONDA_STREAM(s), x, mean, invstd, gamma, beta,
                      static_cast<const _Float16*>(res), (size_t)res_plane, res_amax, static_cast<_Float16*>(out), (size_t)out_plane,
-                     out_amax, total8, C, relu);
+                     out_amax, total8, C, relu, relu_mask);
   return ONDA_LAUNCH_RESULT();
 }
 
@@ -433,21 +447,21 @@ int64_t onda_bn_bwd_l2_ws(int64_t M, int C) {
 
 int onda_bn_bwd_l2(const float* dout, const void* out, int64_t out_plane, const float* x, const float* mean, const float* invstd,
                    const float* gamma, const float* xhat_amax, void* dx, int64_t dx_plane, float* dx_amax, float* dres, float* ws,
-                   int64_t M, int C, int relu, onda_stream_t s) {
-  ONDA_REQUIRE(dout && x && mean && invstd && gamma && xhat_amax && dx && dx_amax && ws && C % 8 == 0 && (!relu || out));
+                   int64_t M, int C, int relu, const uint8_t* relu_mask, onda_stream_t s) {
+  ONDA_REQUIRE(dout && x && mean && invstd && gamma && xhat_amax && dx && dx_amax && ws && C % 8 == 0 && (!relu || out || relu_mask));
   ONDA_REQUIRE(256 % (C / 8) == 0 || (C / 8) % 256 == 0);
   if (!ONDA_ALIGNED16(dout) || !ONDA_ALIGNED16(x) || !ONDA_ALIGNED16(dx) || (out && !ONDA_ALIGNED16(out))) return ONDA_EALIGN;
   const ColPlan3 p = col_plan3(M, C);
   float* sums = ws + (size_t)p.chunks * 3 * C;
   hipStream_t st = ONDA_STREAM(s);
   hipLaunchKernelGGL(bn_bwd_reduce_l2_kernel, dim3(p.gridx, p.chunks), dim3(256), 0, st, dout, static_cast<const _Float16*>(out),
-                     (size_t)out_plane, x, mean, invstd, dres, M, C, relu, p.cx, p.rows_per_chunk, ws);
+                     (size_t)out_plane, x, mean, invstd, dres, M, C, relu, p.cx, p.rows_per_chunk, ws, relu_mask);
   hipLaunchKernelGGL(bn_bwd_sums_l2_kernel, dim3((C + 15) / 16), dim3(256), 0, st, ws, p.chunks, C, 1.0 / (double)M, gamma, invstd,
                      xhat_amax, sums, dx_amax);
   const size_t total8 = (size_t)M * C / 8;
   hipLaunchKernelGGL(bn_bwd_apply_l2_kernel, dim3(ew_grid(total8)), dim3(256), 0, st, dout, static_cast<const _Float16*>(out),
                      (size_t)out_plane, x, mean, invstd, gamma, sums, static_cast<_Float16*>(dx), (size_t)dx_plane, dx_amax, total8,
-                     C, (float)(1.0 / (double)M), relu);
+                     C, (float)(1.0 / (double)M), relu, relu_mask);
   return ONDA_LAUNCH_RESULT();
 }
 

@@ -833,6 +833,9 @@ class BNTrainFn(torch.autograd.Function):
         return dx, None, None, None, dres, None, None, None
 
 
+RELU_BITMASK = os.environ.get("ONDA_RELU_BITMASK", "1") == "1"  # measurement knob: 0 = the backward reads out's first limb
+
+
 class BNTrainLimbFn(torch.autograd.Function):
     """BNTrainFn whose output exists as limb planes only ("f16x2" / "dma"): the output of a train-mode BatchNorm
     (+residual, +ReLU) is consumed by convolutions, a later residual add and its own backward mask -- all of which
@@ -861,12 +864,15 @@ class BNTrainLimbFn(torch.autograd.Function):
             for t in running:
                 torch.autograd.graph.increment_version(t)
         planes = torch.empty(2, M, C, device=dev, dtype=torch.float16)
+        # [out > 0] as one bit per element for the backward passes (they would read 2 bytes of `planes` per element instead)
+        mask = torch.empty(M * C // 8, device=dev, dtype=torch.uint8) if relu and RELU_BITMASK and any(ctx.needs_input_grad) else None
         call("onda_bn_apply_l2", _p(y), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(res.planes) if res is not None else None,
              res.plane if res is not None else 0, _p(res.amax) if res is not None else None, _p(planes), M * C, _p(out_amax),
-             M, C, int(relu), _stream())
+             M, C, int(relu), _p(mask), _stream())
         lb = Limbs(planes, out_amax, C, M * C)
         ctx.save_for_backward(y, mean, invstd, gamma, xhat_amax)
-        ctx.out_limbs = lb if relu else None
+        ctx.out_limbs = lb if relu and mask is None else None
+        ctx.relu_mask = mask
         ctx.relu, ctx.has_res = relu, residual is not None
         ctx.res_sink = _sink_of(residual) if (residual is not None and ctx.needs_input_grad[4]) else None
         return limb_only((B, H, W, C), dev, lb)
@@ -890,7 +896,7 @@ class BNTrainLimbFn(torch.autograd.Function):
         ol = ctx.out_limbs
         call("onda_bn_bwd_l2", _p(dout), _p(ol.planes) if ol is not None else None, ol.plane if ol is not None else 0, _p(y),
              _p(mean), _p(invstd), _p(gamma), _p(xhat_amax), _p(planes), M * C, _p(dx_amax),
-             _p(dres) if (need_res and ctx.relu) else None, _p(ws), M, C, int(ctx.relu), _stream())
+             _p(dres) if (need_res and ctx.relu) else None, _p(ws), M, C, int(ctx.relu), _p(ctx.relu_mask), _stream())
         dx = limb_only((B, H, W, C), dev, Limbs(planes, dx_amax, C, M * C))
         if need_res:
             dres = _sink_give(ctx.res_sink, dres, ctx.relu)
