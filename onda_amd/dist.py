@@ -20,8 +20,13 @@ import torch
 import torch.distributed as dist
 
 
+# test hook: ONDA_DIST_FORCE=1 runs the whole exchange path (flat gradient views, bucket hooks, collectives, tail) with
+# ONE rank -- the only way to drive RCCL itself on a single-GPU box (it refuses two ranks on one device)
+_FORCE = os.environ.get("ONDA_DIST_FORCE", "0") == "1"
+
+
 def is_on():
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or _FORCE)
 
 
 def world_size():
@@ -43,8 +48,9 @@ def init_from_env(backend=None):
     if "ONDA_FORCE_DEVICE" in os.environ:
         local = int(os.environ["ONDA_FORCE_DEVICE"])
     backend = backend or os.environ.get("ONDA_DIST_BACKEND")
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or _FORCE) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"

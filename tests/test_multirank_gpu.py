@@ -61,3 +61,36 @@ def test_two_ranks_stay_identical_and_match_the_sequential_emulation(tmp_path):
             before = a[f"init_{who}"] if s == 0 else a[f"s{s - 1}_{who}"]
             rel = np.linalg.norm(x - y) / np.linalg.norm(x - before)
             assert rel <= (0.02 if s == 0 else 0.6), (s, who, rel)
+
+
+def test_one_rank_over_rccl_matches_the_plain_step(tmp_path):
+    """RCCL itself (backend "nccl") refuses two ranks on one device, so a single-GPU box can only drive it with ONE rank:
+    ONDA_DIST_FORCE=1 keeps the whole exchange path on -- flat gradient views, bucket hooks firing from the autograd
+    thread, asynchronous all-reduces on RCCL's stream, the tail with prototype statistics / monitor scalars / running
+    statistics, the switch scalars -- and the result must equal the plain single-process step."""
+    nccl_file, plain_file = str(tmp_path / "nccl.npz"), str(tmp_path / "plain.npz")
+    env = dict(os.environ, ONDA_MR_OUT=nccl_file, ONDA_DIST_FORCE="1", ONDA_DIST_BACKEND="nccl")
+    env.pop("ONDA_MR_SHARDS", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(HERE, "multirank_worker.py")]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("MULTIRANK")][-1]
+    assert "world=1" in line and "nan" not in line.lower(), line
+    env = dict(os.environ, ONDA_MR_OUT=plain_file, ONDA_MR_SHARDS="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "ONDA_DIST_FORCE"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(HERE, "multirank_worker.py")], env=env, capture_output=True, text=True,
+                         timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    a, b = np.load(nccl_file), np.load(plain_file)
+    for s in range(2):
+        for k in ("proto", "sqmean", "counter"):
+            np.testing.assert_allclose(a[f"s{s}_{k}"], b[f"s{s}_{k}"], rtol=2e-4, atol=1e-5, err_msg=f"step {s} {k}")
+        np.testing.assert_allclose(a[f"s{s}_monitor"], b[f"s{s}_monitor"], rtol=1e-4 if s == 0 else 5e-3, atol=1e-6)
+        assert np.array_equal(a[f"s{s}_switch"], b[f"s{s}_switch"])
+        for who in ("student", "teacher"):
+            x, y = a[f"s{s}_{who}"], b[f"s{s}_{who}"]
+            before = a[f"init_{who}"] if s == 0 else a[f"s{s - 1}_{who}"]
+            rel = np.linalg.norm(x - y) / np.linalg.norm(x - before)
+            assert rel <= (0.02 if s == 0 else 0.6), (s, who, rel)
