@@ -253,16 +253,17 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 }
 
 // ---- GroupNorm --------------------------------------------------------------------------
-// One wave per (image, group): lanes stride over chunks x channels-of-the-group.
+// One workgroup per (image, group): 256 threads stride over chunks x channels-of-the-group, waves combined in fixed order
+// (one wave per pair walked 16+ dependent iterations: 17 us for 30 KB).
 __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ partials, int chunks, int B,
                                                           int C, int groups, double count, float eps, float* mean,
                                                           float* rstd) {
-  const int lane = threadIdx.x & 63;
-  const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (idx >= B * groups) return;
+  __shared__ double red[2][4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int idx = blockIdx.x;
   const int b = idx / groups, g = idx % groups, cpg = C / groups;
   double s1 = 0.0, s2 = 0.0;
-  for (int i = lane; i < chunks * cpg; i += 64) {
+  for (int i = threadIdx.x; i < chunks * cpg; i += 256) {
     const int k = i / cpg, j = i - k * cpg;
     const size_t base = (((size_t)b * chunks + k) * 2) * C + g * cpg + j;
     s1 += (double)partials[base];
@@ -270,7 +271,14 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
   }
   s1 = wave_sum_d(s1);
   s2 = wave_sum_d(s2);
-  if (lane != 0) return;
+  if (lane == 0) {
+    red[0][wave] = s1;
+    red[1][wave] = s2;
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  s1 = ((red[0][0] + red[0][1]) + red[0][2]) + red[0][3];
+  s2 = ((red[1][0] + red[1][1]) + red[1][2]) + red[1][3];
   const double mu = s1 / count;
   double var = s2 / count - mu * mu;
   if (var < 0.0) var = 0.0;
@@ -469,7 +477,7 @@ int onda_gn_fwd(const float* x, int ldx, const float* gamma, const float* beta, 
   SqStats f{x, HW, ldx};
   int rc = launch_colreduce(f, B, HW, C, ws, p, ONDA_STREAM(s));
   if (rc) return rc;
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3((B * groups + 3) / 4), dim3(256), 0, ONDA_STREAM(s), ws, p.chunks, B,
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(B * groups), dim3(256), 0, ONDA_STREAM(s), ws, p.chunks, B,
                      C, groups, (double)HW * (C / groups), eps, mean, rstd);
   const size_t total4 = (size_t)B * HW * C / 4;
   hipLaunchKernelGGL(gn_apply_kernel, dim3(ew_grid(total4)), dim3(256), 0, ONDA_STREAM(s), x, ldx, gamma, beta, chmul,
