@@ -489,7 +489,7 @@ def _best_splitk(M, cout, cin, taps, tiles, G, rate):
     t_ideal = 2.0 * M * cout * cin * taps / rate              # seconds at the kernel's typical rate
     wbytes = 4.0 * cout * cin * taps
     best, best_t = 1, None
-    for sk in range(1, 129):
+    for sk in range(1, 257):
         if sk > 1 and (M // sk < 256 or sk * wbytes > (512 << 20)):
             break
         blocks = tiles * sk
