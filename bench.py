@@ -178,8 +178,8 @@ def committed_traffic(kernel_family):
     read from inside the process, so the number is the last profiled one; the file says which source hash it was
     taken on (`library_src`), to be compared with `config.library`."""
     best = None
-    stem = {"conv_l2_kernel<0>": "conv_l2_kernel<4, 2", "conv_l2_kernel<1>": "conv_l2_kernel<2, 2",
-            "conv_l2_kernel<2>": "conv_l2_kernel<4, 1"}.get(kernel_family, kernel_family.split("<")[0] + "<")
+    # bench names ("conv_l2_kernel<4,2>", "conv_l2x_kernel<4,2>", ...) -> the prefix of the demangled name in the profile
+    stem = kernel_family.replace(",", ", ").rstrip(">") if kernel_family.startswith("conv_l2") else kernel_family.split("<")[0] + "<"
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json"))):
         try:
             blob = json.load(open(path))

@@ -55,6 +55,7 @@ SIGNATURES = {
     "onda_debug_stamps": (None, [P]),
     "onda_conv2d_fwd_l2_limbs": (I, [P, L, P, P, P, P, P, P, P, P, P]),
     "onda_conv_l2_variant": (I, [L, I]),
+    "onda_conv_l2_kernel_id": (I, [L, I, I, I]),
     "onda_conv_l2_tiles_m": (I, [L, I, I, I]),
     "onda_conv_wgrad_l2_variant": (I, [I, I]),
     "onda_conv2d_wgrad_l2": (I, [P, L, P, P, L, P, P, I, I, POINTER(OndaConv), P]),

@@ -1586,6 +1586,16 @@ int onda_conv_l2_variant(int64_t M, int Cout) {
   return t256 >= 200 ? 0 : 1;
 }
 
+/* which device kernel onda_conv2d_fwd_l2 launches for a problem: the tile variant (0: 256 x 128, 1: 128 x 128, 2: 256 x 64
+ * = conv_l2_kernel<4,2> / <2,2> / <4,1>), or 3: conv_l2x_kernel<4,2>, the continuous K-step stream taken by 256 x 128
+ * problems with at most 32 K-steps per tile (bench.py names its per-kernel figures after this) */
+int onda_conv_l2_kernel_id(int64_t M, int Cout, int taps, int Cin) {
+  const int variant = onda_conv_l2_variant(M, Cout);
+  static const int xt = getenv("ONDA_L2_XT") ? atoi(getenv("ONDA_L2_XT")) : 1;
+  const bool short_k = taps * (Cin / 32) <= 32 || xt == 2;
+  return variant == 0 && xt && short_k ? 3 : variant;
+}
+
 }  // extern "C"
 
 namespace {

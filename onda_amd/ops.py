@@ -51,6 +51,14 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+_L2_KERNELS = ("conv_l2_kernel<4,2>", "conv_l2_kernel<2,2>", "conv_l2_kernel<4,1>", "conv_l2x_kernel<4,2>")
+
+
+def _l2_name(M, cout, taps, cin):
+    """The device kernel a pre-split forward / data-gradient problem runs on (for bench.py's per-kernel figures)."""
+    return _L2_KERNELS[query("onda_conv_l2_kernel_id", M, cout, taps, cin)] if PROFILE is not None else ""
+
+
 def _launch(name, flops, fn_name, *args, tag=None):
     if PROFILE is None:
         return call(fn_name, *args)
@@ -366,7 +374,7 @@ def conv_forward(x, wp, k, stride, dil, pad, cout, out=None, scale=None, shift=N
         lo = OndaLimbOut(_p(planes), M * cout, _p(bound), _p(true), _p(limb_out), _p(xl.true_amax),
                          _p(res.planes) if res is not None else None, res.plane if res is not None else 0,
                          _p(res.amax) if res is not None else None, _p(res.true_amax) if res is not None else None)
-        _launch("conv_l2_kernel<%d>" % query("onda_conv_l2_variant", M, cout), 2.0 * M * cout * k * k * Cin,
+        _launch(_l2_name(M, cout, k * k, Cin), 2.0 * M * cout * k * k * Cin,
                 "onda_conv2d_fwd_l2_limbs", _p(xl.planes), xl.plane, _p(xl.amax), _p(wp.limbs), _p(wp.amax), _p(scale), _p(shift),
                 byref(lo), _p(_conv_ws(dev)), byref(d), _stream(), tag=("fwd", M, cout, Cin, k, stride, dil))
         return limb_only((B, Ho, Wo, cout), dev, Limbs(planes, bound, cout, M * cout, true_amax=true)), None, 0
@@ -391,7 +399,7 @@ def conv_forward(x, wp, k, stride, dil, pad, cout, out=None, scale=None, shift=N
         xl = limbs_of(x)
         d.ldx = xl.ld
         yamax = amax_slot(x.device) if (scale is not None or relu) else None
-        _launch("conv_l2_kernel<%d>" % query("onda_conv_l2_variant", B * Ho * Wo, cout), 2.0 * B * Ho * Wo * cout * k * k * Cin,
+        _launch(_l2_name(B * Ho * Wo, cout, k * k, Cin), 2.0 * B * Ho * Wo * cout * k * k * Cin,
                 "onda_conv2d_fwd_l2", _p(xl.planes), xl.plane, _p(xl.amax), _p(wp.limbs), _p(wp.amax), _p(out), _p(scale),
                 _p(shift), _p(residual), _p(stats), stats_rows, _p(_conv_ws(x.device)), _p(yamax), byref(d), _stream(),
                 tag=("fwd", B * Ho * Wo, cout, Cin, k, stride, dil))
@@ -432,7 +440,7 @@ def conv_dgrad(dy, wpd, k, stride, dil, pad, cin, in_hw, accumulate=None):
         d = _desc(B, Ho, Wo, Co, Hi, Wi, cin, k, 1, dil, dil * (k - 1) - pad, ldy, cin, cin)
         dyl = limbs_of(dy)
         d.ldx = dyl.ld
-        _launch("conv_l2_kernel<%d>" % query("onda_conv_l2_variant", B * Hi * Wi, cin), 2.0 * B * Ho * Wo * cin * k * k * Co,
+        _launch(_l2_name(B * Hi * Wi, cin, k * k, Co), 2.0 * B * Ho * Wo * cin * k * k * Co,
                 "onda_conv2d_fwd_l2", _p(dyl.planes), dyl.plane, _p(dyl.amax), _p(wpd.limbs), _p(wpd.amax), _p(accumulate), None,
                 None, _p(accumulate), None, 2, _p(_conv_ws(dy.device)), None, byref(d), _stream(),
                 tag=("dgrad", B * Hi * Wi, cin, Co, k, stride, dil))
@@ -449,7 +457,7 @@ def conv_dgrad(dy, wpd, k, stride, dil, pad, cin, in_hw, accumulate=None):
         dyl = limbs_of(dy)
         d.ldx = dyl.ld
         Mo = B * Ho * Wo if stride != 1 else B * Hi * Wi
-        _launch("conv_l2_kernel<%d>" % query("onda_conv_l2_variant", Mo, cin), 2.0 * B * Ho * Wo * cin * k * k * Co,
+        _launch(_l2_name(Mo, cin, k * k, Co), 2.0 * B * Ho * Wo * cin * k * k * Co,
                 "onda_conv2d_fwd_l2", _p(dyl.planes), dyl.plane, _p(dyl.amax), _p(wpd.limbs), _p(wpd.amax), _p(dx), None, None,
                 None, None, 2, _p(_conv_ws(dy.device)), None, byref(d), _stream(),
                 tag=("dgrad", Mo, cin, Co, k, stride, dil))
