@@ -134,6 +134,51 @@ class da_model:
             self.eval_metric_list = []
         return report
 
+    def test_on_samples(self, validation_loaders, count=10):
+        """Class maps of the first `count` samples of every validation set (reference :181-200, which wraps each into a
+        wandb image through ``segment_sample``, evaluate.py:112-120; wandb is outside the hot path): the map comes from the
+        fused upsample -> argmax kernel, the entry is {"image", "prediction" u8[H,W], "label", "caption"}."""
+        self.models_eval()
+        log = {}
+        width, height = self.cfg.SCHEME.RESOLUTION
+        with torch.no_grad():
+            for set_name, loader in validation_loaders.items():
+                it = iter(loader)
+                for i in range(count):
+                    sample = next(it)
+                    image, label = sample["image"][0], sample["label"][0]
+                    out = self.model(image.unsqueeze(0).to(self.device))[1]
+                    out = out["out"] if isinstance(out, dict) else out
+                    log[f"Condition {set_name} sample {i}"] = {
+                        "image": image.cpu().numpy(), "prediction": ops.upsample_argmax(out, (height, width))[0].cpu().numpy(),
+                        "label": label.cpu().numpy(), "caption": f"Sample from {set_name}"}
+        self.models_default_config()
+        return log
+
+    def save_prediction(self, prediction):
+        """One file per batch under PREDICTION_SAVE/<set>/batch-<n>.pt (reference :222-235)."""
+        key = self.cfg_spec.set_
+        base_path = os.path.join(self.cfg_spec.PREDICTION_SAVE, "_".join(str(key)))
+        if key not in self.prediction_counter:
+            self.prediction_counter[key] = 0
+            os.makedirs(base_path, exist_ok=True)
+        torch.save(prediction, os.path.join(base_path, f"batch-{self.prediction_counter[key]}.pt"))
+        self.prediction_counter[key] += 1
+
+    def run_predictions(self, trg_loader, log_fn=None):
+        """Student logits of every target batch to disk, with the mean max-probability logged (reference :237-250; the
+        log goes to `log_fn` or the logging sink instead of wandb.log)."""
+        from onda_amd import logging as olog
+        emit = log_fn or olog.log
+        self.models_eval()
+        with torch.no_grad():
+            for i, batch in enumerate(trg_loader):
+                out = self.model(batch["image"].to(self.device))[1]["out"]
+                confidence = out.softmax(dim=1).max(dim=1)[0].mean()
+                emit({"Prediction confidence": confidence, "Progress": i * 100.0 / len(trg_loader)})
+                self.save_prediction(out.cpu())
+        self.models_default_config()
+
     def save_model(self, model_dict=None, prefix=""):
         if model_dict is None:
             model_dict = {"model": self.model}

@@ -556,6 +556,45 @@ def test_evaluate_path_matches_oracle(tmp_path):
     assert ev.model.training is False  # evaluation.models_default_config keeps eval mode
 
 
+def test_prediction_utilities_match_oracle(tmp_path):
+    """da_model.test_on_samples / run_predictions / save_prediction (reference adaptation_model.py:181-250): the class maps
+    of the first samples equal the oracle's interp -> argmax maps, the saved logits are the eval-mode forward's, the
+    logged confidence is their mean max-probability."""
+    from onda_amd.config import hybrid_switch_cfg
+    from onda_amd.framework.domain_adaptation.methods.adaptation_model import evaluation
+    from onda_amd.synthetic import synth_batch, synth_tensor
+    from oracle import model as omodel
+    cfg, spec = hybrid_switch_cfg(128, 64, DEV, "NONE", batch_size=2)
+    spec.PREDICTION_SAVE = str(tmp_path / "pred")
+    spec.set_ = ("rain", 25)
+    ev = evaluation(build_model(1, 3.0), cfg, spec)
+    loader = [synth_batch(2, 64, 128, seed=400 + i) for i in range(3)]
+    log = ev.test_on_samples({"val": loader}, count=3)
+    sd = {k: synth_tensor(k, torch.empty(shape, dtype=dt), 1, 3.0).to(dt) for k, shape, dt in omodel.state_spec()}
+    outs = []
+    with torch.no_grad():
+        for i, b in enumerate(loader):
+            _, o = omodel.forward(b["image"], sd, omodel.BNMode(False))
+            outs.append(o["out"])
+            _, amap = omodel.upsample_argmax(o["out"][:1], (64, 128))
+            entry = log[f"Condition val sample {i}"]
+            mism = (torch.from_numpy(entry["prediction"]).long() != amap[0].long()).float().mean().item()
+            assert mism <= 2e-3, mism  # (ties of the random-weight logits; G1 pins the bit-exact case)
+            assert entry["caption"] == "Sample from val" and entry["label"].shape == (64, 128)
+    logged = []
+    ev.run_predictions(loader, log_fn=logged.append)
+    files = sorted((tmp_path / "pred").glob("*/batch-*.pt"))
+    assert [f.name for f in files] == ["batch-0.pt", "batch-1.pt", "batch-2.pt"] and files[0].parent.name == "_".join(str(spec.set_))
+    for i, f in enumerate(files):
+        saved = torch.load(f)
+        err = (saved.double() - outs[i].double()).abs().max().item()
+        assert err <= 2e-3 * outs[i].abs().max().item(), ("saved logits", err)
+        conf = outs[i].softmax(dim=1).max(dim=1)[0].mean().item()
+        assert float(logged[i]["Prediction confidence"]) == pytest.approx(conf, rel=2e-3)
+        assert logged[i]["Progress"] == pytest.approx(i * 100.0 / 3)
+    assert ev.model.training is False
+
+
 def test_segmentation_step_config2(golden):
     """BASELINE config 2 (segmentation.py:62-88): train-mode forward -> bilinear upsample to the
     label resolution -> CE -> backward -> SGD step, against the oracle on the CPU."""
