@@ -324,6 +324,9 @@ int onda_proto_sigma(const float* proto, const float* sqmean, const float* count
 int onda_proto_assign(const float* feat, int ldf, const float* prior, int ldp, const float* proto, const float* sigma,
                       int mahalanobis, float tau, float thresh, int64_t* labels, float* soft, float* result,
                       float* ws, int64_t N, int C, int K, onda_stream_t s);
+/* the distance matrix alone (:111-138 `mahalanobis_distance` / `distance`): dist[N][K] = D[k] - min_k D, direct form */
+int onda_proto_distances(const float* feat, int ldf, const float* proto, const float* sigma, int mahalanobis, float* dist,
+                         int64_t N, int C, int K, onda_stream_t s);
 /* per-class sums of feat and feat^2 under `cls` (:76-86): sums[2][K][C], counts[K].
  * ws: onda_proto_sums_ws(N, C, K) floats. */
 int64_t onda_proto_sums_ws(int64_t N, int C, int K);

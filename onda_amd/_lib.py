@@ -96,6 +96,7 @@ SIGNATURES = {
     "onda_proto_sigma": (I, [P, P, P, P, I, I, P]),
     "onda_proto_assign_blocks": (I, [L]),
     "onda_proto_assign": (I, [P, I, P, I, P, P, I, F, F, P, P, P, P, L, I, I, P]),
+    "onda_proto_distances": (I, [P, I, P, P, I, P, L, I, I, P]),
     "onda_proto_sums_ws": (L, [L, I, I]),
     "onda_proto_class_sums": (I, [P, I, P, P, P, P, L, I, I, P]),
     "onda_proto_ema": (I, [P, P, P, P, F, I, I, P]),

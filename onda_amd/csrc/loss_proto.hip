@@ -196,6 +196,34 @@ __global__ void proto_sigma_kernel(const float* __restrict__ proto, const float*
   sigma[ch] = sqrtf(gsq - gm * gm);
 }
 
+// The distance matrix by itself (prototype_handler.distance / mahalanobis_distance, :111-138): dist[n][k] = D[k] - min_k D,
+// the direct form of proto_assign_kernel; one wave per pixel.
+__global__ __launch_bounds__(256) void proto_distances_kernel(const float* __restrict__ feat, int ldf,
+                                                              const float* __restrict__ proto,
+                                                              const float* __restrict__ sigma, int mahalanobis,
+                                                              float* __restrict__ dist, int64_t N, int K) {
+  __shared__ __attribute__((aligned(16))) float sp[KMAX * 256];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  for (int i = t; i < K * 64; i += 256) reinterpret_cast<f32x4*>(sp)[i] = reinterpret_cast<const f32x4*>(proto)[i];
+  __syncthreads();
+  f32x4 sg = {1.f, 1.f, 1.f, 1.f};
+  if (mahalanobis) sg = *reinterpret_cast<const f32x4*>(sigma + lane * 4);
+  for (int64_t n = (int64_t)blockIdx.x * 4 + wave; n < N; n += (int64_t)gridDim.x * 4) {
+    const f32x4 f = *reinterpret_cast<const f32x4*>(feat + (size_t)n * ldf + lane * 4);
+    float mine = 0.f, dmin = INFINITY;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k)
+      if (k < K) {
+        f32x4 df = f - reinterpret_cast<const f32x4*>(sp)[k * 64 + lane];
+        if (mahalanobis) df = df / sg;
+        const float d = sqrtf(wave_sum(df[0] * df[0] + df[1] * df[1] + df[2] * df[2] + df[3] * df[3]));
+        dmin = fminf(dmin, d);
+        if (k == lane) mine = d;
+      }
+    if (lane < K) dist[(size_t)n * K + lane] = mine - dmin;
+  }
+}
+
 // One wave per pixel; lane l owns channels 4l..4l+3 (C == 256).
 __global__ __launch_bounds__(256) void proto_assign_kernel(const float* __restrict__ feat, int ldf,
                                                            const float* __restrict__ prior, int ldp,
@@ -696,6 +724,17 @@ int onda_proto_assign(const float* feat, int ldf, const float* prior, int ldp, c
                      mahalanobis, tau, thresh, labels, soft, ws + 3 * PA_GRID, N, K, list, list_len);
   hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(192), 0, ONDA_STREAM(s), ws, PA_GRID + PA_LIST_GRID, 3,
                      (float)(1.0 / (double)N), result);
+  return ONDA_LAUNCH_RESULT();
+}
+
+int onda_proto_distances(const float* feat, int ldf, const float* proto, const float* sigma, int mahalanobis, float* dist,
+                         int64_t N, int C, int K, onda_stream_t s) {
+  ONDA_REQUIRE(feat && proto && dist && N >= 1 && C == 256 && K >= 1 && K <= KMAX && ldf % 4 == 0 && (!mahalanobis || sigma));
+  if (!ONDA_ALIGNED16(feat) || !ONDA_ALIGNED16(proto) || (sigma && !ONDA_ALIGNED16(sigma))) return ONDA_EALIGN;
+  int64_t nb = (N + 3) / 4;
+  if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(proto_distances_kernel, dim3((unsigned)nb), dim3(256), 0, ONDA_STREAM(s), feat, ldf, proto, sigma, mahalanobis,
+                     dist, N, K);
   return ONDA_LAUNCH_RESULT();
 }
 

@@ -142,6 +142,35 @@ class prototype_handler:
         flat, K, C = self.class_statistics(feat, out)
         self.ma_from_statistics(flat, K, C)
 
+    def onehot(self, matrix):
+        """One-hot rows of the row-wise argmax (reference :83-86)."""
+        return torch.zeros_like(matrix, dtype=torch.float32).scatter_(1, matrix.argmax(dim=1, keepdim=True), 1.0)
+
+    def get_proto_array(self, feat, out):
+        """(per-class feature sums [K,C], per-class pixel counts [K]) under argmax(out) (reference :76-81) -- the
+        class-sum kernel's first output; `ma` / `append` use both moments at once."""
+        sums, counts, _, _ = self._class_sums(feat, out)
+        return sums[0], counts
+
+    # ---- distance matrices by themselves (reference :111-138; pseudo_labels computes them inside its one pass) -------
+    def _distances(self, feat, maha):
+        frows, ldf, N, C = _rows(feat)
+        K = self.prototypes.shape[0]
+        dist = torch.empty(N, K, device=frows.device, dtype=torch.float32)
+        call("onda_proto_distances", _p(frows), ldf, _p(self.prototypes), _p(self.global_var()) if maha else None, int(maha),
+             _p(dist), N, C, K, ops._stream())
+        return dist
+
+    def mahalanobis_distance(self, feat):
+        return self._distances(feat, True)
+
+    def distance(self, feat):
+        return self._distances(feat, False)
+
+    @property
+    def distance_measure(self):
+        return self.mahalanobis_distance if self.distance_metric == "mahalanobis" else self.distance
+
     def _touch(self):
         self._cache_key = None
         for t in (self.prototypes, self.squared_mean, self.counter):

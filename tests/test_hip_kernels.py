@@ -666,6 +666,34 @@ def test_ema_multi():
     assert torch.equal(kd[2].cpu(), qs[2])
 
 
+@pytest.mark.parametrize("metric", ["mahalanobis", "euclidean"])
+def test_prototype_distance_matrices(metric):
+    """prototype_handler.distance / mahalanobis_distance / distance_measure, onehot and get_proto_array (reference
+    prototype_handler.py:76-86, :111-138) against the oracle; N not a multiple of the pixels per workgroup."""
+    from onda_amd.framework.domain_adaptation.methods.prototype_handler import prototype_handler
+    from onda_amd.synthetic import synth_prototypes
+    from oracle import prototypes as op
+    g = torch.Generator().manual_seed(17)
+    proto, sq, cnt = synth_prototypes()
+    feat = proto[torch.randint(0, 19, (2 * 9 * 13,), generator=g)].reshape(2, 9, 13, 256) + 0.7 * torch.randn(2, 9, 13, 256, generator=g)
+    feat = feat.permute(0, 3, 1, 2).contiguous()
+    h = prototype_handler(0.9995, 1, 0.3, metric)
+    h.prototypes, h.squared_mean, h.counter = proto.to(DEV), sq.to(DEV), cnt.to(DEV)
+    ref = op.distances(feat, (proto, sq, cnt), metric)
+    got = h.distance_measure(feat.to(DEV))
+    assert got.shape == ref.shape and got.min(dim=1)[0].abs().max().item() == 0.0
+    close(got, ref, 2e-6, f"{metric} distances")
+    close(h.mahalanobis_distance(feat.to(DEV)) if metric == "mahalanobis" else h.distance(feat.to(DEV)), ref, 2e-6, "named")
+    out = torch.randn(2, 19, 9, 13, generator=g)
+    rows = op.to_rows(out)
+    oh = h.onehot(rows.to(DEV)).cpu()
+    assert torch.equal(oh.argmax(1), rows.argmax(1)) and torch.equal(oh.sum(1), torch.ones(rows.shape[0]))
+    sums, counts = h.get_proto_array(feat.to(DEV), out.to(DEV))
+    s_ref, n_ref = op.class_sums(feat, out)
+    close(sums, s_ref, 1e-5, "proto array")
+    assert torch.equal(counts.cpu(), n_ref)
+
+
 @pytest.mark.parametrize("sk,Co,taps,Cin,co_real,ci_real,flat_k", [
     (128, 64, 1, 64, 64, 64, 0),      # 16 slab groups per element, vector store
     (32, 256, 1, 1024, 256, 1024, 0),  # 4 slab groups
