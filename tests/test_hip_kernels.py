@@ -35,6 +35,7 @@ CONV_CASES = [
     (256, 512, 1, 2, 1, 0, 17, 33, False),
     (64, 64, 3, 1, 1, 1, 17, 33, False),
     (128, 128, 3, 1, 1, 1, 9, 17, False),
+    (128, 128, 3, 1, 1, 1, 8, 8, False),   # ONE 128 x 128 tile cut over all 512 resident workgroups: 512 candidate pieces, 36 live
     (256, 256, 3, 1, 2, 2, 9, 17, False),
     (512, 512, 3, 1, 4, 4, 9, 17, False),
     (2048, 256, 3, 1, 6, 6, 9, 17, True),
