@@ -52,6 +52,11 @@ def init_from_env(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if os.environ["MASTER_ADDR"] in ("127.0.0.1", "localhost", "::1"):
+            # one node: the bootstrap sockets of RCCL and gloo go over the loopback interface instead of whatever the
+            # container's hostname resolves to (it may not resolve, or resolve to an address nothing listens on)
+            os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
