@@ -17,6 +17,8 @@ torch.set_num_threads(min(16, os.cpu_count() or 1))
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    if not config.pluginmanager.hasplugin("timeout"):  # (the marker stays legal where pytest-timeout is absent)
+        config.addinivalue_line("markers", "timeout(seconds): per-test time limit (pytest-timeout)")
 
 
 def pytest_collection_modifyitems(config, items):
