@@ -7,6 +7,7 @@ images per GPU (BASELINE.json configs[2]; configs[3] when launched on N GPUs).
     python bench.py --gpus 1 --steps 10 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N ...      # without a launcher: starts the N ranks itself (fresh child processes), or fails
 
 Rank 0 prints ONE JSON line.  `value` counts all ranks' target images over the max-over-ranks time of exactly K steps
 (inputs already resident in HBM).  Default = weak scaling: every rank adapts on its own micro-batch of 4; the
@@ -17,16 +18,21 @@ Other BASELINE configs: `--config 1` (forward-only evaluation of 8 frames), `--c
 step), `--config 5` (the adaptation step at 1024x2048).
 
 The line carries its own context: `dtype` names the arithmetic the convolutions run in; `config.exact_f32` re-times 3
-steps with the exact fp32-MFMA kernels; `--eager` times the same step on PyTorch-ROCm eager (MIOpen fp32) in this
-process (`config.eager_rocm`; without the flag the committed measurement is quoted); `roofline` is measured live with HIP events on the launch stream in
-extra, instrumented steps after the timed region; `cpu_baseline` times the CPU oracle (oracle/step.py, the restatement
-of the reference pinned by the golden vectors) on the host cores, rank 0, N=1; `config.library` ties the binary to the
-sources (hash compiled into libonda_hip.so vs hash of the sources on disk).
+steps with the exact fp32-MFMA kernels; `config.eager_rocm` times the same step on PyTorch-ROCm eager (MIOpen fp32) in
+this process -- live by default when MIOpen's tuned find-db travels with the tree (tools/miopen_db: seconds), with
+`--eager` otherwise (MIOpen's kernel search: ~10 minutes), and `vs_baseline` = value / that live eager rate;
+`config.other_configs` holds short driver-timed runs of BASELINE configs 1, 2, 5 and of the static branch; `roofline`
+is measured live with HIP events on the launch stream in extra, instrumented steps after the timed region;
+`cpu_baseline` times the CPU oracle (oracle/step.py, the restatement of the reference pinned by the golden vectors) on
+the host cores at the GPU line's batch size, rank 0, N=1; `config.library` ties the binary to the sources (hash
+compiled into libonda_hip.so vs hash of the sources on disk).
 """
 import argparse
 import glob
 import json
 import os
+import socket
+import subprocess
 import sys
 import tempfile
 import time
@@ -58,8 +64,12 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--eager", action="store_true",
-                    help="also time the step on PyTorch-ROCm eager in this process (MIOpen's kernel search takes ~10 minutes)")
+                    help="time the step on PyTorch-ROCm eager in this process even without a tuned MIOpen find-db in the tree "
+                         "(MIOpen's kernel search then takes ~10 minutes)")
+    ap.add_argument("--no-eager", action="store_true")
     ap.add_argument("--no-exact-f32", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the short runs of BASELINE configs 1, 2, 5 and of the static branch (config.other_configs)")
     args = ap.parse_args()
     if args.height is None:
         args.height, args.width = (1024, 2048) if args.config == 5 else (512, 1024)
@@ -95,13 +105,21 @@ def build_adapter(args, device, tmp, shards=1):
     return da, src, trg
 
 
+def fresh(batch):
+    """The batch as a loader would deliver it: NEW tensor objects every step (same device storage -- inputs stay resident
+    in HBM).  Anything the operator layer remembers on an input tensor (ops.stem_patches caches the stem's patch matrix on
+    the image tensor, so that teacher / static / student share it WITHIN a step) therefore never survives into the next
+    step: every timed step pays its absmax + patch passes (round-2 verdict: 4 patch launches in 10 steps)."""
+    return {k: (v.detach() if torch.is_tensor(v) else v) for k, v in batch.items()}
+
+
 def one_step(da, src, trg, i, total, shards=1):
     da.adjust_learning_rate(i, total)
     if shards == 1:
-        log = da.step([src[i % 2]], trg[i % 2])
+        log = da.step([fresh(src[i % 2])], fresh(trg[i % 2]))
     else:
         base = (i % 2) * shards
-        log = da.step_sharded([([src[base + j]], trg[base + j]) for j in range(shards)])
+        log = da.step_sharded([([fresh(src[base + j])], fresh(trg[base + j])) for j in range(shards)])
     da.update_ema()
     return log
 
@@ -215,7 +233,7 @@ def cpu_baseline(args):
     # host; 32 threads is about the best it does, and it is what is reported
     cores = min(32, os.cpu_count() or 1)
     torch.set_num_threads(cores)
-    b = 1
+    b = args.batch  # the GPU line's unit: same batch (same BatchNorm batch), same step
     ad, src, trg, omodel = _oracle_adapter(args, "cpu", b)
     times = []
     for _ in range(2):
@@ -227,8 +245,25 @@ def cpu_baseline(args):
     dt = times[-1]
     return {"value": round(b / dt, 5), "unit": "images/s", "cores": cores, "kind": "port",
             "sample": f"hybrid step (+update_ema) of the CPU oracle on {b} image(s) per step at {args.width}x{args.height} "
-                      f"(the GPU line: {args.batch} per step), branch={'dynamic' if ad.switch.current else 'static'}; 1 warm-up "
+                      f"(the GPU line's batch), branch={'dynamic' if ad.switch.current else 'static'}; 1 warm-up "
                       f"({times[0]:.1f} s) + 1 timed step ({dt:.1f} s), torch CPU fp32, {cores} threads"}
+
+
+MIOPEN_DB = os.path.join(ROOT, "tools", "miopen_db")  # MIOpen's user find-db + kernel cache of THIS workload, in-tree
+
+
+def miopen_db_ready():
+    """Has MIOpen's kernel search for this workload's convolutions been done before (`python bench.py --eager` on an MI355X
+    fills tools/miopen_db) and do its results travel with the tree?  Then the live eager leg costs seconds instead of ten minutes."""
+    return bool(glob.glob(os.path.join(MIOPEN_DB, "*.ufdb.txt")) or glob.glob(os.path.join(MIOPEN_DB, "*.udb.txt")))
+
+
+def point_miopen_at_tree():
+    """MIOpen reads these when its first handle is created (the first eager convolution; the HIP path never calls
+    MIOpen).  The directory must be writable: a miss makes MIOpen search and append."""
+    os.makedirs(MIOPEN_DB, exist_ok=True)
+    os.environ.setdefault("MIOPEN_USER_DB_PATH", MIOPEN_DB)
+    os.environ.setdefault("MIOPEN_CUSTOM_CACHE_DIR", os.path.join(MIOPEN_DB, "cache"))
 
 
 def eager_rocm(args, device):
@@ -427,11 +462,74 @@ def run_forward_only(args, device, rank, world):
             "unit": "images/s", "dt": dt, "scaling": "weak", "config": cfg_out, "roofline": roof}
 
 
+def other_configs(args, device):
+    """Short driver-timed runs (1 warm-up + 3 timed passes each, no instrumentation) of the BASELINE configurations the
+    default line does not time: config 1 (forward-only, 8 frames), config 2 (supervised step), config 5 (the adaptation step
+    at 1024x2048) and config 3 on the STATIC side of the switch."""
+    import copy
+    import gc
+    out = {}
+    plan = [("config1_forward_only_8_frames", dict(config=1, height=512, width=1024), run_forward_only),
+            ("config2_supervised_step", dict(config=2, height=512, width=1024), run_segmentation),
+            ("config3_static_branch", dict(config=3, height=512, width=1024, branch="static"), run_adaptation),
+            ("config5_adaptation_1024x2048", dict(config=5, height=1024, width=2048), run_adaptation)]
+    for name, over, run in plan:
+        sub = copy.copy(args)
+        sub.warmup, sub.steps, sub.no_roofline, sub.no_exact_f32, sub.global_batch = 1, 3, True, True, 0
+        for k, v in over.items():
+            setattr(sub, k, v)
+        try:
+            res = run(sub, device, 0, 1)
+            out[name] = {"value": res["value"], "unit": res["unit"], "ms_per_step": round(res["dt"] / sub.steps * 1e3, 3),
+                         "steps": sub.steps, "warmup": sub.warmup, "metric": res["metric"]}
+            if "branch" in res["config"]:
+                out[name]["branch"] = res["config"]["branch"]
+        except Exception as exc:  # a side measurement must never take the headline line down with it
+            out[name] = {"error": f"{type(exc).__name__}: {exc}"}
+        gc.collect()
+        torch.cuda.empty_cache()
+    return out
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as FRESH child processes (this parent never
+    touches the GPU: no exec, no re-launch behind a HIP call), one per device, rendezvous on the loopback interface,
+    rank 0's JSON line relayed on stdout.  Any failure -- fewer devices than ranks, a rank that dies -- is a non-zero exit:
+    a line that says `n_gpus: 1` is never printed for `--gpus 8`."""
+    n = args.gpus
+    forced = "ONDA_FORCE_DEVICE" in os.environ  # test hook: several ranks on one device (over gloo)
+    have = torch.cuda.device_count()  # (counting devices does not initialise the GPU)
+    if not forced and have < n:
+        raise SystemExit(f"bench.py --gpus {n}: this node shows {have} GPU(s); refusing to print a line for fewer ranks than asked")
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    text = out.decode()
+    sys.stdout.write(text)
+    sys.stdout.flush()
+    if any(codes):
+        raise SystemExit(f"bench.py --gpus {n}: rank exit codes {codes}")
+    lines = [ln for ln in text.splitlines() if ln.startswith("{")]
+    if not lines or json.loads(lines[-1]).get("n_gpus") != n:
+        raise SystemExit(f"bench.py --gpus {n}: rank 0 did not report {n} ranks")
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args)
+    point_miopen_at_tree()
     from onda_amd import dist as odist
     rank, world, local = odist.init_from_env()
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (the HIP path has no CPU fallback)")
@@ -443,29 +541,47 @@ def main():
     run = {1: run_forward_only, 2: run_segmentation, 3: run_adaptation, 5: run_adaptation}[args.config]
     res = run(args, device, rank, world)
     dt = res.pop("dt")
-    cpu = eager = None
+    cpu = eager = others = None
     headline = args.config in (3, 5) and not args.global_batch
+    default_line = headline and args.config == 3 and (args.height, args.width) == (512, 1024) and args.batch == 4
     if rank == 0 and world == 1 and headline:
-        if args.eager and (args.height, args.width) == (512, 1024):
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+        if default_line and not args.no_other_configs:
+            others = other_configs(args, device)
+        # the PyTorch-ROCm eager comparison runs LIVE whenever MIOpen's search results for this workload are in the tree
+        # (seconds); without them only on request (--eager: the search takes ~10 minutes and fills tools/miopen_db)
+        if default_line and not args.no_eager and (args.eager or miopen_db_ready()):
             eager = eager_rocm(args, device)
+            gc.collect()
+            torch.cuda.empty_cache()
         if not args.no_cpu_baseline:
             cpu = cpu_baseline(args)
     if rank == 0:
         dtype, note = arithmetic()
         res["config"].update({"conv_mode": note, "conv_accuracy": conv_accuracy_probe(device), "library": lib})
+        vs = None
+        if others:
+            res["config"]["other_configs"] = others
         if eager:
             eager["speedup_of_this_repo"] = round(eager["ms_per_step"] / (dt / args.steps * 1e3), 3)
             res["config"]["eager_rocm"] = eager
-        elif headline and (args.height, args.width) == (512, 1024) and args.batch == 4:
-            # MIOpen's kernel search makes the live leg a ten-minute affair (--eager); the committed measurement of the same
-            # step (same GPU model, same workload, builder-run) is quoted instead, with its source
+            # BASELINE.md publishes no number for this metric; the reference point the north star names (">= 5x the
+            # reference single-GPU PyTorch step") is measured in this same run, on this same GPU
+            vs = round(res["value"] / eager["images_per_s"], 3)
+            res["config"]["vs_baseline_is"] = ("value / config.eager_rocm.images_per_s: the same step on PyTorch-ROCm eager (MIOpen "
+                                               "fp32, tuned), timed live in this run on this GPU (BASELINE.md holds no published number)")
+        elif default_line:
+            # no tuned MIOpen find-db in the tree and no --eager: the committed measurement of the same step (same GPU
+            # model, same workload, builder-run) is quoted with its source; vs_baseline stays null
             committed = {"ms_per_step": 302.9, "source": "profiles/r01_b_eager_pytorch_rocm.txt (tools/eager_baseline.py: MIOpen fp32, "
                          "cudnn.benchmark=True; with the reference's own flags -- benchmark off, deterministic on -- 11.3 s per step)"}
             committed["speedup_of_this_repo"] = round(committed["ms_per_step"] / (dt / args.steps * 1e3), 3)
             res["config"]["eager_rocm_committed"] = committed
         line = {"metric": res["metric"], "value": res["value"], "unit": res["unit"], "n_gpus": world, "steps": args.steps,
                 "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
-                "scaling": res["scaling"], "vs_baseline": None, "dtype": dtype, "data": "synthetic", "config": res["config"],
+                "scaling": res["scaling"], "vs_baseline": vs, "dtype": dtype, "data": "synthetic", "config": res["config"],
                 "roofline": res["roofline"], "cpu_baseline": cpu}
         print(json.dumps(line), flush=True)
     if odist.is_on():

@@ -50,7 +50,9 @@ def init_from_env(backend=None):
     backend = backend or os.environ.get("ONDA_DIST_BACKEND")
     if (world > 1 or _FORCE) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29531")
+        # no launcher-provided port: derive one from the parent process (the ranks of one job share their launcher, two jobs
+        # on a node do not), instead of one fixed port that two jobs or tests on the same node would fight over
+        os.environ.setdefault("MASTER_PORT", str(20000 + os.getppid() % 20000))
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if os.environ["MASTER_ADDR"] in ("127.0.0.1", "localhost", "::1"):
             # one node: the bootstrap sockets of RCCL and gloo go over the loopback interface instead of whatever the
@@ -141,8 +143,23 @@ class GradSync:
         # the last bucket carries the tail
         self._close_bucket(start, total + tail_floats, members)
         self._remaining = [0] * len(self.buckets)
-        for p in params:
-            p.register_post_accumulate_grad_hook(self._on_grad)
+        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in params]
+
+    def close(self):
+        """Detach from the module: hooks removed, gradients given storage of their own again (the flat buffer can be
+        freed), nothing left pointing at this exchange.  Building a second exchange over the same module (a second
+        adapter, tests) must close the first one."""
+        if not self.active:
+            return
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+        with torch.no_grad():
+            for p in self.params:
+                if p.grad is not None:
+                    p.grad = p.grad.detach().clone()
+        self.active = False
+        self.flat = self.tail = None
 
     def _close_bucket(self, start, end, members):
         idx = len(self.buckets)
@@ -163,6 +180,7 @@ class GradSync:
             return
         self._armed = True
         self._pending = []
+        self._seen = set()
         self._launched = [False] * len(self.buckets)
         for i, (_, _, members) in enumerate(self.buckets):
             self._remaining[i] = len(members)
@@ -170,14 +188,38 @@ class GradSync:
     def _on_grad(self, p):
         self.grad_ready(p)
 
+    @torch.no_grad()
+    def _rebind(self, p):
+        """Make `p.grad` the parameter's slot of the flat buffer again.  Autograd allocates a fresh gradient tensor when
+        it finds `.grad is None` (after ``zero_grad(set_to_none=True)``, or an optimizer rebuilt without ``flat_zero``):
+        the value is moved into the slot BEFORE the slot's bucket can go out."""
+        off, n = self._slot[id(p)]
+        g = p.grad
+        if g is None:
+            self.flat[off:off + n].zero_()
+        elif g.data_ptr() != self.flat.data_ptr() + 4 * off:
+            self.flat[off:off + n].copy_(g.reshape(-1))
+        else:
+            return False
+        p.grad = self.flat[off:off + n].view_as(p)
+        return True
+
     def grad_ready(self, p):
         """A parameter's gradient for this step is complete (autograd hook, or ops.Conv2dFn after it has accumulated the
         weight gradient in place)."""
         if not (self.active and self._armed):
             return
         i = self._bucket_of.get(id(p))
-        if i is None or self._launched[i]:
+        if i is None:
             return
+        if self._launched[i]:
+            # cannot happen while every member is counted once per step; a bucket that is already on the wire must never
+            # be patched behind its all-reduce (the advisor's finding) -- fail instead of exchanging a stale slot
+            raise RuntimeError("onda_amd.dist: a gradient arrived after its bucket had been all-reduced")
+        if id(p) in self._seen:
+            return  # a second signal for the same parameter in one pass (hook + Conv2dFn) counts once
+        self._seen.add(id(p))
+        self._rebind(p)  # the slot holds the gradient before the bucket can leave
         self._remaining[i] -= 1
         if self._remaining[i] <= 0 and i != len(self.buckets) - 1:  # the last bucket waits for the tail (finish)
             self._launch(i)
@@ -196,15 +238,14 @@ class GradSync:
         if not self._armed:
             self.arm()
         self._armed = False
-        # a gradient that autograd re-allocated (someone set .grad to None) is copied into its slot
+        # parameters that produced no gradient signal in the armed pass (no gradient this step, or one that was complete
+        # before arm()): their buckets have NOT been launched (a bucket leaves only when every member has signalled), so
+        # a gradient autograd re-allocated can still be moved into its slot here
         for p in self.params:
-            off, n = self._slot[id(p)]
-            g = p.grad
-            if g is None:
-                p.grad = self.flat[off:off + n].view_as(p)
-            elif g.data_ptr() != self.flat.data_ptr() + 4 * off:
-                self.flat[off:off + n].copy_(g.reshape(-1))
-                p.grad = self.flat[off:off + n].view_as(p)
+            if not self._launched[self._bucket_of[id(p)]]:
+                self._rebind(p)
+            elif p.grad is None or p.grad.data_ptr() != self.flat.data_ptr() + 4 * self._slot[id(p)][0]:
+                raise RuntimeError("onda_amd.dist: a gradient left the flat buffer after its bucket had been all-reduced")
         for i in range(len(self.buckets)):
             if not self._launched[i]:
                 self._launch(i)

@@ -143,9 +143,7 @@ class da_model:
         width, height = self.cfg.SCHEME.RESOLUTION
         with torch.no_grad():
             for set_name, loader in validation_loaders.items():
-                it = iter(loader)
-                for i in range(count):
-                    sample = next(it)
+                for i, sample in zip(range(count), loader):  # (a set with fewer samples gives what it has)
                     image, label = sample["image"][0], sample["label"][0]
                     out = self.model(image.unsqueeze(0).to(self.device))[1]
                     out = out["out"] if isinstance(out, dict) else out

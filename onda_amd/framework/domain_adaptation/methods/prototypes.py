@@ -159,8 +159,16 @@ class online_proDA(da_model):
             super().load_model(spec.LOAD_MODEL)
         self.dynamic_update_counter = 0
         self._img_cache = None
+        # one exchange per model: a second adapter over the same model (per-domain construction, tests) first detaches the
+        # previous one (its hooks, its 46 M-float buffer, its claim on ops.GRAD_READY)
+        previous = model.__dict__.get("_onda_grad_sync")
+        if previous is not None:
+            previous.close()
+            if ops.GRAD_READY == previous.grad_ready:
+                ops.GRAD_READY = None
         self._grad_sync = odist.GradSync(self.model, tail_floats=self._tail_size(),
                                          skip=(lambda name: name.startswith("layer5.")) if not self.model.multi_level else None)
+        model.__dict__["_onda_grad_sync"] = self._grad_sync
         if self._grad_sync.active:
             ops.GRAD_READY = self._grad_sync.grad_ready
             self.optimizer.flat_zero = self._grad_sync.zero
@@ -614,12 +622,21 @@ class online_proDA(da_model):
             self.evaluate_update_dynamic()
             self.update_ema()
             log["Total buffer updates"] = self.buffer_update(target_sample, update_prob, trainloader)
-            if (i_iter + 1) % len(targetloader) == 0:
+            if (i_iter + 1) % len(targetloader) == 0:  # epoch end (reference :512-518)
                 if validation_loaders:
                     log.update(self.evaluate_all(validation_loaders))
-                self.save_model()
+                    if not unset(self.cfg.OTHERS.GENERATE_SAMPLES_EVERY):
+                        log.update(self.test_on_samples(validation_loaders))
+                self._save_on_rank0()
             emit(log)
-        self.save_model()
+        self._save_on_rank0()
+
+    def _save_on_rank0(self):
+        """Checkpoint + prototypes written once per job: the replicas are identical, and several ranks writing the same
+        paths at the same time tear the files (the reference is single-process)."""
+        if odist.rank() == 0:
+            self.save_model()
+        odist.barrier()
 
 
 class _Cycle:

@@ -78,11 +78,15 @@ class SegmentationTrainer:
 
 
 def save_model(model, epoch, cfg):
-    root = cfg.OTHERS.SNAPSHOT_DIR
-    if unset(root) or root == "NONE":
-        return
+    """``model_train_<source set>.pth`` under the snapshot directory, overwritten every epoch (reference :141-151: the file
+    later runs name as MODEL.LOAD / LOAD_MODEL)."""
+    root, set_ = cfg.SNAPSHOT_DIR, None
+    if unset(root):
+        root, set_ = cfg.OTHERS.SNAPSHOT_DIR, cfg.SCHEME.SOURCE
+    else:
+        set_ = cfg.DOMAIN_ANALYSIS.DATASET.TRAIN
     os.makedirs(root, exist_ok=True)
-    torch.save(model.state_dict(), os.path.join(root, f"model_{epoch}.pth"))
+    torch.save(model.state_dict(), os.path.join(root, f"model_train_{set_}.pth"))
 
 
 def train(model, train_loader, validation_loaders, cfg, cfg_spec=None):

@@ -299,6 +299,7 @@ class ResNetMulti(nn.Module):
 
     def __deepcopy__(self, memo):
         packer = self.__dict__.pop("_packer", None)  # buffers of the packed weights belong to one model instance
+        sync = self.__dict__.pop("_onda_grad_sync", None)  # ... and so does its gradient exchange (onda_amd/dist.py)
         try:
             cls = self.__class__
             new = cls.__new__(cls)
@@ -309,6 +310,8 @@ class ResNetMulti(nn.Module):
         finally:
             if packer is not None:
                 self.__dict__["_packer"] = packer
+            if sync is not None:
+                self.__dict__["_onda_grad_sync"] = sync
         return new
 
     def _stem(self, x):

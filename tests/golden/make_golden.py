@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Generate the golden vectors (G1-G11) by IMPORTING the reference on CPU.
+"""Generate the golden vectors (G1-G13) by IMPORTING the reference on CPU.
 
 Run in the build container only (the reference does not exist on the GPU box):
 
@@ -455,6 +455,64 @@ def g10():
         print("g10 branch", res["branch"], {k: round(v, 5) for k, v in lg.items() if np.isscalar(v)})
 
 
+def _full_step(name, width, height, batch, head_scale, seeds=(1000, 2000)):
+    """One hybrid_proDA step (+update_ema) of the reference at a full size: the recipe of g10 with the size, the batch and
+    the head scale (= which side of the switch the synthetic state sits on) as arguments."""
+    import warnings
+    with tempfile.TemporaryDirectory() as tmp:
+        cfg, spec = make_cfg(tmp)
+        cfg.SCHEME.RESOLUTION = [width, height]
+        cfg.TRAINING.BATCH_SIZE = batch
+        model = ref_model(1, head_scale)
+        da = hybrid_proDA(model, cfg, spec)
+        src = [synth_batch(batch, height, width, seed=seeds[0] + i) for i in range(2)]
+        trg = synth_batch(batch, height, width, seed=seeds[1])
+        torch.manual_seed(123)
+        da.update_dynamic()
+        switch_batch_statistics(da.model, False)
+        da.calculate_prototypes(src)
+        switch_batch_statistics(da.model, True)
+        res = {"proto0": da.prototypes.prototypes.clone(), "counter0": da.prototypes.counter.clone()}
+        da.optimizer.zero_grad()
+        da.adjust_learning_rate(0, 6)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            log = da.step([src[0]], trg)
+        da.update_ema()
+        lg = tolog(log)
+        res["log_json"] = np.array(json.dumps({k: v for k, v in lg.items() if np.isscalar(v)}))
+        soft = trg["stored_predictions"].to(torch.float32)
+        top2 = soft.topk(2, dim=1)[0]
+        res["labels"] = soft.argmax(1).to(torch.uint8)
+        res["tie_mask"] = np.packbits(((top2[:, 0] - top2[:, 1]) < 2e-3).numpy())
+        res["soft_digest"] = digest(soft, 4096)
+        res["soft_max"] = soft.max(1)[0].to(torch.float16)
+        res["proto1"], res["sqmean1"] = da.prototypes.prototypes.clone(), da.prototypes.squared_mean.clone()
+        res["branch"] = np.array(da.model_select.current)
+        names, dig = [], []
+        for who, mod in (("student.", da.model), ("teacher.", da.ema_model)):
+            for n, p in mod.state_dict().items():
+                names.append(who + n)
+                dig.append(digest(p.float(), 64))
+        res["state_names"], res["state_digest"] = np.array(names), np.stack(dig)
+        res["shape"] = np.array([batch, height, width])
+        save(name, **res)
+        print(name, "branch", res["branch"], {k: round(v, 5) for k, v in lg.items() if np.isscalar(v)})
+
+
+def g12():
+    """The step bench.py TIMES (BASELINE config 3 as the default line runs it): 512x1024, batch 4, head x1 = the DYNAMIC
+    branch, source seeds 1000/1001, target seed 2000."""
+    _full_step("g12_step_bench_dynamic", 1024, 512, 4, 1.0)
+
+
+def g13():
+    """One adaptation step at BASELINE config 5's resolution, 1024x2048 (feature grid 129x257).  Batch 2, not 4: the
+    reference's CPU step holds ~12 GB per 512x1024 bs-4 step, i.e. ~48 GB at 1024x2048 bs 4 -- more than this 64 GB
+    container can give it beside the build; the batch changes the pixel count M only, not a single kernel shape."""
+    _full_step("g13_step_1024x2048", 2048, 1024, 2, 40.0, seeds=(1300, 2300))
+
+
 def g11():
     """Eval-mode forward of one full-resolution frame of BASELINE config 5 (1 x 3 x 1024 x 2048): class map of
     interp(out).softmax.argmax, its tie mask, the logits on a 4-pixel grid and digests."""
@@ -470,6 +528,6 @@ def g11():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13"]
     for w in which:
         globals()[w]()

@@ -103,3 +103,53 @@ def test_flat_bucketed_gradient_exchange_with_tail():
         assert torch.equal(avg0[k], avg1[k])
     assert torch.equal(tail0, torch.arange(6.0) * 3) and torch.equal(tail0, tail1)
     assert not torch.equal(skipped0, skipped1)
+
+
+def _lost_grad_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from onda_amd import dist as od
+    od.init_from_env("gloo")
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(64, 32), torch.nn.ReLU(), torch.nn.Linear(32, 8), torch.nn.Linear(8, 4))
+    sync = od.GradSync(net, bucket_floats=1000)
+    assert len(sync.buckets) >= 2
+    result = {}
+    for mode in ("none_before_step", "none_between_passes"):
+        sync.zero()
+        x = torch.randn(16, 64) * (rank + 1)
+        if mode == "none_before_step":
+            net.zero_grad(set_to_none=True)      # every .grad leaves the flat buffer: autograd will allocate fresh tensors
+        net(x).sum().backward()
+        if mode == "none_between_passes":
+            net[0].weight.grad = None            # ... or one gradient disappears mid-step (its first-pass part is lost everywhere)
+            net[3].bias.grad = net[3].bias.grad.clone()  # ... or is replaced by a tensor outside the buffer
+        sync.arm()
+        net(x * 0.5).pow(2).sum().backward()
+        local = {n: p.grad.detach().clone() for n, p in net.named_parameters()}
+        sync.finish()
+        for name, p in net.named_parameters():   # back inside the flat buffer, at its own slot
+            off, n = sync._slot[id(p)]
+            assert p.grad.data_ptr() == sync.flat.data_ptr() + 4 * off, (mode, name)
+        result[mode] = (local, {n: p.grad.detach().clone() for n, p in net.named_parameters()})
+    # a second exchange over the same module detaches the first (hooks gone, gradients own their storage again)
+    sync.close()
+    assert not sync.active and all(p.grad.data_ptr() != 0 and p._post_accumulate_grad_hooks in (None, {}) or
+                                   len(p._post_accumulate_grad_hooks) == 0 for p in net.parameters())
+    out[rank] = result
+    dist.destroy_process_group()
+
+
+def test_gradient_that_left_the_flat_buffer_is_exchanged_correctly():
+    """The advisor's finding: a gradient autograd re-allocated (``.grad`` was None, or replaced) used to be copied into its
+    slot only AFTER the slot's bucket had been all-reduced -- the exchanged values were stale and replicas diverged.  Now
+    the value is moved into the slot when the parameter signals (before its bucket can leave): every rank ends with the
+    rank-mean of the gradients the ranks actually computed."""
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_lost_grad_worker, args=(2, port, out), nprocs=2, join=True)
+    for mode in ("none_before_step", "none_between_passes"):
+        (local0, avg0), (local1, avg1) = out[0][mode], out[1][mode]
+        for k in local0:
+            assert torch.allclose(avg0[k], (local0[k] + local1[k]) / 2, rtol=1e-6, atol=1e-7), (mode, k)
+            assert torch.equal(avg0[k], avg1[k]), (mode, k)

@@ -335,3 +335,16 @@ def test_switch_plans_of_the_prototype_methods():
     assert plan() == (1.0, 0.0)
     vsel.evaluate(-1e-3)
     assert plan() == (0.0, 1)
+
+
+def test_bench_refuses_more_ranks_than_devices():
+    """`python bench.py --gpus 8` on a node that does not show 8 GPUs: non-zero exit, no JSON line (never `n_gpus: 1`)."""
+    import subprocess
+    import sys
+    if torch.cuda.device_count() >= 8:
+        pytest.skip("this node has 8 GPUs")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "ONDA_FORCE_DEVICE")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8"], env=env, capture_output=True, text=True,
+                         timeout=300)
+    assert out.returncode != 0 and "{" not in out.stdout and "refusing" in out.stderr
