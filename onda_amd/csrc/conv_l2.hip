@@ -129,167 +129,161 @@ __global__ __launch_bounds__(256) void stem_im2col_l2_kernel(const float* __rest
 }
 
 // ---- epilogue of a (64*WM) x (64*WN) tile held as 4 x 4 MFMA tiles of 16 x 16 per wave ----------------------------
-// The accumulator layout has a lane's 16 values of one MFMA column 4 rows apart: stored as they stand that is 64
-// four-byte stores per lane in 64-byte runs, and the store ISSUE (not bandwidth) is what a tile then waits for
-// (measured: 26 000 cycles per 256 x 128 tile, more than the K loop of a 1 x 1 convolution with 256 input
-// channels).  So each wave transposes its 64 x 64 sub-tile through LDS, 16 rows at a time, and stores whole
-// 256-byte row segments as 16-byte vectors: 16 stores per lane, scale / shift loaded once per lane.
-// `scratch`: LDS nobody else touches during the epilogue: 4 KiB per wave, then WM*BN*4 + WM*WN floats of statistics.
+// Accumulator layout.  The K loops feed the WEIGHT fragment into the MFMA's A slot and the ACTIVATION fragment into its
+// B slot (both fragments have the same lane layout: row l & 15, k-chunk l >> 4), so the hardware leaves block (i, j)
+// TRANSPOSED in the accumulators: lane l holds pixel  i*16 + (l & 15)  and the four CONSECUTIVE channels
+// j*16 + 4*(l >> 4) + e, e = 0..3 -- 16 contiguous bytes of an NHWC row.  The epilogue therefore stores every block
+// straight from the registers as one 16-byte vector per lane (16 stores per wave and tile, each covering 16 pixel rows
+// x 64 bytes; the neighbouring block fills the other half of the 128-byte lines right behind it).
+// History: with the activations in the A slot a lane held 4 PIXELS of one channel -- 64 four-byte stores per lane
+// (round 1: 26 000 cycles per 256 x 128 tile, store issue) or a transposition of every wave's sub-tile through 4 KiB
+// of LDS (round 2: 64 ds_write_b32 + 16 ds_read_b128 per wave, 11 200 cycles per tile and a barrier for the scratch).
 // COUNTED: every wave issues exactly 16 output stores (buffer stores; rows past M / channels past Cout get an
 // out-of-range offset and are dropped by the hardware) -- conv_l2x_kernel counts them in its vmcnt waits.
-// x[lane] (+, min, max) x[lane ^ 16] and x[lane ^ 32] on the VALU (v_permlane16/32_swap: gfx950), four values per call.
-// (Inline assembly: this compiler folds the builtin's two results into one when both inputs are the same value.)
-#define ONDA_SWAP4(INSN, A, B)                                                                                          \
-  asm volatile("s_nop 1\n\t" INSN " %0, %4\n\t" INSN " %1, %5\n\t" INSN " %2, %6\n\t" INSN " %3, %7\n\ts_nop 0"         \
-               : "+v"(A[0]), "+v"(A[1]), "+v"(A[2]), "+v"(A[3]), "+v"(B[0]), "+v"(B[1]), "+v"(B[2]), "+v"(B[3]))
-__device__ __forceinline__ void rows_reduce4(float& s1, float& s2, float& mn, float& mx) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  float A[4] = {s1, s2, mn, mx}, B[4] = {s1, s2, mn, mx};
-  ONDA_SWAP4("v_permlane16_swap_b32", A, B);
-  float C[4] = {A[0] + B[0], A[1] + B[1], fminf(A[2], B[2]), fmaxf(A[3], B[3])};
-  float D[4] = {C[0], C[1], C[2], C[3]};
-  ONDA_SWAP4("v_permlane32_swap_b32", C, D);
-  s1 = C[0] + D[0];
-  s2 = C[1] + D[1];
-  mn = fminf(C[2], D[2]);
-  mx = fmaxf(C[3], D[3]);
-#endif
+// `scratch`: WM*BN*4 + NW floats of LDS nobody else touches during the epilogue (statistics / max across waves; not
+// touched at all when the tile has neither).
+template <int CTRL>
+__device__ __forceinline__ float dpp16(float v) {  // the value of another lane of the same 16-lane row (VALU, no LDS)
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
 }
+// reduce over the 16 lanes of a row (the 16 pixels of a block): xor 1, xor 2 (quad permutes), quad <-> quad
+// (row_half_mirror), half <-> half (row_mirror); afterwards every lane of the row holds the result
+#define ONDA_ROW16(OP, v)              \
+  do {                                 \
+    v = OP(v, dpp16<0xB1>(v));         \
+    v = OP(v, dpp16<0x4E>(v));         \
+    v = OP(v, dpp16<0x141>(v));        \
+    v = OP(v, dpp16<0x140>(v));        \
+  } while (0)
+__device__ __forceinline__ float addf(float a, float b) { return a + b; }
 
 // AFFINE = false: no per-channel scale / shift, residual or ReLU (train-mode convolutions, plain data gradients): the
 // epilogue then issues no global LOAD at all.  That matters in the continuous stream (COUNTED): vmcnt counts in issue
 // order, so waiting for any load issued here means waiting for the next tile's DMAs that are already in flight, and
 // the compiler has to place such a wait (vmcnt(0)) as soon as a load MAY have been issued.  For the same reason the
 // barriers of the COUNTED path are bare s_barrier + lgkmcnt waits, not __syncthreads() (whose release fence is a
-// vmcnt(0)): measured 4 000 of the epilogue's 13 000 cycles.
+// vmcnt(0)).
 template <int WM, int WN, bool COUNTED = false, bool AFFINE = true>
 __device__ __forceinline__ void l2_epilogue(const ConvK& a, const f32x4 (&acc)[4][4], unsigned char* scratch, int tile_m, int m0,
                                             int n0, int wm, int wn, int lane, float ua, float ub, unsigned y_bytes = 0) {
   // `acc` holds RAW sums (operand units: value * 2^ea * 2^eb); ua = 2^-ea, ub = 2^-eb (exact) are applied to the four
   // statistics of a column and folded into the per-channel scale of the output instead of to all 64 accumulators
   constexpr int BN = 64 * WN, NW = WM * WN, NT = NW * 64;
-  constexpr int TRS = 68;  // floats per row of the transposition buffer: rows 4 apart land 16 banks apart (ds_write_b32
-                           // banks are (a/4) % 32 per 32-lane half; 64 would put lanes l and l+16 on one bank)
   const OndaConv& c = a.c;
   const int t = threadIdx.x, wave = t >> 6;
+  const int pl = lane & 15, q = lane >> 4;  // pixel of a block, 4-channel group of a block
   // diagnostics: the phases of the workgroup's LAST tile (overwritten per tile: no load here, see AFFINE)
   unsigned long long* est = a.stamps != nullptr && t == 0 ? a.stamps + (size_t)blockIdx.x * 32 + 24 : nullptr;
   if (est) est[0] = __builtin_amdgcn_s_memtime();
-  float* red = reinterpret_cast<float*>(scratch + NW * (16 * TRS * 4));
+  float* red = reinterpret_cast<float*>(scratch);
   const int SR = a.stats_rows;  // 2, or 4 with the per-channel min / max of the raw tile (rows past M count as zeros:
                                 // the extrema only have to BOUND the tensor's, norm_l2.hip)
   if (a.stats != nullptr) {
 #pragma unroll
-    for (int jn = 0; jn < 4; ++jn) {
-      float s1 = 0.f, s2 = 0.f, mn = 3.0e38f, mxv = -3.0e38f;
+    for (int j = 0; j < 4; ++j) {
+      f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1, mn = {3.0e38f, 3.0e38f, 3.0e38f, 3.0e38f}, mxv = -mn;
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < 4; ++i) {
+        const f32x4 v = acc[i][j];
+        s1 += v;
+        s2 += v * v;
+        if (SR == 4) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            mn[e] = fminf(mn[e], v[e]);
+            mxv[e] = fmaxf(mxv[e], v[e]);
+          }
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        ONDA_ROW16(addf, s1[e]);
+        ONDA_ROW16(addf, s2[e]);
+        if (SR == 4) {
+          ONDA_ROW16(fminf, mn[e]);
+          ONDA_ROW16(fmaxf, mxv[e]);
+        }
+      }
+      if (pl == 0) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float v = acc[i][jn][e];
-          s1 += v;
-          s2 += v * v;
-          mn = fminf(mn, v);
-          mxv = fmaxf(mxv, v);
+          const int col = (wn * 4 + j) * 16 + 4 * q + e;
+          *reinterpret_cast<f32x4*>(red + (wm * BN + col) * 4) =
+              f32x4{(s1[e] * ua) * ub, (((s2[e] * ua) * ub) * ua) * ub, (mn[e] * ua) * ub, (mxv[e] * ua) * ub};
         }
-      rows_reduce4(s1, s2, mn, mxv);
-      if (lane < 16) {
-        const int col = (wn * 4 + jn) * 16 + lane;
-        red[(wm * BN + col) * 4 + 0] = (s1 * ua) * ub;
-        red[(wm * BN + col) * 4 + 1] = (((s2 * ua) * ub) * ua) * ub;
-        red[(wm * BN + col) * 4 + 2] = (mn * ua) * ub;
-        red[(wm * BN + col) * 4 + 3] = (mxv * ua) * ub;
       }
     }
   }
 
   if (est) est[1] = __builtin_amdgcn_s_memtime();
   const bool plain = (c.out_os == 1 && c.Hf == c.Ho && c.Wf == c.Wo);
-  // after the transposition: lane -> row 4*r + (lane >> 4) of a 16-row chunk (r = 0..3), columns 4*(lane & 15) .. +3
-  const int cl = (lane & 15) * 4, rl = lane >> 4;
-  const int n = n0 + wn * 64 + cl;
-  const bool vn = n < c.Cout;  // Cout is a multiple of 4
-  f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-  if constexpr (AFFINE) {
-    if (vn && a.scale) sc = *reinterpret_cast<const f32x4*>(a.scale + n);
-    if (vn && a.shift) sh = *reinterpret_cast<const f32x4*>(a.shift + n);
+  const int nb = n0 + wn * 64 + 4 * q;  // this lane's channels of block j: nb + 16 j .. + 3
+  f32x4 sc[4], sh[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    sc[j] = f32x4{1.f, 1.f, 1.f, 1.f};
+    sh[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (AFFINE) {
+      const bool vn = nb + 16 * j < c.Cout;  // Cout is a multiple of 4
+      if (vn && a.scale) sc[j] = *reinterpret_cast<const f32x4*>(a.scale + nb + 16 * j);
+      if (vn && a.shift) sh[j] = *reinterpret_cast<const f32x4*>(a.shift + nb + 16 * j);
+    }
+    sc[j] = (sc[j] * ua) * ub;
   }
-  sc = (sc * ua) * ub;
-  float* tr = reinterpret_cast<float*>(scratch + wave * (16 * TRS * 4));
   float mx = 0.f;
+  const int mw = m0 + wm * 64 + pl;  // this lane's output row of block row i: mw + 16 i
   // the residual (a shortcut in eval mode; the running gradient sum of a shared activation, ops.GradSink) is fetched
-  // up front -- 16 independent 16-byte loads per lane into the registers the second accumulator set just vacated --
-  // instead of one round trip per 16-row chunk in the store loop
+  // up front -- 16 independent 16-byte loads per lane into the registers the second accumulator set just vacated
   f32x4 rv[4][4];
   if (AFFINE && a.res) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = m0 + (wm * 4 + i) * 16 + 4 * r + rl;
-        const bool live = m < a.M && vn;
-        rv[i][r] = live ? *reinterpret_cast<const f32x4*>(a.res + (size_t)m * c.ldr + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < 4; ++j) {
+        const int m = mw + 16 * i, n = nb + 16 * j;
+        const bool live = m < a.M && n < c.Cout;
+        rv[i][j] = live ? *reinterpret_cast<const f32x4*>(a.res + (size_t)m * c.ldr + n) : f32x4{0.f, 0.f, 0.f, 0.f};
       }
   }
-  // Dense output (row m of the GEMM is row m of y: every convolution but the strided data gradient): the address of
-  // (i, r) is a per-lane base plus a workgroup-uniform term -- one VALU add per store instead of the 64-bit index
-  // arithmetic; with buffer stores (COUNTED) the rows past M lie past the end of the buffer (y_bytes covers M dense
-  // rows) and the columns past Cout carry an out-of-range base: the hardware drops both, no per-row test.
   const bool track = a.amax != nullptr;
-  const bool full_rows = m0 + 64 * WM <= a.M;
-  const int mw = m0 + wm * 64 + rl;  // this lane's output row for (i, r) = (0, 0)
-  const unsigned vbase = vn ? (unsigned)(((size_t)mw * c.ldy + n) * 4) : OOB;
-  float* const ybase = a.y + (size_t)mw * c.ldy + n;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    // this wave's own rows of the buffer: only its own earlier reads have to be out of the way
+    const int m = mw + 16 * i;
+    const bool vm = m < a.M;
+    size_t orow = (size_t)m;
+    if (!plain) {  // scattered rows (stride-2 data gradient)
+      const int mm = vm ? m : 0;
+      const int wo = mm % c.Wo, tq = mm / c.Wo;
+      const int ho = tq % c.Ho, b = tq / c.Ho;
+      orow = ((size_t)b * c.Hf + (size_t)ho * c.out_os) * c.Wf + (size_t)wo * c.out_os;
+    }
 #pragma unroll
-    for (int jn = 0; jn < 4; ++jn)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) tr[(4 * (lane >> 4) + e) * TRS + jn * 16 + (lane & 15)] = acc[i][jn][e];
-    __builtin_amdgcn_wave_barrier();  // one wave, and the LDS executes a wave's instructions in order: no wait, no s_barrier
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = 4 * r + rl;
-      f32x4 v = *reinterpret_cast<const f32x4*>(tr + row * TRS + cl);
-      const int m = mw + i * 16 + 4 * r;
-      const bool live = (full_rows || m < a.M) && vn;
+    for (int j = 0; j < 4; ++j) {
+      const int n = nb + 16 * j;
+      const bool live = vm && n < c.Cout;
+      f32x4 v = acc[i][j];
       if constexpr (AFFINE) {
-        v = v * sc + sh;
-        if (a.res) v += rv[i][r];
+        v = v * sc[j] + sh[j];
+        if (a.res) v += rv[i][j];
         if (c.relu) {
 #pragma unroll
-          for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
         }
       } else {
-        v = v * sc;
+        v = v * sc[j];
       }
-      if (plain) {
-        if constexpr (COUNTED) {
+      if constexpr (COUNTED) {
 #if defined(__HIP_DEVICE_COMPILE__)
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), make_rsrc(a.y, y_bytes),
-                                                 vbase + (unsigned)((i * 16 + 4 * r) * c.ldy * 4), 0, 0);
+        // dense output: rows past M lie past the end of the buffer (y_bytes covers M dense rows), columns past Cout and
+        // dead scattered rows carry an out-of-range offset: the hardware drops them, the store COUNT stays exact
+        const unsigned off = (n < c.Cout && (plain || vm)) ? (unsigned)((orow * c.ldy + n) * 4) : OOB;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), make_rsrc(a.y, y_bytes), off, 0, 0);
 #endif
-        } else if (live) {
-          *reinterpret_cast<f32x4*>(ybase + (size_t)((i * 16 + 4 * r) * c.ldy)) = v;
-        }
-      } else {  // scattered rows (stride-2 data gradient)
-        const int mm = live ? m : 0;
-        const int wo = mm % c.Wo, tq = mm / c.Wo;
-        const int ho = tq % c.Ho, b = tq / c.Ho;
-        const size_t orow = ((size_t)b * c.Hf + (size_t)ho * c.out_os) * c.Wf + (size_t)wo * c.out_os;
-        if constexpr (COUNTED) {
-#if defined(__HIP_DEVICE_COMPILE__)
-          const unsigned off = live ? (unsigned)((orow * c.ldy + n) * 4) : OOB;
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), make_rsrc(a.y, y_bytes), off, 0, 0);
-#endif
-        } else if (live) {
-          *reinterpret_cast<f32x4*>(a.y + orow * c.ldy + n) = v;
-        }
+      } else if (live) {
+        *reinterpret_cast<f32x4*>(a.y + orow * c.ldy + n) = v;
       }
       if (track && live) mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
     }
-    __builtin_amdgcn_wave_barrier();
   }
   if (est) est[2] = __builtin_amdgcn_s_memtime();
   float* ar = red + WM * BN * 4;
@@ -312,10 +306,11 @@ __device__ __forceinline__ void l2_epilogue(const ConvK& a, const f32x4 (&acc)[4
       float s1 = 0.f, s2 = 0.f, mn = 3.0e38f, mxv = -3.0e38f;
 #pragma unroll
       for (int w_ = 0; w_ < WM; ++w_) {
-        s1 += red[(w_ * BN + col) * 4 + 0];
-        s2 += red[(w_ * BN + col) * 4 + 1];
-        mn = fminf(mn, red[(w_ * BN + col) * 4 + 2]);
-        mxv = fmaxf(mxv, red[(w_ * BN + col) * 4 + 3]);
+        const f32x4 p = *reinterpret_cast<const f32x4*>(red + (w_ * BN + col) * 4);
+        s1 += p[0];
+        s2 += p[1];
+        mn = fminf(mn, p[2]);
+        mxv = fmaxf(mxv, p[3]);
       }
       float* dst = a.stats + (size_t)tile_m * SR * c.Cout + n0 + col;
       dst[0] = s1;
@@ -336,6 +331,18 @@ __device__ __forceinline__ void l2_epilogue(const ConvK& a, const f32x4 (&acc)[4
   if (est) est[4] = __builtin_amdgcn_s_memtime();
 }
 
+// raw accumulators of a partial (stream-K) tile -> slot[BM][BN] (row-major, what conv_l2_fixup_kernel sums): one 16-byte
+// store per block and lane
+template <int BN>
+__device__ __forceinline__ void l2_store_partial(float* slot, const f32x4 (&acc)[4][4], int wm, int wn, int lane) {
+  const int pl = lane & 15, q = lane >> 4;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      *reinterpret_cast<f32x4*>(slot + ((wm * 4 + i) * 16 + pl) * BN + (wn * 4 + j) * 16 + 4 * q) = acc[i][j];
+}
+
 // ---- epilogue that writes LIMB PLANES (eval mode: conv + folded BatchNorm [+ residual limbs] [+ ReLU] -> the next conv's
 // operand format, no fp32 tensor and no split pass in between).  The planes' scale has to exist before the first element
 // is stored: it comes from an a-priori bound
@@ -350,71 +357,71 @@ __device__ __forceinline__ float limb_out_bound(const ConvK& a) {
   return b * 1.0001f;  // (fp32 rounding of the sums and of the bound itself)
 }
 
+// (same transposed accumulator layout as l2_epilogue: a lane's four values of a block are four consecutive channels of
+//  one pixel -- 8 bytes of each plane)
 template <int WM, int WN, bool COUNTED>
 __device__ __forceinline__ void l2_epilogue_limbs(const ConvK& a, const f32x4 (&acc)[4][4], unsigned char* scratch, int m0, int n0,
                                                   int wm, int wn, int lane, float ua, float ub) {
-  constexpr int BN = 64 * WN, NW = WM * WN;
-  constexpr int TRS = 68;
+  constexpr int NW = WM * WN;
   const OndaConv& c = a.c;
   if constexpr (COUNTED) asm volatile("" : "+v"(lane));
   int t = threadIdx.x;
   if constexpr (COUNTED) asm volatile("" : "+v"(t));
   const int wave = t >> 6;
+  const int pl = lane & 15, q = lane >> 4;
   const float bound = limb_out_bound(a);
   const float so = scale_from(bound).s;
   if (t == 0) a.ybound[(blockIdx.x & (ONDA_AMAX_SLOTS - 1)) * AMAX_STRIDE] = bound;
   const float ri = a.resl != nullptr ? scale_of(a.res_amax).inv : 0.f;
-  const int cl = (lane & 15) * 4, rl = lane >> 4;
-  const int n = n0 + wn * 64 + cl;
-  const bool vn = n < c.Cout;
-  f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-  if (vn && a.scale) sc = *reinterpret_cast<const f32x4*>(a.scale + n);
-  if (vn && a.shift) sh = *reinterpret_cast<const f32x4*>(a.shift + n);
-  sc = (sc * ua) * ub;
-  float* tr = reinterpret_cast<float*>(scratch + wave * (16 * TRS * 4));
-  float* ar = reinterpret_cast<float*>(scratch + NW * (16 * TRS * 4));
-  const int mw = m0 + wm * 64 + rl;
-  // residual limbs, all 16 row positions of this lane up front (8 bytes per plane each)
+  const int nb = n0 + wn * 64 + 4 * q;
+  const int mw = m0 + wm * 64 + pl;
+  f32x4 sc[4], sh[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const bool vn = nb + 16 * j < c.Cout;
+    sc[j] = f32x4{1.f, 1.f, 1.f, 1.f};
+    sh[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (vn && a.scale) sc[j] = *reinterpret_cast<const f32x4*>(a.scale + nb + 16 * j);
+    if (vn && a.shift) sh[j] = *reinterpret_cast<const f32x4*>(a.shift + nb + 16 * j);
+    sc[j] = (sc[j] * ua) * ub;
+  }
+  float* ar = reinterpret_cast<float*>(scratch);
+  // residual limbs, all 16 blocks of this lane up front (8 bytes per plane each)
   u32x2 r1[4][4], r2[4][4];
   if (a.resl != nullptr) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = mw + i * 16 + 4 * r;
-        const bool live = m < a.M && vn;
+      for (int j = 0; j < 4; ++j) {
+        const int m = mw + 16 * i, n = nb + 16 * j;
+        const bool live = m < a.M && n < c.Cout;
         const _Float16* p = a.resl + (size_t)(live ? m : 0) * c.ldr + (live ? n : 0);
-        r1[i][r] = live ? *reinterpret_cast<const u32x2*>(p) : u32x2{0u, 0u};
-        r2[i][r] = live ? *reinterpret_cast<const u32x2*>(p + a.resplane) : u32x2{0u, 0u};
+        r1[i][j] = live ? *reinterpret_cast<const u32x2*>(p) : u32x2{0u, 0u};
+        r2[i][j] = live ? *reinterpret_cast<const u32x2*>(p + a.resplane) : u32x2{0u, 0u};
       }
   }
   float mx = 0.f;
   const size_t plane_bytes = (size_t)a.M * c.ldy * 2;  // one plane as a buffer: rows past M fall outside
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
+    const int m = mw + 16 * i;
 #pragma unroll
-    for (int jn = 0; jn < 4; ++jn)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) tr[(4 * (lane >> 4) + e) * TRS + jn * 16 + (lane & 15)] = acc[i][jn][e];
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = 4 * r + rl;
-      f32x4 v = *reinterpret_cast<const f32x4*>(tr + row * TRS + cl);
-      const int m = mw + i * 16 + 4 * r;
+    for (int j = 0; j < 4; ++j) {
+      const int n = nb + 16 * j;
+      const bool vn = n < c.Cout;
       const bool live = m < a.M && vn;
-      v = v * sc + sh;
+      f32x4 v = acc[i][j] * sc[j] + sh[j];
       if (a.resl != nullptr) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-          const f32x2 p1 = unpack2h(r1[i][r][h]), p2 = unpack2h(r2[i][r][h]);
+          const f32x2 p1 = unpack2h(r1[i][j][h]), p2 = unpack2h(r2[i][j][h]);
           v[2 * h] += (p1[0] + p2[0] * LIMB2_UNSCALE) * ri;
           v[2 * h + 1] += (p1[1] + p2[1] * LIMB2_UNSCALE) * ri;
         }
       }
       if (c.relu) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
       }
       if (live) mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
       const f32x4 w = v * so;
@@ -438,7 +445,6 @@ __device__ __forceinline__ void l2_epilogue_limbs(const ConvK& a, const f32x4 (&
         *reinterpret_cast<u32x2*>(dst + a.yplane) = l2;
       }
     }
-    __builtin_amdgcn_wave_barrier();
   }
   if (a.amax != nullptr) {  // the true maximum of what was stored (bounds the next layer)
     mx = wave_max(mx);
@@ -656,7 +662,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_l2_kernel(const ConvK 
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) accx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][0], bf[j], accx[i][j], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) accx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i][0], accx[i][j], 0, 0, 0);
       if constexpr (!STAGGER) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) b1[j] = *reinterpret_cast<const f16x8*>(Bb + j * 1024);
@@ -664,11 +670,11 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_l2_kernel(const ConvK 
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) accx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][1], b1[j], accx[i][j], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) accx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b1[j], af[i][1], accx[i][j], 0, 0, 0);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][0], b1[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b1[j], af[i][0], acc[i][j], 0, 0, 0);
     };
     if constexpr (!STAGGER) {
       // (a two-stage ring -- half the LDS, two workgroups per CU hide each other's waits -- has one step in flight)
@@ -721,7 +727,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_l2_kernel(const ConvK 
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (acc[i][j] * unscale_a) * unscale_b;
       float* slot = a.ws + ((size_t)swz * 2 + (u - (k_end - k_begin) == u_begin ? 0 : 1)) * (BM * BN);
-      conv_store_partial<BN, 4, 4, 16>(slot, acc, wm, wn, lane);
+      l2_store_partial<BN>(slot, acc, wm, wn, lane);
       continue;
     }
     // (the epilogue folds the two exact unscale factors into its per-column constants; if their PRODUCT left the normal
@@ -734,7 +740,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_l2_kernel(const ConvK 
         for (int j = 0; j < 4; ++j) acc[i][j] = (acc[i][j] * ua) * ub;
       ua = ub = 1.f;
     }
-    __syncthreads();
+    if (a.stats != nullptr || a.amax != nullptr) __syncthreads();  // the epilogue's cross-wave scratch lives in the ring
     if (a.yl != nullptr) l2_epilogue_limbs<WM, WN, false>(a, acc, lds, m0, n0, wm, wn, lane, ua, ub);
     else l2_epilogue<WM, WN>(a, acc, lds, tile_m, m0, n0, wm, wn, lane, ua, ub);
     if (DBG == 5) {
@@ -953,17 +959,17 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_l2x_kernel(const ConvK
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) accx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][0], bf[j], accx[i][j], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) accx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i][0], accx[i][j], 0, 0, 0);
 #pragma unroll
       for (int j = 0; j < 4; ++j) bf[j] = *reinterpret_cast<const f16x8*>(Bb + j * 1024);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) accx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][1], bf[j], accx[i][j], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) accx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i][1], accx[i][j], 0, 0, 0);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][0], bf[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i][0], acc[i][j], 0, 0, 0);
       if (late) issue_step();
     }
     stamp();
@@ -977,7 +983,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_l2x_kernel(const ConvK
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (acc[i][j] * unscale_a) * unscale_b;
       float* slot = a.ws + ((size_t)swz * 2 + (first_piece ? 0 : 1)) * (BM * BN);
-      conv_store_partial<BN, 4, 4, 16>(slot, acc, wm, wn, lane);
+      l2_store_partial<BN>(slot, acc, wm, wn, lane);
       stores_young = 2;
       stamp();
       continue;
@@ -992,9 +998,10 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_l2x_kernel(const ConvK
         for (int j = 0; j < 4; ++j) acc[i][j] = (acc[i][j] * ua) * ub;
       ua = ub = 1.f;
     }
-    // every wave has its fragments of the last step (they fed its MFMAs): that stage is scratch now.  A bare barrier:
-    // the DMAs of the next two steps stay in flight (see l2_epilogue)
-    __builtin_amdgcn_s_barrier();
+    // every wave has its fragments of the last step (they fed its MFMAs): that stage is scratch now (the statistics' and
+    // the maximum's cross-wave reduction; a tile with neither touches no LDS and needs no barrier).  A bare barrier: the
+    // DMAs of the next two steps stay in flight (see l2_epilogue)
+    if (a.stats != nullptr || a.amax != nullptr) __builtin_amdgcn_s_barrier();
     const int scratch = st_read == 0 ? (STAGES - 1) * STAGE : st_read - STAGE;  // the stage read last
     if (limb_out)
       l2_epilogue_limbs<WM, WN, true>(a, acc, lds + scratch, (tile / a.tilesN) * BM, (tile % a.tilesN) * BN, wm, wn, lane, ua, ub);
@@ -1472,18 +1479,18 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_wgrad_l2_kernel(const 
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) accx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][0], bf[j], accx[i][j], 0, 0, 0);
+      for (int j = 0; j < 4; ++j) accx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i][0], accx[i][j], 0, 0, 0);
     if constexpr (!STAGGER) lds_wait(b1[0], b1[1], b1[2], b1[3]);
     if constexpr (STAGGER) issue_second_part();
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) accx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][1], b1[j], accx[i][j], 0, 0, 0);
+      for (int j = 0; j < 4; ++j) accx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b1[j], af[i][1], accx[i][j], 0, 0, 0);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][0], b1[j], acc[i][j], 0, 0, 0);
+      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b1[j], af[i][0], acc[i][j], 0, 0, 0);
   };
   if constexpr (!STAGGER) {
     for (; i_cur < nlive; ++i_cur) {
@@ -1527,26 +1534,20 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_wgrad_l2_kernel(const 
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = ((acc[i][j] + accx[i][j] * LIMB2_UNSCALE) * unscale_a) * unscale_b;
   if (stp) stp[2] = __builtin_amdgcn_s_memtime();
-  __syncthreads();
-  // slab store through the wave's own 4 KiB of LDS: 16 rows (output channels) x 64 input channels at a time, 16-byte stores
-  float* tr = reinterpret_cast<float*>(lds + (t >> 6) * 4096);
-  const int cl = (lane & 15) * 4, rl = lane >> 4;
-  const int cc = c0 + wn * 64 + cl;
+  // slab store straight from the accumulators: the x fragment sits in the MFMA's A slot, so a lane holds, for output
+  // channel n = i*16 + (lane & 15), the four CONSECUTIVE input channels j*16 + 4*(lane >> 4) + e -- 16 bytes of a slab row
+  {
+    const int pl = lane & 15, q = lane >> 4;
+    const int cb = c0 + wn * 64 + 4 * q;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 4; ++i) {
+      const int n = n0 + (wm * 4 + i) * 16 + pl;
 #pragma unroll
-    for (int jn = 0; jn < 4; ++jn)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) tr[(4 * (lane >> 4) + e) * 64 + jn * 16 + (lane & 15)] = acc[i][jn][e];
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = 4 * r + rl;
-      const f32x4 v = *reinterpret_cast<const f32x4*>(tr + row * 64 + cl);
-      const int n = n0 + (wm * 4 + i) * 16 + row;
-      if (n < c.Cout && cc < c.Cin) *reinterpret_cast<f32x4*>(a.slabs + (((size_t)ks * c.Cout + n) * a.taps + tap) * c.Cin + cc) = v;
+      for (int j = 0; j < 4; ++j) {
+        const int cc = cb + 16 * j;
+        if (n < c.Cout && cc < c.Cin) *reinterpret_cast<f32x4*>(a.slabs + (((size_t)ks * c.Cout + n) * a.taps + tap) * c.Cin + cc) = acc[i][j];
+      }
     }
-    __builtin_amdgcn_wave_barrier();
   }
   if (stp) stp[3] = __builtin_amdgcn_s_memtime();
 }
