@@ -44,6 +44,8 @@ typedef struct OndaConv {
   int Hf, Wf;           /* [B,Hf,Wf] grid (out_os=1,Hf=Ho,Wf=Wo normally; 2 for the dgrad of */
                         /* the stride-2 1x1 convs, deeplabv2.py:22-24,351-357)              */
   int relu;
+  const int32_t* run_if; /* NULL, or a device int: the launch does nothing when *run_if == 0 (a predicate decided on the
+                          * device, onda_switch_step; honoured by the pre-split kernels of csrc/conv_l2.hip, EINVAL elsewhere) */
 } OndaConv;
 
 /* Number of float partials conv_fwd writes when `stats` != NULL: tiles_m * 2 * Cout, where
@@ -153,8 +155,10 @@ void onda_debug_stamps(void* buffer);
 int onda_stem_im2col_l2(const float* x_nchw, const float* xamax, void* dst, int64_t plane, int B, int H, int W, int Ho, int Wo,
                         int Kp, onda_stream_t s);
 int onda_conv_l2_variant(int64_t M, int Cout);  /* tile shape used for an (M, Cout) problem: 0 256x128, 1 128x128, 2 256x64 */
-/* device kernel launched for a problem: 0 / 1 / 2 = conv_l2_kernel<4,2> / <2,2> / <4,1>, 3 = conv_l2x_kernel<4,2> (256x128 tiles,
- * at most 32 K-steps per tile: the continuous K-step stream); bench.py names its per-kernel figures after this */
+/* device kernel launched for a problem: 0 / 1 / 2 = conv_l2_kernel<4,2> / <2,2> / <4,1>, 3 = conv_l2x_kernel<4,2> (256x128 tiles:
+ * one continuous K-step stream over a workgroup's tiles), 4 = conv_l2s_kernel<3,2> (that stream with the two halves of the
+ * workgroup one slot apart; the default for tiles of at most 32 K-steps; env ONDA_L2_XT picks); bench.py names its
+ * per-kernel figures after this */
 int onda_conv_l2_kernel_id(int64_t M, int Cout, int taps, int Cin);
 int onda_conv_l2_tiles_m(int64_t M, int Cout, int taps, int Cin);  /* rows of the `stats` partials the conv writes for this problem */
 /* stats_rows: 2 = stats[tile][sum, sumsq][Cout] as onda_conv2d_fwd; 4 = also the per-channel min and max of the raw
@@ -372,6 +376,36 @@ int onda_resize_nearest_lut(const unsigned char* in, unsigned char* out, int Win
 
 /* library identity, for the loader's sanity check */
 const char* onda_version(void);
+
+/* ---- the hybrid switch on the device (csrc/switch.hip) ---------------------------------------------------------------
+ * One monitored series + the two-state machine that reads it, advanced by ONE small launch per adaptation step:
+ * replaces Monitor.add / avg / exp / dev_avg for the key "prior static" (framework/utils/monitoring.py:7-96) and
+ * model_select.evaluate (prototypes_hybrid_switch.py:22-34) on the step's path -- no read-back, no host decision.
+ *   state  : onda_switch_state_doubles(limit) doubles, zero-initialised: [0] exp, [1] avg (median), [2] dev_avg, [3] the
+ *            confidence the machine looked at, [8..) the ring of the last `limit` samples
+ *   istate : 8 int32, zero-initialised except [2] = [3] = the start state (0 static, 1 dynamic): [0] count, [1] head,
+ *            [2] current, [3] current_dev, [4] steps
+ *   sample : device scalar (float, or double when sample_f64)
+ *   taps   : limit-1 doubles (np.hamming(limit-1) for "hamming", ones for "mean"; unused for level_kind 1 = "median")
+ *   flag   : device int32, receives `current` -- the predicate of the dynamic model's launches (OndaConv::run_if)
+ * Float64 arithmetic in numpy's order of operations: fixture G5 is reproduced bit for bit. */
+typedef struct OndaSwitchCfg {
+  int limit;         /* AVG_MONITOR_SIZE */
+  int level_kind;    /* 0: weighted level sum(taps*w)/taps_total, 1: median */
+  int use_exp;       /* EXP_PR_STATIC: the machine reads the exponential average instead of the median */
+  int pad_;
+  double exp_const, one_minus_exp_const, taps_total;
+  double gray_lo, gray_hi, dev_threshold;
+} OndaSwitchCfg;
+int onda_switch_state_doubles(int limit);
+int onda_switch_step(double* state, int32_t* istate, const void* sample, int sample_f64, const double* taps,
+                     const OndaSwitchCfg* cfg, int32_t* flag, onda_stream_t s);
+/* out[i] = *flag ? wb * b[i] : wa * a[i]: the prior of prototypes_hybrid_switch.py:57-75 picked on the device (`b` may hold
+ * anything when *flag == 0: the predicated dynamic forward did not run) */
+int onda_select_prior(const int32_t* flag, const float* a, float wa, const float* b, float wb, float* out, int64_t n,
+                      onda_stream_t s);
+/* out[0] = *flag ? v[0] : NaN (a monitor sample that exists on one side of the switch only) */
+int onda_gate_scalar(const int32_t* flag, const float* v, float* out, onda_stream_t s);
 
 #ifdef __cplusplus
 }

@@ -15,7 +15,14 @@ I, L, F = c_int, c_int64, c_float
 
 
 class OndaConv(Structure):
-    _fields_ = [(n, c_int) for n in ("B Hi Wi Cin Ho Wo Cout kh kw stride dil pad ldx ldy ldr out_os Hf Wf relu").split()]
+    _fields_ = [(n, c_int) for n in ("B Hi Wi Cin Ho Wo Cout kh kw stride dil pad ldx ldy ldr out_os Hf Wf relu").split()] + \
+               [("run_if", c_void_p)]
+
+
+class OndaSwitchCfg(Structure):
+    _fields_ = [("limit", c_int), ("level_kind", c_int), ("use_exp", c_int), ("pad_", c_int), ("exp_const", ctypes.c_double),
+                ("one_minus_exp_const", ctypes.c_double), ("taps_total", ctypes.c_double), ("gray_lo", ctypes.c_double),
+                ("gray_hi", ctypes.c_double), ("dev_threshold", ctypes.c_double)]
 
 
 class OndaLimbOut(Structure):
@@ -54,6 +61,10 @@ SIGNATURES = {
     "onda_stem_im2col_l2": (I, [P, P, P, L, I, I, I, I, I, I, P]),
     "onda_debug_stamps": (None, [P]),
     "onda_conv2d_fwd_l2_limbs": (I, [P, L, P, P, P, P, P, P, P, P, P]),
+    "onda_switch_state_doubles": (I, [I]),
+    "onda_switch_step": (I, [P, P, P, I, P, POINTER(OndaSwitchCfg), P, P]),
+    "onda_select_prior": (I, [P, P, F, P, F, P, L, P]),
+    "onda_gate_scalar": (I, [P, P, P, P]),
     "onda_conv_l2_variant": (I, [L, I]),
     "onda_conv_l2_kernel_id": (I, [L, I, I, I]),
     "onda_conv_l2_tiles_m": (I, [L, I, I, I]),

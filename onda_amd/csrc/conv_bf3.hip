@@ -529,6 +529,7 @@ int onda_pack_weight_bf3(const float* w_oihw, void* dst, int Cout, int Cin, int 
 int onda_conv2d_fwd_bf3(const float* x, const void* w3, float* y, const float* scale, const float* shift,
                         const float* residual, float* stats, float* ws, const OndaConv* c, onda_stream_t s) {
   ONDA_REQUIRE(x && w3 && y && c);
+  ONDA_REQUIRE(c->run_if == nullptr);  // device predicates: pre-split kernels only (conv_l2.hip)
   ONDA_REQUIRE(c->Cin > 0 && c->Cin % 32 == 0 && c->Cout > 0 && c->Cout % 4 == 0 && c->ldx % 4 == 0 && c->ldx >= c->Cin);
   ONDA_REQUIRE(c->kh >= 1 && c->kw >= 1 && c->stride >= 1 && c->dil >= 1 && c->out_os >= 1);
   if (!ONDA_ALIGNED16(x) || !ONDA_ALIGNED16(w3)) return ONDA_EALIGN;

@@ -689,6 +689,7 @@ int onda_conv2d_fwd_h2(const float* x, const float* xamax, const void* w2, const
                        const float* scale, const float* shift, const float* residual, float* stats, float* ws,
                        float* yamax, const OndaConv* c, onda_stream_t s) {
   ONDA_REQUIRE(x && xamax && w2 && wamax && y && c);
+  ONDA_REQUIRE(c->run_if == nullptr);  // device predicates: pre-split kernels only (conv_l2.hip)
   ONDA_REQUIRE(c->Cin > 0 && c->Cin % 32 == 0 && c->Cout > 0 && c->Cout % 4 == 0 && c->ldx % 4 == 0 && c->ldx >= c->Cin);
   ONDA_REQUIRE(c->kh >= 1 && c->kw >= 1 && c->stride >= 1 && c->dil >= 1 && c->out_os >= 1);
   if (!ONDA_ALIGNED16(x) || !ONDA_ALIGNED16(w2)) return ONDA_EALIGN;

@@ -163,7 +163,10 @@ __device__ __forceinline__ float addf(float a, float b) { return a + b; }
 // the compiler has to place such a wait (vmcnt(0)) as soon as a load MAY have been issued.  For the same reason the
 // barriers of the COUNTED path are bare s_barrier + lgkmcnt waits, not __syncthreads() (whose release fence is a
 // vmcnt(0)).
-template <int WM, int WN, bool COUNTED = false, bool AFFINE = true>
+// DEFER (conv_l2s_kernel, whose workgroup halves run one slot apart and cannot meet at a barrier inside an epilogue): the
+// statistics partials are left in `scratch` for l2_stats_finish (called one barrier later by the same half), the
+// maximum goes out as one atomic per WAVE; no barrier in here.
+template <int WM, int WN, bool COUNTED = false, bool AFFINE = true, bool DEFER = false>
 __device__ __forceinline__ void l2_epilogue(const ConvK& a, const f32x4 (&acc)[4][4], unsigned char* scratch, int tile_m, int m0,
                                             int n0, int wm, int wn, int lane, float ua, float ub, unsigned y_bytes = 0) {
   // `acc` holds RAW sums (operand units: value * 2^ea * 2^eb); ua = 2^-ea, ub = 2^-eb (exact) are applied to the four
@@ -286,6 +289,10 @@ __device__ __forceinline__ void l2_epilogue(const ConvK& a, const f32x4 (&acc)[4
     }
   }
   if (est) est[2] = __builtin_amdgcn_s_memtime();
+  if constexpr (DEFER) {
+    if (a.amax != nullptr) amax_update(a.amax, mx);
+    return;
+  }
   float* ar = red + WM * BN * 4;
   if (a.amax != nullptr) {
     mx = wave_max(mx);
@@ -359,7 +366,7 @@ __device__ __forceinline__ float limb_out_bound(const ConvK& a) {
 
 // (same transposed accumulator layout as l2_epilogue: a lane's four values of a block are four consecutive channels of
 //  one pixel -- 8 bytes of each plane)
-template <int WM, int WN, bool COUNTED>
+template <int WM, int WN, bool COUNTED, bool DEFER = false>
 __device__ __forceinline__ void l2_epilogue_limbs(const ConvK& a, const f32x4 (&acc)[4][4], unsigned char* scratch, int m0, int n0,
                                                   int wm, int wn, int lane, float ua, float ub) {
   constexpr int NW = WM * WN;
@@ -446,6 +453,10 @@ __device__ __forceinline__ void l2_epilogue_limbs(const ConvK& a, const f32x4 (&
       }
     }
   }
+  if constexpr (DEFER) {
+    if (a.amax != nullptr) amax_update(a.amax, mx);
+    return;
+  }
   if (a.amax != nullptr) {  // the true maximum of what was stored (bounds the next layer)
     mx = wave_max(mx);
     if (lane == 0) ar[wave] = mx;
@@ -470,6 +481,7 @@ template <int WM, int WN, int STAGES, int OCC, bool SK, int DBG = 0>
 __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_l2_kernel(const ConvK a, unsigned xplane, unsigned wplane, unsigned x_bytes,
                                                                    unsigned w_bytes, const float* __restrict__ xamax,
                                                                    const float* __restrict__ wamax) {
+  if (a.c.run_if != nullptr && *a.c.run_if == 0) return;  // predicated launch (onda_switch_step decided on the device)
   constexpr int NW = WM * WN;
   constexpr int BM = 64 * WM, BN = 64 * WN;
   constexpr int PLANE_A = BM * 64, PLANE_B = BN * 64;  // one limb plane of a stage: 64-byte rows
@@ -660,21 +672,21 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_l2_kernel(const ConvK 
     };
     auto compute = [&]() {  // "C": 48 MFMAs (one wave per SIMD: the b1 fragments are fetched behind the first 16)
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) accx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i][0], accx[i][j], 0, 0, 0);
+        for (int i = 0; i < 4; ++i) accx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i][0], accx[i][j], 0, 0, 0);
       if constexpr (!STAGGER) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) b1[j] = *reinterpret_cast<const f16x8*>(Bb + j * 1024);
       }
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) accx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b1[j], af[i][1], accx[i][j], 0, 0, 0);
+        for (int i = 0; i < 4; ++i) accx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b1[j], af[i][1], accx[i][j], 0, 0, 0);
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b1[j], af[i][0], acc[i][j], 0, 0, 0);
+        for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b1[j], af[i][0], acc[i][j], 0, 0, 0);
     };
     if constexpr (!STAGGER) {
       // (a two-stage ring -- half the LDS, two workgroups per CU hide each other's waits -- has one step in flight)
@@ -769,6 +781,7 @@ template <int WM, int WN, int STAGES, int OCC>
 __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_l2x_kernel(const ConvK a, unsigned xplane, unsigned wplane, unsigned x_bytes,
                                                                     unsigned w_bytes, unsigned y_bytes, const float* __restrict__ xamax,
                                                                     const float* __restrict__ wamax) {
+  if (a.c.run_if != nullptr && *a.c.run_if == 0) return;  // predicated launch (onda_switch_step decided on the device)
   constexpr int NW = WM * WN;
   constexpr int BM = 64 * WM, BN = 64 * WN;
   constexpr int PLANE_A = BM * 64, PLANE_B = BN * 64;
@@ -957,19 +970,19 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_l2x_kernel(const ConvK
       if (!late) issue_step();
       prepare();
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) accx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i][0], accx[i][j], 0, 0, 0);
+        for (int i = 0; i < 4; ++i) accx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i][0], accx[i][j], 0, 0, 0);
 #pragma unroll
       for (int j = 0; j < 4; ++j) bf[j] = *reinterpret_cast<const f16x8*>(Bb + j * 1024);
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) accx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i][1], accx[i][j], 0, 0, 0);
+        for (int i = 0; i < 4; ++i) accx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i][1], accx[i][j], 0, 0, 0);
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i][0], acc[i][j], 0, 0, 0);
+        for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i][0], acc[i][j], 0, 0, 0);
       if (late) issue_step();
     }
     stamp();
@@ -1016,6 +1029,300 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_l2x_kernel(const ConvK
   }
 }
 
+// ---- the continuous K-step stream with the SLOT STAGGER of conv_l2_kernel ------------------------------------------------
+// conv_l2x_kernel keeps the DMA stream running across tiles but leaves its two waves per SIMD in phase: all eight waves
+// read their fragments together (8 x 16 KB through the 128 B/clk LDS port: ~1 000 cycles in which no MFMA issues), then
+// queue their MFMAs behind one another -- 2 550 cycles per K-step against 1 536 of MFMA -- and every tile ends with an
+// epilogue during which the matrix pipe idles.  Here the stream is cut into SLOTS separated by workgroup barriers and the
+// second half of the workgroup (waves 4..7 = tile rows 128..255) runs ONE SLOT LATE:
+//     early:  P(k) | C(k) | P(k+1) | C(k+1) | ... | C(last) | E      | P(first')| C(first') ...
+//     late :       | P(k) | C(k)   | P(k+1) | ... | P(last) | C(last)| E        | P(first') ...
+// P = wait for the step's DMAs, issue the DMAs of step k+2, read ALL fragments; C = 48 MFMAs, no LDS access; E = the
+// tile's epilogue (16 stores per wave straight from the accumulators + the statistics' VALU work).  In every slot one
+// wave of each SIMD computes while the other prepares or stores: an epilogue costs the matrix pipe ONE slot per tile (the
+// slot in which the late half stores while the early half prepares), instead of the whole epilogue.
+// The halves never meet at a barrier inside an epilogue, so nothing in it may need one: a half's statistics partials go
+// to its own LDS region (outside the ring, which stays live) and are summed over the half's two wave rows ONE barrier
+// later by l2_stats_finish -- each half owns a row of `stats` per tile (row 2*tile_m + half; bn_finalize sums over all
+// rows anyway) -- and the running maximum is one atomic per wave (DEFER in l2_epilogue).
+// vmcnt arithmetic (issue order per wave): the early half waits for step k at the START of P(k): outstanding
+// [k][k+1], after an epilogue [k+1][k+2][stores], then [k+2][stores][k+3]: two waits during which the stores are younger
+// than the step waited for.  The late half waits for step k+1 at the END of P(k) (the early half reads that stage one
+// barrier later): outstanding [k+1][k+2], after its epilogue [k+2][stores][k+3]: one such wait.
+template <int BN>
+__device__ __forceinline__ void l2_stats_finish(const ConvK& a, const float* red_half, int row, int n0, int th) {
+  // th: thread index inside the half (0..255); its two wave rows' partials -> stats[row]
+  const OndaConv& c = a.c;
+  if (th < BN && n0 + th < c.Cout) {
+    const f32x4 p0 = *reinterpret_cast<const f32x4*>(red_half + th * 4);
+    const f32x4 p1 = *reinterpret_cast<const f32x4*>(red_half + (BN + th) * 4);
+    const int SR = a.stats_rows;
+    float* dst = a.stats + (size_t)row * SR * c.Cout + n0 + th;
+    dst[0] = p0[0] + p1[0];
+    dst[c.Cout] = p0[1] + p1[1];
+    if (SR == 4) {
+      dst[2 * c.Cout] = fminf(p0[2], p1[2]);
+      dst[3 * c.Cout] = fmaxf(p0[3], p1[3]);
+    }
+  }
+}
+
+template <int STAGES, int OCC>
+__global__ __launch_bounds__(512, OCC) void conv_l2s_kernel(const ConvK a, unsigned xplane, unsigned wplane, unsigned x_bytes,
+                                                            unsigned w_bytes, unsigned y_bytes, const float* __restrict__ xamax,
+                                                            const float* __restrict__ wamax) {
+  if (a.c.run_if != nullptr && *a.c.run_if == 0) return;  // predicated launch (onda_switch_step decided on the device)
+  constexpr int WM = 4, WN = 2, NW = 8;
+  constexpr int BM = 256, BN = 128;
+  constexpr int PLANE_A = BM * 64, PLANE_B = BN * 64;
+  constexpr int A_BYTES = 2 * PLANE_A, STAGE = A_BYTES + 2 * PLANE_B;
+  constexpr int APW = (BM / 16) / NW, BPW = (BN / 16) / NW;
+  constexpr int DPW = 2 * (APW + BPW);
+  constexpr int EST = 16;  // stores every wave issues per epilogue / partial tile (limb-plane output: 2 * EST)
+  static_assert(STAGES == 3 && DPW + 2 * EST <= 63, "ring of three; vmcnt holds 6 bits");
+  constexpr int RED_HALF = 2 * BN * 4;  // floats: two wave rows x BN columns x (sum, sumsq, min, max)
+  __shared__ __attribute__((aligned(16))) unsigned char lds[STAGES * STAGE + 2 * RED_HALF * 4];
+
+  const OndaConv& c = a.c;
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const bool late = wave >= NW / 2;
+  const int half = late ? 1 : 0;
+  float* red_half = reinterpret_cast<float*>(lds + STAGES * STAGE) + half * RED_HALF;
+  const int nblk = gridDim.x, bid = blockIdx.x;
+  const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
+  const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  const int KT = a.taps * a.kcper;
+  const int tiles_all = a.tilesM * a.tilesN, tiles_dp = a.tiles_dp;
+  const long long U = (long long)(tiles_all - tiles_dp) * KT;
+  const long long u_begin = swz * U / nblk, u_end = (swz + 1) * U / nblk;
+  const int wstride = a.taps * c.Cin;
+  const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, x_bytes), rw = make_rsrc(a.w, w_bytes);
+  const Scale2 sx = scale_of(xamax), sw = scale_of(wamax);
+  const float unscale_a = sx.inv, unscale_b = sw.inv;
+  const int lrow = lane >> 2;
+  const unsigned cq16 = (unsigned)(((lane & 3) ^ swz_row(lrow)) << 4);
+  const int frag = (lane & 15) * 64 + (((lane >> 4) ^ swz_row(lane & 15)) << 4);
+
+  // ---- work items: (tile, k_begin, k_end); a cursor is (whole tile index, stream-K unit) ------------------------------
+  struct Cursor {
+    int dp_tile;
+    long long u;
+  };
+  auto item_valid = [&](const Cursor& cu) { return cu.dp_tile < tiles_dp || cu.u < u_end; };
+  auto item_of = [&](const Cursor& cu, int& tile, int& k_begin, int& k_end) {
+    if (cu.dp_tile < tiles_dp) {
+      tile = cu.dp_tile;
+      k_begin = 0;
+      k_end = KT;
+    } else {
+      tile = tiles_dp + (int)(cu.u / KT);
+      k_begin = (int)(cu.u - (long long)(tile - tiles_dp) * KT);
+      k_end = (int)min((long long)KT, k_begin + (u_end - cu.u));
+    }
+  };
+  auto item_next = [&](Cursor& cu, int k_begin, int k_end) {
+    if (cu.dp_tile < tiles_dp) cu.dp_tile += nblk; else cu.u += k_end - k_begin;
+  };
+
+  // ---- issue side (identical to conv_l2x_kernel) -----------------------------------------------------------------------
+  Cursor ci{swz, u_begin};
+  int i_left = 0;
+  int hi0[APW], wi0[APW], bH[APW], tap_i = 0, c0_i = 0;
+  unsigned bofs[BPW], aofs[APW];
+  int st_issue = 0, st_read = 0, in_flight = 0;
+  auto set_tap = [&](int tp) {
+    const int rr = tp / c.kw, ss = tp - rr * c.kw;
+#pragma unroll
+    for (int d = 0; d < APW; ++d) {
+      const int hi = hi0[d] + rr * c.dil, wi = wi0[d] + ss * c.dil;
+      const bool ok = (unsigned)hi < (unsigned)c.Hi && (unsigned)wi < (unsigned)c.Wi;
+      aofs[d] = ok ? (unsigned)(((bH[d] + hi) * c.Wi + wi) * c.ldx) * 2u + cq16 : OOB;
+    }
+  };
+  auto open_issue_item = [&]() {
+    int tile, k_begin, k_end;
+    item_of(ci, tile, k_begin, k_end);
+    i_left = k_end - k_begin;
+    const int m0 = (tile / a.tilesN) * BM, n0 = (tile % a.tilesN) * BN;
+#pragma unroll
+    for (int d = 0; d < APW; ++d) {
+      const int m = m0 + (wave * APW + d) * 16 + lrow;
+      const bool vm = m < a.M;
+      const int mm = vm ? m : 0;
+      const int wo = mm % c.Wo, tq = mm / c.Wo;
+      const int ho = tq % c.Ho, b = tq / c.Ho;
+      hi0[d] = vm ? ho * c.stride - c.pad : -(1 << 28);
+      wi0[d] = wo * c.stride - c.pad;
+      bH[d] = b * c.Hi;
+    }
+#pragma unroll
+    for (int d = 0; d < BPW; ++d) {
+      const int n = n0 + (wave * BPW + d) * 16 + lrow;
+      bofs[d] = n < c.Cout ? (unsigned)n * wstride * 2u + cq16 : OOB;
+    }
+    tap_i = k_begin / a.kcper;
+    c0_i = (k_begin - tap_i * a.kcper) * BK;
+    set_tap(tap_i);
+    item_next(ci, k_begin, k_end);
+  };
+  auto issue_step = [&]() {
+    if (i_left == 0) {
+      if (!item_valid(ci)) return;
+      open_issue_item();
+    }
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int sa = c0_i * 2, sb = (tap_i * c.Cin + c0_i) * 2;
+#pragma unroll
+    for (int l = 0; l < 2; ++l) {
+#pragma unroll
+      for (int d = 0; d < APW; ++d) {
+        unsigned char* dst = lds + st_issue + l * PLANE_A + (wave * APW + d) * 1024;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)dst, 16, aofs[d], sa + l * xplane, 0, 0);
+      }
+#pragma unroll
+      for (int d = 0; d < BPW; ++d) {
+        unsigned char* dst = lds + st_issue + A_BYTES + l * PLANE_B + (wave * BPW + d) * 1024;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)dst, 16, bofs[d], sb + l * wplane, 0, 0);
+      }
+    }
+#endif
+    st_issue = st_issue + STAGE == STAGES * STAGE ? 0 : st_issue + STAGE;
+    ++in_flight;
+    --i_left;
+    c0_i += BK;
+    if (c0_i == c.Cin) {
+      c0_i = 0;
+      ++tap_i;
+      if (i_left > 0) set_tap(tap_i);
+    }
+  };
+
+  // ---- compute side ----------------------------------------------------------------------------------------------------
+  f16x8 af[4][2], bf[4], b1[4];
+  auto prepare = [&]() {  // every fragment of the stage at st_read: the compute slot touches no LDS
+    const unsigned char* Ab = lds + st_read + wm * 64 * 64 + frag;
+    const unsigned char* Bb = lds + st_read + A_BYTES + wn * 64 * 64 + frag;
+    st_read = st_read + STAGE == STAGES * STAGE ? 0 : st_read + STAGE;
+#pragma unroll
+    for (int l = 0; l < 2; ++l)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i][l] = *reinterpret_cast<const f16x8*>(Ab + l * PLANE_A + i * 1024);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bf[j] = *reinterpret_cast<const f16x8*>(Bb + PLANE_B + j * 1024);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b1[j] = *reinterpret_cast<const f16x8*>(Bb + j * 1024);
+  };
+  int stores_young = 0;
+  const bool limb_out = a.yl != nullptr;
+  auto wait_step = [&]() {  // this wave's DMAs of its oldest step in flight have landed (no step in flight: nothing to wait for)
+    if (in_flight == 0) return;
+    if (in_flight > 1) {
+      if (stores_young && limb_out) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPW + 2 * EST) : "memory");
+      else if (stores_young) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPW + EST) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPW) : "memory");
+    } else {
+      if (stores_young && limb_out) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * EST) : "memory");
+      else if (stores_young) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(EST) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    if (stores_young) --stores_young;
+    --in_flight;
+  };
+  auto slot = [&]() {  // slot boundary: what this wave wrote to LDS (statistics partials) is visible to its half afterwards
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  };
+
+  Cursor cc{swz, u_begin};
+  int pending_row = -1, pending_n0 = 0;  // statistics of the half's last epilogue, to be summed one barrier later
+  issue_step();
+  issue_step();
+  if (late) {  // one slot behind; the early half reads stage 0 right after this barrier
+    wait_step();
+    __builtin_amdgcn_s_barrier();
+  }
+  while (item_valid(cc)) {
+    int tile, k_begin, k_end;
+    item_of(cc, tile, k_begin, k_end);
+    const bool whole = k_begin == 0 && k_end == KT;
+    const bool first_piece = cc.dp_tile >= tiles_dp && cc.u == u_begin;
+    item_next(cc, k_begin, k_end);
+    f32x4 acc[4][4], accx[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[i][j][e] = accx[i][j][e] = 0.f;
+    for (int kt = k_begin; kt < k_end; ++kt) {
+      if (!late) wait_step();       // (early) own DMAs of this step
+      slot();                       // ---- P ----
+      if (pending_row >= 0) {
+        l2_stats_finish<BN>(a, red_half, pending_row, pending_n0, t & 255);
+        pending_row = -1;
+      }
+      issue_step();                 // two steps ahead in the stream, whatever tile that is
+      prepare();
+      if (late) wait_step();        // (late) own DMAs of the NEXT step: the early half reads that stage one barrier from here
+      slot();                       // ---- C ----
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) accx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i][0], accx[i][j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) accx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b1[j], af[i][1], accx[i][j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b1[j], af[i][0], acc[i][j], 0, 0, 0);
+    }
+    slot();                         // ---- E ----
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = acc[i][j] + accx[i][j] * LIMB2_UNSCALE;
+    if (!whole) {  // stream-K piece: raw accumulators to this workgroup's slot (16 stores per lane)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (acc[i][j] * unscale_a) * unscale_b;
+      float* slot_ws = a.ws + ((size_t)swz * 2 + (first_piece ? 0 : 1)) * (BM * BN);
+      l2_store_partial<BN>(slot_ws, acc, wm, wn, lane);
+      stores_young = late ? 1 : 2;
+      continue;
+    }
+    float ua = unscale_a, ub = unscale_b;
+    if (const float u = ua * ub; !(u >= 0x1p-100f && u <= 0x1p100f)) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (acc[i][j] * ua) * ub;
+      ua = ub = 1.f;
+    }
+    const int tile_m = tile / a.tilesN, m0 = tile_m * BM, n0 = (tile % a.tilesN) * BN;
+    // (the half's wave rows are wm - 2*half = 0, 1 of its statistics region)
+    unsigned char* scratch = reinterpret_cast<unsigned char*>(red_half) - (size_t)(2 * half) * BN * 16;
+    if (limb_out)
+      l2_epilogue_limbs<WM, WN, true, true>(a, acc, scratch, m0, n0, wm, wn, lane, ua, ub);
+    else if (a.scale != nullptr || a.shift != nullptr || a.res != nullptr || c.relu)
+      l2_epilogue<WM, WN, true, true, true>(a, acc, scratch, tile_m, m0, n0, wm, wn, lane, ua, ub, y_bytes);
+    else
+      l2_epilogue<WM, WN, true, false, true>(a, acc, scratch, tile_m, m0, n0, wm, wn, lane, ua, ub, y_bytes);
+    if (a.stats != nullptr) {
+      pending_row = 2 * tile_m + half;
+      pending_n0 = n0;
+    }
+    stores_young = late ? 1 : 2;
+  }
+  // the halves end one slot apart; a half's last statistics become visible at its next barrier
+  slot();
+  if (pending_row >= 0) l2_stats_finish<BN>(a, red_half, pending_row, pending_n0, t & 255);
+  if (!late) __builtin_amdgcn_s_barrier();
+}
+
 // ---- stream-K remainder: partial tiles -> output, in ONE wide launch ---------------------------------------------------
 // A remainder tile was cut into pieces by the workgroups of conv_l2_kernel<.., SK = true> (raw accumulators in `ws`).
 // One workgroup per 8 rows of a remainder tile sums that tile's pieces in ascending-workgroup order (fixed order:
@@ -1023,8 +1330,11 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_l2x_kernel(const ConvK
 // own row, the others: extra rows behind the regular ones -- bn_finalize sums over all rows anyway), so no second stage
 // and no cross-workgroup reduction is needed.  Replaces the two-launch piece_sum + fixup of the older kernels
 // (measured there: 31 us per convolution, 5.4 ms per adaptation step).
+// row_mul: statistics rows per tile row written by the main kernel (2 for conv_l2s_kernel, whose workgroup halves own a row
+// each): a remainder tile's sum goes to row row_mul * tile_m, the other rows of that tile row become identities.
 template <int BM, int BN>
-__global__ __launch_bounds__(256) void conv_l2_fixup_kernel(const ConvK a, int G, int rows_regular) {
+__global__ __launch_bounds__(256) void conv_l2_fixup_kernel(const ConvK a, int G, int rows_regular, int row_mul) {
+  if (a.c.run_if != nullptr && *a.c.run_if == 0) return;  // predicated launch (onda_switch_step decided on the device)
   constexpr int C4 = BN / 4;      // float4 columns of a tile row
   constexpr int RG = 256 / C4;    // rows covered by the workgroup (one element group per thread)
   constexpr int SUB = BM / RG;    // sub-blocks per tile
@@ -1047,19 +1357,22 @@ __global__ __launch_bounds__(256) void conv_l2_fixup_kernel(const ConvK a, int G
   const int n = tile_n * BN + col;
   const bool vn = n < c.Cout;
   const int SR = a.stats_rows;
-  float* srow = a.stats ? a.stats + (size_t)(sub == 0 ? tile_m : rows_regular + (tile_m - first_m) * (SUB - 1) + sub - 1) * SR * c.Cout + n
+  float* srow = a.stats ? a.stats + (size_t)(sub == 0 ? tile_m * row_mul : rows_regular + (tile_m - first_m) * (SUB - 1) + sub - 1) * SR * c.Cout + n
                         : nullptr;
-  if (vs == ve) {  // computed whole by one workgroup: its own epilogue ran; the extra statistic rows are identities
-    if (srow && sub != 0 && rg == 0 && vn) {
-      *reinterpret_cast<f32x4*>(srow) = f32x4{0.f, 0.f, 0.f, 0.f};
-      *reinterpret_cast<f32x4*>(srow + c.Cout) = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (SR == 4) {
-        *reinterpret_cast<f32x4*>(srow + 2 * c.Cout) = f32x4{3.0e38f, 3.0e38f, 3.0e38f, 3.0e38f};
-        *reinterpret_cast<f32x4*>(srow + 3 * c.Cout) = f32x4{-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
-      }
+  auto identity_row = [&](float* row) {
+    *reinterpret_cast<f32x4*>(row) = f32x4{0.f, 0.f, 0.f, 0.f};
+    *reinterpret_cast<f32x4*>(row + c.Cout) = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (SR == 4) {
+      *reinterpret_cast<f32x4*>(row + 2 * c.Cout) = f32x4{3.0e38f, 3.0e38f, 3.0e38f, 3.0e38f};
+      *reinterpret_cast<f32x4*>(row + 3 * c.Cout) = f32x4{-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
     }
+  };
+  if (vs == ve) {  // computed whole by one workgroup: its own epilogue ran; the extra statistic rows are identities
+    if (srow && sub != 0 && rg == 0 && vn) identity_row(srow);
     return;
   }
+  if (srow && sub == 0 && rg == 0 && vn)  // a summed remainder tile: the main kernel wrote none of its rows
+    for (int extra = 1; extra < row_mul; ++extra) identity_row(srow + (size_t)extra * SR * c.Cout);
   // the workgroups whose K range meets this tile, compacted in ascending order (with fewer remainder K-steps than
   // workgroups some ranges are empty); entry = workgroup * 2 + (0: its first piece, 1: its second)
   const int npieces = ve - vs + 1;
@@ -1477,20 +1790,20 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_wgrad_l2_kernel(const 
       for (int j = 0; j < 4; ++j) b1[j] = tr_read8(base + fb[j][0], base + fb[j][1]);
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) accx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i][0], accx[i][j], 0, 0, 0);
+      for (int i = 0; i < 4; ++i) accx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i][0], accx[i][j], 0, 0, 0);
     if constexpr (!STAGGER) lds_wait(b1[0], b1[1], b1[2], b1[3]);
     if constexpr (STAGGER) issue_second_part();
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) accx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b1[j], af[i][1], accx[i][j], 0, 0, 0);
+      for (int i = 0; i < 4; ++i) accx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b1[j], af[i][1], accx[i][j], 0, 0, 0);
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b1[j], af[i][0], acc[i][j], 0, 0, 0);
+      for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b1[j], af[i][0], acc[i][j], 0, 0, 0);
   };
   if constexpr (!STAGGER) {
     for (; i_cur < nlive; ++i_cur) {
@@ -1590,12 +1903,7 @@ int onda_conv_l2_variant(int64_t M, int Cout) {
 /* which device kernel onda_conv2d_fwd_l2 launches for a problem: the tile variant (0: 256 x 128, 1: 128 x 128, 2: 256 x 64
  * = conv_l2_kernel<4,2> / <2,2> / <4,1>), or 3: conv_l2x_kernel<4,2>, the continuous K-step stream taken by 256 x 128
  * problems with at most 32 K-steps per tile (bench.py names its per-kernel figures after this) */
-int onda_conv_l2_kernel_id(int64_t M, int Cout, int taps, int Cin) {
-  const int variant = onda_conv_l2_variant(M, Cout);
-  static const int xt = getenv("ONDA_L2_XT") ? atoi(getenv("ONDA_L2_XT")) : 1;
-  const bool short_k = taps * (Cin / 32) <= 32 || xt == 2;
-  return variant == 0 && xt && short_k ? 3 : variant;
-}
+int onda_conv_l2_kernel_id(int64_t M, int Cout, int taps, int Cin);
 
 }  // extern "C"
 
@@ -1605,9 +1913,17 @@ namespace {
 struct L2Schedule {
   int variant, BM, BN, tilesM, tilesN, G, rem, sub;
   bool balanced;
+  int stream;   // 0: conv_l2_kernel, 1: conv_l2x_kernel (continuous stream), 2: conv_l2s_kernel (stream + slot stagger)
+  int row_mul;  // statistics rows the main kernel writes per tile row
   int rem_rows() const { return tilesM - (tilesM * tilesN - rem) / tilesN; }  // tile rows that hold remainder tiles
-  int stats_rows_total() const { return tilesM + (balanced ? rem_rows() * (sub - 1) : 0); }
+  int stats_rows_total() const { return row_mul * tilesM + (balanced ? rem_rows() * (sub - 1) : 0); }
 };
+// ONDA_L2_XT: 0 = one cold start per tile everywhere (conv_l2_kernel); 1 = conv_l2x_kernel for tiles of at most 32 K-steps;
+// 3 = conv_l2s_kernel for those (default); 4 = conv_l2s_kernel for every 256 x 128 problem; 2 = conv_l2x_kernel for every one
+int l2_xt() {
+  static const int xt = getenv("ONDA_L2_XT") ? atoi(getenv("ONDA_L2_XT")) : 3;
+  return xt;
+}
 bool l2_small_ring2() {
   static const int on = getenv("ONDA_L2_RING2") ? atoi(getenv("ONDA_L2_RING2")) : 1;
   return on != 0;
@@ -1634,11 +1950,25 @@ L2Schedule l2_schedule(long long M, int Cout, int taps, int Cin, bool have_ws) {
     if (force == 1 || !have_ws) q.balanced = false;
     else if (force == 2) q.balanced = q.rem != 0;
   }
+  // short K loops (1 x 1 convolutions up to 1024 input channels) gain from the continuous stream: their per-tile start and
+  // epilogue rival the K loop itself
+  const int xt = l2_xt();
+  const bool short_k = KT <= 32;
+  q.stream = 0;
+  if (q.variant == 0 && xt) q.stream = (xt == 2 || (xt == 1 && short_k)) ? 1 : ((xt == 4 || (xt == 3 && short_k)) ? 2 : 0);
+  q.row_mul = q.stream == 2 ? 2 : 1;
   return q;
 }
 }  // namespace
 
 extern "C" {
+
+/* the device kernel a problem runs on: 0..2 = conv_l2_kernel<4,2> / <2,2> / <4,1> (the tile variant), 3 = conv_l2x_kernel<4,2>,
+ * 4 = conv_l2s_kernel */
+int onda_conv_l2_kernel_id(int64_t M, int Cout, int taps, int Cin) {
+  const L2Schedule q = l2_schedule(M, Cout, taps, Cin, true);
+  return q.stream ? 2 + q.stream : q.variant;
+}
 
 /* rows of the `stats` partials the conv will write for this problem (tile rows + the extra rows of a stream-K remainder) */
 int onda_conv_l2_tiles_m(int64_t M, int Cout, int taps, int Cin) { return l2_schedule(M, Cout, taps, Cin, true).stats_rows_total(); }
@@ -1708,26 +2038,30 @@ static int l2_fwd_impl(const void* xl, int64_t xplane, const float* xamax, const
       hipLaunchKernelGGL((conv_l2_kernel<WM_, WN_, ST_, OCC_, true>), dim3(q.G), dim3(WM_ * WN_ * 64), 0, st, k, xpl, wpl, x_bytes, \
                          w_bytes, xamax, wamax);                                                                            \
       hipLaunchKernelGGL((conv_l2_fixup_kernel<64 * WM_, 64 * WN_>), dim3(q.rem_rows() * q.tilesN, q.sub), dim3(256), 0, st, k, q.G, \
-                         q.tilesM);                                                                                           \
+                         q.tilesM, 1);                                                                                        \
     } else {                                                                                                                 \
       hipLaunchKernelGGL((conv_l2_kernel<WM_, WN_, ST_, OCC_, false>), dim3(tiles), dim3(WM_ * WN_ * 64), 0, st, k, xpl, wpl,    \
                          x_bytes, w_bytes, xamax, wamax);                                                                   \
     }                                                                                                                        \
   } while (0)
-  static const int xt = getenv("ONDA_L2_XT") ? atoi(getenv("ONDA_L2_XT")) : 1;  // 0: one cold start per tile (conv_l2_kernel)
   // the output as a buffer: last byte any tile can store (dense rows of ldy floats; scattered stride-2 gradients included)
   const long long y_rows = (long long)c->B * (c->out_os == 1 && c->Hf == c->Ho && c->Wf == c->Wo ? (long long)c->Ho * c->Wo : (long long)c->Hf * c->Wf);
   const long long y_total = ((y_rows - 1) * c->ldy + c->Cout) * 4;
-  // short K loops (1 x 1 convolutions up to 1024 input channels) gain 6-17 % from the continuous stream; long ones lose
-  // ~4 % against the slot-staggered kernel, whose per-tile start / end they amortise anyway (measured per shape, one process)
-  const bool short_k = k.taps * k.kcper <= 32 || xt == 2;
-  if (xt && short_k && q.variant == 0 && y_total < 0x7FFFF000ll) {
+  if (q.stream) {
+    // (the stream kernels store through a buffer descriptor: 32-bit offsets.  The number of statistics rows was fixed by the
+    //  kernel choice, so a larger output cannot quietly fall back to the other kernel)
+    ONDA_REQUIRE(y_total < 0x7FFFF000ll);
     if (!q.balanced) k.tiles_dp = tiles;  // persistent either way: whole tiles only
-    const int grid = tiles < q.G ? tiles : q.G;
-    hipLaunchKernelGGL((conv_l2x_kernel<4, 2, 3, 2>), dim3(q.balanced ? q.G : grid), dim3(512), 0, st, k, xpl, wpl, x_bytes, w_bytes,
-                       (unsigned)y_total, xamax, wamax);
+    const int grid = q.balanced ? q.G : (tiles < q.G ? tiles : q.G);
+    if (q.stream == 2)
+      hipLaunchKernelGGL((conv_l2s_kernel<3, 2>), dim3(grid), dim3(512), 0, st, k, xpl, wpl, x_bytes, w_bytes, (unsigned)y_total, xamax,
+                         wamax);
+    else
+      hipLaunchKernelGGL((conv_l2x_kernel<4, 2, 3, 2>), dim3(grid), dim3(512), 0, st, k, xpl, wpl, x_bytes, w_bytes, (unsigned)y_total,
+                         xamax, wamax);
     if (q.balanced)
-      hipLaunchKernelGGL((conv_l2_fixup_kernel<256, 128>), dim3(q.rem_rows() * q.tilesN, q.sub), dim3(256), 0, st, k, q.G, q.tilesM);
+      hipLaunchKernelGGL((conv_l2_fixup_kernel<256, 128>), dim3(q.rem_rows() * q.tilesN, q.sub), dim3(256), 0, st, k, q.G,
+                         q.row_mul * q.tilesM, q.row_mul);
     return ONDA_LAUNCH_RESULT();
   }
   if (q.variant == 0) L2_LAUNCH(4, 2, 3, 2);

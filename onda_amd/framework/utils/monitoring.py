@@ -60,8 +60,9 @@ class Monitor(object):
         self._series = {}
         self._level = _level_function(dev_func, limit - 1)
         self._unbounded = 1 << 16  # limit None: the reference keeps every sample
-        self._pending = None       # (keys, pinned host tensor, event) of an add_device whose copy may still be in flight
-        self._pinned = []          # two pinned staging buffers, used alternately
+        self._pending = []         # FIFO of (keys, pinned host tensor, event): add_device transfers not yet in the rings
+        self._pinned = []          # free pinned staging buffers
+        self.gated = set()         # keys whose device samples may be NaN = "no sample this step" (DeviceSwitch)
 
     # ---- mode ------------------------------------------------------------------------------------------------------
     def eval(self):
@@ -71,19 +72,26 @@ class Monitor(object):
         self.freeze = False
 
     def reset(self):
-        self._pending = None
+        self._pending = []
         self._series = {}
 
-    def _flush(self, item=None):
-        """Samples of the last add_device enter their rings (waits for its copy if that has not finished).  A query
-        for one series that the pending transfer does not feed leaves it alone."""
-        if self._pending is None or (item is not None and item not in self._pending[0]):
+    def _flush(self, item=None, block=True):
+        """Samples of finished add_device transfers enter their rings, oldest transfer first.  block=True waits for every
+        transfer (a statistic is about to be read); a query for ONE series that no pending transfer feeds waits for
+        nothing.  block=False takes what has arrived and stops at the first transfer still in flight (order is kept)."""
+        if not self._pending or (item is not None and not any(item in p[0] for p in self._pending)):
             return
-        keys, host, event = self._pending
-        self._pending = None
-        event.synchronize()
-        for key, value in zip(keys, host[: len(keys)].tolist()):
-            self._push(key, value)
+        while self._pending:
+            keys, host, event = self._pending[0]
+            if not block and not event.query():
+                return
+            event.synchronize()
+            self._pending.pop(0)
+            for key, value in zip(keys, host[: len(keys)].tolist()):
+                if value != value and key in self.gated:
+                    continue  # NaN on a gated key: the quantity did not exist this step
+                self._push(key, value)
+            self._pinned.append(host)
 
     # ---- samples ---------------------------------------------------------------------------------------------------
     def _push(self, key, value, reset=False):
@@ -96,28 +104,31 @@ class Monitor(object):
     def add(self, values, reset=False):
         if self.freeze:
             return 0
-        self._flush()
+        self._flush()  # (host samples enter behind everything added before them)
         for key, value in values.items():
             self._push(key, value.item() if isinstance(value, torch.Tensor) else value, reset)
 
     def add_device(self, keys, packed):
-        """keys[i] <- packed[i] for a 1-D device tensor `packed`: one read-back for all of them."""
+        """keys[i] <- packed[i] for a 1-D device tensor `packed`: one read-back for all of them, never waited for here."""
         if self.freeze:
             return 0
-        self._flush()
+        self._flush(block=False)
         if not packed.is_cuda:
+            self._flush()
             for key, value in zip(keys, packed.tolist()):
-                self._push(key, value)
+                if not (value != value and key in self.gated):
+                    self._push(key, value)
             return
         n = packed.numel()
-        if len(self._pinned) < 2 or self._pinned[0].numel() < n:
-            self._pinned = [torch.empty(max(n, 16), dtype=torch.float32, pin_memory=True) for _ in range(2)]
-        host = self._pinned.pop(0)
-        self._pinned.append(host)
+        host = next((h for h in self._pinned if h.numel() >= n), None)
+        if host is not None:
+            self._pinned.remove(host)
+        else:
+            host = torch.empty(max(n, 16), dtype=torch.float32, pin_memory=True)
         host[:n].copy_(packed.detach().reshape(-1).float(), non_blocking=True)
         event = torch.cuda.Event()
         event.record()
-        self._pending = (list(keys), host, event)
+        self._pending.append((list(keys), host, event))
         if _SYNC_TRANSFERS:
             self._flush()
 
@@ -158,3 +169,44 @@ class Monitor(object):
     def exp_dict(self):
         self._flush()
         return {key: s.ema for key, s in self._series.items()}
+
+
+class DeviceSwitch:
+    """``Monitor`` for ONE series plus ``model_select`` (prototypes_hybrid_switch.py:22-34), kept and advanced on the
+    GPU: ``step(sample)`` = add the sample, take median / exponential average / trend, run the two-state machine -- one
+    small launch, no read-back.  ``flag`` (device int32[1]) is the machine's state: 0 static, 1 dynamic."""
+
+    def __init__(self, device, limit, exp_const=0.01, dev_func="hamming", gray_area=(0.84, 0.88), dev_threshold=0.0002,
+                 start=0, use_exp=False):
+        from onda_amd import _lib
+        from onda_amd._lib import OndaSwitchCfg, query
+        if dev_func not in ("hamming", "mean", "median"):
+            raise ValueError(f"unknown DEV_MONITOR_FUNC {dev_func!r}")
+        span = max(limit - 1, 1)
+        taps = np.hamming(span) if dev_func == "hamming" else np.ones(span)
+        self.cfg = OndaSwitchCfg(int(limit), 1 if dev_func == "median" else 0, int(bool(use_exp)), 0, float(exp_const),
+                                 float(1 - exp_const), float(np.sum(taps)), float(gray_area[0]), float(gray_area[1]),
+                                 float(dev_threshold))
+        self.taps = torch.from_numpy(taps.astype(np.float64)).to(device)
+        self.state = torch.zeros(query("onda_switch_state_doubles", int(limit)), dtype=torch.float64, device=device)
+        self.istate = torch.zeros(8, dtype=torch.int32, device=device)
+        self.istate[2:4] = int(start)
+        self.flag = torch.full((1,), int(start), dtype=torch.int32, device=device)
+        self._lib = _lib
+
+    def step(self, sample):
+        """`sample`: device scalar, float32 (or float64: the scripted sequences of the tests)."""
+        from ctypes import byref
+        sample = sample.detach().reshape(1)
+        if sample.dtype not in (torch.float32, torch.float64):
+            sample = sample.float()
+        self._lib.call("onda_switch_step", self.state.data_ptr(), self.istate.data_ptr(), sample.data_ptr(),
+                       int(sample.dtype == torch.float64), self.taps.data_ptr(), byref(self.cfg), self.flag.data_ptr(),
+                       torch.cuda.current_stream().cuda_stream)
+        return self.flag
+
+    # blocking reads: for tests and for code that looks at the switch between steps (never on the step's own path)
+    def read(self):
+        st, ist = self.state[:4].tolist(), self.istate[:5].tolist()
+        return {"exp": st[0], "avg": st[1], "dev": st[2], "confidence": st[3], "count": ist[0], "current": ist[2],
+                "current_dev": ist[3], "steps": ist[4]}

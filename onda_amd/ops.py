@@ -51,7 +51,7 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-_L2_KERNELS = ("conv_l2_kernel<4,2>", "conv_l2_kernel<2,2>", "conv_l2_kernel<4,1>", "conv_l2x_kernel<4,2>")
+_L2_KERNELS = ("conv_l2_kernel<4,2>", "conv_l2_kernel<2,2>", "conv_l2_kernel<4,1>", "conv_l2x_kernel<4,2>", "conv_l2s_kernel<3,2>")
 
 
 def _l2_name(M, cout, taps, cin):
@@ -101,9 +101,36 @@ def conv_out_size(n, k, stride, dil, pad):
 
 
 # ------------------------------------------------------------------------------- conv plumbing
+# A device int32 the convolutions launched inside ``predicated(flag)`` carry as their predicate: each launch does nothing
+# when the flag is 0 (the dynamic model's forward pass under the device-side hybrid switch).  Only the pre-split kernels
+# honour it; the other conv modes refuse a predicate (EINVAL) rather than ignore it.
+PREDICATE = None
+
+
+class predicated:
+    """``with ops.predicated(flag):`` -- no-grad forward passes only (nothing in a backward pass reads the flag)."""
+
+    def __init__(self, flag):
+        self.flag = flag
+
+    def __enter__(self):
+        global PREDICATE
+        self.old, PREDICATE = PREDICATE, self.flag
+        return self
+
+    def __exit__(self, *exc):
+        global PREDICATE
+        PREDICATE = self.old
+        return False
+
+
+def predicates_supported():
+    return CONV_MODE == "f16x2" and H2_PATH == "dma"
+
+
 def _desc(B, Hi, Wi, Cin, Ho, Wo, Cout, k, stride, dil, pad, ldx, ldy, ldr=0, out_os=1, Hf=None, Wf=None, relu=0):
     return OndaConv(B, Hi, Wi, Cin, Ho, Wo, Cout, k, k, stride, dil, pad, ldx, ldy, ldr, out_os,
-                    Ho if Hf is None else Hf, Wo if Wf is None else Wf, int(relu))
+                    Ho if Hf is None else Hf, Wo if Wf is None else Wf, int(relu), _p(PREDICATE))
 
 
 _CONV_WS = {}
@@ -1157,6 +1184,21 @@ def upsample_argmax_hist(out, labels, hist, num_classes):
     H, W = labels.shape[1:]
     call("onda_upsample_argmax_hist", _p(rows), ld, _p(labels), _p(hist), None, B, h, w, num_classes, H, W, _stream())
     return hist
+
+
+# ------------------------------------------------------------------------------- device-side switch
+def select_prior(flag, a, wa, b, wb):
+    """flag ? wb * b : wa * a, elementwise, as a true select (`b` may be garbage when flag == 0)."""
+    out = torch.empty_like(a)
+    call("onda_select_prior", _p(flag), _p(a.contiguous()), float(wa), _p(b.contiguous()), float(wb), _p(out), a.numel(), _stream())
+    return out
+
+
+def gate_scalar(flag, v):
+    """flag ? v : NaN as a device scalar."""
+    out = torch.empty(1, device=v.device, dtype=torch.float32)
+    call("onda_gate_scalar", _p(flag), _p(v.detach().reshape(1).float()), _p(out), _stream())
+    return out[0]
 
 
 # ------------------------------------------------------------------------------- multi-tensor

@@ -928,3 +928,80 @@ def test_f16x2_scale_equivariance_full_size():
         assert torch.isfinite(y0).all() and y0.abs().max() > 0
     finally:
         ops.CONV_MODE = old
+
+
+@pytest.mark.parametrize("dev_func", ["hamming", "mean", "median"])
+def test_device_switch_reproduces_the_reference_trajectories(golden, dev_func):
+    """csrc/switch.hip against the reference's Monitor + model_select (fixture G5, captured from the imported reference
+    with the "hamming" trend; the other two trend functions against this repo's host-side Monitor, which G5 pins on the
+    CPU): median, exponential average and trend of every one of the 520 steps BIT FOR BIT in float64, the switch state
+    identical at every step -- including the 199 steps before the window is full and the two transitions."""
+    from onda_amd.framework.domain_adaptation.methods.prototypes_hybrid_switch import model_select
+    from onda_amd.framework.utils.monitoring import DeviceSwitch, Monitor
+    g = golden("g5_switch")
+    seq = g["seq"]
+    sw = DeviceSwitch(DEV, 200, 0.003, dev_func, (0.83, 0.9), 0.0002, model_select.static)
+    mon, sel = Monitor(200, 0.003, dev_func), model_select(model_select.static, [0.83, 0.9], 0.0002)
+    samples = torch.from_numpy(seq).to(DEV)
+    got = np.zeros((len(seq), 4))
+    cur = np.zeros(len(seq), dtype=np.int64)
+    trace_s = torch.zeros(len(seq), 4, dtype=torch.float64, device=DEV)
+    trace_i = torch.zeros(len(seq), dtype=torch.int32, device=DEV)
+    for i in range(len(seq)):
+        sw.step(samples[i])
+        trace_s[i] = sw.state[:4]          # (device-side copies: no read-back inside the loop)
+        trace_i[i] = sw.istate[2]
+        mon.add({"prior static": float(seq[i])})
+        a, d = mon.avg("prior static"), mon.dev_avg("prior static")
+        sel.evaluate(a, d)
+        got[i] = (mon.exp("prior static"), a, d, a)
+        cur[i] = sel.current
+    dev_s, dev_i = trace_s.cpu().numpy(), trace_i.cpu().numpy()
+    assert np.array_equal(dev_s[:, 0], got[:, 0]), "exponential average"
+    assert np.array_equal(dev_s[:, 1], got[:, 1]), "median"
+    assert np.array_equal(dev_s[:, 2], got[:, 2]), "trend"
+    assert np.array_equal(dev_i, cur)
+    if dev_func == "hamming":  # ... and the host monitor is the reference's (G5)
+        assert np.array_equal(dev_s[:, 1], g["avg"]) and np.array_equal(dev_s[:, 0], g["exp"]) and np.array_equal(dev_s[:, 2], g["dev"])
+        assert np.array_equal(dev_i, g["current"]) and len(set(g["current"].tolist())) == 2
+    assert sw.read()["steps"] == len(seq) and sw.read()["count"] == 200
+    # float32 samples (what a step feeds) take the same path
+    sw32 = DeviceSwitch(DEV, 4, 0.1, "mean", (0.3, 0.6), 0.01, 0)
+    for v in (0.25, 0.5, 0.75, 1.0, 0.125):
+        sw32.step(torch.tensor(v, device=DEV))
+    r = sw32.read()
+    assert r["avg"] == 0.625 and r["count"] == 4 and r["current"] == 0 and r["dev"] == pytest.approx((0.75 + 1.0 + 0.125) / 3 - (0.5 + 0.75 + 1.0) / 3)
+
+
+def test_predicated_convolutions_and_select():
+    """OndaConv::run_if: a conv launched under a device flag of 0 writes nothing (whole tiles, stream-K pieces and their
+    fix-up included), under 1 it is the plain conv; select_prior / gate_scalar pick by the same flag and never read the
+    side that was not computed."""
+    from onda_amd import ops
+    old, ops.CONV_MODE = ops.CONV_MODE, "f16x2"
+    try:
+        g = torch.Generator().manual_seed(5)
+        flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+        # 4 x 65 x 129 pixels, 256 -> 256: 264 tiles of 256 x 128 on the stream kernel + a stream-K remainder with its fix-up;
+        # 2 x 33 x 65, 256 -> 128: the four-wave 128 x 128 tiles
+        for (B, H, W, cout) in ((4, 65, 129, 256), (2, 33, 65, 128)):
+            x = torch.randn(B, H, W, 256, generator=g).to(DEV)
+            w = (torch.randn(cout, 256, 1, 1, generator=g) * 0.05).to(DEV)
+            wp = ops.pack_weight_fwd(w)
+            ref, _, _ = ops.conv_forward(x, wp, 1, 1, 1, 0, cout)
+            out = torch.full_like(ref, 7.0)
+            flag.fill_(0)
+            with ops.predicated(flag):
+                ops.conv_forward(x, wp, 1, 1, 1, 0, cout, out=out)
+            assert ops.PREDICATE is None and bool((out == 7.0).all())
+            flag.fill_(1)
+            with ops.predicated(flag):
+                ops.conv_forward(x, wp, 1, 1, 1, 0, cout, out=out)
+            assert torch.equal(out, ref)
+        a, b = torch.randn(1000, 19, device=DEV), torch.full((1000, 19), float("nan"), device=DEV)
+        flag.fill_(0)
+        assert torch.equal(ops.select_prior(flag, a, 1.0, b, 2.0), a) and torch.isnan(ops.gate_scalar(flag, a[0, 0]))
+        flag.fill_(1)
+        assert torch.equal(ops.select_prior(flag, b, 1.0, a, 2.0), 2.0 * a) and ops.gate_scalar(flag, a[0, 0]).item() == a[0, 0].item()
+    finally:
+        ops.CONV_MODE = old

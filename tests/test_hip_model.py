@@ -438,6 +438,63 @@ def test_f16x2_steps_track_the_exact_f32_steps(tmp_path, conv_mode):
     assert seen[1]["worst_log_rel"] <= 2e-3 and seen[1]["update_rel_l2"] <= 5e-2, seen
 
 
+def test_a_step_never_stops_the_host(tmp_path, conv_mode):
+    """With the switch on the device NOTHING in an adaptation step waits for the GPU: behind ~1.5 s of queued device work
+    the host gets through step() + update_ema() in a fraction of the time that work takes to drain (the host-decided
+    switch -- ONDA_DEVICE_SWITCH=0, every other conv mode -- has to wait for the static model's confidence there).  Also:
+    both sides of the switch through the device path, static (predicated dynamic pass returns at once) and dynamic."""
+    if conv_mode != "f16x2":
+        pytest.skip("the device-side switch runs with the default (pre-split) kernels")
+    import time
+    from onda_amd.config import hybrid_switch_cfg
+    from onda_amd.framework.handlers import get_adapt_method, get_model
+    from onda_amd.framework.domain_adaptation.methods.adaptation_model import switch_batch_statistics
+    from onda_amd.synthetic import fill_state_dict, synth_batch
+    for head, branch in ((40.0, 0), (1.0, 1)):
+        cfg, spec = hybrid_switch_cfg(256, 128, DEV, str(tmp_path), batch_size=2)
+        model = get_model(cfg, 19)
+        fill_state_dict(model, 1, head)
+        da = get_adapt_method(cfg)(model, cfg, spec)
+        assert da._dsw is not None and da.model_select.device_switch is da._dsw
+        src = [{k: v.to(DEV) for k, v in synth_batch(2, 128, 256, seed=100 + i).items()} for i in range(2)]
+        trg = [{k: v.to(DEV) for k, v in synth_batch(2, 128, 256, seed=200 + i).items()} for i in range(2)]
+        da.update_dynamic()
+        switch_batch_statistics(da.model, False)
+        da.calculate_prototypes(src, save=False)
+        switch_batch_statistics(da.model, True)
+        da.optimizer.zero_grad()
+        logs = []
+        for i in range(3):  # (allocator, pinned buffers and kernels warm)
+            da.adjust_learning_rate(i, 10)
+            logs.append(da.step([src[i % 2]], {k: v.detach() for k, v in trg[i % 2].items()}))
+            da.update_ema()
+        torch.cuda.synchronize()
+        assert da.model_select.current == branch
+        big = torch.randn(8192, 8192, device=DEV)
+        for _ in range(3):
+            big = big @ big * 1e-4
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(40):
+            big = big @ big * 1e-4
+        queued = time.perf_counter() - t0
+        da.adjust_learning_rate(3, 10)
+        log = da.step([src[1]], {k: v.detach() for k, v in trg[1].items()})
+        da.update_ema()
+        issued = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        drained = time.perf_counter() - t0
+        assert queued < 0.2 * drained, (queued, drained)  # the matmuls really were a backlog
+        assert issued < 0.6 * drained, (branch, issued, drained)
+        # ... and the log is complete once somebody looks (both sides: "prior dynamic" exists only on the dynamic side)
+        keys = set(log.keys())
+        assert ("prior dynamic confidence ma" in keys) == (branch == 1), sorted(keys)
+        assert {"prior static confidence ma", "prior EMA confidence ma", "model confidence ma", "dev avg prior static"} <= keys
+        assert np.isfinite(float(log["Total target loss"])) and da.model_select.current == branch
+        del da, model, big
+        torch.cuda.empty_cache()
+
+
 def test_step_sharded_matches_the_oracle_emulation_of_two_ranks(tmp_path, conv_mode):
     """``step_sharded`` with two micro-batches (= what two data-parallel ranks compute: rank-local batch statistics,
     averaged gradients, one switch decision from averaged confidences, summed prototype statistics, averaged running

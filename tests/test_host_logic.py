@@ -27,7 +27,8 @@ def test_library_exports_every_declared_symbol():
         assert n in _lib.SIGNATURES, f"{n} has no ctypes prototype"
     assert set(_lib.SIGNATURES) == set(names)
     assert b"gfx950" in lib.onda_version()
-    assert ctypes.sizeof(_lib.OndaConv) == 19 * 4 and ctypes.sizeof(_lib.OndaSgdEntry) == 48
+    assert ctypes.sizeof(_lib.OndaConv) == 19 * 4 + 4 + 8 and ctypes.sizeof(_lib.OndaSgdEntry) == 48  # 19 ints, pad, run_if
+    assert ctypes.sizeof(_lib.OndaSwitchCfg) == 16 + 6 * 8
     assert lib.onda_conv_tiles_m(33540) == 263
 
 
@@ -228,10 +229,10 @@ def test_step_log_resolves_its_monitor_entries_on_first_read():
     assert log.get("missing", 7) == 7 and len(calls) == 1
 
 
-def test_monitor_pending_transfer_is_selective(monkeypatch):
-    """A query for a series the pending device transfer does not feed leaves the transfer alone (the switch decision
-    reads "prior static" in the middle of a step while the previous step's scalars may still be in flight); any query
-    that involves a pending series, and any later add, drains it first (sample order per series is kept)."""
+def test_monitor_pending_transfers_are_a_fifo_that_add_device_never_waits_for():
+    """Device transfers queue up; a query for a series no pending transfer feeds leaves them alone; any query that involves
+    a pending series, and any host-side add, drains them in order (sample order per series is kept); a non-blocking drain
+    (what add_device does) stops at the first transfer still in flight; NaN on a gated key means "no sample"."""
     from onda_amd.framework.utils import monitoring
     m = monitoring.Monitor(5, 0.1, "hamming")
     m.add({"prior static": 0.5, "model": 0.1})
@@ -239,16 +240,32 @@ def test_monitor_pending_transfer_is_selective(monkeypatch):
     class _Event:
         waited = 0
 
+        def __init__(self, done=True):
+            self.done = done
+
+        def query(self):
+            return self.done
+
         def synchronize(self):
             _Event.waited += 1
-    host = torch.tensor([0.2, 0.3])
-    m._pending = (["model", "prior"], host, _Event())
-    assert m.avg("prior static") == 0.5 and m.dev_avg("prior static") == 0 and _Event.waited == 0 and m._pending is not None
-    assert m.avg("model") == pytest.approx(0.15) and _Event.waited == 1 and m._pending is None
+    m._pending = [(["model", "prior"], torch.tensor([0.2, 0.3]), _Event())]
+    assert m.avg("prior static") == 0.5 and m.dev_avg("prior static") == 0 and _Event.waited == 0 and len(m._pending) == 1
+    assert m.avg("model") == pytest.approx(0.15) and _Event.waited == 1 and not m._pending
     assert m.current_dict["model"] == pytest.approx([0.1, 0.2]) and m.avg("prior") == pytest.approx(0.3)
-    m._pending = (["model"], torch.tensor([0.4]), _Event())
+    m._pending = [(["model"], torch.tensor([0.4]), _Event())]
     m.add({"model": 0.5})  # the pending sample enters its ring BEFORE the new one
     assert m.current_dict["model"] == pytest.approx([0.1, 0.2, 0.4, 0.5]) and _Event.waited == 2
+    # two transfers, the older one still in flight: a non-blocking drain takes nothing (order!), a read takes both
+    m._pending = [(["prior"], torch.tensor([0.6]), _Event(done=False)), (["prior"], torch.tensor([0.7]), _Event())]
+    m._flush(block=False)
+    assert len(m._pending) == 2 and _Event.waited == 2
+    assert m.current_dict["prior"] == pytest.approx([0.3, 0.6, 0.7]) and not m._pending
+    # gated key: NaN = the quantity did not exist this step (the dynamic prior while the switch is static)
+    m.gated.add("prior dynamic")
+    m._pending = [(["prior dynamic", "model"], torch.tensor([float("nan"), 0.9]), _Event())]
+    assert "prior dynamic" not in m.avg() and m.current_dict["model"][-1] == pytest.approx(0.9)
+    m.add_device(["prior dynamic"], torch.tensor([0.25]))
+    assert m.avg("prior dynamic") == 0.25
 
 
 def test_replay_buffer_mirror():
