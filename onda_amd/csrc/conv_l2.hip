@@ -1067,7 +1067,7 @@ __device__ __forceinline__ void l2_stats_finish(const ConvK& a, const float* red
   }
 }
 
-template <int STAGES, int OCC>
+template <int STAGES, int OCC, bool TAPSKIP>
 __global__ __launch_bounds__(512, OCC) void conv_l2s_kernel(const ConvK a, unsigned xplane, unsigned wplane, unsigned x_bytes,
                                                             unsigned w_bytes, unsigned y_bytes, const float* __restrict__ xamax,
                                                             const float* __restrict__ wamax) {
@@ -1124,12 +1124,37 @@ __global__ __launch_bounds__(512, OCC) void conv_l2s_kernel(const ConvK a, unsig
   auto item_next = [&](Cursor& cu, int k_begin, int k_end) {
     if (cu.dp_tile < tiles_dp) cu.dp_tile += nblk; else cu.u += k_end - k_begin;
   };
+  // Filter taps whose input rows all lie outside the image for EVERY output row of a tile contribute exact zeros: a whole
+  // tile skips them (conv_l2_kernel explains; stream-K pieces keep the full K range their unit arithmetic is written in).
+  // Issue side and compute side derive the same mask from the tile index.
+  const unsigned all_taps = a.taps >= 32 ? 0xFFFFFFFFu : ((1u << a.taps) - 1u);
+  auto live_taps = [&](int tile, bool whole) -> unsigned {
+    if (!TAPSKIP || !(whole && a.taps > 1 && a.skip_dead_taps)) return all_taps;
+    const int m0 = (tile / a.tilesN) * BM, m_last = min(a.M, m0 + BM) - 1;
+    const int r0 = m0 / c.Wo, r1 = m_last / c.Wo;
+    const int ho0 = r0 % c.Ho;
+    unsigned live = 0;
+    for (int tp = 0; tp < a.taps; ++tp) {
+      const int dh = (tp / c.kw) * c.dil - c.pad;
+      bool alive = false;
+      for (int rr = r0, ho = ho0; rr <= r1; ++rr) {
+        alive |= (unsigned)(ho * c.stride + dh) < (unsigned)c.Hi;
+        if (++ho == c.Ho) ho = 0;
+      }
+      live |= (alive ? 1u : 0u) << tp;
+    }
+    return live ? live : 1u;
+  };
+  auto next_live = [&](unsigned live, int tp) {
+    while (tp < a.taps && !((live >> tp) & 1u)) ++tp;
+    return tp;
+  };
 
   // ---- issue side (identical to conv_l2x_kernel) -----------------------------------------------------------------------
   Cursor ci{swz, u_begin};
   int i_left = 0;
   int hi0[APW], wi0[APW], bH[APW], tap_i = 0, c0_i = 0;
-  unsigned bofs[BPW], aofs[APW];
+  unsigned bofs[BPW], aofs[APW], live_i = all_taps;
   int st_issue = 0, st_read = 0, in_flight = 0;
   auto set_tap = [&](int tp) {
     const int rr = tp / c.kw, ss = tp - rr * c.kw;
@@ -1143,7 +1168,8 @@ __global__ __launch_bounds__(512, OCC) void conv_l2s_kernel(const ConvK a, unsig
   auto open_issue_item = [&]() {
     int tile, k_begin, k_end;
     item_of(ci, tile, k_begin, k_end);
-    i_left = k_end - k_begin;
+    live_i = live_taps(tile, k_begin == 0 && k_end == KT);
+    i_left = live_i == all_taps ? k_end - k_begin : __builtin_popcount(live_i) * a.kcper;
     const int m0 = (tile / a.tilesN) * BM, n0 = (tile % a.tilesN) * BN;
 #pragma unroll
     for (int d = 0; d < APW; ++d) {
@@ -1161,8 +1187,8 @@ __global__ __launch_bounds__(512, OCC) void conv_l2s_kernel(const ConvK a, unsig
       const int n = n0 + (wave * BPW + d) * 16 + lrow;
       bofs[d] = n < c.Cout ? (unsigned)n * wstride * 2u + cq16 : OOB;
     }
-    tap_i = k_begin / a.kcper;
-    c0_i = (k_begin - tap_i * a.kcper) * BK;
+    tap_i = live_i == all_taps ? k_begin / a.kcper : next_live(live_i, 0);
+    c0_i = live_i == all_taps ? (k_begin - tap_i * a.kcper) * BK : 0;
     set_tap(tap_i);
     item_next(ci, k_begin, k_end);
   };
@@ -1193,7 +1219,7 @@ __global__ __launch_bounds__(512, OCC) void conv_l2s_kernel(const ConvK a, unsig
     c0_i += BK;
     if (c0_i == c.Cin) {
       c0_i = 0;
-      ++tap_i;
+      tap_i = next_live(live_i, tap_i + 1);
       if (i_left > 0) set_tap(tap_i);
     }
   };
@@ -1248,6 +1274,8 @@ __global__ __launch_bounds__(512, OCC) void conv_l2s_kernel(const ConvK a, unsig
     const bool whole = k_begin == 0 && k_end == KT;
     const bool first_piece = cc.dp_tile >= tiles_dp && cc.u == u_begin;
     item_next(cc, k_begin, k_end);
+    const unsigned live_c = live_taps(tile, whole);
+    const int nsteps = live_c == all_taps ? k_end - k_begin : __builtin_popcount(live_c) * a.kcper;
     f32x4 acc[4][4], accx[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -1255,7 +1283,7 @@ __global__ __launch_bounds__(512, OCC) void conv_l2s_kernel(const ConvK a, unsig
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[i][j][e] = accx[i][j][e] = 0.f;
-    for (int kt = k_begin; kt < k_end; ++kt) {
+    for (int kt = 0; kt < nsteps; ++kt) {
       if (!late) wait_step();       // (early) own DMAs of this step
       slot();                       // ---- P ----
       if (pending_row >= 0) {
@@ -2053,9 +2081,12 @@ static int l2_fwd_impl(const void* xl, int64_t xplane, const float* xamax, const
     ONDA_REQUIRE(y_total < 0x7FFFF000ll);
     if (!q.balanced) k.tiles_dp = tiles;  // persistent either way: whole tiles only
     const int grid = q.balanced ? q.G : (tiles < q.G ? tiles : q.G);
-    if (q.stream == 2)
-      hipLaunchKernelGGL((conv_l2s_kernel<3, 2>), dim3(grid), dim3(512), 0, st, k, xpl, wpl, x_bytes, w_bytes, (unsigned)y_total, xamax,
-                         wamax);
+    if (q.stream == 2 && k.taps > 1 && k.skip_dead_taps && c->dil > 1)  // (dilated 3 x 3: whole tiles skip dead filter taps)
+      hipLaunchKernelGGL((conv_l2s_kernel<3, 2, true>), dim3(grid), dim3(512), 0, st, k, xpl, wpl, x_bytes, w_bytes, (unsigned)y_total,
+                         xamax, wamax);
+    else if (q.stream == 2)
+      hipLaunchKernelGGL((conv_l2s_kernel<3, 2, false>), dim3(grid), dim3(512), 0, st, k, xpl, wpl, x_bytes, w_bytes, (unsigned)y_total,
+                         xamax, wamax);
     else
       hipLaunchKernelGGL((conv_l2x_kernel<4, 2, 3, 2>), dim3(grid), dim3(512), 0, st, k, xpl, wpl, x_bytes, w_bytes, (unsigned)y_total,
                          xamax, wamax);
