@@ -155,10 +155,8 @@ void onda_debug_stamps(void* buffer);
 int onda_stem_im2col_l2(const float* x_nchw, const float* xamax, void* dst, int64_t plane, int B, int H, int W, int Ho, int Wo,
                         int Kp, onda_stream_t s);
 int onda_conv_l2_variant(int64_t M, int Cout);  /* tile shape used for an (M, Cout) problem: 0 256x128, 1 128x128, 2 256x64 */
-/* device kernel launched for a problem: 0 / 1 / 2 = conv_l2_kernel<4,2> / <2,2> / <4,1>, 3 = conv_l2x_kernel<4,2> (256x128 tiles:
- * one continuous K-step stream over a workgroup's tiles), 4 = conv_l2s_kernel<3,2> (that stream with the two halves of the
- * workgroup one slot apart; the default for tiles of at most 32 K-steps; env ONDA_L2_XT picks); bench.py names its
- * per-kernel figures after this */
+/* device kernel launched for a problem: 0 / 1 / 2 = conv_l2_kernel<4,2> / <2,2> / <4,1>, 3 = conv_l2x_kernel<4,2> (256x128 tiles,
+ * at most 32 K-steps per tile: the continuous K-step stream); bench.py names its per-kernel figures after this */
 int onda_conv_l2_kernel_id(int64_t M, int Cout, int taps, int Cin);
 int onda_conv_l2_tiles_m(int64_t M, int Cout, int taps, int Cin);  /* rows of the `stats` partials the conv writes for this problem */
 /* stats_rows: 2 = stats[tile][sum, sumsq][Cout] as onda_conv2d_fwd; 4 = also the per-channel min and max of the raw

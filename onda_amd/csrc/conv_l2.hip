@@ -129,170 +129,169 @@ __global__ __launch_bounds__(256) void stem_im2col_l2_kernel(const float* __rest
 }
 
 // ---- epilogue of a (64*WM) x (64*WN) tile held as 4 x 4 MFMA tiles of 16 x 16 per wave ----------------------------
-// Accumulator layout.  The K loops feed the WEIGHT fragment into the MFMA's A slot and the ACTIVATION fragment into its
-// B slot (both fragments have the same lane layout: row l & 15, k-chunk l >> 4), so the hardware leaves block (i, j)
-// TRANSPOSED in the accumulators: lane l holds pixel  i*16 + (l & 15)  and the four CONSECUTIVE channels
-// j*16 + 4*(l >> 4) + e, e = 0..3 -- 16 contiguous bytes of an NHWC row.  The epilogue therefore stores every block
-// straight from the registers as one 16-byte vector per lane (16 stores per wave and tile, each covering 16 pixel rows
-// x 64 bytes; the neighbouring block fills the other half of the 128-byte lines right behind it).
-// History: with the activations in the A slot a lane held 4 PIXELS of one channel -- 64 four-byte stores per lane
-// (round 1: 26 000 cycles per 256 x 128 tile, store issue) or a transposition of every wave's sub-tile through 4 KiB
-// of LDS (round 2: 64 ds_write_b32 + 16 ds_read_b128 per wave, 11 200 cycles per tile and a barrier for the scratch).
+// The accumulator layout has a lane's 16 values of one MFMA column 4 rows apart: stored as they stand that is 64
+// four-byte stores per lane in 64-byte runs, and the store ISSUE (not bandwidth) is what a tile then waits for
+// (measured: 26 000 cycles per 256 x 128 tile, more than the K loop of a 1 x 1 convolution with 256 input
+// channels).  So each wave transposes its 64 x 64 sub-tile through LDS, 16 rows at a time, and stores whole
+// 256-byte row segments as 16-byte vectors: 16 stores per lane, scale / shift loaded once per lane.
+// `scratch`: LDS nobody else touches during the epilogue: 4 KiB per wave, then WM*BN*4 + WM*WN floats of statistics.
 // COUNTED: every wave issues exactly 16 output stores (buffer stores; rows past M / channels past Cout get an
 // out-of-range offset and are dropped by the hardware) -- conv_l2x_kernel counts them in its vmcnt waits.
-// `scratch`: WM*BN*4 + NW floats of LDS nobody else touches during the epilogue (statistics / max across waves; not
-// touched at all when the tile has neither).
-template <int CTRL>
-__device__ __forceinline__ float dpp16(float v) {  // the value of another lane of the same 16-lane row (VALU, no LDS)
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+// x[lane] (+, min, max) x[lane ^ 16] and x[lane ^ 32] on the VALU (v_permlane16/32_swap: gfx950), four values per call.
+// (Inline assembly: this compiler folds the builtin's two results into one when both inputs are the same value.)
+#define ONDA_SWAP4(INSN, A, B)                                                                                          \
+  asm volatile("s_nop 1\n\t" INSN " %0, %4\n\t" INSN " %1, %5\n\t" INSN " %2, %6\n\t" INSN " %3, %7\n\ts_nop 0"         \
+               : "+v"(A[0]), "+v"(A[1]), "+v"(A[2]), "+v"(A[3]), "+v"(B[0]), "+v"(B[1]), "+v"(B[2]), "+v"(B[3]))
+__device__ __forceinline__ void rows_reduce4(float& s1, float& s2, float& mn, float& mx) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  float A[4] = {s1, s2, mn, mx}, B[4] = {s1, s2, mn, mx};
+  ONDA_SWAP4("v_permlane16_swap_b32", A, B);
+  float C[4] = {A[0] + B[0], A[1] + B[1], fminf(A[2], B[2]), fmaxf(A[3], B[3])};
+  float D[4] = {C[0], C[1], C[2], C[3]};
+  ONDA_SWAP4("v_permlane32_swap_b32", C, D);
+  s1 = C[0] + D[0];
+  s2 = C[1] + D[1];
+  mn = fminf(C[2], D[2]);
+  mx = fmaxf(C[3], D[3]);
+#endif
 }
-// reduce over the 16 lanes of a row (the 16 pixels of a block): xor 1, xor 2 (quad permutes), quad <-> quad
-// (row_half_mirror), half <-> half (row_mirror); afterwards every lane of the row holds the result
-#define ONDA_ROW16(OP, v)              \
-  do {                                 \
-    v = OP(v, dpp16<0xB1>(v));         \
-    v = OP(v, dpp16<0x4E>(v));         \
-    v = OP(v, dpp16<0x141>(v));        \
-    v = OP(v, dpp16<0x140>(v));        \
-  } while (0)
-__device__ __forceinline__ float addf(float a, float b) { return a + b; }
 
 // AFFINE = false: no per-channel scale / shift, residual or ReLU (train-mode convolutions, plain data gradients): the
 // epilogue then issues no global LOAD at all.  That matters in the continuous stream (COUNTED): vmcnt counts in issue
 // order, so waiting for any load issued here means waiting for the next tile's DMAs that are already in flight, and
 // the compiler has to place such a wait (vmcnt(0)) as soon as a load MAY have been issued.  For the same reason the
 // barriers of the COUNTED path are bare s_barrier + lgkmcnt waits, not __syncthreads() (whose release fence is a
-// vmcnt(0)).
-// DEFER (conv_l2s_kernel, whose workgroup halves run one slot apart and cannot meet at a barrier inside an epilogue): the
-// statistics partials are left in `scratch` for l2_stats_finish (called one barrier later by the same half), the
-// maximum goes out as one atomic per WAVE; no barrier in here.
-template <int WM, int WN, bool COUNTED = false, bool AFFINE = true, bool DEFER = false>
+// vmcnt(0)): measured 4 000 of the epilogue's 13 000 cycles.
+template <int WM, int WN, bool COUNTED = false, bool AFFINE = true>
 __device__ __forceinline__ void l2_epilogue(const ConvK& a, const f32x4 (&acc)[4][4], unsigned char* scratch, int tile_m, int m0,
                                             int n0, int wm, int wn, int lane, float ua, float ub, unsigned y_bytes = 0) {
   // `acc` holds RAW sums (operand units: value * 2^ea * 2^eb); ua = 2^-ea, ub = 2^-eb (exact) are applied to the four
   // statistics of a column and folded into the per-channel scale of the output instead of to all 64 accumulators
   constexpr int BN = 64 * WN, NW = WM * WN, NT = NW * 64;
+  constexpr int TRS = 68;  // floats per row of the transposition buffer: rows 4 apart land 16 banks apart (ds_write_b32
+                           // banks are (a/4) % 32 per 32-lane half; 64 would put lanes l and l+16 on one bank)
   const OndaConv& c = a.c;
   const int t = threadIdx.x, wave = t >> 6;
-  const int pl = lane & 15, q = lane >> 4;  // pixel of a block, 4-channel group of a block
   // diagnostics: the phases of the workgroup's LAST tile (overwritten per tile: no load here, see AFFINE)
   unsigned long long* est = a.stamps != nullptr && t == 0 ? a.stamps + (size_t)blockIdx.x * 32 + 24 : nullptr;
   if (est) est[0] = __builtin_amdgcn_s_memtime();
-  float* red = reinterpret_cast<float*>(scratch);
+  float* red = reinterpret_cast<float*>(scratch + NW * (16 * TRS * 4));
   const int SR = a.stats_rows;  // 2, or 4 with the per-channel min / max of the raw tile (rows past M count as zeros:
                                 // the extrema only have to BOUND the tensor's, norm_l2.hip)
   if (a.stats != nullptr) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1, mn = {3.0e38f, 3.0e38f, 3.0e38f, 3.0e38f}, mxv = -mn;
+    for (int jn = 0; jn < 4; ++jn) {
+      float s1 = 0.f, s2 = 0.f, mn = 3.0e38f, mxv = -3.0e38f;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const f32x4 v = acc[i][j];
-        s1 += v;
-        s2 += v * v;
-        if (SR == 4) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            mn[e] = fminf(mn[e], v[e]);
-            mxv[e] = fmaxf(mxv[e], v[e]);
-          }
-        }
-      }
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        ONDA_ROW16(addf, s1[e]);
-        ONDA_ROW16(addf, s2[e]);
-        if (SR == 4) {
-          ONDA_ROW16(fminf, mn[e]);
-          ONDA_ROW16(fmaxf, mxv[e]);
-        }
-      }
-      if (pl == 0) {
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const int col = (wn * 4 + j) * 16 + 4 * q + e;
-          *reinterpret_cast<f32x4*>(red + (wm * BN + col) * 4) =
-              f32x4{(s1[e] * ua) * ub, (((s2[e] * ua) * ub) * ua) * ub, (mn[e] * ua) * ub, (mxv[e] * ua) * ub};
+          const float v = acc[i][jn][e];
+          s1 += v;
+          s2 += v * v;
+          mn = fminf(mn, v);
+          mxv = fmaxf(mxv, v);
         }
+      rows_reduce4(s1, s2, mn, mxv);
+      if (lane < 16) {
+        const int col = (wn * 4 + jn) * 16 + lane;
+        red[(wm * BN + col) * 4 + 0] = (s1 * ua) * ub;
+        red[(wm * BN + col) * 4 + 1] = (((s2 * ua) * ub) * ua) * ub;
+        red[(wm * BN + col) * 4 + 2] = (mn * ua) * ub;
+        red[(wm * BN + col) * 4 + 3] = (mxv * ua) * ub;
       }
     }
   }
 
   if (est) est[1] = __builtin_amdgcn_s_memtime();
   const bool plain = (c.out_os == 1 && c.Hf == c.Ho && c.Wf == c.Wo);
-  const int nb = n0 + wn * 64 + 4 * q;  // this lane's channels of block j: nb + 16 j .. + 3
-  f32x4 sc[4], sh[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    sc[j] = f32x4{1.f, 1.f, 1.f, 1.f};
-    sh[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if constexpr (AFFINE) {
-      const bool vn = nb + 16 * j < c.Cout;  // Cout is a multiple of 4
-      if (vn && a.scale) sc[j] = *reinterpret_cast<const f32x4*>(a.scale + nb + 16 * j);
-      if (vn && a.shift) sh[j] = *reinterpret_cast<const f32x4*>(a.shift + nb + 16 * j);
-    }
-    sc[j] = (sc[j] * ua) * ub;
+  // after the transposition: lane -> row 4*r + (lane >> 4) of a 16-row chunk (r = 0..3), columns 4*(lane & 15) .. +3
+  const int cl = (lane & 15) * 4, rl = lane >> 4;
+  const int n = n0 + wn * 64 + cl;
+  const bool vn = n < c.Cout;  // Cout is a multiple of 4
+  f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+  if constexpr (AFFINE) {
+    if (vn && a.scale) sc = *reinterpret_cast<const f32x4*>(a.scale + n);
+    if (vn && a.shift) sh = *reinterpret_cast<const f32x4*>(a.shift + n);
   }
+  sc = (sc * ua) * ub;
+  float* tr = reinterpret_cast<float*>(scratch + wave * (16 * TRS * 4));
   float mx = 0.f;
-  const int mw = m0 + wm * 64 + pl;  // this lane's output row of block row i: mw + 16 i
   // the residual (a shortcut in eval mode; the running gradient sum of a shared activation, ops.GradSink) is fetched
-  // up front -- 16 independent 16-byte loads per lane into the registers the second accumulator set just vacated
+  // up front -- 16 independent 16-byte loads per lane into the registers the second accumulator set just vacated --
+  // instead of one round trip per 16-row chunk in the store loop
   f32x4 rv[4][4];
   if (AFFINE && a.res) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int m = mw + 16 * i, n = nb + 16 * j;
-        const bool live = m < a.M && n < c.Cout;
-        rv[i][j] = live ? *reinterpret_cast<const f32x4*>(a.res + (size_t)m * c.ldr + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + (wm * 4 + i) * 16 + 4 * r + rl;
+        const bool live = m < a.M && vn;
+        rv[i][r] = live ? *reinterpret_cast<const f32x4*>(a.res + (size_t)m * c.ldr + n) : f32x4{0.f, 0.f, 0.f, 0.f};
       }
   }
+  // Dense output (row m of the GEMM is row m of y: every convolution but the strided data gradient): the address of
+  // (i, r) is a per-lane base plus a workgroup-uniform term -- one VALU add per store instead of the 64-bit index
+  // arithmetic; with buffer stores (COUNTED) the rows past M lie past the end of the buffer (y_bytes covers M dense
+  // rows) and the columns past Cout carry an out-of-range base: the hardware drops both, no per-row test.
   const bool track = a.amax != nullptr;
+  const bool full_rows = m0 + 64 * WM <= a.M;
+  const int mw = m0 + wm * 64 + rl;  // this lane's output row for (i, r) = (0, 0)
+  const unsigned vbase = vn ? (unsigned)(((size_t)mw * c.ldy + n) * 4) : OOB;
+  float* const ybase = a.y + (size_t)mw * c.ldy + n;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int m = mw + 16 * i;
-    const bool vm = m < a.M;
-    size_t orow = (size_t)m;
-    if (!plain) {  // scattered rows (stride-2 data gradient)
-      const int mm = vm ? m : 0;
-      const int wo = mm % c.Wo, tq = mm / c.Wo;
-      const int ho = tq % c.Ho, b = tq / c.Ho;
-      orow = ((size_t)b * c.Hf + (size_t)ho * c.out_os) * c.Wf + (size_t)wo * c.out_os;
-    }
+    // this wave's own rows of the buffer: only its own earlier reads have to be out of the way
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = nb + 16 * j;
-      const bool live = vm && n < c.Cout;
-      f32x4 v = acc[i][j];
+    for (int jn = 0; jn < 4; ++jn)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) tr[(4 * (lane >> 4) + e) * TRS + jn * 16 + (lane & 15)] = acc[i][jn][e];
+    __builtin_amdgcn_wave_barrier();  // one wave, and the LDS executes a wave's instructions in order: no wait, no s_barrier
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 4 * r + rl;
+      f32x4 v = *reinterpret_cast<const f32x4*>(tr + row * TRS + cl);
+      const int m = mw + i * 16 + 4 * r;
+      const bool live = (full_rows || m < a.M) && vn;
       if constexpr (AFFINE) {
-        v = v * sc[j] + sh[j];
-        if (a.res) v += rv[i][j];
+        v = v * sc + sh;
+        if (a.res) v += rv[i][r];
         if (c.relu) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+          for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
         }
       } else {
-        v = v * sc[j];
+        v = v * sc;
       }
-      if constexpr (COUNTED) {
+      if (plain) {
+        if constexpr (COUNTED) {
 #if defined(__HIP_DEVICE_COMPILE__)
-        // dense output: rows past M lie past the end of the buffer (y_bytes covers M dense rows), columns past Cout and
-        // dead scattered rows carry an out-of-range offset: the hardware drops them, the store COUNT stays exact
-        const unsigned off = (n < c.Cout && (plain || vm)) ? (unsigned)((orow * c.ldy + n) * 4) : OOB;
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), make_rsrc(a.y, y_bytes), off, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), make_rsrc(a.y, y_bytes),
+                                                 vbase + (unsigned)((i * 16 + 4 * r) * c.ldy * 4), 0, 0);
 #endif
-      } else if (live) {
-        *reinterpret_cast<f32x4*>(a.y + orow * c.ldy + n) = v;
+        } else if (live) {
+          *reinterpret_cast<f32x4*>(ybase + (size_t)((i * 16 + 4 * r) * c.ldy)) = v;
+        }
+      } else {  // scattered rows (stride-2 data gradient)
+        const int mm = live ? m : 0;
+        const int wo = mm % c.Wo, tq = mm / c.Wo;
+        const int ho = tq % c.Ho, b = tq / c.Ho;
+        const size_t orow = ((size_t)b * c.Hf + (size_t)ho * c.out_os) * c.Wf + (size_t)wo * c.out_os;
+        if constexpr (COUNTED) {
+#if defined(__HIP_DEVICE_COMPILE__)
+          const unsigned off = live ? (unsigned)((orow * c.ldy + n) * 4) : OOB;
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), make_rsrc(a.y, y_bytes), off, 0, 0);
+#endif
+        } else if (live) {
+          *reinterpret_cast<f32x4*>(a.y + orow * c.ldy + n) = v;
+        }
       }
       if (track && live) mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
     }
+    __builtin_amdgcn_wave_barrier();
   }
   if (est) est[2] = __builtin_amdgcn_s_memtime();
-  if constexpr (DEFER) {
-    if (a.amax != nullptr) amax_update(a.amax, mx);
-    return;
-  }
   float* ar = red + WM * BN * 4;
   if (a.amax != nullptr) {
     mx = wave_max(mx);
@@ -313,11 +312,10 @@ __device__ __forceinline__ void l2_epilogue(const ConvK& a, const f32x4 (&acc)[4
       float s1 = 0.f, s2 = 0.f, mn = 3.0e38f, mxv = -3.0e38f;
 #pragma unroll
       for (int w_ = 0; w_ < WM; ++w_) {
-        const f32x4 p = *reinterpret_cast<const f32x4*>(red + (w_ * BN + col) * 4);
-        s1 += p[0];
-        s2 += p[1];
-        mn = fminf(mn, p[2]);
-        mxv = fmaxf(mxv, p[3]);
+        s1 += red[(w_ * BN + col) * 4 + 0];
+        s2 += red[(w_ * BN + col) * 4 + 1];
+        mn = fminf(mn, red[(w_ * BN + col) * 4 + 2]);
+        mxv = fmaxf(mxv, red[(w_ * BN + col) * 4 + 3]);
       }
       float* dst = a.stats + (size_t)tile_m * SR * c.Cout + n0 + col;
       dst[0] = s1;
@@ -338,18 +336,6 @@ __device__ __forceinline__ void l2_epilogue(const ConvK& a, const f32x4 (&acc)[4
   if (est) est[4] = __builtin_amdgcn_s_memtime();
 }
 
-// raw accumulators of a partial (stream-K) tile -> slot[BM][BN] (row-major, what conv_l2_fixup_kernel sums): one 16-byte
-// store per block and lane
-template <int BN>
-__device__ __forceinline__ void l2_store_partial(float* slot, const f32x4 (&acc)[4][4], int wm, int wn, int lane) {
-  const int pl = lane & 15, q = lane >> 4;
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      *reinterpret_cast<f32x4*>(slot + ((wm * 4 + i) * 16 + pl) * BN + (wn * 4 + j) * 16 + 4 * q) = acc[i][j];
-}
-
 // ---- epilogue that writes LIMB PLANES (eval mode: conv + folded BatchNorm [+ residual limbs] [+ ReLU] -> the next conv's
 // operand format, no fp32 tensor and no split pass in between).  The planes' scale has to exist before the first element
 // is stored: it comes from an a-priori bound
@@ -364,71 +350,71 @@ __device__ __forceinline__ float limb_out_bound(const ConvK& a) {
   return b * 1.0001f;  // (fp32 rounding of the sums and of the bound itself)
 }
 
-// (same transposed accumulator layout as l2_epilogue: a lane's four values of a block are four consecutive channels of
-//  one pixel -- 8 bytes of each plane)
-template <int WM, int WN, bool COUNTED, bool DEFER = false>
+template <int WM, int WN, bool COUNTED>
 __device__ __forceinline__ void l2_epilogue_limbs(const ConvK& a, const f32x4 (&acc)[4][4], unsigned char* scratch, int m0, int n0,
                                                   int wm, int wn, int lane, float ua, float ub) {
-  constexpr int NW = WM * WN;
+  constexpr int BN = 64 * WN, NW = WM * WN;
+  constexpr int TRS = 68;
   const OndaConv& c = a.c;
   if constexpr (COUNTED) asm volatile("" : "+v"(lane));
   int t = threadIdx.x;
   if constexpr (COUNTED) asm volatile("" : "+v"(t));
   const int wave = t >> 6;
-  const int pl = lane & 15, q = lane >> 4;
   const float bound = limb_out_bound(a);
   const float so = scale_from(bound).s;
   if (t == 0) a.ybound[(blockIdx.x & (ONDA_AMAX_SLOTS - 1)) * AMAX_STRIDE] = bound;
   const float ri = a.resl != nullptr ? scale_of(a.res_amax).inv : 0.f;
-  const int nb = n0 + wn * 64 + 4 * q;
-  const int mw = m0 + wm * 64 + pl;
-  f32x4 sc[4], sh[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const bool vn = nb + 16 * j < c.Cout;
-    sc[j] = f32x4{1.f, 1.f, 1.f, 1.f};
-    sh[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (vn && a.scale) sc[j] = *reinterpret_cast<const f32x4*>(a.scale + nb + 16 * j);
-    if (vn && a.shift) sh[j] = *reinterpret_cast<const f32x4*>(a.shift + nb + 16 * j);
-    sc[j] = (sc[j] * ua) * ub;
-  }
-  float* ar = reinterpret_cast<float*>(scratch);
-  // residual limbs, all 16 blocks of this lane up front (8 bytes per plane each)
+  const int cl = (lane & 15) * 4, rl = lane >> 4;
+  const int n = n0 + wn * 64 + cl;
+  const bool vn = n < c.Cout;
+  f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+  if (vn && a.scale) sc = *reinterpret_cast<const f32x4*>(a.scale + n);
+  if (vn && a.shift) sh = *reinterpret_cast<const f32x4*>(a.shift + n);
+  sc = (sc * ua) * ub;
+  float* tr = reinterpret_cast<float*>(scratch + wave * (16 * TRS * 4));
+  float* ar = reinterpret_cast<float*>(scratch + NW * (16 * TRS * 4));
+  const int mw = m0 + wm * 64 + rl;
+  // residual limbs, all 16 row positions of this lane up front (8 bytes per plane each)
   u32x2 r1[4][4], r2[4][4];
   if (a.resl != nullptr) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int m = mw + 16 * i, n = nb + 16 * j;
-        const bool live = m < a.M && n < c.Cout;
+      for (int r = 0; r < 4; ++r) {
+        const int m = mw + i * 16 + 4 * r;
+        const bool live = m < a.M && vn;
         const _Float16* p = a.resl + (size_t)(live ? m : 0) * c.ldr + (live ? n : 0);
-        r1[i][j] = live ? *reinterpret_cast<const u32x2*>(p) : u32x2{0u, 0u};
-        r2[i][j] = live ? *reinterpret_cast<const u32x2*>(p + a.resplane) : u32x2{0u, 0u};
+        r1[i][r] = live ? *reinterpret_cast<const u32x2*>(p) : u32x2{0u, 0u};
+        r2[i][r] = live ? *reinterpret_cast<const u32x2*>(p + a.resplane) : u32x2{0u, 0u};
       }
   }
   float mx = 0.f;
   const size_t plane_bytes = (size_t)a.M * c.ldy * 2;  // one plane as a buffer: rows past M fall outside
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int m = mw + 16 * i;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = nb + 16 * j;
-      const bool vn = n < c.Cout;
+    for (int jn = 0; jn < 4; ++jn)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) tr[(4 * (lane >> 4) + e) * TRS + jn * 16 + (lane & 15)] = acc[i][jn][e];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 4 * r + rl;
+      f32x4 v = *reinterpret_cast<const f32x4*>(tr + row * TRS + cl);
+      const int m = mw + i * 16 + 4 * r;
       const bool live = m < a.M && vn;
-      f32x4 v = acc[i][j] * sc[j] + sh[j];
+      v = v * sc + sh;
       if (a.resl != nullptr) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-          const f32x2 p1 = unpack2h(r1[i][j][h]), p2 = unpack2h(r2[i][j][h]);
+          const f32x2 p1 = unpack2h(r1[i][r][h]), p2 = unpack2h(r2[i][r][h]);
           v[2 * h] += (p1[0] + p2[0] * LIMB2_UNSCALE) * ri;
           v[2 * h + 1] += (p1[1] + p2[1] * LIMB2_UNSCALE) * ri;
         }
       }
       if (c.relu) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
       }
       if (live) mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
       const f32x4 w = v * so;
@@ -452,10 +438,7 @@ __device__ __forceinline__ void l2_epilogue_limbs(const ConvK& a, const f32x4 (&
         *reinterpret_cast<u32x2*>(dst + a.yplane) = l2;
       }
     }
-  }
-  if constexpr (DEFER) {
-    if (a.amax != nullptr) amax_update(a.amax, mx);
-    return;
+    __builtin_amdgcn_wave_barrier();
   }
   if (a.amax != nullptr) {  // the true maximum of what was stored (bounds the next layer)
     mx = wave_max(mx);
@@ -672,21 +655,21 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_l2_kernel(const ConvK 
     };
     auto compute = [&]() {  // "C": 48 MFMAs (one wave per SIMD: the b1 fragments are fetched behind the first 16)
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) accx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i][0], accx[i][j], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) accx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][0], bf[j], accx[i][j], 0, 0, 0);
       if constexpr (!STAGGER) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) b1[j] = *reinterpret_cast<const f16x8*>(Bb + j * 1024);
       }
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) accx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b1[j], af[i][1], accx[i][j], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) accx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][1], b1[j], accx[i][j], 0, 0, 0);
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b1[j], af[i][0], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][0], b1[j], acc[i][j], 0, 0, 0);
     };
     if constexpr (!STAGGER) {
       // (a two-stage ring -- half the LDS, two workgroups per CU hide each other's waits -- has one step in flight)
@@ -739,7 +722,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_l2_kernel(const ConvK 
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (acc[i][j] * unscale_a) * unscale_b;
       float* slot = a.ws + ((size_t)swz * 2 + (u - (k_end - k_begin) == u_begin ? 0 : 1)) * (BM * BN);
-      l2_store_partial<BN>(slot, acc, wm, wn, lane);
+      conv_store_partial<BN, 4, 4, 16>(slot, acc, wm, wn, lane);
       continue;
     }
     // (the epilogue folds the two exact unscale factors into its per-column constants; if their PRODUCT left the normal
@@ -752,7 +735,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_l2_kernel(const ConvK 
         for (int j = 0; j < 4; ++j) acc[i][j] = (acc[i][j] * ua) * ub;
       ua = ub = 1.f;
     }
-    if (a.stats != nullptr || a.amax != nullptr) __syncthreads();  // the epilogue's cross-wave scratch lives in the ring
+    __syncthreads();
     if (a.yl != nullptr) l2_epilogue_limbs<WM, WN, false>(a, acc, lds, m0, n0, wm, wn, lane, ua, ub);
     else l2_epilogue<WM, WN>(a, acc, lds, tile_m, m0, n0, wm, wn, lane, ua, ub);
     if (DBG == 5) {
@@ -938,6 +921,10 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_l2x_kernel(const ConvK
   };
 
   const bool late = a.late_issue && wave >= NW / 2;
+  if (a.dephase > 0) {  // the 32 workgroups of an XCD in four phases: their epilogues' store bursts share one L2 / fabric port
+    const unsigned long long until = __builtin_amdgcn_s_memtime() + (unsigned long long)(((bid >> 3) & 3) * a.dephase);
+    while (__builtin_amdgcn_s_memtime() < until) __builtin_amdgcn_s_sleep(8);
+  }
   Cursor cc{swz, u_begin};
   int n_stamp = 0;
   auto stamp = [&]() {
@@ -970,19 +957,19 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_l2x_kernel(const ConvK
       if (!late) issue_step();
       prepare();
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) accx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i][0], accx[i][j], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) accx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][0], bf[j], accx[i][j], 0, 0, 0);
 #pragma unroll
       for (int j = 0; j < 4; ++j) bf[j] = *reinterpret_cast<const f16x8*>(Bb + j * 1024);
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) accx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i][1], accx[i][j], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) accx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][1], bf[j], accx[i][j], 0, 0, 0);
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i][0], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][0], bf[j], acc[i][j], 0, 0, 0);
       if (late) issue_step();
     }
     stamp();
@@ -996,7 +983,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_l2x_kernel(const ConvK
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (acc[i][j] * unscale_a) * unscale_b;
       float* slot = a.ws + ((size_t)swz * 2 + (first_piece ? 0 : 1)) * (BM * BN);
-      l2_store_partial<BN>(slot, acc, wm, wn, lane);
+      conv_store_partial<BN, 4, 4, 16>(slot, acc, wm, wn, lane);
       stores_young = 2;
       stamp();
       continue;
@@ -1011,10 +998,9 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_l2x_kernel(const ConvK
         for (int j = 0; j < 4; ++j) acc[i][j] = (acc[i][j] * ua) * ub;
       ua = ub = 1.f;
     }
-    // every wave has its fragments of the last step (they fed its MFMAs): that stage is scratch now (the statistics' and
-    // the maximum's cross-wave reduction; a tile with neither touches no LDS and needs no barrier).  A bare barrier: the
-    // DMAs of the next two steps stay in flight (see l2_epilogue)
-    if (a.stats != nullptr || a.amax != nullptr) __builtin_amdgcn_s_barrier();
+    // every wave has its fragments of the last step (they fed its MFMAs): that stage is scratch now.  A bare barrier:
+    // the DMAs of the next two steps stay in flight (see l2_epilogue)
+    __builtin_amdgcn_s_barrier();
     const int scratch = st_read == 0 ? (STAGES - 1) * STAGE : st_read - STAGE;  // the stage read last
     if (limb_out)
       l2_epilogue_limbs<WM, WN, true>(a, acc, lds + scratch, (tile / a.tilesN) * BM, (tile % a.tilesN) * BN, wm, wn, lane, ua, ub);
@@ -1029,328 +1015,6 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_l2x_kernel(const ConvK
   }
 }
 
-// ---- the continuous K-step stream with the SLOT STAGGER of conv_l2_kernel ------------------------------------------------
-// conv_l2x_kernel keeps the DMA stream running across tiles but leaves its two waves per SIMD in phase: all eight waves
-// read their fragments together (8 x 16 KB through the 128 B/clk LDS port: ~1 000 cycles in which no MFMA issues), then
-// queue their MFMAs behind one another -- 2 550 cycles per K-step against 1 536 of MFMA -- and every tile ends with an
-// epilogue during which the matrix pipe idles.  Here the stream is cut into SLOTS separated by workgroup barriers and the
-// second half of the workgroup (waves 4..7 = tile rows 128..255) runs ONE SLOT LATE:
-//     early:  P(k) | C(k) | P(k+1) | C(k+1) | ... | C(last) | E      | P(first')| C(first') ...
-//     late :       | P(k) | C(k)   | P(k+1) | ... | P(last) | C(last)| E        | P(first') ...
-// P = wait for the step's DMAs, issue the DMAs of step k+2, read ALL fragments; C = 48 MFMAs, no LDS access; E = the
-// tile's epilogue (16 stores per wave straight from the accumulators + the statistics' VALU work).  In every slot one
-// wave of each SIMD computes while the other prepares or stores: an epilogue costs the matrix pipe ONE slot per tile (the
-// slot in which the late half stores while the early half prepares), instead of the whole epilogue.
-// The halves never meet at a barrier inside an epilogue, so nothing in it may need one: a half's statistics partials go
-// to its own LDS region (outside the ring, which stays live) and are summed over the half's two wave rows ONE barrier
-// later by l2_stats_finish -- each half owns a row of `stats` per tile (row 2*tile_m + half; bn_finalize sums over all
-// rows anyway) -- and the running maximum is one atomic per wave (DEFER in l2_epilogue).
-// vmcnt arithmetic (issue order per wave): the early half waits for step k at the START of P(k): outstanding
-// [k][k+1], after an epilogue [k+1][k+2][stores], then [k+2][stores][k+3]: two waits during which the stores are younger
-// than the step waited for.  The late half waits for step k+1 at the END of P(k) (the early half reads that stage one
-// barrier later): outstanding [k+1][k+2], after its epilogue [k+2][stores][k+3]: one such wait.
-template <int BN>
-__device__ __forceinline__ void l2_stats_finish(const ConvK& a, const float* red_half, int row, int n0, int th) {
-  // th: thread index inside the half (0..255); its two wave rows' partials -> stats[row]
-  const OndaConv& c = a.c;
-  if (th < BN && n0 + th < c.Cout) {
-    const f32x4 p0 = *reinterpret_cast<const f32x4*>(red_half + th * 4);
-    const f32x4 p1 = *reinterpret_cast<const f32x4*>(red_half + (BN + th) * 4);
-    const int SR = a.stats_rows;
-    float* dst = a.stats + (size_t)row * SR * c.Cout + n0 + th;
-    dst[0] = p0[0] + p1[0];
-    dst[c.Cout] = p0[1] + p1[1];
-    if (SR == 4) {
-      dst[2 * c.Cout] = fminf(p0[2], p1[2]);
-      dst[3 * c.Cout] = fmaxf(p0[3], p1[3]);
-    }
-  }
-}
-
-template <int STAGES, int OCC, bool TAPSKIP>
-__global__ __launch_bounds__(512, OCC) void conv_l2s_kernel(const ConvK a, unsigned xplane, unsigned wplane, unsigned x_bytes,
-                                                            unsigned w_bytes, unsigned y_bytes, const float* __restrict__ xamax,
-                                                            const float* __restrict__ wamax) {
-  if (a.c.run_if != nullptr && *a.c.run_if == 0) return;  // predicated launch (onda_switch_step decided on the device)
-  constexpr int WM = 4, WN = 2, NW = 8;
-  constexpr int BM = 256, BN = 128;
-  constexpr int PLANE_A = BM * 64, PLANE_B = BN * 64;
-  constexpr int A_BYTES = 2 * PLANE_A, STAGE = A_BYTES + 2 * PLANE_B;
-  constexpr int APW = (BM / 16) / NW, BPW = (BN / 16) / NW;
-  constexpr int DPW = 2 * (APW + BPW);
-  constexpr int EST = 16;  // stores every wave issues per epilogue / partial tile (limb-plane output: 2 * EST)
-  static_assert(STAGES == 3 && DPW + 2 * EST <= 63, "ring of three; vmcnt holds 6 bits");
-  constexpr int RED_HALF = 2 * BN * 4;  // floats: two wave rows x BN columns x (sum, sumsq, min, max)
-  __shared__ __attribute__((aligned(16))) unsigned char lds[STAGES * STAGE + 2 * RED_HALF * 4];
-
-  const OndaConv& c = a.c;
-  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int wm = wave / WN, wn = wave % WN;
-  const bool late = wave >= NW / 2;
-  const int half = late ? 1 : 0;
-  float* red_half = reinterpret_cast<float*>(lds + STAGES * STAGE) + half * RED_HALF;
-  const int nblk = gridDim.x, bid = blockIdx.x;
-  const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
-  const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  const int KT = a.taps * a.kcper;
-  const int tiles_all = a.tilesM * a.tilesN, tiles_dp = a.tiles_dp;
-  const long long U = (long long)(tiles_all - tiles_dp) * KT;
-  const long long u_begin = swz * U / nblk, u_end = (swz + 1) * U / nblk;
-  const int wstride = a.taps * c.Cin;
-  const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, x_bytes), rw = make_rsrc(a.w, w_bytes);
-  const Scale2 sx = scale_of(xamax), sw = scale_of(wamax);
-  const float unscale_a = sx.inv, unscale_b = sw.inv;
-  const int lrow = lane >> 2;
-  const unsigned cq16 = (unsigned)(((lane & 3) ^ swz_row(lrow)) << 4);
-  const int frag = (lane & 15) * 64 + (((lane >> 4) ^ swz_row(lane & 15)) << 4);
-
-  // ---- work items: (tile, k_begin, k_end); a cursor is (whole tile index, stream-K unit) ------------------------------
-  struct Cursor {
-    int dp_tile;
-    long long u;
-  };
-  auto item_valid = [&](const Cursor& cu) { return cu.dp_tile < tiles_dp || cu.u < u_end; };
-  auto item_of = [&](const Cursor& cu, int& tile, int& k_begin, int& k_end) {
-    if (cu.dp_tile < tiles_dp) {
-      tile = cu.dp_tile;
-      k_begin = 0;
-      k_end = KT;
-    } else {
-      tile = tiles_dp + (int)(cu.u / KT);
-      k_begin = (int)(cu.u - (long long)(tile - tiles_dp) * KT);
-      k_end = (int)min((long long)KT, k_begin + (u_end - cu.u));
-    }
-  };
-  auto item_next = [&](Cursor& cu, int k_begin, int k_end) {
-    if (cu.dp_tile < tiles_dp) cu.dp_tile += nblk; else cu.u += k_end - k_begin;
-  };
-  // Filter taps whose input rows all lie outside the image for EVERY output row of a tile contribute exact zeros: a whole
-  // tile skips them (conv_l2_kernel explains; stream-K pieces keep the full K range their unit arithmetic is written in).
-  // Issue side and compute side derive the same mask from the tile index.
-  const unsigned all_taps = a.taps >= 32 ? 0xFFFFFFFFu : ((1u << a.taps) - 1u);
-  auto live_taps = [&](int tile, bool whole) -> unsigned {
-    if (!TAPSKIP || !(whole && a.taps > 1 && a.skip_dead_taps)) return all_taps;
-    const int m0 = (tile / a.tilesN) * BM, m_last = min(a.M, m0 + BM) - 1;
-    const int r0 = m0 / c.Wo, r1 = m_last / c.Wo;
-    const int ho0 = r0 % c.Ho;
-    unsigned live = 0;
-    for (int tp = 0; tp < a.taps; ++tp) {
-      const int dh = (tp / c.kw) * c.dil - c.pad;
-      bool alive = false;
-      for (int rr = r0, ho = ho0; rr <= r1; ++rr) {
-        alive |= (unsigned)(ho * c.stride + dh) < (unsigned)c.Hi;
-        if (++ho == c.Ho) ho = 0;
-      }
-      live |= (alive ? 1u : 0u) << tp;
-    }
-    return live ? live : 1u;
-  };
-  auto next_live = [&](unsigned live, int tp) {
-    while (tp < a.taps && !((live >> tp) & 1u)) ++tp;
-    return tp;
-  };
-
-  // ---- issue side (identical to conv_l2x_kernel) -----------------------------------------------------------------------
-  Cursor ci{swz, u_begin};
-  int i_left = 0;
-  int hi0[APW], wi0[APW], bH[APW], tap_i = 0, c0_i = 0;
-  unsigned bofs[BPW], aofs[APW], live_i = all_taps;
-  int st_issue = 0, st_read = 0, in_flight = 0;
-  auto set_tap = [&](int tp) {
-    const int rr = tp / c.kw, ss = tp - rr * c.kw;
-#pragma unroll
-    for (int d = 0; d < APW; ++d) {
-      const int hi = hi0[d] + rr * c.dil, wi = wi0[d] + ss * c.dil;
-      const bool ok = (unsigned)hi < (unsigned)c.Hi && (unsigned)wi < (unsigned)c.Wi;
-      aofs[d] = ok ? (unsigned)(((bH[d] + hi) * c.Wi + wi) * c.ldx) * 2u + cq16 : OOB;
-    }
-  };
-  auto open_issue_item = [&]() {
-    int tile, k_begin, k_end;
-    item_of(ci, tile, k_begin, k_end);
-    live_i = live_taps(tile, k_begin == 0 && k_end == KT);
-    i_left = live_i == all_taps ? k_end - k_begin : __builtin_popcount(live_i) * a.kcper;
-    const int m0 = (tile / a.tilesN) * BM, n0 = (tile % a.tilesN) * BN;
-#pragma unroll
-    for (int d = 0; d < APW; ++d) {
-      const int m = m0 + (wave * APW + d) * 16 + lrow;
-      const bool vm = m < a.M;
-      const int mm = vm ? m : 0;
-      const int wo = mm % c.Wo, tq = mm / c.Wo;
-      const int ho = tq % c.Ho, b = tq / c.Ho;
-      hi0[d] = vm ? ho * c.stride - c.pad : -(1 << 28);
-      wi0[d] = wo * c.stride - c.pad;
-      bH[d] = b * c.Hi;
-    }
-#pragma unroll
-    for (int d = 0; d < BPW; ++d) {
-      const int n = n0 + (wave * BPW + d) * 16 + lrow;
-      bofs[d] = n < c.Cout ? (unsigned)n * wstride * 2u + cq16 : OOB;
-    }
-    tap_i = live_i == all_taps ? k_begin / a.kcper : next_live(live_i, 0);
-    c0_i = live_i == all_taps ? (k_begin - tap_i * a.kcper) * BK : 0;
-    set_tap(tap_i);
-    item_next(ci, k_begin, k_end);
-  };
-  auto issue_step = [&]() {
-    if (i_left == 0) {
-      if (!item_valid(ci)) return;
-      open_issue_item();
-    }
-#if defined(__HIP_DEVICE_COMPILE__)
-    const int sa = c0_i * 2, sb = (tap_i * c.Cin + c0_i) * 2;
-#pragma unroll
-    for (int l = 0; l < 2; ++l) {
-#pragma unroll
-      for (int d = 0; d < APW; ++d) {
-        unsigned char* dst = lds + st_issue + l * PLANE_A + (wave * APW + d) * 1024;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)dst, 16, aofs[d], sa + l * xplane, 0, 0);
-      }
-#pragma unroll
-      for (int d = 0; d < BPW; ++d) {
-        unsigned char* dst = lds + st_issue + A_BYTES + l * PLANE_B + (wave * BPW + d) * 1024;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)dst, 16, bofs[d], sb + l * wplane, 0, 0);
-      }
-    }
-#endif
-    st_issue = st_issue + STAGE == STAGES * STAGE ? 0 : st_issue + STAGE;
-    ++in_flight;
-    --i_left;
-    c0_i += BK;
-    if (c0_i == c.Cin) {
-      c0_i = 0;
-      tap_i = next_live(live_i, tap_i + 1);
-      if (i_left > 0) set_tap(tap_i);
-    }
-  };
-
-  // ---- compute side ----------------------------------------------------------------------------------------------------
-  f16x8 af[4][2], bf[4], b1[4];
-  auto prepare = [&]() {  // every fragment of the stage at st_read: the compute slot touches no LDS
-    const unsigned char* Ab = lds + st_read + wm * 64 * 64 + frag;
-    const unsigned char* Bb = lds + st_read + A_BYTES + wn * 64 * 64 + frag;
-    st_read = st_read + STAGE == STAGES * STAGE ? 0 : st_read + STAGE;
-#pragma unroll
-    for (int l = 0; l < 2; ++l)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) af[i][l] = *reinterpret_cast<const f16x8*>(Ab + l * PLANE_A + i * 1024);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) bf[j] = *reinterpret_cast<const f16x8*>(Bb + PLANE_B + j * 1024);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) b1[j] = *reinterpret_cast<const f16x8*>(Bb + j * 1024);
-  };
-  int stores_young = 0;
-  const bool limb_out = a.yl != nullptr;
-  auto wait_step = [&]() {  // this wave's DMAs of its oldest step in flight have landed (no step in flight: nothing to wait for)
-    if (in_flight == 0) return;
-    if (in_flight > 1) {
-      if (stores_young && limb_out) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPW + 2 * EST) : "memory");
-      else if (stores_young) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPW + EST) : "memory");
-      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPW) : "memory");
-    } else {
-      if (stores_young && limb_out) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * EST) : "memory");
-      else if (stores_young) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(EST) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    if (stores_young) --stores_young;
-    --in_flight;
-  };
-  auto slot = [&]() {  // slot boundary: what this wave wrote to LDS (statistics partials) is visible to its half afterwards
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-  };
-
-  Cursor cc{swz, u_begin};
-  int pending_row = -1, pending_n0 = 0;  // statistics of the half's last epilogue, to be summed one barrier later
-  issue_step();
-  issue_step();
-  if (late) {  // one slot behind; the early half reads stage 0 right after this barrier
-    wait_step();
-    __builtin_amdgcn_s_barrier();
-  }
-  while (item_valid(cc)) {
-    int tile, k_begin, k_end;
-    item_of(cc, tile, k_begin, k_end);
-    const bool whole = k_begin == 0 && k_end == KT;
-    const bool first_piece = cc.dp_tile >= tiles_dp && cc.u == u_begin;
-    item_next(cc, k_begin, k_end);
-    const unsigned live_c = live_taps(tile, whole);
-    const int nsteps = live_c == all_taps ? k_end - k_begin : __builtin_popcount(live_c) * a.kcper;
-    f32x4 acc[4][4], accx[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc[i][j][e] = accx[i][j][e] = 0.f;
-    for (int kt = 0; kt < nsteps; ++kt) {
-      if (!late) wait_step();       // (early) own DMAs of this step
-      slot();                       // ---- P ----
-      if (pending_row >= 0) {
-        l2_stats_finish<BN>(a, red_half, pending_row, pending_n0, t & 255);
-        pending_row = -1;
-      }
-      issue_step();                 // two steps ahead in the stream, whatever tile that is
-      prepare();
-      if (late) wait_step();        // (late) own DMAs of the NEXT step: the early half reads that stage one barrier from here
-      slot();                       // ---- C ----
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) accx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i][0], accx[i][j], 0, 0, 0);
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) accx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b1[j], af[i][1], accx[i][j], 0, 0, 0);
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b1[j], af[i][0], acc[i][j], 0, 0, 0);
-    }
-    slot();                         // ---- E ----
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = acc[i][j] + accx[i][j] * LIMB2_UNSCALE;
-    if (!whole) {  // stream-K piece: raw accumulators to this workgroup's slot (16 stores per lane)
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (acc[i][j] * unscale_a) * unscale_b;
-      float* slot_ws = a.ws + ((size_t)swz * 2 + (first_piece ? 0 : 1)) * (BM * BN);
-      l2_store_partial<BN>(slot_ws, acc, wm, wn, lane);
-      stores_young = late ? 1 : 2;
-      continue;
-    }
-    float ua = unscale_a, ub = unscale_b;
-    if (const float u = ua * ub; !(u >= 0x1p-100f && u <= 0x1p100f)) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (acc[i][j] * ua) * ub;
-      ua = ub = 1.f;
-    }
-    const int tile_m = tile / a.tilesN, m0 = tile_m * BM, n0 = (tile % a.tilesN) * BN;
-    // (the half's wave rows are wm - 2*half = 0, 1 of its statistics region)
-    unsigned char* scratch = reinterpret_cast<unsigned char*>(red_half) - (size_t)(2 * half) * BN * 16;
-    if (limb_out)
-      l2_epilogue_limbs<WM, WN, true, true>(a, acc, scratch, m0, n0, wm, wn, lane, ua, ub);
-    else if (a.scale != nullptr || a.shift != nullptr || a.res != nullptr || c.relu)
-      l2_epilogue<WM, WN, true, true, true>(a, acc, scratch, tile_m, m0, n0, wm, wn, lane, ua, ub, y_bytes);
-    else
-      l2_epilogue<WM, WN, true, false, true>(a, acc, scratch, tile_m, m0, n0, wm, wn, lane, ua, ub, y_bytes);
-    if (a.stats != nullptr) {
-      pending_row = 2 * tile_m + half;
-      pending_n0 = n0;
-    }
-    stores_young = late ? 1 : 2;
-  }
-  // the halves end one slot apart; a half's last statistics become visible at its next barrier
-  slot();
-  if (pending_row >= 0) l2_stats_finish<BN>(a, red_half, pending_row, pending_n0, t & 255);
-  if (!late) __builtin_amdgcn_s_barrier();
-}
-
 // ---- stream-K remainder: partial tiles -> output, in ONE wide launch ---------------------------------------------------
 // A remainder tile was cut into pieces by the workgroups of conv_l2_kernel<.., SK = true> (raw accumulators in `ws`).
 // One workgroup per 8 rows of a remainder tile sums that tile's pieces in ascending-workgroup order (fixed order:
@@ -1358,10 +1022,8 @@ __global__ __launch_bounds__(512, OCC) void conv_l2s_kernel(const ConvK a, unsig
 // own row, the others: extra rows behind the regular ones -- bn_finalize sums over all rows anyway), so no second stage
 // and no cross-workgroup reduction is needed.  Replaces the two-launch piece_sum + fixup of the older kernels
 // (measured there: 31 us per convolution, 5.4 ms per adaptation step).
-// row_mul: statistics rows per tile row written by the main kernel (2 for conv_l2s_kernel, whose workgroup halves own a row
-// each): a remainder tile's sum goes to row row_mul * tile_m, the other rows of that tile row become identities.
 template <int BM, int BN>
-__global__ __launch_bounds__(256) void conv_l2_fixup_kernel(const ConvK a, int G, int rows_regular, int row_mul) {
+__global__ __launch_bounds__(256) void conv_l2_fixup_kernel(const ConvK a, int G, int rows_regular) {
   if (a.c.run_if != nullptr && *a.c.run_if == 0) return;  // predicated launch (onda_switch_step decided on the device)
   constexpr int C4 = BN / 4;      // float4 columns of a tile row
   constexpr int RG = 256 / C4;    // rows covered by the workgroup (one element group per thread)
@@ -1385,22 +1047,19 @@ __global__ __launch_bounds__(256) void conv_l2_fixup_kernel(const ConvK a, int G
   const int n = tile_n * BN + col;
   const bool vn = n < c.Cout;
   const int SR = a.stats_rows;
-  float* srow = a.stats ? a.stats + (size_t)(sub == 0 ? tile_m * row_mul : rows_regular + (tile_m - first_m) * (SUB - 1) + sub - 1) * SR * c.Cout + n
+  float* srow = a.stats ? a.stats + (size_t)(sub == 0 ? tile_m : rows_regular + (tile_m - first_m) * (SUB - 1) + sub - 1) * SR * c.Cout + n
                         : nullptr;
-  auto identity_row = [&](float* row) {
-    *reinterpret_cast<f32x4*>(row) = f32x4{0.f, 0.f, 0.f, 0.f};
-    *reinterpret_cast<f32x4*>(row + c.Cout) = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (SR == 4) {
-      *reinterpret_cast<f32x4*>(row + 2 * c.Cout) = f32x4{3.0e38f, 3.0e38f, 3.0e38f, 3.0e38f};
-      *reinterpret_cast<f32x4*>(row + 3 * c.Cout) = f32x4{-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
-    }
-  };
   if (vs == ve) {  // computed whole by one workgroup: its own epilogue ran; the extra statistic rows are identities
-    if (srow && sub != 0 && rg == 0 && vn) identity_row(srow);
+    if (srow && sub != 0 && rg == 0 && vn) {
+      *reinterpret_cast<f32x4*>(srow) = f32x4{0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<f32x4*>(srow + c.Cout) = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (SR == 4) {
+        *reinterpret_cast<f32x4*>(srow + 2 * c.Cout) = f32x4{3.0e38f, 3.0e38f, 3.0e38f, 3.0e38f};
+        *reinterpret_cast<f32x4*>(srow + 3 * c.Cout) = f32x4{-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
+      }
+    }
     return;
   }
-  if (srow && sub == 0 && rg == 0 && vn)  // a summed remainder tile: the main kernel wrote none of its rows
-    for (int extra = 1; extra < row_mul; ++extra) identity_row(srow + (size_t)extra * SR * c.Cout);
   // the workgroups whose K range meets this tile, compacted in ascending order (with fewer remainder K-steps than
   // workgroups some ranges are empty); entry = workgroup * 2 + (0: its first piece, 1: its second)
   const int npieces = ve - vs + 1;
@@ -1818,20 +1477,20 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_wgrad_l2_kernel(const 
       for (int j = 0; j < 4; ++j) b1[j] = tr_read8(base + fb[j][0], base + fb[j][1]);
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) accx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i][0], accx[i][j], 0, 0, 0);
+      for (int j = 0; j < 4; ++j) accx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][0], bf[j], accx[i][j], 0, 0, 0);
     if constexpr (!STAGGER) lds_wait(b1[0], b1[1], b1[2], b1[3]);
     if constexpr (STAGGER) issue_second_part();
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) accx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b1[j], af[i][1], accx[i][j], 0, 0, 0);
+      for (int j = 0; j < 4; ++j) accx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][1], b1[j], accx[i][j], 0, 0, 0);
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b1[j], af[i][0], acc[i][j], 0, 0, 0);
+      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][0], b1[j], acc[i][j], 0, 0, 0);
   };
   if constexpr (!STAGGER) {
     for (; i_cur < nlive; ++i_cur) {
@@ -1875,20 +1534,26 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_wgrad_l2_kernel(const 
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = ((acc[i][j] + accx[i][j] * LIMB2_UNSCALE) * unscale_a) * unscale_b;
   if (stp) stp[2] = __builtin_amdgcn_s_memtime();
-  // slab store straight from the accumulators: the x fragment sits in the MFMA's A slot, so a lane holds, for output
-  // channel n = i*16 + (lane & 15), the four CONSECUTIVE input channels j*16 + 4*(lane >> 4) + e -- 16 bytes of a slab row
-  {
-    const int pl = lane & 15, q = lane >> 4;
-    const int cb = c0 + wn * 64 + 4 * q;
+  __syncthreads();
+  // slab store through the wave's own 4 KiB of LDS: 16 rows (output channels) x 64 input channels at a time, 16-byte stores
+  float* tr = reinterpret_cast<float*>(lds + (t >> 6) * 4096);
+  const int cl = (lane & 15) * 4, rl = lane >> 4;
+  const int cc = c0 + wn * 64 + cl;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int n = n0 + (wm * 4 + i) * 16 + pl;
+  for (int i = 0; i < 4; ++i) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int cc = cb + 16 * j;
-        if (n < c.Cout && cc < c.Cin) *reinterpret_cast<f32x4*>(a.slabs + (((size_t)ks * c.Cout + n) * a.taps + tap) * c.Cin + cc) = acc[i][j];
-      }
+    for (int jn = 0; jn < 4; ++jn)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) tr[(4 * (lane >> 4) + e) * 64 + jn * 16 + (lane & 15)] = acc[i][jn][e];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 4 * r + rl;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(tr + row * 64 + cl);
+      const int n = n0 + (wm * 4 + i) * 16 + row;
+      if (n < c.Cout && cc < c.Cin) *reinterpret_cast<f32x4*>(a.slabs + (((size_t)ks * c.Cout + n) * a.taps + tap) * c.Cin + cc) = v;
     }
+    __builtin_amdgcn_wave_barrier();
   }
   if (stp) stp[3] = __builtin_amdgcn_s_memtime();
 }
@@ -1931,7 +1596,12 @@ int onda_conv_l2_variant(int64_t M, int Cout) {
 /* which device kernel onda_conv2d_fwd_l2 launches for a problem: the tile variant (0: 256 x 128, 1: 128 x 128, 2: 256 x 64
  * = conv_l2_kernel<4,2> / <2,2> / <4,1>), or 3: conv_l2x_kernel<4,2>, the continuous K-step stream taken by 256 x 128
  * problems with at most 32 K-steps per tile (bench.py names its per-kernel figures after this) */
-int onda_conv_l2_kernel_id(int64_t M, int Cout, int taps, int Cin);
+int onda_conv_l2_kernel_id(int64_t M, int Cout, int taps, int Cin) {
+  const int variant = onda_conv_l2_variant(M, Cout);
+  static const int xt = getenv("ONDA_L2_XT") ? atoi(getenv("ONDA_L2_XT")) : 1;
+  const bool short_k = taps * (Cin / 32) <= 32 || xt == 2;
+  return variant == 0 && xt && short_k ? 3 : variant;
+}
 
 }  // extern "C"
 
@@ -1941,17 +1611,9 @@ namespace {
 struct L2Schedule {
   int variant, BM, BN, tilesM, tilesN, G, rem, sub;
   bool balanced;
-  int stream;   // 0: conv_l2_kernel, 1: conv_l2x_kernel (continuous stream), 2: conv_l2s_kernel (stream + slot stagger)
-  int row_mul;  // statistics rows the main kernel writes per tile row
   int rem_rows() const { return tilesM - (tilesM * tilesN - rem) / tilesN; }  // tile rows that hold remainder tiles
-  int stats_rows_total() const { return row_mul * tilesM + (balanced ? rem_rows() * (sub - 1) : 0); }
+  int stats_rows_total() const { return tilesM + (balanced ? rem_rows() * (sub - 1) : 0); }
 };
-// ONDA_L2_XT: 0 = one cold start per tile everywhere (conv_l2_kernel); 1 = conv_l2x_kernel for tiles of at most 32 K-steps;
-// 3 = conv_l2s_kernel for those (default); 4 = conv_l2s_kernel for every 256 x 128 problem; 2 = conv_l2x_kernel for every one
-int l2_xt() {
-  static const int xt = getenv("ONDA_L2_XT") ? atoi(getenv("ONDA_L2_XT")) : 3;
-  return xt;
-}
 bool l2_small_ring2() {
   static const int on = getenv("ONDA_L2_RING2") ? atoi(getenv("ONDA_L2_RING2")) : 1;
   return on != 0;
@@ -1978,25 +1640,11 @@ L2Schedule l2_schedule(long long M, int Cout, int taps, int Cin, bool have_ws) {
     if (force == 1 || !have_ws) q.balanced = false;
     else if (force == 2) q.balanced = q.rem != 0;
   }
-  // short K loops (1 x 1 convolutions up to 1024 input channels) gain from the continuous stream: their per-tile start and
-  // epilogue rival the K loop itself
-  const int xt = l2_xt();
-  const bool short_k = KT <= 32;
-  q.stream = 0;
-  if (q.variant == 0 && xt) q.stream = (xt == 2 || (xt == 1 && short_k)) ? 1 : ((xt == 4 || (xt == 3 && short_k)) ? 2 : 0);
-  q.row_mul = q.stream == 2 ? 2 : 1;
   return q;
 }
 }  // namespace
 
 extern "C" {
-
-/* the device kernel a problem runs on: 0..2 = conv_l2_kernel<4,2> / <2,2> / <4,1> (the tile variant), 3 = conv_l2x_kernel<4,2>,
- * 4 = conv_l2s_kernel */
-int onda_conv_l2_kernel_id(int64_t M, int Cout, int taps, int Cin) {
-  const L2Schedule q = l2_schedule(M, Cout, taps, Cin, true);
-  return q.stream ? 2 + q.stream : q.variant;
-}
 
 /* rows of the `stats` partials the conv will write for this problem (tile rows + the extra rows of a stream-K remainder) */
 int onda_conv_l2_tiles_m(int64_t M, int Cout, int taps, int Cin) { return l2_schedule(M, Cout, taps, Cin, true).stats_rows_total(); }
@@ -2039,6 +1687,8 @@ static int l2_fwd_impl(const void* xl, int64_t xplane, const float* xamax, const
   k.skip_dead_taps = !noskip;
   static const int late_issue = getenv("ONDA_L2X_LATE") ? atoi(getenv("ONDA_L2X_LATE")) : 1;
   k.late_issue = late_issue;
+  static const int dephase = getenv("ONDA_L2X_DEPHASE") ? atoi(getenv("ONDA_L2X_DEPHASE")) : 0;
+  k.dephase = dephase;
   static const int stamp_on = getenv("ONDA_L2X_STAMP") ? atoi(getenv("ONDA_L2X_STAMP")) : 0;
   if (stamp_on)  // the last 64 KiB of the workspace (beyond anything the schedules use: checked below)
     k.stamps = reinterpret_cast<unsigned long long*>(ws + onda_conv_ws_floats()) - 1024 * 32;
@@ -2059,6 +1709,7 @@ static int l2_fwd_impl(const void* xl, int64_t xplane, const float* xamax, const
   const unsigned xpl = (unsigned)(xplane * 2), wpl = (unsigned)(limb_elems * 2);
   const int tiles = k.tilesM * k.tilesN;
   k.tiles_dp = tiles - q.rem;
+  if (tiles < 3 * q.G) k.dephase = 0;  // (a start offset can only pay over several rounds of tiles)
   hipStream_t st = ONDA_STREAM(s);
 #define L2_LAUNCH(WM_, WN_, ST_, OCC_)                                                                                       \
   do {                                                                                                                       \
@@ -2066,33 +1717,26 @@ static int l2_fwd_impl(const void* xl, int64_t xplane, const float* xamax, const
       hipLaunchKernelGGL((conv_l2_kernel<WM_, WN_, ST_, OCC_, true>), dim3(q.G), dim3(WM_ * WN_ * 64), 0, st, k, xpl, wpl, x_bytes, \
                          w_bytes, xamax, wamax);                                                                            \
       hipLaunchKernelGGL((conv_l2_fixup_kernel<64 * WM_, 64 * WN_>), dim3(q.rem_rows() * q.tilesN, q.sub), dim3(256), 0, st, k, q.G, \
-                         q.tilesM, 1);                                                                                        \
+                         q.tilesM);                                                                                           \
     } else {                                                                                                                 \
       hipLaunchKernelGGL((conv_l2_kernel<WM_, WN_, ST_, OCC_, false>), dim3(tiles), dim3(WM_ * WN_ * 64), 0, st, k, xpl, wpl,    \
                          x_bytes, w_bytes, xamax, wamax);                                                                   \
     }                                                                                                                        \
   } while (0)
+  static const int xt = getenv("ONDA_L2_XT") ? atoi(getenv("ONDA_L2_XT")) : 1;  // 0: one cold start per tile (conv_l2_kernel)
   // the output as a buffer: last byte any tile can store (dense rows of ldy floats; scattered stride-2 gradients included)
   const long long y_rows = (long long)c->B * (c->out_os == 1 && c->Hf == c->Ho && c->Wf == c->Wo ? (long long)c->Ho * c->Wo : (long long)c->Hf * c->Wf);
   const long long y_total = ((y_rows - 1) * c->ldy + c->Cout) * 4;
-  if (q.stream) {
-    // (the stream kernels store through a buffer descriptor: 32-bit offsets.  The number of statistics rows was fixed by the
-    //  kernel choice, so a larger output cannot quietly fall back to the other kernel)
-    ONDA_REQUIRE(y_total < 0x7FFFF000ll);
+  // short K loops (1 x 1 convolutions up to 1024 input channels) gain 6-17 % from the continuous stream; long ones lose
+  // ~4 % against the slot-staggered kernel, whose per-tile start / end they amortise anyway (measured per shape, one process)
+  const bool short_k = k.taps * k.kcper <= 32 || xt == 2;
+  if (xt && short_k && q.variant == 0 && y_total < 0x7FFFF000ll) {
     if (!q.balanced) k.tiles_dp = tiles;  // persistent either way: whole tiles only
-    const int grid = q.balanced ? q.G : (tiles < q.G ? tiles : q.G);
-    if (q.stream == 2 && k.taps > 1 && k.skip_dead_taps && c->dil > 1)  // (dilated 3 x 3: whole tiles skip dead filter taps)
-      hipLaunchKernelGGL((conv_l2s_kernel<3, 2, true>), dim3(grid), dim3(512), 0, st, k, xpl, wpl, x_bytes, w_bytes, (unsigned)y_total,
-                         xamax, wamax);
-    else if (q.stream == 2)
-      hipLaunchKernelGGL((conv_l2s_kernel<3, 2, false>), dim3(grid), dim3(512), 0, st, k, xpl, wpl, x_bytes, w_bytes, (unsigned)y_total,
-                         xamax, wamax);
-    else
-      hipLaunchKernelGGL((conv_l2x_kernel<4, 2, 3, 2>), dim3(grid), dim3(512), 0, st, k, xpl, wpl, x_bytes, w_bytes, (unsigned)y_total,
-                         xamax, wamax);
+    const int grid = tiles < q.G ? tiles : q.G;
+    hipLaunchKernelGGL((conv_l2x_kernel<4, 2, 3, 2>), dim3(q.balanced ? q.G : grid), dim3(512), 0, st, k, xpl, wpl, x_bytes, w_bytes,
+                       (unsigned)y_total, xamax, wamax);
     if (q.balanced)
-      hipLaunchKernelGGL((conv_l2_fixup_kernel<256, 128>), dim3(q.rem_rows() * q.tilesN, q.sub), dim3(256), 0, st, k, q.G,
-                         q.row_mul * q.tilesM, q.row_mul);
+      hipLaunchKernelGGL((conv_l2_fixup_kernel<256, 128>), dim3(q.rem_rows() * q.tilesN, q.sub), dim3(256), 0, st, k, q.G, q.tilesM);
     return ONDA_LAUNCH_RESULT();
   }
   if (q.variant == 0) L2_LAUNCH(4, 2, 3, 2);

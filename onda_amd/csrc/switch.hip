@@ -20,27 +20,36 @@ namespace {
 
 constexpr int MAX_WINDOW = 1024;
 
+// Float64 operations that must round exactly once each, as numpy's do.  Defined HERE, under this file's
+// `fp contract(off)`: HIP's __dadd_rn / __dmul_rn are plain inline `a + b` / `a * b` from a header compiled with the
+// default contraction mode, and after inlining the compiler fused them into FMAs (measured: the exponential average
+// differed from numpy's in the last bit).
+__device__ __forceinline__ double dadd(double a, double b) { return a + b; }
+__device__ __forceinline__ double dsub(double a, double b) { return a - b; }
+__device__ __forceinline__ double dmul(double a, double b) { return a * b; }
+__device__ __forceinline__ double ddiv(double a, double b) { return a / b; }
+
 // numpy/_core/src/umath/loops_utils.h.src, @TYPE@_pairwise_sum, on products a[i] * b[i] (np.sum(taps * w): the product
 // array is rounded element by element first).  Runs in one thread: 2 x 199 terms per step.
 __device__ double np_pairwise_sum(const double* a, const double* b, int n) {
   if (n < 8) {
     double res = 0.0;
-    for (int i = 0; i < n; ++i) res = __dadd_rn(res, __dmul_rn(a[i], b[i]));
+    for (int i = 0; i < n; ++i) res = dadd(res, dmul(a[i], b[i]));
     return res;
   }
   if (n <= 128) {
     double r[8];
-    for (int j = 0; j < 8; ++j) r[j] = __dmul_rn(a[j], b[j]);
+    for (int j = 0; j < 8; ++j) r[j] = dmul(a[j], b[j]);
     int i = 8;
     for (; i < n - (n % 8); i += 8)
-      for (int j = 0; j < 8; ++j) r[j] = __dadd_rn(r[j], __dmul_rn(a[i + j], b[i + j]));
-    double res = __dadd_rn(__dadd_rn(__dadd_rn(r[0], r[1]), __dadd_rn(r[2], r[3])), __dadd_rn(__dadd_rn(r[4], r[5]), __dadd_rn(r[6], r[7])));
-    for (; i < n; ++i) res = __dadd_rn(res, __dmul_rn(a[i], b[i]));
+      for (int j = 0; j < 8; ++j) r[j] = dadd(r[j], dmul(a[i + j], b[i + j]));
+    double res = dadd(dadd(dadd(r[0], r[1]), dadd(r[2], r[3])), dadd(dadd(r[4], r[5]), dadd(r[6], r[7])));
+    for (; i < n; ++i) res = dadd(res, dmul(a[i], b[i]));
     return res;
   }
   int n2 = n / 2;
   n2 -= n2 % 8;
-  return __dadd_rn(np_pairwise_sum(a, b, n2), np_pairwise_sum(a + n2, b + n2, n - n2));
+  return dadd(np_pairwise_sum(a, b, n2), np_pairwise_sum(a + n2, b + n2, n - n2));
 }
 
 // sorted[] <- w[0..n) ascending, by rank (ties keep their order): every thread places its own elements
@@ -54,7 +63,7 @@ __device__ void rank_sort(const double* w, double* sorted, int n) {
   __syncthreads();
 }
 __device__ double median_of_sorted(const double* s, int n) {
-  return (n & 1) ? s[n / 2] : __ddiv_rn(__dadd_rn(s[n / 2 - 1], s[n / 2]), 2.0);
+  return (n & 1) ? s[n / 2] : ddiv(dadd(s[n / 2 - 1], s[n / 2]), 2.0);
 }
 
 // state (doubles): [0] exp, [1] avg, [2] dev_avg, [3] the confidence the switch looked at, [8 ..) the ring
@@ -79,7 +88,7 @@ __global__ __launch_bounds__(256) void switch_step_kernel(double* __restrict__ s
       ring[head] = v;
       head = (head + 1) % limit;
       count = count < limit ? count + 1 : limit;
-      state[0] = __dadd_rn(__dmul_rn(cfg.one_minus_exp_const, state[0]), __dmul_rn(cfg.exp_const, v));
+      state[0] = dadd(dmul(cfg.one_minus_exp_const, state[0]), dmul(cfg.exp_const, v));
     }
     istate[0] = meta[0] = count;
     istate[1] = meta[1] = head;
@@ -101,12 +110,12 @@ __global__ __launch_bounds__(256) void switch_step_kernel(double* __restrict__ s
       const double a = median_of_sorted(sorted, n);
       __syncthreads();
       rank_sort(w, sorted, n);
-      dev = __dsub_rn(a, median_of_sorted(sorted, n));
+      dev = dsub(a, median_of_sorted(sorted, n));
     } else {  // weighted level ("hamming", or "mean" with taps of one): one thread per level, in two waves
-      if (t == 0) levels[0] = __ddiv_rn(np_pairwise_sum(taps, w + 1, n), cfg.taps_total);
-      if (t == 64) levels[1] = __ddiv_rn(np_pairwise_sum(taps, w, n), cfg.taps_total);
+      if (t == 0) levels[0] = ddiv(np_pairwise_sum(taps, w + 1, n), cfg.taps_total);
+      if (t == 64) levels[1] = ddiv(np_pairwise_sum(taps, w, n), cfg.taps_total);
       __syncthreads();
-      dev = __dsub_rn(levels[0], levels[1]);
+      dev = dsub(levels[0], levels[1]);
     }
   }
   if (t == 0) {

@@ -212,12 +212,17 @@ class GradSync:
         i = self._bucket_of.get(id(p))
         if i is None:
             return
-        if self._launched[i]:
-            # cannot happen while every member is counted once per step; a bucket that is already on the wire must never
-            # be patched behind its all-reduce (the advisor's finding) -- fail instead of exchanging a stale slot
-            raise RuntimeError("onda_amd.dist: a gradient arrived after its bucket had been all-reduced")
         if id(p) in self._seen:
-            return  # a second signal for the same parameter in one pass (hook + Conv2dFn) counts once
+            # a second signal for the same parameter in one pass counts once.  Conv weights signal twice: ops.Conv2dFn calls
+            # in after it has accumulated the weight gradient in place, and autograd's post-accumulate hook fires as well --
+            # also when backward returned None for the parameter.  (Round 2 counted both: buckets left with half of their
+            # members' gradients still to come.  The two-rank tests compare replicas and the sequential emulation at
+            # the tolerance of a train-mode step, which that did not break; the check below would have.)
+            return
+        if self._launched[i]:
+            # a bucket that is already on the wire must never be patched behind its all-reduce (the advisor's finding):
+            # fail instead of exchanging a stale slot
+            raise RuntimeError("onda_amd.dist: a gradient arrived after its bucket had been all-reduced")
         self._seen.add(id(p))
         self._rebind(p)  # the slot holds the gradient before the bucket can leave
         self._remaining[i] -= 1

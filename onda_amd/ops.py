@@ -38,8 +38,9 @@ CONV_MODE = os.environ.get("ONDA_CONV_MODE", "f16x2")
 #   "reg": inside the conv kernel, in registers between two barriers (csrc/conv_h2.hip).
 H2_PATH = os.environ.get("ONDA_H2_PATH", "dma")
 
-# the multi-GPU gradient exchange installs a callable here: called with the weight Parameter once its gradient of the
-# current backward pass has been accumulated in place (autograd's own hooks never fire for it: backward returns None)
+# the multi-GPU gradient exchange installs a callable here: called with the weight Parameter as soon as its gradient of the
+# current backward pass has been accumulated in place (autograd's post-accumulate hook fires for it as well, later: the
+# exchange counts a parameter once)
 GRAD_READY = None
 
 # bench.py sets this to a list to collect (kernel family, algorithmic flops, start event, end event)
@@ -51,7 +52,7 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-_L2_KERNELS = ("conv_l2_kernel<4,2>", "conv_l2_kernel<2,2>", "conv_l2_kernel<4,1>", "conv_l2x_kernel<4,2>", "conv_l2s_kernel<3,2>")
+_L2_KERNELS = ("conv_l2_kernel<4,2>", "conv_l2_kernel<2,2>", "conv_l2_kernel<4,1>", "conv_l2x_kernel<4,2>")
 
 
 def _l2_name(M, cout, taps, cin):

@@ -153,3 +153,64 @@ def test_gradient_that_left_the_flat_buffer_is_exchanged_correctly():
         for k in local0:
             assert torch.allclose(avg0[k], (local0[k] + local1[k]) / 2, rtol=1e-6, atol=1e-7), (mode, k)
             assert torch.equal(avg0[k], avg1[k]), (mode, k)
+
+
+def _double_signal_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from onda_amd import dist as od
+    od.init_from_env("gloo")
+    torch.manual_seed(0)
+
+    class InPlace(torch.autograd.Function):
+        """What ops.Conv2dFn does with a weight: accumulate into .grad in place, signal, return None for the parameter."""
+
+        @staticmethod
+        def forward(ctx, x, w, sync):
+            ctx.save_for_backward(x, w)
+            ctx.sync, ctx.w = sync, w
+            ctx.set_materialize_grads(False)
+            return x @ w
+
+        @staticmethod
+        def backward(ctx, g):
+            x, w = ctx.saved_tensors
+            ctx.w.grad.add_(x.t() @ g)
+            ctx.sync.grad_ready(ctx.w)  # first signal; autograd's post-accumulate hook fires too (second signal)
+            return g @ w.t(), None, None
+
+    ws = [torch.nn.Parameter(torch.randn(40, 40) * 0.1) for _ in range(6)]
+    holder = torch.nn.ParameterList(ws)
+    sync = od.GradSync(holder, bucket_floats=3000)  # two parameters per bucket
+    assert [len(b[2]) for b in sync.buckets] == [2, 2, 2, 0]  # (the last bucket carries the tail only)
+    sync.zero()
+    x = torch.randn(8, 40) * (rank + 1)
+    y = x
+    sync.arm()
+    for w in ws:
+        y = InPlace.apply(y, w, sync)
+    y.sum().backward()
+    launched_early = sum(sync._launched)
+    sync.finish()
+    # this rank's own gradients, from plain autograd on copies (the flat buffer may already hold sums by now)
+    refs = [w.detach().clone().requires_grad_(True) for w in ws]
+    y = x
+    for w in refs:
+        y = y @ w
+    y.sum().backward()
+    out[rank] = ([w.grad.clone() for w in refs], [w.grad.clone() for w in ws], launched_early)
+    dist.destroy_process_group()
+
+
+def test_parameters_that_signal_twice_count_once():
+    """A conv weight signals the exchange twice per pass (explicitly after its in-place accumulation, and through autograd's
+    post-accumulate hook, which fires even though backward returns None for it).  Counted twice, a bucket would leave
+    when half of its members are complete; every rank must end with the mean of the COMPLETE gradients."""
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_double_signal_worker, args=(2, port, out), nprocs=2, join=True)
+    (l0, a0, early0), (l1, a1, _) = out[0], out[1]
+    assert early0 == 3  # the three full buckets went out during the backward pass, each only when BOTH members were complete
+    for i in range(6):
+        assert torch.allclose(a0[i], (l0[i] + l1[i]) / 2, rtol=1e-6, atol=1e-7), i
+        assert torch.equal(a0[i], a1[i])
