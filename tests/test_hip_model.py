@@ -431,11 +431,13 @@ def test_f16x2_steps_track_the_exact_f32_steps(tmp_path, conv_mode):
     if os.path.isdir(out_dir):
         with open(os.path.join(out_dir, "f16x2_vs_f32_steps.json"), "w") as f:
             json.dump(seen, f)
-    # step 0 starts from identical weights: the two arithmetics differ by their own rounding only.  Step 1 runs on weights
-    # that already differ by that rounding, seen through a train-mode pass on random weights (the conditioning that makes
-    # the REFERENCE's own second update move by 19 % with its thread count): measured 1e-4 on the logs there
+    # step 0 starts from identical weights: the two arithmetics differ by their own rounding only (measured: logs 1e-6,
+    # update 1.2e-4).  Step 1 runs on weights that already differ by that much, seen through a train-mode pass on random
+    # weights -- the conditioning that makes the REFERENCE's own second update move by 19 % with its thread count --:
+    # measured logs 1.0e-4, update 4.6e-3 (a factor 38 in one step; the reference's 60 % tolerance there is that factor
+    # applied to ITS fp32 noise)
     assert seen[0]["worst_log_rel"] <= 1e-4 and seen[0]["update_rel_l2"] <= 1e-3 and seen[0]["labels_differ"] == 0, seen
-    assert seen[1]["worst_log_rel"] <= 2e-3 and seen[1]["update_rel_l2"] <= 5e-2, seen
+    assert seen[1]["worst_log_rel"] <= 1e-3 and seen[1]["update_rel_l2"] <= 2e-2, seen
 
 
 def test_a_step_never_stops_the_host(tmp_path, conv_mode):
