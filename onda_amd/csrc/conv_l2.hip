@@ -921,10 +921,6 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_l2x_kernel(const ConvK
   };
 
   const bool late = a.late_issue && wave >= NW / 2;
-  if (a.dephase > 0) {  // the 32 workgroups of an XCD in four phases: their epilogues' store bursts share one L2 / fabric port
-    const unsigned long long until = __builtin_amdgcn_s_memtime() + (unsigned long long)(((bid >> 3) & 3) * a.dephase);
-    while (__builtin_amdgcn_s_memtime() < until) __builtin_amdgcn_s_sleep(8);
-  }
   Cursor cc{swz, u_begin};
   int n_stamp = 0;
   auto stamp = [&]() {
@@ -1687,8 +1683,6 @@ static int l2_fwd_impl(const void* xl, int64_t xplane, const float* xamax, const
   k.skip_dead_taps = !noskip;
   static const int late_issue = getenv("ONDA_L2X_LATE") ? atoi(getenv("ONDA_L2X_LATE")) : 1;
   k.late_issue = late_issue;
-  static const int dephase = getenv("ONDA_L2X_DEPHASE") ? atoi(getenv("ONDA_L2X_DEPHASE")) : 0;
-  k.dephase = dephase;
   static const int stamp_on = getenv("ONDA_L2X_STAMP") ? atoi(getenv("ONDA_L2X_STAMP")) : 0;
   if (stamp_on)  // the last 64 KiB of the workspace (beyond anything the schedules use: checked below)
     k.stamps = reinterpret_cast<unsigned long long*>(ws + onda_conv_ws_floats()) - 1024 * 32;
@@ -1709,7 +1703,6 @@ static int l2_fwd_impl(const void* xl, int64_t xplane, const float* xamax, const
   const unsigned xpl = (unsigned)(xplane * 2), wpl = (unsigned)(limb_elems * 2);
   const int tiles = k.tilesM * k.tilesN;
   k.tiles_dp = tiles - q.rem;
-  if (tiles < 3 * q.G) k.dephase = 0;  // (a start offset can only pay over several rounds of tiles)
   hipStream_t st = ONDA_STREAM(s);
 #define L2_LAUNCH(WM_, WN_, ST_, OCC_)                                                                                       \
   do {                                                                                                                       \
