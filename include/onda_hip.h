@@ -348,8 +348,9 @@ typedef struct OndaSgdEntry {
   int first_block; /* flat launch: blocks of the entries before this one, ceil(n / onda_multi_tensor_block()) each */
 } OndaSgdEntry;
 int onda_multi_tensor_block(void); /* elements per workgroup of the multi-tensor launches */
-int onda_sgd_multi(const OndaSgdEntry* table, int n, float momentum, float weight_decay, int64_t total_blocks,
-                   onda_stream_t s);
+/* grad_scale multiplies every gradient element on the way in (1 normally; 1 / world when `g` holds rank sums) */
+int onda_sgd_multi(const OndaSgdEntry* table, int n, float momentum, float weight_decay, float grad_scale,
+                   int64_t total_blocks, onda_stream_t s);
 /* k = k*keep + q*blend  (keep=0, blend=1 copies a buffer, prototypes.py:415-416) */
 typedef struct OndaEmaEntry { float* k; const float* q; int64_t n; float keep; float blend; int first_block; } OndaEmaEntry;
 int onda_ema_multi(const OndaEmaEntry* table, int n, int64_t total_blocks, onda_stream_t s);

@@ -112,7 +112,7 @@ SIGNATURES = {
     "onda_proto_class_sums": (I, [P, I, P, P, P, P, L, I, I, P]),
     "onda_proto_ema": (I, [P, P, P, P, F, I, I, P]),
     "onda_proto_append": (I, [P, P, P, P, P, I, I, P]),
-    "onda_sgd_multi": (I, [P, I, F, F, L, P]),
+    "onda_sgd_multi": (I, [P, I, F, F, F, L, P]),
     "onda_ema_multi": (I, [P, I, L, P]),
     "onda_multi_tensor_block": (I, []),
     "onda_resample_h_u8": (I, [P, P, I, I, I, P, P, I, P]),

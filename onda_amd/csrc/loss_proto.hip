@@ -598,8 +598,10 @@ __device__ __forceinline__ void sgd_one(float& p, float& b, float g, float lr, f
   }
 }
 
+// grad_scale: every gradient element is multiplied by it on the way in (1 / world: the exchanged buffer holds rank SUMS, the
+// division never becomes a pass of its own over 184 MB)
 __global__ __launch_bounds__(256) void sgd_multi_kernel(const OndaSgdEntry* __restrict__ table, int n_entries, float momentum,
-                                                        float wd) {
+                                                        float wd, float grad_scale) {
   const OndaSgdEntry e = table[mt_entry_of(table, n_entries, blockIdx.x)];
   const int64_t i0 = (int64_t)(blockIdx.x - e.first_block) * MT_BLOCK, i1 = i0 + MT_BLOCK < e.n ? i0 + MT_BLOCK : e.n;
   const bool vec = ((reinterpret_cast<size_t>(e.p) | reinterpret_cast<size_t>(e.g) | reinterpret_cast<size_t>(e.buf)) & 15) == 0;
@@ -612,7 +614,7 @@ __global__ __launch_bounds__(256) void sgd_multi_kernel(const OndaSgdEntry* __re
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         float pj = p[j], bj = b[j];
-        sgd_one(pj, bj, g[j], e.lr, momentum, wd, e.times, e.fresh);
+        sgd_one(pj, bj, g[j] * grad_scale, e.lr, momentum, wd, e.times, e.fresh);
         p[j] = pj;
         b[j] = bj;
       }
@@ -623,7 +625,7 @@ __global__ __launch_bounds__(256) void sgd_multi_kernel(const OndaSgdEntry* __re
   }
   for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
     float p = e.p[i], b = e.fresh ? 0.f : e.buf[i];
-    sgd_one(p, b, e.g[i], e.lr, momentum, wd, e.times, e.fresh);
+    sgd_one(p, b, e.g[i] * grad_scale, e.lr, momentum, wd, e.times, e.fresh);
     e.p[i] = p;
     e.buf[i] = b;
   }
@@ -771,10 +773,10 @@ int onda_proto_append(float* proto, float* sqmean, float* counter, const float* 
   return ONDA_LAUNCH_RESULT();
 }
 
-int onda_sgd_multi(const OndaSgdEntry* table, int n, float momentum, float weight_decay, int64_t max_n,
+int onda_sgd_multi(const OndaSgdEntry* table, int n, float momentum, float weight_decay, float grad_scale, int64_t max_n,
                    onda_stream_t s) {
   ONDA_REQUIRE(table && n >= 1 && max_n >= 1 && max_n < (1ll << 31));  // max_n: total blocks (flat launch)
-  hipLaunchKernelGGL(sgd_multi_kernel, dim3((unsigned)max_n), dim3(256), 0, ONDA_STREAM(s), table, n, momentum, weight_decay);
+  hipLaunchKernelGGL(sgd_multi_kernel, dim3((unsigned)max_n), dim3(256), 0, ONDA_STREAM(s), table, n, momentum, weight_decay, grad_scale);
   return ONDA_LAUNCH_RESULT();
 }
 

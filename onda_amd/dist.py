@@ -235,9 +235,11 @@ class GradSync:
         self._pending.append(dist.all_reduce(self.flat[start:end], op=dist.ReduceOp.SUM, async_op=True))
 
     @torch.no_grad()
-    def finish(self):
+    def finish(self, mean=True):
         """After the last backward pass: exchange whatever has not gone out yet (parameters without a gradient this step,
-        the tail), wait, and turn gradient sums into means.  Returns the number of floats exchanged."""
+        the tail), wait, and turn gradient sums into means -- or, with mean=False, leave the rank SUMS for an optimizer
+        that scales them on the way in (ReplaySGD.grad_scale: no extra pass over the buffer).  Returns the number of
+        floats exchanged."""
         if not self.active:
             return 0
         if not self._armed:
@@ -257,8 +259,9 @@ class GradSync:
         for work in self._pending:
             work.wait()
         self._pending = []
-        ngrad = self.flat.numel() - self.tail_floats
-        self.flat[:ngrad] /= dist.get_world_size()
+        if mean:
+            ngrad = self.flat.numel() - self.tail_floats
+            self.flat[:ngrad] /= dist.get_world_size()
         return self.flat.numel()
 
     # ---- the round-1 entry point (gradients only, no overlap) --------------------------------------------------------

@@ -440,8 +440,9 @@ class online_proDA(da_model):
             nb = sum(b.numel() for b in bufs)
             if bufs:
                 torch.cat([b.reshape(-1) for b in bufs], out=tail[n1 + 16:n1 + 16 + nb])
-            sync.finish()
+            sync.finish(mean=False)  # the buffer holds rank sums: the optimizer divides on the way in
             world = odist.world_size()
+            self.optimizer.grad_scale = 1.0 / world
             stats = tail[:n1]
             packed = tail[n1:n1 + packed.numel()] / world
             if bufs:

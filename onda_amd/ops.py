@@ -1240,15 +1240,16 @@ def _table(entries, struct, device):
     return dev
 
 
-def sgd_multi(items, momentum, weight_decay):
-    """items: list of (param, grad, buf, lr, times, fresh).  One launch for all tensors."""
+def sgd_multi(items, momentum, weight_decay, grad_scale=1.0):
+    """items: list of (param, grad, buf, lr, times, fresh).  One launch for all tensors; every gradient element is
+    multiplied by `grad_scale` on the way in."""
     blk, ents, first = query("onda_multi_tensor_block"), [], 0
     for p, g, b, lr, times, fresh in items:
         ents.append(_lib.OndaSgdEntry(p.data_ptr(), g.data_ptr(), b.data_ptr(), p.numel(), float(lr), int(times), int(fresh), first))
         first += -(-p.numel() // blk)
     dev = items[0][0].device
     table = _table(ents, _lib.OndaSgdEntry, dev)
-    call("onda_sgd_multi", _p(table), len(ents), float(momentum), float(weight_decay), first, _stream())
+    call("onda_sgd_multi", _p(table), len(ents), float(momentum), float(weight_decay), float(grad_scale), first, _stream())
     for p, *_ in items:
         torch.autograd.graph.increment_version(p)
 

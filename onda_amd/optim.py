@@ -24,6 +24,7 @@ class ReplaySGD(torch.optim.Optimizer):
             super().__init__(params, dict(lr=lr, momentum=momentum, weight_decay=weight_decay))
 
     flat_zero = None  # set by the multi-GPU gradient exchange: gradients are views of one flat buffer, zeroed in place
+    grad_scale = 1.0  # the next step() multiplies the gradients by this (1 / world after an exchange that left rank SUMS)
 
     def zero_grad(self, set_to_none=True):
         if self.flat_zero is not None:
@@ -52,4 +53,5 @@ class ReplaySGD(torch.optim.Optimizer):
                 key = (group["momentum"], group["weight_decay"])
                 by_cfg.setdefault(key, []).append((p, g, st["momentum_buffer"], group["lr"], counts[id(p)], fresh))
         for (momentum, wd), items in by_cfg.items():
-            ops.sgd_multi(items, momentum, wd)
+            ops.sgd_multi(items, momentum, wd, self.grad_scale)
+        self.grad_scale = 1.0

@@ -653,6 +653,18 @@ def test_replay_sgd_golden(golden):
         assert w3._version > v
         for n, p in ps.items():
             close(p, torch.from_numpy(g[f"{n}_after{s}"]), 2e-6, f"{n} step {s}")
+    # grad_scale (rank sums left by the gradient exchange): sums x 1/world give the same trajectory, for one step() only
+    qs = {n: torch.nn.Parameter(torch.from_numpy(g[n + "_init"]).to(DEV)) for n in ("w3", "w4", "w1", "h1")}
+    opt2 = ReplaySGD([{"params": [qs[k] for k in ("w3", "w4", "w1", "w3", "w4", "w3", "w4", "w4")], "lr": 8e-4},
+                      {"params": [qs["h1"]], "lr": 1e-4}], lr=1e-5, momentum=0.9, weight_decay=1e-4)
+    for s in range(2):
+        for n, p in qs.items():
+            p.grad = torch.from_numpy(g[f"{n}_grad{s}"]).to(DEV) * 4.0
+        opt2.grad_scale = 0.25
+        opt2.step()
+        assert opt2.grad_scale == 1.0
+        for n, p in qs.items():
+            close(p, torch.from_numpy(g[f"{n}_after{s}"]), 2e-6, f"scaled {n} step {s}")
 
 
 def test_ema_multi():
