@@ -267,11 +267,18 @@ __device__ __forceinline__ void l2_epilogue(const ConvK& a, const f32x4 (&acc)[4
       if (plain) {
         if constexpr (COUNTED) {
 #if defined(__HIP_DEVICE_COMPILE__)
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), make_rsrc(a.y, y_bytes),
-                                                 vbase + (unsigned)((i * 16 + 4 * r) * c.ldy * 4), 0, 0);
+          // (aux bit 1 = nt: a streaming store -- the output is not read again by this kernel and must not push the operand
+          //  tiles out of the 4 MB L2 its XCD's workgroups share; measurement knob ONDA_L2_NT)
+          if (a.nt)
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), make_rsrc(a.y, y_bytes),
+                                                   vbase + (unsigned)((i * 16 + 4 * r) * c.ldy * 4), 0, 2);
+          else
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), make_rsrc(a.y, y_bytes),
+                                                   vbase + (unsigned)((i * 16 + 4 * r) * c.ldy * 4), 0, 0);
 #endif
         } else if (live) {
-          *reinterpret_cast<f32x4*>(ybase + (size_t)((i * 16 + 4 * r) * c.ldy)) = v;
+          f32x4* dst = reinterpret_cast<f32x4*>(ybase + (size_t)((i * 16 + 4 * r) * c.ldy));
+          if (a.nt) __builtin_nontemporal_store(v, dst); else *dst = v;
         }
       } else {  // scattered rows (stride-2 data gradient)
         const int mm = live ? m : 0;
@@ -1681,6 +1688,8 @@ static int l2_fwd_impl(const void* xl, int64_t xplane, const float* xamax, const
   }
   static const int noskip = getenv("ONDA_L2_NOSKIP") ? atoi(getenv("ONDA_L2_NOSKIP")) : 0;
   k.skip_dead_taps = !noskip;
+  static const int nt_stores = getenv("ONDA_L2_NT") ? atoi(getenv("ONDA_L2_NT")) : 0;
+  k.nt = nt_stores;
   static const int late_issue = getenv("ONDA_L2X_LATE") ? atoi(getenv("ONDA_L2X_LATE")) : 1;
   k.late_issue = late_issue;
   static const int stamp_on = getenv("ONDA_L2X_STAMP") ? atoi(getenv("ONDA_L2X_STAMP")) : 0;
