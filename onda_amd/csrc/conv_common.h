@@ -19,7 +19,6 @@ struct ConvK {
   float* amax = nullptr;  // optional: running max|y| of the stored output (amax_update, common.h)
   int skip_dead_taps = 1;  // whole tiles skip filter taps that only see padding (conv_l2.hip)
   int late_issue = 1;      // conv_l2x_kernel: second half of the waves issues its DMAs behind its MFMAs
-  int nt = 0;              // conv_l2*: dense fp32 output rows leave as non-temporal (streaming) stores
   // ---- limb-plane OUTPUT (eval-mode conv + folded BatchNorm whose result feeds other convs; conv_l2.hip) ----------------
   _Float16* yl = nullptr;           // out planes [2][M][ldy] f16 (dense rows); when set, `y` is not written
   long long yplane = 0;             // f16 elements between the two planes

@@ -28,6 +28,18 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr float LIMB2_SCALE = 2048.f, LIMB2_UNSCALE = 1.f / 2048.f;
+
+// Output tiles leave as NON-TEMPORAL (streaming) stores: a convolution never reads its output again, and every round of
+// tiles writes as many bytes as the 4 MB L2 of an XCD holds -- allocated normally they push the weight panel and the
+// activation rows the XCD's workgroups share out of it (measured on the short-K 1x1 convolutions: -7..8 % with `nt`).
+#ifndef ONDA_NT_OUT
+#define ONDA_NT_OUT 1
+#endif
+constexpr int NT_AUX = ONDA_NT_OUT ? 2 : 0;  // buffer instruction cache policy: bit 1 = nt
+template <class T>
+__device__ __forceinline__ void store_out(T* p, T v) {
+  if constexpr (ONDA_NT_OUT) __builtin_nontemporal_store(v, p); else *p = v;
+}
 constexpr unsigned OOB = 0x80000000u;  // every operand is < 2 GiB - 4 KiB (checked on the host)
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
@@ -267,18 +279,11 @@ __device__ __forceinline__ void l2_epilogue(const ConvK& a, const f32x4 (&acc)[4
       if (plain) {
         if constexpr (COUNTED) {
 #if defined(__HIP_DEVICE_COMPILE__)
-          // (aux bit 1 = nt: a streaming store -- the output is not read again by this kernel and must not push the operand
-          //  tiles out of the 4 MB L2 its XCD's workgroups share; measurement knob ONDA_L2_NT)
-          if (a.nt)
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), make_rsrc(a.y, y_bytes),
-                                                   vbase + (unsigned)((i * 16 + 4 * r) * c.ldy * 4), 0, 2);
-          else
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), make_rsrc(a.y, y_bytes),
-                                                   vbase + (unsigned)((i * 16 + 4 * r) * c.ldy * 4), 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), make_rsrc(a.y, y_bytes),
+                                                 vbase + (unsigned)((i * 16 + 4 * r) * c.ldy * 4), 0, NT_AUX);
 #endif
         } else if (live) {
-          f32x4* dst = reinterpret_cast<f32x4*>(ybase + (size_t)((i * 16 + 4 * r) * c.ldy));
-          if (a.nt) __builtin_nontemporal_store(v, dst); else *dst = v;
+          store_out(reinterpret_cast<f32x4*>(ybase + (size_t)((i * 16 + 4 * r) * c.ldy)), v);
         }
       } else {  // scattered rows (stride-2 data gradient)
         const int mm = live ? m : 0;
@@ -288,10 +293,10 @@ __device__ __forceinline__ void l2_epilogue(const ConvK& a, const f32x4 (&acc)[4
         if constexpr (COUNTED) {
 #if defined(__HIP_DEVICE_COMPILE__)
           const unsigned off = live ? (unsigned)((orow * c.ldy + n) * 4) : OOB;
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), make_rsrc(a.y, y_bytes), off, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), make_rsrc(a.y, y_bytes), off, 0, NT_AUX);
 #endif
         } else if (live) {
-          *reinterpret_cast<f32x4*>(a.y + orow * c.ldy + n) = v;
+          store_out(reinterpret_cast<f32x4*>(a.y + orow * c.ldy + n), v);
         }
       }
       if (track && live) mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
@@ -436,13 +441,13 @@ __device__ __forceinline__ void l2_epilogue_limbs(const ConvK& a, const f32x4 (&
       if constexpr (COUNTED) {
 #if defined(__HIP_DEVICE_COMPILE__)
         const unsigned off = vn ? (unsigned)(((size_t)m * c.ldy + n) * 2) : OOB;  // rows past M: past the plane's end
-        __builtin_amdgcn_raw_buffer_store_b64(l1, make_rsrc(a.yl, (unsigned)plane_bytes), off, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b64(l2, make_rsrc(a.yl + a.yplane, (unsigned)plane_bytes), off, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(l1, make_rsrc(a.yl, (unsigned)plane_bytes), off, 0, NT_AUX);
+        __builtin_amdgcn_raw_buffer_store_b64(l2, make_rsrc(a.yl + a.yplane, (unsigned)plane_bytes), off, 0, NT_AUX);
 #endif
       } else if (live) {
         _Float16* dst = a.yl + (size_t)m * c.ldy + n;
-        *reinterpret_cast<u32x2*>(dst) = l1;
-        *reinterpret_cast<u32x2*>(dst + a.yplane) = l2;
+        store_out(reinterpret_cast<u32x2*>(dst), l1);
+        store_out(reinterpret_cast<u32x2*>(dst + a.yplane), l2);
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -1688,8 +1693,6 @@ static int l2_fwd_impl(const void* xl, int64_t xplane, const float* xamax, const
   }
   static const int noskip = getenv("ONDA_L2_NOSKIP") ? atoi(getenv("ONDA_L2_NOSKIP")) : 0;
   k.skip_dead_taps = !noskip;
-  static const int nt_stores = getenv("ONDA_L2_NT") ? atoi(getenv("ONDA_L2_NT")) : 0;
-  k.nt = nt_stores;
   static const int late_issue = getenv("ONDA_L2X_LATE") ? atoi(getenv("ONDA_L2X_LATE")) : 1;
   k.late_issue = late_issue;
   static const int stamp_on = getenv("ONDA_L2X_STAMP") ? atoi(getenv("ONDA_L2X_STAMP")) : 0;

@@ -71,6 +71,22 @@ __device__ __forceinline__ void join8(const u32x4 l1, const u32x4 l2, f32x4& v0,
 
 #define LD4(p) (*reinterpret_cast<const f32x4*>(p))
 
+// The big tensors of these passes are touched once per launch (8-20 bytes per element streamed through): with
+// ONDA_NT_BN their loads and stores carry the non-temporal hint, so that they do not cycle through the L2.
+// (A measurement switch: see DESIGN.md for what it measured.)
+#ifndef ONDA_NT_BN
+#define ONDA_NT_BN 0
+#endif
+template <class T>
+__device__ __forceinline__ T ld_stream(const T* p) {
+  if constexpr (ONDA_NT_BN) return __builtin_nontemporal_load(p); else return *p;
+}
+template <class T>
+__device__ __forceinline__ void st_stream(T* p, T v) {
+  if constexpr (ONDA_NT_BN) __builtin_nontemporal_store(v, p); else *p = v;
+}
+#define LD4S(p) ld_stream(reinterpret_cast<const f32x4*>(p))
+
 // Column reduction of small partial tables [rows][NV][C] (conv tile statistics, the backward reduction's chunks), 16
 // channels per 256-thread workgroup: thread t reads the 16-byte channel quad (t & 3) of the rows t >> 2, t >> 2 + 64, ...
 // (64-byte segments instead of the 4-byte, row-strided reads of a wave per channel: 16 times fewer cache-line requests
@@ -227,20 +243,20 @@ __global__ __launch_bounds__(256) void bn_apply_l2_kernel(const float* __restric
     }
     u32x4 l1, l2;
     split8(v0 * so, v1 * so, l1, l2);
-    *reinterpret_cast<u32x4*>(out + e * 8) = l1;
-    *reinterpret_cast<u32x4*>(out + out_plane + e * 8) = l2;
+    st_stream(reinterpret_cast<u32x4*>(out + e * 8), l1);
+    st_stream(reinterpret_cast<u32x4*>(out + out_plane + e * 8), l2);
   };
   size_t e = e0;
   // two independent items per iteration: all loads of both are issued before the first is used
   for (; e + stride < total8; e += 2 * stride) {
     const size_t f = e + stride;
-    const f32x4 a0 = LD4(x + e * 8), a1 = LD4(x + e * 8 + 4), b0 = LD4(x + f * 8), b1 = LD4(x + f * 8 + 4);
+    const f32x4 a0 = LD4S(x + e * 8), a1 = LD4S(x + e * 8 + 4), b0 = LD4S(x + f * 8), b1 = LD4S(x + f * 8 + 4);
     u32x4 ra1 = {}, ra2 = {}, rb1 = {}, rb2 = {};
     if (res) {
-      ra1 = *reinterpret_cast<const u32x4*>(res + e * 8);
-      ra2 = *reinterpret_cast<const u32x4*>(res + res_plane + e * 8);
-      rb1 = *reinterpret_cast<const u32x4*>(res + f * 8);
-      rb2 = *reinterpret_cast<const u32x4*>(res + res_plane + f * 8);
+      ra1 = ld_stream(reinterpret_cast<const u32x4*>(res + e * 8));
+      ra2 = ld_stream(reinterpret_cast<const u32x4*>(res + res_plane + e * 8));
+      rb1 = ld_stream(reinterpret_cast<const u32x4*>(res + f * 8));
+      rb2 = ld_stream(reinterpret_cast<const u32x4*>(res + res_plane + f * 8));
     }
     one(e, a0, a1, ra1, ra2);
     one(f, b0, b1, rb1, rb2);
@@ -394,15 +410,15 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_l2_kernel(const float* __res
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const size_t o = e * 8 + 4 * h;
-      f32x4 g = LD4(dout + o);
+      f32x4 g = LD4S(dout + o);
       if (relu) g = relu_mask4(out, mask, o, g);
-      const f32x4 xh = (LD4(x + o) - mu[h]) * is[h];
+      const f32x4 xh = (LD4S(x + o) - mu[h]) * is[h];
       v[h] = gi[h] * (g - m1[h] - xh * m2[h]);
     }
     u32x4 l1, l2;
     split8(v[0] * sd, v[1] * sd, l1, l2);
-    *reinterpret_cast<u32x4*>(dx + e * 8) = l1;
-    *reinterpret_cast<u32x4*>(dx + dx_plane + e * 8) = l2;
+    st_stream(reinterpret_cast<u32x4*>(dx + e * 8), l1);
+    st_stream(reinterpret_cast<u32x4*>(dx + dx_plane + e * 8), l2);
   }
 }
 
