@@ -423,7 +423,7 @@ def run_segmentation(args, device, rank, world):
     tf = args.batch * (gf[0] + gf[1]) / 1e3 if gf else None
     cfg_out = {"workload": f"segmentation.train step (fwd -> bilinear upsample -> CE -> bwd -> SGD), {args.width}x{args.height}, "
                            f"bs={args.batch} per GPU, DeepLabV2-ResNet50 ProDA head, random-init weights",
-               "baseline_config": 2, "global_batch": world * args.batch, "parallelism": f"dp{world} (replicas: no exchange)",
+               "baseline_config": 2, "global_batch": world * args.batch, "parallelism": f"dp{world}",
                "conv_tflop_per_step_per_gpu": tf, "final_loss": round(float(loss), 5)}
     if tf:
         cfg_out["step_conv_tflops_per_gpu"] = round(tf / (dt / args.steps), 2)

@@ -14,6 +14,7 @@ import os
 import numpy as np
 import torch
 
+from onda_amd import dist as odist
 from onda_amd import logging as olog
 from onda_amd import ops
 from onda_amd.config import unset
@@ -33,6 +34,17 @@ class SegmentationTrainer:
         self.optimizer = ReplaySGD(model.optim_parameters(self.base_lr), lr=self.base_lr, momentum=cfg_spec.MOMENTUM,
                                    weight_decay=cfg_spec.WEIGHT_DECAY)
         self.steps_done = 0
+        # several ranks: batch-sharded data parallel -- the same flat-buffer gradient exchange as the adaptation step
+        # (buckets leave while the backward pass is still running; BatchNorm batch statistics stay rank-local)
+        previous = model.__dict__.get("_onda_grad_sync")
+        if previous is not None:
+            previous.close()
+        skip = (lambda name: name.startswith("layer5.")) if not getattr(model, "multi_level", True) else None
+        self._grad_sync = odist.GradSync(model, skip=skip)
+        model.__dict__["_onda_grad_sync"] = self._grad_sync
+        if self._grad_sync.active:
+            ops.GRAD_READY = self._grad_sync.grad_ready
+            self.optimizer.flat_zero = self._grad_sync.zero
 
     def loss(self, batch):
         """loss_calc(interp(prediction), label) (+ 0.1 x the auxiliary head's when multi_level), segmentation.py:70-80."""
@@ -58,7 +70,11 @@ class SegmentationTrainer:
         """One training step (segmentation.py:66-88); returns the loss as a device scalar."""
         self.optimizer.zero_grad()
         loss = self.loss(batch)
+        self._grad_sync.arm()
         loss.backward()
+        if self._grad_sync.active:
+            self._grad_sync.finish(mean=False)  # rank sums; the optimizer divides on the way in
+            self.optimizer.grad_scale = 1.0 / odist.world_size()
         self.optimizer.step()
         if total_steps:
             self.adjust_learning_rate(total_steps)

@@ -119,3 +119,9 @@ def test_bench_launches_its_own_ranks():
     line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["config"]["parallelism"] == "dp2" and line["config"]["global_batch"] == 4
     assert line["value"] > 0 and np.isfinite(line["config"]["final_loss"])
+    # BASELINE config 2 (supervised step) shards the same way: SegmentationTrainer runs the same gradient exchange
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--config", "2"] + small, env=env,
+                         capture_output=True, text=True, timeout=420)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["parallelism"] == "dp2" and np.isfinite(line["config"]["final_loss"])
