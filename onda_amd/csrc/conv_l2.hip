@@ -649,11 +649,26 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_l2_kernel(const ConvK 
     };
     // fragments: A limbs stay in registers; B limbs stream 2 -> 1 (smaller products first): a1*b2, a2*b1, a1*b1
     f16x8 af[4][2], bf[4], b1[4];
+    if constexpr (DBG == 8) {  // (ablation: some value in every fragment register)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        af[i][0] = af[i][1] = f16x8{(_Float16)1.f, (_Float16)0.5f, (_Float16)lane, 0, 0, 0, 0, 0};
+        bf[i] = b1[i] = f16x8{(_Float16)0.25f, (_Float16)2.f, (_Float16)lane, 0, 0, 0, 0, 0};
+      }
+    }
     const unsigned char *Ab, *Bb;
     auto prepare = [&]() {  // "P": first fragments of the stage at st_read (ALL of them when the halves are staggered)
       Ab = lds + st_read + wm * 64 * 64 + frag;
       Bb = lds + st_read + A_BYTES + wn * 64 * 64 + frag;
       st_read = st_read + STAGE == STAGES * STAGE ? 0 : st_read + STAGE;
+      if constexpr (DBG == 8) return;  // ablation: no fragment reads at all (the MFMAs run on whatever the registers hold)
+      if constexpr (DBG == 7) {        // ablation: half of the fragment reads (first limbs only, used for every product)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[i][1] = af[i][0] = *reinterpret_cast<const f16x8*>(Ab + i * 1024);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b1[j] = bf[j] = *reinterpret_cast<const f16x8*>(Bb + j * 1024);
+        return;
+      }
 #pragma unroll
       for (int l = 0; l < 2; ++l)
 #pragma unroll
@@ -670,7 +685,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_l2_kernel(const ConvK 
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) accx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][0], bf[j], accx[i][j], 0, 0, 0);
-      if constexpr (!STAGGER) {
+      if constexpr (!STAGGER && DBG != 7 && DBG != 8) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) b1[j] = *reinterpret_cast<const f16x8*>(Bb + j * 1024);
       }
@@ -1744,6 +1759,28 @@ static int l2_fwd_impl(const void* xl, int64_t xplane, const float* xamax, const
       hipLaunchKernelGGL((conv_l2_fixup_kernel<256, 128>), dim3(q.rem_rows() * q.tilesN, q.sub), dim3(256), 0, st, k, q.G, q.tilesM);
     return ONDA_LAUNCH_RESULT();
   }
+#ifdef ONDA_L2_ABLATIONS  // measurement builds only (tools/README.md): ONDA_L2_DBG = 1 no vmcnt waits, 2 no DMA in the K loop,
+  {                       // 7 half of the LDS fragment reads, 8 none -- wrong results, valid timings
+    static const int dbg = getenv("ONDA_L2_DBG") ? atoi(getenv("ONDA_L2_DBG")) : 0;
+#define L2_DBG_LAUNCH(D_)                                                                                                      \
+  do {                                                                                                                         \
+    if (q.balanced) {                                                                                                          \
+      hipLaunchKernelGGL((conv_l2_kernel<4, 2, 3, 2, true, D_>), dim3(q.G), dim3(512), 0, st, k, xpl, wpl, x_bytes, w_bytes, xamax, \
+                         wamax);                                                                                               \
+      hipLaunchKernelGGL((conv_l2_fixup_kernel<256, 128>), dim3(q.rem_rows() * q.tilesN, q.sub), dim3(256), 0, st, k, q.G, q.tilesM); \
+    } else {                                                                                                                   \
+      hipLaunchKernelGGL((conv_l2_kernel<4, 2, 3, 2, false, D_>), dim3(tiles), dim3(512), 0, st, k, xpl, wpl, x_bytes, w_bytes, xamax, \
+                         wamax);                                                                                               \
+    }                                                                                                                          \
+    return ONDA_LAUNCH_RESULT();                                                                                               \
+  } while (0)
+    if (q.variant == 0 && dbg == 1) L2_DBG_LAUNCH(1);
+    if (q.variant == 0 && dbg == 2) L2_DBG_LAUNCH(2);
+    if (q.variant == 0 && dbg == 7) L2_DBG_LAUNCH(7);
+    if (q.variant == 0 && dbg == 8) L2_DBG_LAUNCH(8);
+#undef L2_DBG_LAUNCH
+  }
+#endif
   if (q.variant == 0) L2_LAUNCH(4, 2, 3, 2);
   else if (q.variant == 1 && l2_small_ring2()) L2_LAUNCH(2, 2, 2, 2);
   else if (q.variant == 1) L2_LAUNCH(2, 2, 3, 1);

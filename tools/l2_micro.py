@@ -13,6 +13,8 @@ SHAPES = [  # (B,H,W,Cin,Cout,k,dil)
     (4, 65, 129, 128, 512, 1, 1), (4, 65, 129, 512, 128, 1, 1), (4, 129, 257, 64, 256, 1, 1), (4, 129, 257, 256, 64, 1, 1),
     (4, 65, 129, 128, 128, 3, 1), (4, 129, 257, 64, 64, 3, 1), (4, 129, 257, 64, 64, 1, 1), (4, 256, 512, 160, 64, 1, 1),
 ]
+if os.environ.get("LONGK"):  # the long K loops (conv_l2_kernel<4,2>): layer3 / layer4 3x3 and an ASPP branch
+    SHAPES = [(4, 65, 129, 256, 256, 3, 2), (4, 65, 129, 512, 512, 3, 4), (4, 65, 129, 2048, 256, 3, 12), (4, 65, 129, 2048, 512, 1, 1)]
 if os.environ.get("QUICK6"):
     SHAPES = SHAPES[:6]
 if os.environ.get("SMALL"):
