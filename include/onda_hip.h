@@ -375,6 +375,8 @@ int onda_resize_nearest_lut(const unsigned char* in, unsigned char* out, int Win
 
 /* library identity, for the loader's sanity check */
 const char* onda_version(void);
+/* factor the second limb of every limb plane is stored with (2048 = 2^11; 1 in measurement builds, csrc/common.h) */
+float onda_limb2_scale(void);
 
 /* ---- the hybrid switch on the device (csrc/switch.hip) ---------------------------------------------------------------
  * One monitored series + the two-state machine that reads it, advanced by ONE small launch per adaptation step:

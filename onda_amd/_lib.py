@@ -119,6 +119,7 @@ SIGNATURES = {
     "onda_resample_v_norm": (I, [P, P, I, I, I, P, P, I, POINTER(c_float), POINTER(c_float), I, P]),
     "onda_resize_nearest_lut": (I, [P, P, I, I, I, P, P, P, P]),
     "onda_version": (c_char_p, []),
+    "onda_limb2_scale": (F, []),
 }
 
 _lib = None

@@ -5,6 +5,12 @@
 
 #include "onda_hip.h"
 
+// "f16x2" limb planes: the second limb is stored times LIMB2_SCALE (2^11) so that it keeps 11 bits down to 2^-28 of a tensor's
+// maximum; the cross products then carry that factor and live in accumulators of their own.  A measurement build with
+// -DONDA_LIMB2_SCALE=1.f stores it un-scaled (what a single-accumulator kernel would need; DESIGN.md section 7, "Next (0)").
+#ifndef ONDA_LIMB2_SCALE
+#define ONDA_LIMB2_SCALE 2048.f
+#endif
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 

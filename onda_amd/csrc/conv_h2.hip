@@ -47,7 +47,7 @@ __device__ __forceinline__ f32x2 unpack2h(unsigned p) {
 // h2 * 2^11 lives in the first limb's own exponent range instead of sliding into f16 subnormals for small
 // elements.  The cross products a1*b2' + a2'*b1 go to a second accumulator set that is folded in with 2^-11
 // at the end (exact scaling): full two-limb precision for every element down to 2^-28 of the tensor maximum.
-constexpr float LIMB2_SCALE = 2048.f, LIMB2_UNSCALE = 1.f / 2048.f;
+constexpr float LIMB2_SCALE = ONDA_LIMB2_SCALE, LIMB2_UNSCALE = 1.f / ONDA_LIMB2_SCALE;  // common.h
 
 // float4 (already scaled) -> two limbs, each 4 f16 packed in 8 bytes
 __device__ __forceinline__ void split2(const f32x4 v, u32x2& l1, u32x2& l2) {

@@ -27,7 +27,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr float LIMB2_SCALE = 2048.f, LIMB2_UNSCALE = 1.f / 2048.f;
+constexpr float LIMB2_SCALE = ONDA_LIMB2_SCALE, LIMB2_UNSCALE = 1.f / ONDA_LIMB2_SCALE;  // common.h
 
 // Output tiles leave as NON-TEMPORAL (streaming) stores: a convolution never reads its output again, and every round of
 // tiles writes as many bytes as the 4 MB L2 of an XCD holds -- allocated normally they push the weight panel and the

@@ -793,6 +793,8 @@ int onda_ema_multi(const OndaEmaEntry* table, int n, int64_t max_n, onda_stream_
 #ifndef ONDA_SRC_HASH
 #define ONDA_SRC_HASH "unknown"
 #endif
+float onda_limb2_scale(void) { return ONDA_LIMB2_SCALE; }
+
 const char* onda_version(void) { return "onda_hip 0.2 (gfx950) src=" ONDA_SRC_HASH; }
 
 }  // extern "C"

@@ -273,7 +273,7 @@ def materialize(x):
     planes = lb.planes.reshape(2, B * H * W, lb.ld)[:, :, :C].float()
     amax = lb.amax.max()
     e = torch.where((amax > 0) & (amax < 3e38), 15 - torch.frexp(amax)[1], torch.zeros((), dtype=torch.int32, device=x.device))
-    return ((planes[0] + planes[1] / 2048.0) * torch.ldexp(torch.ones((), device=x.device), -e)).reshape(B, H, W, C)
+    return ((planes[0] + planes[1] / query("onda_limb2_scale")) * torch.ldexp(torch.ones((), device=x.device), -e)).reshape(B, H, W, C)
 
 
 def _use_l2(wp, cin):
