@@ -92,12 +92,12 @@ class hybrid_proDA(online_proDA):
         self.model_select = model_select(model_select.static, cfg_spec.GRAY_AREA, cfg_spec.DEV_THRESH)
         super().__init__(model, cfg, cfg_spec)
         self._dsw = None
-        if DEVICE_SWITCH and torch.device(self.device).type == "cuda" and cfg_spec.STATIC_LAMBDA > 0:
+        if DEVICE_SWITCH and torch.device(self.device).type == "cuda" and cfg_spec.STATIC_LAMBDA > 0 and self.intensity_ma.limit:
             spec = cfg_spec
             smoothed = not unset(spec.EXP_PR_STATIC) and bool(spec.EXP_PR_STATIC)
-            self._dsw = DeviceSwitch(self.device, spec.AVG_MONITOR_SIZE,
-                                     self.intensity_ma.exp_const, "hamming" if unset(spec.DEV_MONITOR_FUNC) else spec.DEV_MONITOR_FUNC,
-                                     spec.GRAY_AREA, spec.DEV_THRESH, model_select.static, smoothed)
+            monitor = self.intensity_ma  # the device series takes the host monitor's own settings (window, constant, trend)
+            self._dsw = DeviceSwitch(self.device, monitor.limit, monitor.exp_const, monitor.dev_func, spec.GRAY_AREA,
+                                     spec.DEV_THRESH, model_select.static, smoothed)
             self.model_select.device_switch = self._dsw
             self.intensity_ma.gated.add("prior dynamic")
 

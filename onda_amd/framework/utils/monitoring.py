@@ -56,6 +56,7 @@ class Monitor(object):
     def __init__(self, limit=None, exp_const=0.01, dev_func="hamming"):
         self.limit = limit
         self.exp_const = exp_const
+        self.dev_func = dev_func
         self.freeze = False
         self._series = {}
         self._level = _level_function(dev_func, limit - 1)
