@@ -78,12 +78,12 @@ __device__ __forceinline__ void join8(const u32x4 l1, const u32x4 l2, f32x4& v0,
 #define ONDA_NT_BN 0
 #endif
 template <class T>
-__device__ __forceinline__ T ld_stream(const T* p) {
-  if constexpr (ONDA_NT_BN) return __builtin_nontemporal_load(p); else return *p;
+__device__ __forceinline__ T ld_stream(const T* p) {  // (bit 0: loads)
+  if constexpr (ONDA_NT_BN & 1) return __builtin_nontemporal_load(p); else return *p;
 }
 template <class T>
-__device__ __forceinline__ void st_stream(T* p, T v) {
-  if constexpr (ONDA_NT_BN) __builtin_nontemporal_store(v, p); else *p = v;
+__device__ __forceinline__ void st_stream(T* p, T v) {  // (bit 1: stores)
+  if constexpr (ONDA_NT_BN & 2) __builtin_nontemporal_store(v, p); else *p = v;
 }
 #define LD4S(p) ld_stream(reinterpret_cast<const f32x4*>(p))
 
@@ -424,7 +424,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_l2_kernel(const float* __res
 
 static inline unsigned ew_grid(size_t total) {
   size_t g = (total + 255) / 256;
-  if (g > 8192) g = 8192;
+#ifndef ONDA_EW_GRID_CAP
+#define ONDA_EW_GRID_CAP 8192
+#endif
+  if (g > ONDA_EW_GRID_CAP) g = ONDA_EW_GRID_CAP;
   if (g < 1) g = 1;
   return (unsigned)g;
 }
