@@ -425,7 +425,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_l2_kernel(const float* __res
 static inline unsigned ew_grid(size_t total) {
   size_t g = (total + 255) / 256;
 #ifndef ONDA_EW_GRID_CAP
-#define ONDA_EW_GRID_CAP 8192
+#define ONDA_EW_GRID_CAP 4096  // (8192: +0.2..0.7 ms per step on two boxes, 16384: +0.6; 1024..3072: within the noise of 4096)
 #endif
   if (g > ONDA_EW_GRID_CAP) g = ONDA_EW_GRID_CAP;
   if (g < 1) g = 1;
