@@ -8,7 +8,7 @@ base class's.
 On the GPU the switch itself lives on the device (``framework.utils.monitoring.DeviceSwitch`` = csrc/switch.hip: the
 "prior static" series, its median / trend and the two-state machine advanced by one small launch per step).  The
 dynamic model's forward pass is then launched EVERY step with the machine's state as the predicate of its convolutions
-(they return at once while the switch is static: ~0.3 ms of empty launches instead of a 7 ms pass), the prior is picked
+(they return at once while the switch is static: ~1 ms of empty launches instead of a 7 ms pass), the prior is picked
 by a select kernel, and nothing the step needs ever visits the host: no blocking read-back inside a step, and with
 several ranks no host between the switch scalars' all-reduce and the decision.  The host-side ``Monitor`` keeps
 receiving every sample (asynchronously) and only feeds the log; ``model_select.current`` reads the device state when
