@@ -727,14 +727,8 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_l2_kernel(const ConvK 
       for (int kt = 0; kt < nsteps; ++kt) {
         if (!late) wait_landed(kt + 1 < nsteps);
         __builtin_amdgcn_s_barrier();
-#if defined(ONDA_L2_READS_FIRST)  // measurement: fragment reads (LDS pipe) issued in front of the DMAs (texture-address pipe)
-        prepare();
-        __builtin_amdgcn_sched_barrier(0);
-        if (DBG != 2 && kt + 2 < nsteps) issue_next();
-#else
         if (DBG != 2 && kt + 2 < nsteps) issue_next();
         prepare();
-#endif
         if (late && kt + 1 < nsteps) wait_landed(kt + 2 < nsteps);
         __builtin_amdgcn_s_barrier();
         compute();
