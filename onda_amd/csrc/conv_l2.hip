@@ -593,7 +593,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_l2_kernel(const ConvK 
       const int sa = c0_i * 2;
       const int sb = (tap_i * c.Cin + c0_i) * 2;
 #pragma unroll
-      for (int l = 0; l < 2; ++l) {
+      for (int l = 0; l < (DBG == 9 ? 1 : 2); ++l) {  // (DBG 9, ablation: the first limb planes only = half of the DMA instructions)
 #pragma unroll
         for (int d = 0; d < APW; ++d) {
           unsigned char* dst = lds + stage_off + l * PLANE_A + (wave * APW + d) * 1024;
@@ -649,7 +649,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_l2_kernel(const ConvK 
     };
     // fragments: A limbs stay in registers; B limbs stream 2 -> 1 (smaller products first): a1*b2, a2*b1, a1*b1
     f16x8 af[4][2], bf[4], b1[4];
-    if constexpr (DBG == 8) {  // (ablation: some value in every fragment register)
+    if constexpr (DBG == 8 || DBG >= 10) {  // (ablation: some value in every fragment register)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         af[i][0] = af[i][1] = f16x8{(_Float16)1.f, (_Float16)0.5f, (_Float16)lane, 0, 0, 0, 0, 0};
@@ -661,7 +661,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_l2_kernel(const ConvK 
       Ab = lds + st_read + wm * 64 * 64 + frag;
       Bb = lds + st_read + A_BYTES + wn * 64 * 64 + frag;
       st_read = st_read + STAGE == STAGES * STAGE ? 0 : st_read + STAGE;
-      if constexpr (DBG == 8) return;  // ablation: no fragment reads at all (the MFMAs run on whatever the registers hold)
+      if constexpr (DBG == 8 || DBG >= 10) return;  // ablation: no fragment reads at all (the MFMAs run on whatever the registers hold)
       if constexpr (DBG == 7) {        // ablation: half of the fragment reads (first limbs only, used for every product)
 #pragma unroll
         for (int i = 0; i < 4; ++i) af[i][1] = af[i][0] = *reinterpret_cast<const f16x8*>(Ab + i * 1024);
@@ -685,7 +685,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_l2_kernel(const ConvK 
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) accx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][0], bf[j], accx[i][j], 0, 0, 0);
-      if constexpr (!STAGGER && DBG != 7 && DBG != 8) {
+      if constexpr (!STAGGER && DBG != 7 && DBG != 8 && DBG < 10) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) b1[j] = *reinterpret_cast<const f16x8*>(Bb + j * 1024);
       }
@@ -726,11 +726,11 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_l2_kernel(const ConvK 
       }
       for (int kt = 0; kt < nsteps; ++kt) {
         if (!late) wait_landed(kt + 1 < nsteps);
-        __builtin_amdgcn_s_barrier();
-        if (DBG != 2 && kt + 2 < nsteps) issue_next();
+        if (DBG != 11) __builtin_amdgcn_s_barrier();  // (DBG 10: neither DMA nor fragment reads; 11: nor the slot barriers)
+        if (DBG != 2 && DBG < 10 && kt + 2 < nsteps) issue_next();
         prepare();
         if (late && kt + 1 < nsteps) wait_landed(kt + 2 < nsteps);
-        __builtin_amdgcn_s_barrier();
+        if (DBG != 11) __builtin_amdgcn_s_barrier();
         compute();
       }
       if (!late) __builtin_amdgcn_s_barrier();
@@ -1760,7 +1760,7 @@ static int l2_fwd_impl(const void* xl, int64_t xplane, const float* xamax, const
     return ONDA_LAUNCH_RESULT();
   }
 #ifdef ONDA_L2_ABLATIONS  // measurement builds only (tools/README.md): ONDA_L2_DBG = 1 no vmcnt waits, 2 no DMA in the K loop,
-  {                       // 7 half of the LDS fragment reads, 8 none -- wrong results, valid timings
+  {                       // 7 half of the LDS fragment reads, 8 none, 9 half of the DMA instructions, 10 neither DMA nor reads, 11 nor barriers -- wrong results, valid timings
     static const int dbg = getenv("ONDA_L2_DBG") ? atoi(getenv("ONDA_L2_DBG")) : 0;
 #define L2_DBG_LAUNCH(D_)                                                                                                      \
   do {                                                                                                                         \
@@ -1778,6 +1778,9 @@ static int l2_fwd_impl(const void* xl, int64_t xplane, const float* xamax, const
     if (q.variant == 0 && dbg == 2) L2_DBG_LAUNCH(2);
     if (q.variant == 0 && dbg == 7) L2_DBG_LAUNCH(7);
     if (q.variant == 0 && dbg == 8) L2_DBG_LAUNCH(8);
+    if (q.variant == 0 && dbg == 9) L2_DBG_LAUNCH(9);
+    if (q.variant == 0 && dbg == 10) L2_DBG_LAUNCH(10);
+    if (q.variant == 0 && dbg == 11) L2_DBG_LAUNCH(11);
 #undef L2_DBG_LAUNCH
   }
 #endif
