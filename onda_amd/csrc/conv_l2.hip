@@ -725,13 +725,25 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_l2_kernel(const ConvK 
         __builtin_amdgcn_s_barrier();
       }
       for (int kt = 0; kt < nsteps; ++kt) {
+        // (DBG 12, measurement: s_memtime of one K-step in the middle of the loop, lane 0 of the first wave of each half)
+        const bool stamp_now = DBG == 12 && kt == nsteps / 2 && lane == 0 && (wave == 0 || wave == NW / 2) && dp && dp_tile == swz;
+        unsigned long long* sp = reinterpret_cast<unsigned long long*>(a.ws) + ((size_t)bid * 2 + (late ? 1 : 0)) * 8;
+        if (stamp_now) sp[0] = __builtin_amdgcn_s_memtime();
         if (!late) wait_landed(kt + 1 < nsteps);
+        if (stamp_now) sp[1] = __builtin_amdgcn_s_memtime();
         if (DBG != 11) __builtin_amdgcn_s_barrier();  // (DBG 10: neither DMA nor fragment reads; 11: nor the slot barriers)
+        if (stamp_now) sp[2] = __builtin_amdgcn_s_memtime();
         if (DBG != 2 && DBG < 10 && kt + 2 < nsteps) issue_next();
+        if (stamp_now) sp[3] = __builtin_amdgcn_s_memtime();
         prepare();
+        if (DBG == 12) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (stamp_now) sp[4] = __builtin_amdgcn_s_memtime();
         if (late && kt + 1 < nsteps) wait_landed(kt + 2 < nsteps);
+        if (stamp_now) sp[5] = __builtin_amdgcn_s_memtime();
         if (DBG != 11) __builtin_amdgcn_s_barrier();
+        if (stamp_now) sp[6] = __builtin_amdgcn_s_memtime();
         compute();
+        if (stamp_now) sp[7] = __builtin_amdgcn_s_memtime();
       }
       if (!late) __builtin_amdgcn_s_barrier();
     }
@@ -1760,7 +1772,8 @@ static int l2_fwd_impl(const void* xl, int64_t xplane, const float* xamax, const
     return ONDA_LAUNCH_RESULT();
   }
 #ifdef ONDA_L2_ABLATIONS  // measurement builds only (tools/README.md): ONDA_L2_DBG = 1 no vmcnt waits, 2 no DMA in the K loop,
-  {                       // 7 half of the LDS fragment reads, 8 none, 9 half of the DMA instructions, 10 neither DMA nor reads, 11 nor barriers -- wrong results, valid timings
+  {                       // 7 half of the LDS fragment reads, 8 none, 9 half of the DMA instructions, 10 neither DMA nor reads, 11 nor barriers -- wrong results, valid timings; 12 = stamps of one K-step's slots into the workspace
+                          // (tools/l2_slot_stamps.py)
     static const int dbg = getenv("ONDA_L2_DBG") ? atoi(getenv("ONDA_L2_DBG")) : 0;
 #define L2_DBG_LAUNCH(D_)                                                                                                      \
   do {                                                                                                                         \
@@ -1781,6 +1794,7 @@ static int l2_fwd_impl(const void* xl, int64_t xplane, const float* xamax, const
     if (q.variant == 0 && dbg == 9) L2_DBG_LAUNCH(9);
     if (q.variant == 0 && dbg == 10) L2_DBG_LAUNCH(10);
     if (q.variant == 0 && dbg == 11) L2_DBG_LAUNCH(11);
+    if (q.variant == 0 && dbg == 12) L2_DBG_LAUNCH(12);
 #undef L2_DBG_LAUNCH
   }
 #endif
