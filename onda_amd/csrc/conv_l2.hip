@@ -726,8 +726,8 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_l2_kernel(const ConvK 
       }
       for (int kt = 0; kt < nsteps; ++kt) {
         // (DBG 12, measurement: s_memtime of one K-step in the middle of the loop, lane 0 of the first wave of each half)
-        const bool stamp_now = DBG == 12 && kt == nsteps / 2 && lane == 0 && (wave == 0 || wave == NW / 2) && dp && dp_tile == swz;
-        unsigned long long* sp = reinterpret_cast<unsigned long long*>(a.ws) + ((size_t)bid * 2 + (late ? 1 : 0)) * 8;
+        const bool stamp_now = DBG == 12 && a.stamps != nullptr && kt == nsteps / 2 && lane == 0 && (wave == 0 || wave == NW / 2) && dp && dp_tile == swz;
+        unsigned long long* sp = a.stamps + ((size_t)bid * 2 + (late ? 1 : 0)) * 8;  // (ONDA_L2X_STAMP=1: the tail of the workspace)
         if (stamp_now) sp[0] = __builtin_amdgcn_s_memtime();
         if (!late) wait_landed(kt + 1 < nsteps);
         if (stamp_now) sp[1] = __builtin_amdgcn_s_memtime();

@@ -5,6 +5,7 @@ of the first wave of each half of every workgroup, at the K-step in the middle o
   second barrier  [7] after the 48 MFMAs have been ISSUED.
 usage: ONDA_LIB_PATH=<ablation lib> ONDA_L2_DBG=12 python tools/l2_slot_stamps.py"""
 import os, sys
+os.environ["ONDA_L2X_STAMP"] = "1"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
@@ -21,10 +22,10 @@ for (B, H, W, Cin, Cout, k, dil) in [(4, 65, 129, 512, 512, 3, 4), (4, 65, 129, 
     for _ in range(3):
         ops.conv_forward(x, wp, k, 1, dil, pad, Cout, out=out)
     torch.cuda.synchronize()
-    ws.view(torch.int64)[: 256 * 2 * 8].zero_()
+    ws.view(torch.int64)[-1024 * 32:].zero_()
     ops.conv_forward(x, wp, k, 1, dil, pad, Cout, out=out)
     torch.cuda.synchronize()
-    st = ws.view(torch.int64)[: 256 * 2 * 8].reshape(256, 2, 8).cpu().double()
+    st = ws.view(torch.int64)[-1024 * 32:][: 256 * 2 * 8].reshape(256, 2, 8).cpu().double()
     names = ["vmcnt wait (early)", "barrier", "DMA issue", "reads issued + returned", "vmcnt wait (late)", "barrier", "48 MFMAs issued"]
     print(f"Cin={Cin} Cout={Cout} k={k} d={dil}:")
     for half, label in ((0, "early half"), (1, "late half ")):
