@@ -680,11 +680,16 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_l2_kernel(const ConvK 
         for (int j = 0; j < 4; ++j) b1[j] = *reinterpret_cast<const f16x8*>(Bb + j * 1024);
       }
     };
+#if defined(ONDA_L2_ZIGZAG)  // measurement: the B fragment of the last MFMA of a row is the first one of the next row
+#define ZZ(i, jj) (((i) & 1) ? 3 - (jj) : (jj))
+#else
+#define ZZ(i, jj) (jj)
+#endif
     auto compute = [&]() {  // "C": 48 MFMAs (one wave per SIMD: the b1 fragments are fetched behind the first 16)
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) accx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][0], bf[j], accx[i][j], 0, 0, 0);
+        for (int jj = 0; jj < 4; ++jj) accx[i][ZZ(i, jj)] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][0], bf[ZZ(i, jj)], accx[i][ZZ(i, jj)], 0, 0, 0);
       if constexpr (!STAGGER && DBG != 7 && DBG != 8 && DBG < 10) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) b1[j] = *reinterpret_cast<const f16x8*>(Bb + j * 1024);
@@ -692,11 +697,11 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_l2_kernel(const ConvK 
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) accx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][1], b1[j], accx[i][j], 0, 0, 0);
+        for (int jj = 0; jj < 4; ++jj) accx[i][ZZ(i, jj)] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][1], b1[ZZ(i, jj)], accx[i][ZZ(i, jj)], 0, 0, 0);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][0], b1[j], acc[i][j], 0, 0, 0);
+        for (int jj = 0; jj < 4; ++jj) acc[i][ZZ(i, jj)] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][0], b1[ZZ(i, jj)], acc[i][ZZ(i, jj)], 0, 0, 0);
     };
     if constexpr (!STAGGER) {
       // (a two-stage ring -- half the LDS, two workgroups per CU hide each other's waits -- has one step in flight)
