@@ -27,6 +27,12 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
+// Order of a 4 x 4 grid of MFMAs: a snake -- row i runs left to right, row i + 1 right to left -- so that consecutive
+// instructions differ in ONE operand fragment only.  These loops run against the chip's power management:
+// fewer operand switches = a slightly higher clock (measured: -1.2 % on the 512 -> 512 3x3 conv, -0.6 % on an ASPP branch,
+// bit-identical results -- every accumulator still sees its K-steps in the same order).
+#define ZZ(i, jj) (((i) & 1) ? 3 - (jj) : (jj))
+
 constexpr float LIMB2_SCALE = ONDA_LIMB2_SCALE, LIMB2_UNSCALE = 1.f / ONDA_LIMB2_SCALE;  // common.h
 
 // Output tiles leave as NON-TEMPORAL (streaming) stores: a convolution never reads its output again, and every round of
@@ -680,11 +686,6 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_l2_kernel(const ConvK 
         for (int j = 0; j < 4; ++j) b1[j] = *reinterpret_cast<const f16x8*>(Bb + j * 1024);
       }
     };
-#if defined(ONDA_L2_ZIGZAG)  // measurement: the B fragment of the last MFMA of a row is the first one of the next row
-#define ZZ(i, jj) (((i) & 1) ? 3 - (jj) : (jj))
-#else
-#define ZZ(i, jj) (jj)
-#endif
     auto compute = [&]() {  // "C": 48 MFMAs (one wave per SIMD: the b1 fragments are fetched behind the first 16)
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -999,17 +1000,17 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_l2x_kernel(const ConvK
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) accx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][0], bf[j], accx[i][j], 0, 0, 0);
+        for (int jj = 0; jj < 4; ++jj) accx[i][ZZ(i, jj)] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][0], bf[ZZ(i, jj)], accx[i][ZZ(i, jj)], 0, 0, 0);
 #pragma unroll
       for (int j = 0; j < 4; ++j) bf[j] = *reinterpret_cast<const f16x8*>(Bb + j * 1024);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) accx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][1], bf[j], accx[i][j], 0, 0, 0);
+        for (int jj = 0; jj < 4; ++jj) accx[i][ZZ(i, jj)] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][1], bf[ZZ(i, jj)], accx[i][ZZ(i, jj)], 0, 0, 0);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][0], bf[j], acc[i][j], 0, 0, 0);
+        for (int jj = 0; jj < 4; ++jj) acc[i][ZZ(i, jj)] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][0], bf[ZZ(i, jj)], acc[i][ZZ(i, jj)], 0, 0, 0);
       if (late) issue_step();
     }
     stamp();
@@ -1519,18 +1520,18 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_wgrad_l2_kernel(const 
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) accx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][0], bf[j], accx[i][j], 0, 0, 0);
+      for (int jj = 0; jj < 4; ++jj) accx[i][ZZ(i, jj)] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][0], bf[ZZ(i, jj)], accx[i][ZZ(i, jj)], 0, 0, 0);
     if constexpr (!STAGGER) lds_wait(b1[0], b1[1], b1[2], b1[3]);
     if constexpr (STAGGER) issue_second_part();
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) accx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][1], b1[j], accx[i][j], 0, 0, 0);
+      for (int jj = 0; jj < 4; ++jj) accx[i][ZZ(i, jj)] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][1], b1[ZZ(i, jj)], accx[i][ZZ(i, jj)], 0, 0, 0);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][0], b1[j], acc[i][j], 0, 0, 0);
+      for (int jj = 0; jj < 4; ++jj) acc[i][ZZ(i, jj)] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][0], b1[ZZ(i, jj)], acc[i][ZZ(i, jj)], 0, 0, 0);
   };
   if constexpr (!STAGGER) {
     for (; i_cur < nlive; ++i_cur) {
