@@ -68,6 +68,7 @@ def parse():
                     help="time the step on PyTorch-ROCm eager in this process even without a tuned MIOpen find-db in the tree "
                          "(MIOpen's kernel search then takes ~10 minutes)")
     ap.add_argument("--no-eager", action="store_true")
+    ap.add_argument("--eager-only", action="store_true", help=argparse.SUPPRESS)  # the child process of the time-boxed eager leg
     ap.add_argument("--no-exact-f32", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the short runs of BASELINE configs 1, 2, 5 and of the static branch (config.other_configs)")
@@ -299,6 +300,28 @@ def eager_rocm(args, device):
     return {"ms_per_step": round(dt * 1e3, 2), "images_per_s": round(args.batch / dt, 3),
             "branch": "dynamic" if ad.switch.current else "static", "leg_seconds": round(time.perf_counter() - t_begin, 1),
             "what": "oracle step on PyTorch-ROCm eager (MIOpen fp32, cudnn.benchmark=True; 2 warm-up + 3 timed steps)"}
+
+
+def eager_rocm_boxed(args):
+    """The eager leg in a CHILD process with a time budget (ONDA_EAGER_BUDGET_S, default 420 s).  With the tuned find-db of
+    tools/miopen_db it takes about a minute; if the db does not match the box's MIOpen after all -- another version, another
+    device string -- MIOpen would search for ten minutes inside the driver's run: the child is then stopped and the committed
+    measurement quoted instead.  (A fresh child that initialises the GPU itself; the parent has released its cached memory.)"""
+    budget = float(os.environ.get("ONDA_EAGER_BUDGET_S", "420"))
+    cmd = [sys.executable, os.path.abspath(__file__), "--eager-only", "--batch", str(args.batch), "--height", str(args.height),
+           "--width", str(args.width), "--branch", args.branch]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
+    try:
+        out, _ = child.communicate(timeout=budget)
+    except subprocess.TimeoutExpired:
+        child.kill()  # (this exact child, by handle)
+        child.communicate()
+        return None, f"the eager leg did not finish within {budget:.0f} s (MIOpen searching: tools/miopen_db does not match this box)"
+    lines = [ln for ln in out.decode().splitlines() if ln.startswith("{")]
+    if child.returncode != 0 or not lines:
+        return None, f"the eager leg's process ended with code {child.returncode}"
+    return json.loads(lines[-1]), None
 
 
 def conv_accuracy_probe(device):
@@ -533,6 +556,10 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return launch_ranks(args)
     point_miopen_at_tree()
+    if args.eager_only:  # child of eager_rocm_boxed: this leg alone, its result as one JSON line
+        torch.cuda.set_device(0)
+        print(json.dumps(eager_rocm(args, "cuda:0")), flush=True)
+        return
     from onda_amd import dist as odist
     rank, world, local = odist.init_from_env()
     if world != args.gpus:
@@ -547,7 +574,7 @@ def main():
     run = {1: run_forward_only, 2: run_segmentation, 3: run_adaptation, 5: run_adaptation}[args.config]
     res = run(args, device, rank, world)
     dt = res.pop("dt")
-    cpu = eager = others = None
+    cpu = eager = others = eager_note = None
     headline = args.config in (3, 5) and not args.global_batch
     default_line = headline and args.config == 3 and (args.height, args.width) == (512, 1024) and args.batch == 4
     if rank == 0 and world == 1 and headline:
@@ -558,10 +585,12 @@ def main():
             others = other_configs(args, device)
         # the PyTorch-ROCm eager comparison runs LIVE whenever MIOpen's search results for this workload are in the tree
         # (seconds); without them only on request (--eager: the search takes ~10 minutes and fills tools/miopen_db)
-        if default_line and not args.no_eager and (args.eager or miopen_db_ready()):
-            eager = eager_rocm(args, device)
+        if default_line and not args.no_eager and args.eager:
+            eager = eager_rocm(args, device)        # the tuning run: in this process, however long MIOpen searches
             gc.collect()
             torch.cuda.empty_cache()
+        elif default_line and not args.no_eager and miopen_db_ready():
+            eager, eager_note = eager_rocm_boxed(args)  # the driver's run: a child process with a time budget
         if not args.no_cpu_baseline:
             cpu = cpu_baseline(args)
     if rank == 0:
@@ -579,6 +608,8 @@ def main():
             res["config"]["vs_baseline_is"] = ("value / config.eager_rocm.images_per_s: the same step on PyTorch-ROCm eager (MIOpen "
                                                "fp32, tuned), timed live in this run on this GPU (BASELINE.md holds no published number)")
         elif default_line:
+            if eager_note:
+                res["config"]["eager_rocm_skipped"] = eager_note
             # no tuned MIOpen find-db in the tree and no --eager: the committed measurement of the same step (same GPU
             # model, same workload, builder-run) is quoted with its source; vs_baseline stays null
             committed = {"ms_per_step": 302.9, "source": "profiles/r01_b_eager_pytorch_rocm.txt (tools/eager_baseline.py: MIOpen fp32, "
