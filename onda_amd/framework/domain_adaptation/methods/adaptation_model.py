@@ -20,10 +20,11 @@ from onda_amd.optim import ReplaySGD
 from onda_amd.framework.utils.func import lr_poly, per_class_iu
 
 
-def switch_batch_statistics(model, setting):
-    """Freeze / unfreeze the running-statistics update of every BatchNorm2d of `model`."""
+def switch_batch_statistics(model, setting, batchnorms=None):
+    """Freeze / unfreeze the running-statistics update of every BatchNorm2d of `model` (`batchnorms`: the list of them,
+    when the caller keeps one -- the walk over the module tree is the cost of this function)."""
     assert isinstance(setting, bool), f"setting value should be a boolean, given: {setting}"
-    for m in model.modules():
+    for m in (model.modules() if batchnorms is None else batchnorms):
         if isinstance(m, nn.BatchNorm2d):
             m.track_running_stats = setting
 

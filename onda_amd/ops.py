@@ -1254,14 +1254,21 @@ def sgd_multi(items, momentum, weight_decay, grad_scale=1.0):
         torch.autograd.graph.increment_version(p)
 
 
-def ema_multi(items):
-    """items: list of (k, q, keep, blend): k = k*keep + q*blend, one launch."""
-    blk, ents, first = query("onda_multi_tensor_block"), [], 0
-    for k, q, keep, blend in items:
-        ents.append(_lib.OndaEmaEntry(k.data_ptr(), q.data_ptr(), k.numel(), float(keep), float(blend), first))
-        first += -(-k.numel() // blk)
-    dev = items[0][0].device
-    table = _table(ents, _lib.OndaEmaEntry, dev)
-    call("onda_ema_multi", _p(table), len(ents), first, _stream())
-    for k, *_ in items:
-        torch.autograd.graph.increment_version(k)
+def ema_multi(items, cache=None):
+    """items: list of (k, q, keep, blend): k = k*keep + q*blend, one launch.  `cache` (a dict the caller keeps next to a
+    FIXED list of tensors): the device table is rebuilt only when an address or a factor changed -- at the end of a step
+    nothing is queued behind the optimizer launch, so the ~1.5 ms of host work that 320 table entries cost were 1.5 ms of
+    idle device per step (tools/trace_gaps.py)."""
+    key = [(k.data_ptr(), q.data_ptr(), keep, blend) for k, q, keep, blend in items]
+    if cache is not None and cache.get("key") == key:
+        table, n, first = cache["table"], cache["n"], cache["blocks"]
+    else:
+        blk, ents, first = query("onda_multi_tensor_block"), [], 0
+        for k, q, keep, blend in items:
+            ents.append(_lib.OndaEmaEntry(k.data_ptr(), q.data_ptr(), k.numel(), float(keep), float(blend), first))
+            first += -(-k.numel() // blk)
+        table, n = _table(ents, _lib.OndaEmaEntry, items[0][0].device), len(ents)
+        if cache is not None:
+            cache.update(key=key, table=table, n=n, blocks=first)
+    call("onda_ema_multi", _p(table), n, first, _stream())
+    torch.autograd.graph.increment_version([k for k, *_ in items])
