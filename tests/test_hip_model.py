@@ -472,22 +472,40 @@ def test_a_step_never_stops_the_host(tmp_path, conv_mode):
             da.update_ema()
         torch.cuda.synchronize()
         assert da.model_select.current == branch
+        # the deterministic half: torch raises on any operation of its own that synchronises (.item(), .cpu(), a blocking copy)
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")  # ("a prototype feature")
+            torch.cuda.set_sync_debug_mode("error")
+        try:
+            da.adjust_learning_rate(3, 10)
+            da.step([src[1]], {k: v.detach() for k, v in trg[1].items()})
+            da.update_ema()
+        finally:
+            torch.cuda.set_sync_debug_mode("default")
+        torch.cuda.synchronize()
+        # the wall-clock half (covers the C library's side as well)
         big = torch.randn(8192, 8192, device=DEV)
         for _ in range(3):
             big = big @ big * 1e-4
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(40):
-            big = big @ big * 1e-4
-        queued = time.perf_counter() - t0
-        da.adjust_learning_rate(3, 10)
-        log = da.step([src[1]], {k: v.detach() for k, v in trg[1].items()})
-        da.update_ema()
-        issued = time.perf_counter() - t0
-        torch.cuda.synchronize()
-        drained = time.perf_counter() - t0
-        assert queued < 0.2 * drained, (queued, drained)  # the matmuls really were a backlog
-        assert issued < 0.6 * drained, (branch, issued, drained)
+        tries = []
+        for attempt in range(3):  # a wall-clock property on a shared box: one clean run out of three proves it (a step that
+            torch.cuda.synchronize()  # reads something back from the device fails every time)
+            t0 = time.perf_counter()
+            for _ in range(40):
+                big = big @ big * 1e-4
+            queued = time.perf_counter() - t0
+            da.adjust_learning_rate(3 + attempt, 10)
+            log = da.step([src[(1 + attempt) % 2]], {k: v.detach() for k, v in trg[(1 + attempt) % 2].items()})
+            da.update_ema()
+            issued = time.perf_counter() - t0
+            torch.cuda.synchronize()
+            drained = time.perf_counter() - t0
+            tries.append((round(queued, 4), round(issued, 4), round(drained, 4)))
+            if queued < 0.2 * drained and issued < 0.6 * drained:  # the matmuls really were a backlog, and the step went in behind it
+                break
+        else:
+            raise AssertionError((branch, tries))
         # ... and the log is complete once somebody looks (both sides: "prior dynamic" exists only on the dynamic side)
         keys = set(log.keys())
         assert ("prior dynamic confidence ma" in keys) == (branch == 1), sorted(keys)
