@@ -7,6 +7,7 @@ Steps are delimited by `sgd_multi_kernel` (one launch per adaptation step); the 
 """
 import collections
 import csv
+import os
 import sys
 
 
@@ -44,6 +45,15 @@ def main(path, skip=4):
     print(f"{steps} steps, {len(rs) / steps:.0f} launches per step; per step: span {span / steps / 1e6:.2f} ms, kernels {busy / steps / 1e6:.2f} ms, "
           f"idle {(span - busy) / steps / 1e6:.2f} ms")
     print("idle time per step by gap length (ms):", {k: round(v / steps / 1e6, 3) for k, v in sorted(hist.items())})
+    if os.environ.get("KERNELS"):  # per-step kernel table (steady state only: set-up launches are not in it)
+        tab = collections.defaultdict(lambda: [0, 0])
+        for r in rs:
+            k = short(r["Kernel_Name"])
+            tab[k][0] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+            tab[k][1] += 1
+        print("kernels (ms per step, launches per step, mean us):")
+        for k, (d, n) in sorted(tab.items(), key=lambda kv: -kv[1][0])[:int(os.environ["KERNELS"])]:
+            print(f"  {d / steps / 1e6:7.3f} {n / steps:7.1f} {d / n / 1e3:8.1f}  {k}")
     print("gaps >= 5 us by site (ms per step, count per step):")
     for (a, b), (g, n) in sorted(sites.items(), key=lambda kv: -kv[1][0])[:25]:
         print(f"  {g / steps / 1e6:7.3f} {n / steps:6.1f}  {a} -> {b}")
