@@ -158,7 +158,7 @@ def measure_roofline(step_fn, steps_done, record=True):
     if not record:
         return None
     fam = {}
-    for name, flops, e0, e1, _tag in ops.PROFILE:
+    for name, flops, e0, e1, _tag in ops.profile_entries(ops.PROFILE):
         f = fam.setdefault(name, [0.0, 0.0, 0])
         f[0] += flops
         f[1] += e0.elapsed_time(e1) * 1e-3
@@ -170,13 +170,11 @@ def measure_roofline(step_fn, steps_done, record=True):
     fwd = [v for k, v in fam.items() if "wgrad" not in k]
     wg = [v for k, v in fam.items() if "wgrad" in k]
     # The roofline of a kernel is the matrix pipe it executes on: `peak` = that pipe's dense peak divided by the MFMA
-    # products the evaluation spends per fp32 product (f16x2: 3, bf16x3: 6, f32: the fp32 MFMA itself), so `frac` =
+    # products the evaluation spends per fp32 product (f16x2: 3, f32: the fp32 MFMA itself), so `frac` =
     # executed MFMA flops / pipe peak.  The fp32 matrix peak (what an unsplit fp32 kernel could reach at most) is
     # reported next to it.
     if "l2" in name or "h2" in name:
         products, what = 3, "f16 MFMA (v_mfma_f32_16x16x32_f16), 3 limb products per fp32 product, fp32 accumulate"
-    elif "bf3" in name:
-        products, what = 6, "bf16 MFMA (v_mfma_f32_16x16x32_bf16), 6 limb products per fp32 product, fp32 accumulate"
     else:
         products, what = 0, "fp32 MFMA (v_mfma_f32_32x32x2_f32)"
     peak = F16_MFMA_PEAK_TFLOPS / products if products else FP32_MFMA_PEAK_TFLOPS
@@ -360,9 +358,6 @@ def arithmetic():
                 "f16x2: fp32 operands scaled by a per-tensor power of two and split into 2 f16 limbs (22 significant bits), 3 limb "
                 "products on the f16 MFMA pipe, fp32 accumulation; 1-3e-7 relative L2 against fp64 = the accuracy of an fp32 FMA "
                 "chain, full accuracy for elements down to 2^-28 of a tensor's maximum; " + path)
-    if ops.CONV_MODE == "bf16x3":
-        return ("f32 (bf16x3 split emulation)", "bf16x3: fp32 operands split exactly into 3 bf16 limbs, 6 limb products on the bf16 "
-                "MFMA pipe, fp32 accumulation (2e-7 relative to the exact-fp32 MFMA kernels)")
     return ("f32", "f32: v_mfma_f32_32x32x2_f32 (exact fp32 fmaf chain)")
 
 
@@ -534,14 +529,15 @@ def launch_ranks(args):
         sock.bind(("127.0.0.1", 0))
         port = sock.getsockname()[1]
     procs = []
+    sink = tempfile.TemporaryFile()  # rank 0's stdout: a file, so that nobody has to drain a pipe while the ranks are watched
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    text = out.decode()
+                                      stdout=sink if r == 0 else subprocess.DEVNULL))
+    codes = watch_ranks(procs)
+    sink.seek(0)
+    text = sink.read().decode()
     sys.stdout.write(text)
     sys.stdout.flush()
     if any(codes):
@@ -551,10 +547,36 @@ def launch_ranks(args):
         raise SystemExit(f"bench.py --gpus {n}: rank 0 did not report {n} ranks")
 
 
+def watch_ranks(procs, poll_s=0.2, grace_s=5.0):
+    """Wait for the self-started ranks.  A rank that ends with a non-zero code while others are still running would
+    leave them inside a rendezvous or a collective until the distributed timeout (tens of minutes): the first such exit
+    stops the others -- these exact children, by handle: terminate, then kill after `grace_s` -- and the caller exits
+    non-zero within seconds.  Returns the exit codes."""
+    while True:
+        codes = [p.poll() for p in procs]
+        if all(c is not None for c in codes):
+            return codes
+        if any(c not in (None, 0) for c in codes):
+            live = [p for p in procs if p.poll() is None]
+            for p in live:
+                p.terminate()
+            deadline = time.monotonic() + grace_s
+            for p in live:
+                try:
+                    p.wait(timeout=max(0.0, deadline - time.monotonic()))
+                except subprocess.TimeoutExpired:
+                    p.kill()
+                    p.wait()
+            return [p.returncode for p in procs]
+        time.sleep(poll_s)
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return launch_ranks(args)
+    if os.environ.get("ONDA_BENCH_FAIL_RANK") == os.environ.get("RANK", ""):
+        raise SystemExit(7)  # test hook: this rank dies at start-up (tests/test_host_logic.py: the launcher must notice)
     point_miopen_at_tree()
     if args.eager_only:  # child of eager_rocm_boxed: this leg alone, its result as one JSON line
         torch.cuda.set_device(0)

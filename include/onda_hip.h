@@ -66,19 +66,9 @@ int64_t onda_conv_ws_floats(void);
 int onda_conv2d_fwd(const float* x, const float* w, float* y, const float* scale, const float* shift,
                     const float* residual, float* stats, float* ws, const OndaConv* c, onda_stream_t s);
 
-/* The same convolution evaluated on the bf16 matrix pipe with fp32-level accuracy: each fp32
- * operand is the exact sum of three bf16 limbs and the six limb products of weight >= 2^-16 are
- * accumulated in fp32 (csrc/conv_bf3.hip).  w3 = onda_pack_weight_bf3 output: limb planes
- * [3][rows][K] bf16 with rows = c->Cout and K = kh*kw*c->Cin (dgrad=0: row n, k = tap*Cin + c;
- * dgrad=1: row c, k = tap'*Cout_pad + n, taps flipped -- the data-gradient operand). */
-int onda_pack_weight_bf3(const float* w_oihw, void* dst, int Cout, int Cin, int taps, int rows_pad, int Kp, int dgrad,
-                         int Cout_pad, onda_stream_t s);
-int onda_conv2d_fwd_bf3(const float* x, const void* w3, float* y, const float* scale, const float* shift,
-                        const float* residual, float* stats, float* ws, const OndaConv* c, onda_stream_t s);
-
 /* ---- "f16x2": the same convolution with TWO f16 limbs per operand and a per-tensor power-of-two
- * scale (csrc/conv_h2.hip): a1*b1 + a1*b2 + a2*b1 on v_mfma_f32_16x16x32_f16, half the MFMA work of the
- * three-limb bf16 split at fp32-GEMM accuracy (3e-7 relative L2 against fp64).
+ * scale (csrc/conv_h2.hip): a1*b1 + a1*b2 + a2*b1 on v_mfma_f32_16x16x32_f16 at fp32-GEMM accuracy (3e-7 relative
+ * L2 against fp64).
  * A tensor's scale travels as `amax`: ONDA_AMAX_FLOATS device floats whose maximum is max|x| (producers spread
  * their atomicMax over ONDA_AMAX_SLOTS slots, one cache line apart); every consumer derives 2^e (max * 2^e in
  * [2^14, 2^15)) from it in-kernel.  amax buffers must be ZERO before their producer runs; producers are
@@ -88,7 +78,8 @@ int onda_conv2d_fwd_bf3(const float* x, const void* w3, float* y, const float* s
 #define ONDA_AMAX_SLOTS 64     /* slots, one 128-byte line apart */
 #define ONDA_AMAX_FLOATS 2048  /* floats per amax buffer */
 int onda_absmax(const float* x, int64_t rows, int C, int ld, float* amax, onda_stream_t s);
-/* OIHW fp32 weights -> dst[2][rows_pad][Kp] f16 limbs of w * 2^e(amax); other arguments as onda_pack_weight_bf3 */
+/* OIHW fp32 weights -> dst[2][rows_pad][Kp] f16 limbs of w * 2^e(amax): limb planes with rows = Cout and K = taps*Cin
+ * (dgrad=0: row n, k = tap*Cin + c; dgrad=1: row c, k = tap'*Cout_pad + n, taps flipped -- the data-gradient operand) */
 int onda_pack_weight_h2(const float* w_oihw, void* dst, int Cout, int Cin, int taps, int rows_pad, int Kp, int dgrad,
                         int Cout_pad, const float* amax, onda_stream_t s);
 /* All conv weights of a model at once: a device table of OIHW tensors -> per tensor max|w| into `amax` (zeroed) and the
@@ -203,9 +194,6 @@ int onda_conv2d_wgrad_h2(const float* x, const float* xamax, const float* dy, co
  * target backward passes of one step without a separate add pass). */
 int onda_conv2d_wgrad(const float* x, const float* dy, float* slabs, int lddy, int splitk,
                       const OndaConv* c, onda_stream_t s);
-/* the same slabs from the split-bf16 evaluation (csrc/conv_bf3.hip) */
-int onda_conv2d_wgrad_bf3(const float* x, const float* dy, float* slabs, int lddy, int splitk,
-                          const OndaConv* c, onda_stream_t s);
 int onda_wgrad_reduce(const float* slabs, float* dw, int splitk, int Cout, int taps, int Cin,
                       int Cout_real, int Cin_real, int flat_k, int accumulate, onda_stream_t s);
 
@@ -399,6 +387,8 @@ typedef struct OndaSwitchCfg {
   double gray_lo, gray_hi, dev_threshold;
 } OndaSwitchCfg;
 int onda_switch_state_doubles(int limit);
+/* the largest monitor window (AVG_MONITOR_SIZE, monitoring.py:16) the device-side switch holds; longer windows keep the host-side switch */
+int onda_switch_max_window(void);
 int onda_switch_step(double* state, int32_t* istate, const void* sample, int sample_f64, const double* taps,
                      const OndaSwitchCfg* cfg, int32_t* flag, onda_stream_t s);
 /* out[i] = *flag ? wb * b[i] : wa * a[i]: the prior of prototypes_hybrid_switch.py:57-75 picked on the device (`b` may hold

@@ -49,8 +49,6 @@ SIGNATURES = {
     "onda_conv_tiles_m": (I, [I]),
     "onda_conv_ws_floats": (L, []),
     "onda_conv2d_fwd": (I, [P, P, P, P, P, P, P, P, POINTER(OndaConv), P]),
-    "onda_pack_weight_bf3": (I, [P, P, I, I, I, I, I, I, I, P]),
-    "onda_conv2d_fwd_bf3": (I, [P, P, P, P, P, P, P, P, POINTER(OndaConv), P]),
     "onda_absmax": (I, [P, L, I, I, P, P]),
     "onda_pack_weight_h2": (I, [P, P, I, I, I, I, I, I, I, P, P]),
     "onda_pack_weights_h2_multi": (I, [P, I, L, P]),
@@ -62,6 +60,7 @@ SIGNATURES = {
     "onda_debug_stamps": (None, [P]),
     "onda_conv2d_fwd_l2_limbs": (I, [P, L, P, P, P, P, P, P, P, P, P]),
     "onda_switch_state_doubles": (I, [I]),
+    "onda_switch_max_window": (I, []),
     "onda_switch_step": (I, [P, P, P, I, P, POINTER(OndaSwitchCfg), P, P]),
     "onda_select_prior": (I, [P, P, F, P, F, P, L, P]),
     "onda_gate_scalar": (I, [P, P, P, P]),
@@ -76,7 +75,6 @@ SIGNATURES = {
     "onda_bn_bwd_l2_ws": (L, [L, I]),
     "onda_bn_bwd_l2": (I, [P, P, L, P, P, P, P, P, P, L, P, P, P, L, I, I, P, P]),
     "onda_conv2d_wgrad": (I, [P, P, P, I, I, POINTER(OndaConv), P]),
-    "onda_conv2d_wgrad_bf3": (I, [P, P, P, I, I, POINTER(OndaConv), P]),
     "onda_wgrad_reduce": (I, [P, P, I, I, I, I, I, I, I, I, P]),
     "onda_pack_weight_fwd": (I, [P, P, I, I, I, I, I, P]),
     "onda_pack_weight_dgrad": (I, [P, P, I, I, I, I, P]),

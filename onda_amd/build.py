@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libonda_hip.so")
-SOURCES = ["conv.hip", "conv_bf3.hip", "conv_h2.hip", "conv_l2.hip", "norm.hip", "norm_l2.hip", "pointwise.hip", "loss_proto.hip",
+SOURCES = ["conv.hip", "conv_h2.hip", "conv_l2.hip", "norm.hip", "norm_l2.hip", "pointwise.hip", "loss_proto.hip",
            "pipeline.hip", "switch.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "conv_common.h"), os.path.join(INCLUDE, "onda_hip.h")]
 

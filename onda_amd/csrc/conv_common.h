@@ -1,4 +1,4 @@
-// Shared between the fp32 and the split-bf16 convolution kernels: argument block, the
+// Shared between the fp32 and the split-precision convolution kernels: argument block, the
 // stream-K partial-tile store and the common epilogue (statistics, scale/shift, residual, ReLU,
 // slice / scatter store) for a 4-wave workgroup of 32x32 or 16x16 MFMA accumulator tiles.
 #pragma once

@@ -1,5 +1,5 @@
 // fp32-accurate convolution on the f16 matrix pipe with TWO limbs ("f16x2"): half the MFMA work of the
-// three-limb bf16 split (conv_bf3.hip), which matters because that kernel is bound by a power-managed
+// three-limb bf16 split (round 1, retired: `git show c558d15:onda_amd/csrc/conv_bf3.hip`), which matters because that kernel is bound by a power-managed
 // clock, not by issue slots or operand delivery.
 //
 //   x * s = h1 + h2 + e,   h1 = f16(x * s), h2 = f16(x * s - h1),   |e| <= 2^-22 |x * s|  (or <= 2^-25 absolute)
@@ -14,7 +14,7 @@
 // gradually.  Measured on outputs that depend ONLY on small elements (a pixel far below the largest one,
 // through a 1x1 conv; tests/test_hip_kernels.py::test_f16x2_interpixel_range): 1.3e-7 down to 2^-24 of the
 // maximum, 6e-7 at 2^-28, 1e-5 at 2^-32 -- 7-8 decades of per-element range at full accuracy, against fp32's
-// own 2^-126; "bf16x3" has no such dependence.
+// own 2^-126; the retired "bf16x3" mode had no such dependence.
 // The product is evaluated as a1*b1 + (a1*b2 + a2*b1), each exact in fp32 (11 x 11 bits),
 // accumulated in fp32 by v_mfma_f32_16x16x32_f16 -- a1*b1 in one accumulator set, the two cross products
 // (2^11 too large) in a second one that is folded in with 2^-11 at the end; what is dropped (a2*b2 and the
@@ -66,7 +66,7 @@ constexpr unsigned CH_OOB = 0x7FFFF000u;  // second addend: row + channel never 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
 }
-// chunk swizzle of the 64-byte-row LDS images (see conv_bf3.hip)
+// chunk swizzle of the 64-byte-row LDS images (as in the retired conv_bf3.hip)
 __device__ __forceinline__ int swz_row(int row) {
   const int q = (row >> 2) & 3;
   return q ^ ((q & 1) << 1) ^ ((row >> 1) & 1);
@@ -459,7 +459,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_h2_kernel(const ConvK a, unsi
 
 
 // ---- weight gradient ------------------------------------------------------------------------------
-// conv_wgrad_bf3_kernel (conv_bf3.hip) with two f16 limbs per operand: the staging thread multiplies its
+// conv_wgrad_bf3_kernel (round 1, retired: `git show c558d15:onda_amd/csrc/conv_bf3.hip`) with two f16 limbs per operand: the staging thread multiplies its
 // operand by that tensor's power-of-two scale before the split, the slabs are written in the operands' own
 // units (acc * 1 / (sx * sdy), exact).  LDS image: 64-byte rows; inside each 16-row block the
 // row index is transposed as a 4 x 4 matrix and the 16-byte chunk index is XOR-ed with row bits

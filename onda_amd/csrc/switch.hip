@@ -56,8 +56,16 @@ __device__ double np_pairwise_sum(const double* a, const double* b, int n) {
 __device__ void rank_sort(const double* w, double* sorted, int n) {
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
     const double v = w[i];
+    const bool vnan = v != v;
     int rank = 0;
-    for (int j = 0; j < n; ++j) rank += (w[j] < v) || (w[j] == v && j < i);
+    // a total order, so that every slot of sorted[] is written: NaN samples (a diverged model) sort behind everything
+    for (int j = 0; j < n; ++j) {
+      const double u = w[j];
+      const bool unan = u != u;
+      const bool less = unan ? false : (vnan ? true : u < v);
+      const bool same = unan ? vnan : (!vnan && u == v);
+      rank += less || (same && j < i);
+    }
     sorted[rank] = v;
   }
   __syncthreads();
@@ -121,7 +129,10 @@ __global__ __launch_bounds__(256) void switch_step_kernel(double* __restrict__ s
   if (t == 0) {
     const double conf = cfg.use_exp ? state[0] : avg;
     int current = istate[2], current_dev = istate[3];
-    if (fabs(dev) > cfg.dev_threshold) current_dev = dev > 0.0 ? 0 : 1;  // a significant trend is remembered (static = 0)
+    // a significant trend is remembered (static = 0); the reference's two one-sided tests, in its order
+    // (prototypes_hybrid_switch.py:24-27: they differ from |dev| > thr for a negative threshold)
+    if (dev > cfg.dev_threshold) current_dev = 0;
+    else if (dev < -cfg.dev_threshold) current_dev = 1;
     if (conf < cfg.gray_lo) current = 1;
     else if (conf > cfg.gray_hi) current = 0;
     else current = current_dev;
@@ -155,6 +166,7 @@ __global__ void gate_scalar_kernel(const int* __restrict__ flag, const float* __
 extern "C" {
 
 int onda_switch_state_doubles(int limit) { return 8 + limit; }
+int onda_switch_max_window(void) { return MAX_WINDOW; }
 
 int onda_switch_step(double* state, int32_t* istate, const void* sample, int sample_f64, const double* taps, const OndaSwitchCfg* cfg,
                      int32_t* flag, onda_stream_t s) {

@@ -50,9 +50,14 @@ def init_from_env(backend=None):
     backend = backend or os.environ.get("ONDA_DIST_BACKEND")
     if (world > 1 or _FORCE) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # no launcher-provided port: derive one from the parent process (the ranks of one job share their launcher, two jobs
-        # on a node do not), instead of one fixed port that two jobs or tests on the same node would fight over
-        os.environ.setdefault("MASTER_PORT", str(20000 + os.getppid() % 20000))
+        if "MASTER_PORT" not in os.environ:
+            # every launcher of this tree hands the port over (torchrun, bench.launch_ranks, the tests).  Guessing one for
+            # several ranks goes wrong silently: ranks behind per-rank wrapper shells (srun, mpirun) would each derive a
+            # different port from their parent and wait for each other until the rendezvous times out.
+            if world > 1:
+                raise RuntimeError("onda_amd.dist: WORLD_SIZE > 1 but MASTER_PORT is not set; the launcher must choose the "
+                                   "rendezvous port (torchrun --master-port P, or export MASTER_PORT)")
+            os.environ["MASTER_PORT"] = str(20000 + os.getppid() % 20000)  # one forced rank (ONDA_DIST_FORCE): any free port
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if os.environ["MASTER_ADDR"] in ("127.0.0.1", "localhost", "::1"):
             # one node: the bootstrap sockets of RCCL and gloo go over the loopback interface instead of whatever the

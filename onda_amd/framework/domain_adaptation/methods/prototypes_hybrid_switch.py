@@ -20,6 +20,7 @@ import torch
 
 from onda_amd import dist as odist
 from onda_amd import ops
+from onda_amd._lib import query
 from onda_amd.config import unset
 from onda_amd.framework.domain_adaptation.methods.prototypes import online_proDA
 from onda_amd.framework.utils.monitoring import DeviceSwitch
@@ -76,8 +77,10 @@ class model_select:
     def evaluate(self, confidence, dev_value):
         if self.freeze:
             return
-        if abs(dev_value) > self.dev_threshold:  # a significant trend is remembered across steps
-            self.current_dev = self.static if dev_value > 0 else self.dynamic
+        if dev_value > self.dev_threshold:  # a significant trend is remembered across steps (the reference's two tests, :24-27)
+            self.current_dev = self.static
+        elif dev_value < -self.dev_threshold:
+            self.current_dev = self.dynamic
         low, high = self.gray_area[0], self.gray_area[1]
         if confidence < low:
             self.current = self.dynamic
@@ -92,7 +95,8 @@ class hybrid_proDA(online_proDA):
         self.model_select = model_select(model_select.static, cfg_spec.GRAY_AREA, cfg_spec.DEV_THRESH)
         super().__init__(model, cfg, cfg_spec)
         self._dsw = None
-        if DEVICE_SWITCH and torch.device(self.device).type == "cuda" and cfg_spec.STATIC_LAMBDA > 0 and self.intensity_ma.limit:
+        if DEVICE_SWITCH and torch.device(self.device).type == "cuda" and cfg_spec.STATIC_LAMBDA > 0 and self.intensity_ma.limit \
+                and self.intensity_ma.limit <= query("onda_switch_max_window"):  # (longer windows: the host-side switch)
             spec = cfg_spec
             smoothed = not unset(spec.EXP_PR_STATIC) and bool(spec.EXP_PR_STATIC)
             monitor = self.intensity_ma  # the device series takes the host monitor's own settings (window, constant, trend)

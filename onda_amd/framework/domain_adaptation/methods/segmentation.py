@@ -40,7 +40,8 @@ class SegmentationTrainer:
         if previous is not None:
             previous.close()
         skip = (lambda name: name.startswith("layer5.")) if not getattr(model, "multi_level", True) else None
-        self._grad_sync = odist.GradSync(model, skip=skip)
+        self._float_buffers = [b for b in model.buffers() if b.dtype == torch.float32]  # BatchNorm running statistics
+        self._grad_sync = odist.GradSync(model, tail_floats=sum(b.numel() for b in self._float_buffers), skip=skip)
         model.__dict__["_onda_grad_sync"] = self._grad_sync
         if self._grad_sync.active:
             ops.GRAD_READY = self._grad_sync.grad_ready
@@ -73,8 +74,19 @@ class SegmentationTrainer:
         self._grad_sync.arm()
         loss.backward()
         if self._grad_sync.active:
+            # the running statistics (each rank's own batch moved them) ride in the tail of the gradient buffer and come
+            # back as rank means: replicas keep identical buffers, so validation and checkpoints do not depend on the rank
+            bufs, tail = self._float_buffers, self._grad_sync.tail
+            if bufs:
+                torch.cat([b.reshape(-1) for b in bufs], out=tail[:tail.numel()])
             self._grad_sync.finish(mean=False)  # rank sums; the optimizer divides on the way in
-            self.optimizer.grad_scale = 1.0 / odist.world_size()
+            world = odist.world_size()
+            self.optimizer.grad_scale = 1.0 / world
+            if bufs:
+                mean = tail / world
+                torch._foreach_copy_(bufs, [v.view_as(b) for v, b in zip(mean.split([b.numel() for b in bufs]), bufs)])
+                for b in bufs:
+                    torch.autograd.graph.increment_version(b)
         self.optimizer.step()
         if total_steps:
             self.adjust_learning_rate(total_steps)
@@ -101,8 +113,10 @@ def save_model(model, epoch, cfg):
         root, set_ = cfg.OTHERS.SNAPSHOT_DIR, cfg.SCHEME.SOURCE
     else:
         set_ = cfg.DOMAIN_ANALYSIS.DATASET.TRAIN
-    os.makedirs(root, exist_ok=True)
-    torch.save(model.state_dict(), os.path.join(root, f"model_train_{set_}.pth"))
+    if odist.rank() == 0:  # the replicas are identical; several ranks writing one path at the same time tear the file
+        os.makedirs(root, exist_ok=True)
+        torch.save(model.state_dict(), os.path.join(root, f"model_train_{set_}.pth"))
+    odist.barrier()
 
 
 def train(model, train_loader, validation_loaders, cfg, cfg_spec=None):

@@ -27,9 +27,11 @@ STEM_K = 160   # 7*7*3 = 147 patch values padded to a multiple of 32
 # How the convolutions (forward, data gradient, weight gradient) are evaluated:
 #   "f16x2" : fp32 operands scaled by a per-tensor power of two and split into two f16 limbs, three
 #             products on the f16 MFMA pipe with fp32 accumulation (the accuracy of an fp32 FMA chain at
-#             16/3 of the fp32-MFMA rate; csrc/conv_h2.hip) -- the default;
-#   "bf16x3": three bf16 limbs, six products on the bf16 MFMA pipe (no scale needed; csrc/conv_bf3.hip);
-#   "f32"   : v_mfma_f32_32x32x2_f32 (an exact fp32 fmaf chain; csrc/conv.hip).
+#             16/3 of the fp32-MFMA rate; csrc/conv_l2.hip, conv_h2.hip) -- the default;
+#   "f32"   : v_mfma_f32_32x32x2_f32 (an exact fp32 fmaf chain; csrc/conv.hip) -- the strict-fp32 leg of bench.py and the
+#             yardstick of test_f16x2_steps_track_the_exact_f32_steps; also what a conv whose weight the f16x2 packers do not
+#             take (element count not a multiple of 4) runs on.
+# (The round-1 "bf16x3" mode -- three bf16 limbs, six products -- was retired in round 4: slower than f16x2, never re-tuned.)
 CONV_MODE = os.environ.get("ONDA_CONV_MODE", "f16x2")
 
 # "f16x2" only -- where the activation operand of forward / data gradient is split into its two limbs:
@@ -63,11 +65,28 @@ def _l2_name(M, cout, taps, cin):
 def _launch(name, flops, fn_name, *args, tag=None):
     if PROFILE is None:
         return call(fn_name, *args)
+    # a launch under a device predicate does its work only while the flag is set: the flag's value at this point of the
+    # stream travels with the entry (profile_entries drops the launches that returned at once -- their flops were not executed)
+    live = PREDICATE.clone() if PREDICATE is not None else None
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     call(fn_name, *args)
     e1.record()
-    PROFILE.append((name, flops, e0, e1, tag))
+    PROFILE.append((name, flops, e0, e1, tag, live))
+
+
+def profile_entries(entries):
+    """(name, flops, e0, e1, tag) of the recorded launches that executed (call after a device synchronize)."""
+    flags = [e[5] for e in entries if e[5] is not None]
+    on = torch.stack([f.reshape(()) for f in flags]).ne(0).tolist() if flags else []
+    out, i = [], 0
+    for e in entries:
+        if e[5] is not None:
+            i += 1
+            if not on[i - 1]:
+                continue
+        out.append(e[:5])
+    return out
 
 
 def _p(t):
@@ -294,19 +313,13 @@ def _pack_h2(weight, rows_pad, kp, dgrad, cout_pad):
 
 
 def pack_weight_fwd(weight, cout_pad=None, kp=None):
-    """OIHW -> [Cout_pad][tap*Cin + c] rows of length kp (zero padded); three bf16 limb planes
-    of the same matrix in "bf16x3" mode, two scaled f16 planes in "f16x2" mode."""
+    """OIHW -> [Cout_pad][tap*Cin + c] rows of length kp (zero padded); two scaled f16 planes in "f16x2" mode."""
     cout, cin, kh, kw = weight.shape
     taps = kh * kw
     cout_pad = cout_pad or cout
     kp = kp or taps * cin
     if CONV_MODE == "f16x2" and weight.numel() % 4 == 0:
         return _pack_h2(weight, cout_pad, kp, 0, cout_pad)
-    if CONV_MODE in ("bf16x3", "f16x2"):
-        dst = torch.empty(3, cout_pad, kp, device=weight.device, dtype=torch.bfloat16)
-        call("onda_pack_weight_bf3", _p(weight.detach().contiguous()), _p(dst), cout, cin, taps, cout_pad, kp, 0,
-             cout_pad, _stream())
-        return dst
     dst = torch.empty(cout_pad, kp, device=weight.device, dtype=torch.float32)
     call("onda_pack_weight_fwd", _p(weight.detach().contiguous()), _p(dst), cout, cin, taps, cout_pad, kp, _stream())
     return dst
@@ -318,11 +331,6 @@ def pack_weight_dgrad(weight, cout_pad=None):
     cout_pad = cout_pad or cout
     if CONV_MODE == "f16x2" and weight.numel() % 4 == 0:
         return _pack_h2(weight, cin, kh * kw * cout_pad, 1, cout_pad)
-    if CONV_MODE in ("bf16x3", "f16x2"):
-        dst = torch.empty(3, cin, kh * kw * cout_pad, device=weight.device, dtype=torch.bfloat16)
-        call("onda_pack_weight_bf3", _p(weight.detach().contiguous()), _p(dst), cout, cin, kh * kw, cin,
-             kh * kw * cout_pad, 1, cout_pad, _stream())
-        return dst
     dst = torch.empty(cin, kh * kw, cout_pad, device=weight.device, dtype=torch.float32)
     call("onda_pack_weight_dgrad", _p(weight.detach().contiguous()), _p(dst), cout, cin, kh * kw, cout_pad, _stream())
     return dst
@@ -444,10 +452,8 @@ def conv_forward(x, wp, k, stride, dil, pad, cout, out=None, scale=None, shift=N
         if yamax is not None:
             tag_amax(out, yamax)
         return out, stats, tiles
-    bf3 = wp.dtype == torch.bfloat16
-    _launch("conv_fwd%s_kernel<128,%d>" % ("_bf3" if bf3 else "", 128 if cout > 64 else 64),
-            2.0 * B * Ho * Wo * cout * k * k * Cin, "onda_conv2d_fwd_bf3" if bf3 else "onda_conv2d_fwd", _p(x), _p(wp), _p(out), _p(scale), _p(shift), _p(residual), _p(stats),
-            _p(_conv_ws(x.device)), byref(d), _stream(),
+    _launch("conv_fwd_kernel<128,%d>" % (128 if cout > 64 else 64), 2.0 * B * Ho * Wo * cout * k * k * Cin, "onda_conv2d_fwd",
+            _p(x), _p(wp), _p(out), _p(scale), _p(shift), _p(residual), _p(stats), _p(_conv_ws(x.device)), byref(d), _stream(),
             tag=("fwd", B * Ho * Wo, cout, Cin, k, stride, dil))
     return out, stats, tiles
 
@@ -498,10 +504,8 @@ def conv_dgrad(dy, wpd, k, stride, dil, pad, cin, in_hw, accumulate=None):
                 None, _p(_conv_ws(dy.device)), None, byref(d), _stream(),
                 tag=("dgrad", B * Ho * Wo if stride != 1 else B * Hi * Wi, cin, Co, k, stride, dil))
         return dx
-    bf3 = wpd.dtype == torch.bfloat16
-    _launch("conv_fwd%s_kernel<128,%d>" % ("_bf3" if bf3 else "", 128 if cin > 64 else 64),
-            2.0 * B * Ho * Wo * cin * k * k * Co, "onda_conv2d_fwd_bf3" if bf3 else "onda_conv2d_fwd", _p(dy), _p(wpd), _p(dx), None, None, None, None, _p(_conv_ws(dy.device)), byref(d),
-            _stream(),
+    _launch("conv_fwd_kernel<128,%d>" % (128 if cin > 64 else 64), 2.0 * B * Ho * Wo * cin * k * k * Co, "onda_conv2d_fwd",
+            _p(dy), _p(wpd), _p(dx), None, None, None, None, _p(_conv_ws(dy.device)), byref(d), _stream(),
             tag=("dgrad", B * Ho * Wo if stride != 1 else B * Hi * Wi, cin, Co, k, stride, dil))
     return dx
 
@@ -568,9 +572,8 @@ def conv_wgrad(x, dy, k, stride, dil, pad, cout_real, cin_real, flat_k=0, into=N
 
 
 def _wgrad_other(x, dy, slabs, sk, d, M, Co, taps, Cin, k, stride, dil):
-    bf3 = CONV_MODE in ("bf16x3", "f16x2")
-    _launch("conv_wgrad%s_kernel<%s>" % ("_bf3" if bf3 else "", "128,128" if (Co > 64 and Cin > 64) else "64,64"),
-            2.0 * M * Co * taps * Cin, "onda_conv2d_wgrad_bf3" if bf3 else "onda_conv2d_wgrad", _p(x), _p(dy), _p(slabs), nhwc_ld(dy), sk, byref(d), _stream(),
+    _launch("conv_wgrad_kernel<%s>" % ("128,128" if (Co > 64 and Cin > 64) else "64,64"), 2.0 * M * Co * taps * Cin,
+            "onda_conv2d_wgrad", _p(x), _p(dy), _p(slabs), nhwc_ld(dy), sk, byref(d), _stream(),
             tag=("wgrad", M, Co, Cin, k, stride, dil, sk))
 
 

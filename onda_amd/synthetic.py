@@ -97,3 +97,28 @@ def synth_prototypes(feat_dim: int = 256, num_classes: int = 19, seed: int = 11)
     squared_mean = proto ** 2 + spread ** 2
     counter = torch.randint(200, 5000, (num_classes,), generator=g).float()
     return proto, squared_mean, counter
+
+
+class ListLoader:
+    """A list of batches with the loader surface the adaptation loop touches (``prototypes.py:466-520`` of the reference:
+    ``len``, iteration restarted when it runs out, ``add_from_batch`` of the replay buffer, ``buffer_db.py``): the
+    synthetic stand-in for a ``DataLoader`` / ``Buffer_db`` in the outer-loop fixture G14 and in the tests that replay
+    it.  ``add_from_batch`` only RECORDS (index, the stored label map of that sample) -- the batches stay what they are,
+    so a run is a function of the seeds alone."""
+
+    def __init__(self, batches):
+        self.batches = list(batches)
+        self.added = []
+
+    def __len__(self):
+        return len(self.batches)
+
+    def __iter__(self):
+        return iter(self.batches)
+
+    def sequential(self):
+        return iter(self.batches)
+
+    def add_from_batch(self, batch, index):
+        stored = batch["stored_predictions"]
+        self.added.append((int(index), stored[index].detach().to("cpu", torch.uint8).clone()))

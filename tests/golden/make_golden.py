@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Generate the golden vectors (G1-G13) by IMPORTING the reference on CPU.
+"""Generate the golden vectors (G1-G14) by IMPORTING the reference on CPU.
 
 Run in the build container only (the reference does not exist on the GPU box):
 
@@ -527,7 +527,120 @@ def g11():
          out_digest=digest(o["out"], 4096), feat_digest=digest(o["feat"], 4096), out_absmax=o["out"].abs().max())
 
 
+# ------------------------------------------------------------------------------------- G14
+G14 = dict(head_scale=7.0, monitor=4, perc_fill=0.0009, np_seed=3, steps=3, val_frames=10, lr=2e-7)
+
+
+def g14_config(cfg, spec):
+    """The settings G14 adds to make_cfg's (shared with the tests that replay it: tests/test_oracle_golden.py,
+    tests/test_hip_model.py): a 4-sample monitor window, so that the trend `dev_avg` -- zero until the window is full
+    (monitoring.py:64-73) -- is live from the 4th step and feeds both model_select and evaluate_update_dynamic within
+    two 3-step domains; a replay-buffer fill rate that makes buffer_update fire; samples at every epoch end; and a
+    learning rate 50x below the yml's: a train-mode step on random weights amplifies rounding differences ~40x per step
+    (the reference's own second update moves by 19 % with its thread count), so at the yml's rate a
+    six-step trajectory would pin nothing after its third step -- at this rate the whole stream is comparable."""
+    spec.AVG_MONITOR_SIZE = G14["monitor"]
+    spec.LEARNING_RATE = G14["lr"]
+    spec.EPOCHS = 1
+    cfg.TRAINING.PERC_FILL_PER_DOMAIN = G14["perc_fill"]
+    cfg.OTHERS.GENERATE_SAMPLES_EVERY = 3
+    cfg.classnum_to_label = {i: str(i) for i in range(19)}
+    cfg.device = cfg.OTHERS.DEVICE
+
+
+def g14():
+    """The OUTER loop the driver calls (train_ouda.py:227-261): two target "domains", each `update_cfg_spec` +
+    `hybrid_proDA.train(src_loader, trg_loader, val_set)` (prototypes.py:466-520) over list-backed synthetic loaders at
+    128x64, batch 2 -- 1 epoch x 3 steps per domain, one validation set of 10 frames.  Domain 0 as a first domain runs
+    (SKIP_CALC False: prototypes from the source loader + an initial evaluation; AUTO_DYNAMIC unset: the dynamic model
+    is refreshed at the start); domain 1 as every later one (SKIP_CALC True, and AUTO_DYNAMIC True through
+    ORDER_OPTIONS: no refresh at the start, `evaluate_update_dynamic` decides -- its 500-step counter is pre-set to 499
+    between the domains so that the decision falls inside the run).  Captured: every dict handed to wandb.log (scalars;
+    sample images as their class maps), the replay-buffer additions, prototypes, the switch trajectory, digests of all
+    four models at the end of each domain."""
+    import warnings
+    import wandb
+    from onda_amd.synthetic import ListLoader
+    logs = []
+
+    class Image:  # the stub's wandb.Image, keeping what the reference hands it (framework/utils/logging.py:13-17)
+        def __init__(self, data, masks=None, caption=None):
+            self.pred = np.asarray(masks["predictions"]["mask_data"]).astype(np.uint8)
+
+    wandb.Image = Image
+    wandb.log = lambda d, *a, **k: logs.append(dict(d))
+    res = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        cfg, spec = make_cfg(tmp)
+        g14_config(cfg, spec)
+        model = ref_model(1, G14["head_scale"])
+        da = hybrid_proDA(model, cfg, spec)
+        n = G14["steps"]
+        src = ListLoader([synth_batch(2, 64, 128, seed=1400 + i) for i in range(2)])
+        domains = [ListLoader([synth_batch(2, 64, 128, seed=1500 + 10 * d + i) for i in range(n)]) for d in range(2)]
+        val = {"val": ListLoader([synth_batch(1, 64, 128, seed=1600 + i) for i in range(G14["val_frames"])])}
+        torch.manual_seed(123)
+        np.random.seed(G14["np_seed"])
+        branch = []
+        step0 = da.step
+
+        def step(*a, **k):  # (records the switch after every step; the step itself is the reference's)
+            out = step0(*a, **k)
+            branch.append([da.model_select.current, da.model_select.current_dev])
+            return out
+        da.step = step
+        f_domain = False
+        for d, (set_, loader) in enumerate(zip(((25,), (50,)), domains)):
+            spec.set_ = set_
+            if d == 1:
+                spec["AUTO_DYNAMIC"] = True           # train_ouda.py:252-256 (SCHEME.ORDER_OPTIONS)
+                da.dynamic_update_counter = 499       # (see the docstring)
+            spec.SKIP_CALC |= f_domain                # train_ouda.py:257-258
+            f_domain = True
+            da.update_cfg_spec(spec)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                da.train(src, loader, val)
+            res[f"proto_d{d}"], res[f"sqmean_d{d}"] = da.prototypes.prototypes.clone(), da.prototypes.squared_mean.clone()
+            res[f"counter_d{d}"] = da.prototypes.counter.clone()
+            res[f"dynamic_counter_d{d}"] = np.array(da.dynamic_update_counter)
+            names, dig = [], []
+            for who, mod in (("student.", da.model), ("teacher.", da.ema_model), ("dynamic.", da.dynamic_model),
+                             ("static.", da.static_model)):
+                for k_, p in mod.state_dict().items():
+                    names.append(who + k_)
+                    dig.append(digest(p.float(), 64))
+            res[f"state_names_d{d}"], res[f"state_digest_d{d}"] = np.array(names), np.stack(dig)
+            res[f"files_d{d}"] = np.array(sorted(os.listdir(tmp)))
+            if d == 0:
+                from framework.domain_adaptation.methods.prototype_handler import prototype_handler as ph
+                chk = ph(0.9995, 1, 0.3, "mahalanobis")
+                assert chk.load(os.path.join(tmp, "proto_(25,).pickle"))
+        res["branch"] = np.array(branch)
+        scalars, nimg = [], 0
+        for i, d in enumerate(logs):
+            row = {}
+            for k_, v in d.items():
+                if isinstance(v, Image):
+                    res[f"log{i}_img_{k_}"] = v.pred
+                    nimg += 1
+                else:
+                    v = tolog({k_: v})[k_]
+                    if np.isscalar(v):
+                        row[k_] = v
+            scalars.append(row)
+        res["logs_json"] = np.array(json.dumps(scalars))
+        res["added_index"] = np.array([i for i, _ in src.added], dtype=np.int64)
+        res["added_maps"] = np.stack([m.numpy() for _, m in src.added]) if src.added else np.zeros((0, 64, 128), np.uint8)
+        res["added_at"] = np.array([i for i, row in enumerate(scalars) if row.get("Total buffer updates", 0) > 0])
+        save("g14_train_loop", **res)
+        print("g14:", len(logs), "log dicts,", nimg, "sample maps,", len(src.added), "buffer additions, branch", branch,
+              "dynamic counters", res["dynamic_counter_d0"], res["dynamic_counter_d1"])
+        for i, row in enumerate(scalars):
+            print(i, {k_: round(v, 5) for k_, v in row.items() if k_ in ("Total target loss", "prior static confidence ma", "dev avg prior static", "Total buffer updates", "Val mIoU model of val", "pseudolabel_pixel_num", "buff_loss")})
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14"]
     for w in which:
         globals()[w]()

@@ -14,10 +14,10 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-@pytest.fixture(autouse=True, params=["f32", "bf16x3", "f16x2"])
+@pytest.fixture(autouse=True, params=["f32", "f16x2"])
 def conv_mode(request):
-    """Every model-level parity test runs with both conv evaluations: exact fp32 MFMA and the
-    three-limb bf16 split (fp32-level accuracy on the bf16 pipe)."""
+    """Every model-level parity test runs with both conv evaluations: exact fp32 MFMA and the two-limb f16 split
+    (fp32-level accuracy on the f16 pipe)."""
     from onda_amd import ops
     old, ops.CONV_MODE = ops.CONV_MODE, request.param
     yield request.param
@@ -348,7 +348,7 @@ def _full_size_step_against(golden, tmp_path, name, width, height, batch, head_s
 def test_full_size_step_golden(golden, tmp_path, conv_mode):
     """BASELINE config 3 on the STATIC side of the switch (head x40): 512x1024, batch 4 (fixture G10)."""
     if conv_mode != "f16x2":
-        pytest.skip("full-size step: default conv mode only (the small-size step runs in all three)")
+        pytest.skip("full-size step: default conv mode only (the small-size step runs in both)")
     _full_size_step_against(golden, tmp_path, "g10_step_full", 1024, 512, 4, 40.0)
 
 
@@ -356,7 +356,7 @@ def test_bench_step_golden(golden, tmp_path, conv_mode):
     """The step bench.py TIMES, in the state it times it in: 512x1024, batch 4, head x1 = the DYNAMIC branch, source seeds
     1000 / 1001, target seed 2000 (fixture G12, captured from the imported reference)."""
     if conv_mode != "f16x2":
-        pytest.skip("full-size step: default conv mode only (the small-size step runs in all three)")
+        pytest.skip("full-size step: default conv mode only (the small-size step runs in both)")
     _full_size_step_against(golden, tmp_path, "g12_step_bench_dynamic", 1024, 512, 4, 1.0)
     assert int(golden("g12_step_bench_dynamic")["branch"]) == 1
 
@@ -365,7 +365,7 @@ def test_full_resolution_step_golden(golden, tmp_path, conv_mode):
     """One adaptation step at BASELINE config 5's resolution, 1024x2048 (feature grid 129x257), batch 2 (fixture G13: the
     reference's CPU step at batch 4 does not fit the build container beside the build; M changes, no kernel shape does)."""
     if conv_mode != "f16x2":
-        pytest.skip("full-size step: default conv mode only (the small-size step runs in all three)")
+        pytest.skip("full-size step: default conv mode only (the small-size step runs in both)")
     _full_size_step_against(golden, tmp_path, "g13_step_1024x2048", 2048, 1024, 2, 40.0, seeds=(1300, 2300))
 
 
@@ -574,7 +574,11 @@ def test_step_sharded_matches_the_oracle_emulation_of_two_ranks(tmp_path, conv_m
         mine, want = da.model.state_dict()[k].detach().float().cpu(), ad.student[k].float()
         num += float(((mine - want) ** 2).sum())
         den += float(((want - b0) ** 2).sum())
-    assert (num / den) ** 0.5 <= 0.03, (num / den) ** 0.5  # post-step weights (running statistics included), as updates
+    # post-step weights (running statistics included), as updates.  This is HIP against torch-CPU fp32: the floor is the
+    # reference's own fp32 noise through a train-mode pass (its step-0 update moves by 0.3 % with its thread count); the
+    # same-kernel comparison of the two layouts is test_multirank_gpu.py (1e-4)
+    print("step_sharded vs oracle emulation, update rel-L2:", (num / den) ** 0.5)
+    assert (num / den) ** 0.5 <= 0.01, (num / den) ** 0.5
 
 
 def test_eval_forward_1024x2048_golden(golden, conv_mode):
@@ -999,3 +1003,79 @@ def test_ragged_sizes_against_oracle(B, H, W):
         g = dict(m.named_parameters())[name].grad.cpu().double()
         r = sdr[name].grad
         assert (g - r).norm() <= 2e-2 * r.norm() + 1e-12, name
+
+
+def test_train_loop_golden(golden, tmp_path):
+    """The OUTER loop the driver calls (train_ouda.py:227-261): `update_cfg_spec` + `hybrid_proDA.train(src, trg, val,
+    log_fn=...)` over two synthetic domains against the reference's captured run (fixture G14): initial prototypes +
+    evaluation, 3 + 3 steps, replay-buffer additions, `evaluate_update_dynamic` refreshing the dynamic model inside the second
+    domain (AUTO_DYNAMIC), epoch-end evaluation + sample maps, the checkpoints and prototype files it leaves behind, and
+    the switch moving to the dynamic side -- decided on the device in the default conv mode, on the host in the other."""
+    import pickle
+    from g14_common import G14, N_MASKS, compare_logs, loaders
+    from onda_amd.config import hybrid_switch_cfg
+    from onda_amd.framework.handlers import get_adapt_method, get_model
+    from onda_amd.framework.model import deeplabv2
+    from onda_amd.synthetic import fill_state_dict
+    from oracle import model as omodel
+    g = golden("g14_train_loop")
+    cfg, spec = hybrid_switch_cfg(128, 64, DEV, str(tmp_path), batch_size=2)
+    spec.AVG_MONITOR_SIZE, spec.EPOCHS, spec.LEARNING_RATE = G14["monitor"], 1, G14["lr"]
+    cfg.TRAINING.PERC_FILL_PER_DOMAIN = G14["perc_fill"]
+    model = get_model(cfg, 19)
+    fill_state_dict(model, 1, G14["head_scale"])
+    init = {k: digest(v.float(), 64)[2:] for k, v in model.state_dict().items()}
+    da = get_adapt_method(cfg)(model, cfg, spec)
+    src, domains, val = loaders()
+    torch.manual_seed(123)
+    np.random.seed(G14["np_seed"])
+    masks = iter([omodel.draw_drop_mask(2) for _ in range(N_MASKS)])  # the reference run's draws, in its order
+    deeplabv2.drop_mask_fn = lambda B, C, p, dev: next(masks).to(dev)
+    logs, branch = [], []
+    step0 = da.step
+
+    def step(*a, **k):
+        out = step0(*a, **k)
+        branch.append([da.model_select.current, da.model_select.current_dev])
+        return out
+    da.step = step
+    try:
+        first = True
+        for d, (set_, loader) in enumerate(zip(((25,), (50,)), domains)):
+            spec.set_ = set_
+            if d == 1:
+                spec["AUTO_DYNAMIC"] = True
+                da.dynamic_update_counter = 499
+                np.testing.assert_allclose(da.prototypes.prototypes.cpu().numpy(), g["proto_d0"], rtol=1e-3, atol=1e-4)
+            spec.SKIP_CALC = bool(spec.SKIP_CALC) or not first
+            first = False
+            da.update_cfg_spec(spec)
+            # (a log sink reads the dictionary when it gets it, as wandb.log does)
+            da.train(src, loader, val, log_fn=lambda entry: logs.append(dict(entry.items())))
+            assert sorted(os.listdir(tmp_path)) == list(g[f"files_d{d}"])
+            assert da.dynamic_update_counter == int(g[f"dynamic_counter_d{d}"])
+        assert next(masks, None) is None  # every mask the reference drew was used, none more
+    finally:
+        deeplabv2.drop_mask_fn = deeplabv2._default_drop_mask
+    worst = {}
+    compare_logs(g, logs, image_key=lambda entry: entry["prediction"], worst=worst)
+    assert np.array_equal(np.array(branch), g["branch"])
+    np.testing.assert_allclose(da.prototypes.prototypes.cpu().numpy(), g["proto_d1"], rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(da.prototypes.squared_mean.cpu().numpy(), g["sqmean_d1"], rtol=1e-3, atol=1e-4)
+    with open(os.path.join(tmp_path, "proto_(50,).pickle"), "rb") as f:  # the 3-tuple the next run's LOAD_PROTO reads
+        stored = pickle.load(f)
+    assert len(stored) == 3 and np.allclose(np.asarray(stored[0].cpu() if torch.is_tensor(stored[0]) else stored[0]), g["proto_d1"], rtol=1e-3, atol=1e-4)
+    assert [i for i, _ in src.added] == list(g["added_index"])
+    for (_, mine), ref in zip(src.added, g["added_maps"]):
+        assert (mine.numpy() != ref).mean() <= 5e-3
+    names, dg = list(g["state_names_d1"]), g["state_digest_d1"]
+    for who, mod, tol in (("static.", da.static_model, 0.0), ("dynamic.", da.dynamic_model, 2e-2), ("student.", da.model, 2e-2),
+                          ("teacher.", da.ema_model, 2e-2)):
+        num = den = 0.0
+        for k, v in mod.state_dict().items():
+            if v.is_floating_point() and v.dim() > 0:
+                row = dg[names.index(who + k)][2:]
+                num += ((digest(v.float(), 64)[2:] - row) ** 2).sum()
+                den += ((row - init[k]) ** 2).sum()
+        assert (den > 0) == (who != "static.") and num ** 0.5 <= tol * den ** 0.5, (who, num ** 0.5, den ** 0.5)
+    print("g14 worst relative deviations:", {k: round(v, 6) for k, v in sorted(worst.items(), key=lambda kv: -kv[1])[:8]})

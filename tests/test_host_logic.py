@@ -365,3 +365,38 @@ def test_bench_refuses_more_ranks_than_devices():
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8"], env=env, capture_output=True, text=True,
                          timeout=300)
     assert out.returncode != 0 and "{" not in out.stdout and "refusing" in out.stderr
+
+
+def test_bench_launcher_stops_the_job_when_a_rank_dies():
+    """A rank that dies while its siblings wait for it (rendezvous, a collective) must end the whole job within seconds,
+    not after the distributed timeout: rank 1 exits at start-up (ONDA_BENCH_FAIL_RANK), rank 0 waits in the rendezvous for
+    it; `bench.py --gpus 2` has to return non-zero, print no line, and do so in well under 30 s."""
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(ONDA_FORCE_DEVICE="0", ONDA_DIST_BACKEND="gloo", ONDA_BENCH_FAIL_RANK="1")
+    t0 = time.monotonic()
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env,
+                         capture_output=True, text=True, timeout=120)
+    took = time.monotonic() - t0
+    assert out.returncode != 0 and "{" not in out.stdout and "rank exit codes" in out.stderr, out.stderr[-800:]
+    assert took < 30, took
+
+
+def test_watch_ranks_kills_only_its_own_children():
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    sleeper = subprocess.Popen([sys.executable, "-c", "import time; time.sleep(600)"])
+    dier = subprocess.Popen([sys.executable, "-c", "import sys, time; time.sleep(0.5); sys.exit(5)"])
+    t0 = time.monotonic()
+    codes = bench.watch_ranks([sleeper, dier], poll_s=0.05, grace_s=2.0)
+    assert time.monotonic() - t0 < 10
+    assert codes[1] == 5 and codes[0] not in (0, None)
+    ok = [subprocess.Popen([sys.executable, "-c", "pass"]) for _ in range(2)]
+    assert bench.watch_ranks(ok, poll_s=0.05) == [0, 0]

@@ -53,14 +53,17 @@ def test_two_ranks_stay_identical_and_match_the_sequential_emulation(tmp_path):
         # (step 1 runs on weights that already differ by the rounding noise of step 0, amplified by a train-mode pass)
         np.testing.assert_allclose(a[f"s{s}_monitor"], b[f"s{s}_monitor"], rtol=1e-4 if s == 0 else 5e-3, atol=1e-6)
         assert np.array_equal(a[f"s{s}_switch"], b[f"s{s}_switch"])
-        # weights, as UPDATES since the previous state: the two layouts differ by fp32 summation order only, seen through
-        # the conditioning of a train-mode pass on random weights (the reference's own update moves by 0.3 % / 19 % when
-        # only its CPU thread count changes)
+        # weights, as UPDATES since the previous state: the two layouts differ by fp32 summation order only -- at step 0
+        # directly (1e-4), at step 1 seen through the conditioning of a train-mode pass on weights that already differ in
+        # their last bits (the reference's own second update moves by 19 % when only its CPU thread count changes,
+        # DESIGN.md section 4)
         for who in ("student", "teacher"):
             x, y = a[f"s{s}_{who}"], b[f"s{s}_{who}"]
             before = a[f"init_{who}"] if s == 0 else a[f"s{s - 1}_{who}"]
             rel = np.linalg.norm(x - y) / np.linalg.norm(x - before)
-            assert rel <= (0.02 if s == 0 else 0.6), (s, who, rel)
+            # step 0: the SAME kernels on the same micro-batches in both layouts, Dropout off -- only the order of the fp32
+            # sums over micro-batches / ranks differs.  (Round 2's half-exchanged buckets passed the old 2 % bound.)
+            assert rel <= (1e-4 if s == 0 else 0.6), (s, who, rel)
 
 
 def test_one_rank_over_rccl_matches_the_plain_step(tmp_path):
@@ -96,7 +99,9 @@ def test_one_rank_over_rccl_matches_the_plain_step(tmp_path):
             x, y = a[f"s{s}_{who}"], b[f"s{s}_{who}"]
             before = a[f"init_{who}"] if s == 0 else a[f"s{s - 1}_{who}"]
             rel = np.linalg.norm(x - y) / np.linalg.norm(x - before)
-            assert rel <= (0.02 if s == 0 else 0.6), (s, who, rel)
+            # step 0: the SAME kernels on the same micro-batches in both layouts, Dropout off -- only the order of the fp32
+            # sums over micro-batches / ranks differs.  (Round 2's half-exchanged buckets passed the old 2 % bound.)
+            assert rel <= (1e-4 if s == 0 else 0.6), (s, who, rel)
 
 
 def test_bench_launches_its_own_ranks():

@@ -228,3 +228,56 @@ def test_g9_input_pipeline(golden):
         assert np.array_equal(t, g[f"tensor{n}"]), n  # fp32 ops in the same order: bit-identical
         full, res = pipeline.labels(g[f"lab{n}"], (W, H), g["lut"])
         assert np.array_equal(full, g[f"label{n}"]) and np.array_equal(res, g[f"label_res{n}"]), n
+
+
+def test_g14_train_loop(golden):
+    """The outer loop (train_ouda.py:227-261 -> prototypes.py:466-520) of the oracle against the reference's captured run:
+    two domains x 3 steps, initial prototypes + evaluation, replay-buffer additions, evaluate_update_dynamic, epoch-end
+    evaluation and sample maps, the switch flipping to the dynamic side in the second domain."""
+    from g14_common import G14, compare_logs, loaders
+    from oracle.loop import OracleLoop, run_domains
+    g = golden("g14_train_loop")
+    sd = oracle_sd(1, G14["head_scale"])
+    ad = OracleAdapter(sd, (torch.zeros(19, 256), torch.zeros(19, 256), torch.zeros(19)), cfg=dict(AVG_MONITOR_SIZE=G14["monitor"], LEARNING_RATE=G14["lr"]))
+    loop = OracleLoop(ad, (64, 128), probability_per_step=G14["perc_fill"] * 1000 / 2)
+    src, domains, val = loaders()
+    torch.manual_seed(123)
+    np.random.seed(G14["np_seed"])
+    logs, branch = [], []
+    step0 = ad.step
+
+    def step(*a, **k):
+        out = step0(*a, **k)
+        branch.append([ad.switch.current, ad.switch.trend])
+        return out
+    ad.step = step
+
+    def between(d):
+        if d == 1:
+            loop.dynamic_update_counter = 499
+            np.testing.assert_allclose(ad.proto[0].numpy(), g["proto_d0"], rtol=1e-3, atol=1e-4)
+    run_domains(loop, src, domains, val, logs.append, order_options={1: {"AUTO_DYNAMIC": True}}, between=between)
+    worst = {}
+    compare_logs(g, logs, worst=worst)
+    assert np.array_equal(np.array(branch), g["branch"])
+    assert loop.dynamic_update_counter == int(g["dynamic_counter_d1"]) == 1
+    np.testing.assert_allclose(ad.proto[0].numpy(), g["proto_d1"], rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(ad.proto[1].numpy(), g["sqmean_d1"], rtol=1e-3, atol=1e-4)
+    assert [i for i, _ in src.added] == list(g["added_index"])
+    for (_, mine), ref in zip(src.added, g["added_maps"]):
+        assert (mine.numpy() != ref).mean() <= 5e-3
+    # weights as UPDATES since the initial state.  The dynamic model was refreshed inside domain 1 (it is the student as
+    # it was after step 1 of that domain, not the initial one); the static model never moves
+    names, dg = list(g["state_names_d1"]), g["state_digest_d1"]
+    init = oracle_sd(1, G14["head_scale"])
+    for who, state, tol in (("static.", ad.static, 0.0), ("dynamic.", ad.dynamic, 2e-2), ("student.", ad.student, 2e-2),
+                            ("teacher.", ad.ema, 2e-2)):
+        num = den = 0.0
+        for k, v in state.items():
+            if v.is_floating_point() and v.dim() > 0:
+                row = dg[names.index(who + k)][2:]
+                num += ((digest(v.float(), 64)[2:] - row) ** 2).sum()
+                den += ((row - digest(init[k].float(), 64)[2:]) ** 2).sum()
+        assert (den > 0) == (who != "static.") and num ** 0.5 <= tol * den ** 0.5, (who, num ** 0.5, den ** 0.5)
+        worst[who + "update"] = (num / max(den, 1e-30)) ** 0.5
+    print("g14 oracle worst relative deviations:", {k: round(v, 6) for k, v in sorted(worst.items(), key=lambda kv: -kv[1])[:8]})

@@ -21,7 +21,7 @@ for it in range(3):
     m.zero_grad()
 torch.cuda.synchronize()
 agg = collections.OrderedDict()
-for name, flops, e0, e1, tag in ops.PROFILE:
+for name, flops, e0, e1, tag in ops.profile_entries(ops.PROFILE):
     a = agg.setdefault((name, tag), [0.0, 0.0, 0])
     a[0] += flops; a[1] += e0.elapsed_time(e1); a[2] += 1
 tot = sum(a[1] for a in agg.values())
