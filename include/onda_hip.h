@@ -46,6 +46,10 @@ typedef struct OndaConv {
   int relu;
   const int32_t* run_if; /* NULL, or a device int: the launch does nothing when *run_if == 0 (a predicate decided on the
                           * device, onda_switch_step; honoured by the pre-split kernels of csrc/conv_l2.hip, EINVAL elsewhere) */
+  int64_t stat_split;    /* 0, or the GEMM row at which a second ROW GROUP starts (two micro-batches in one launch, each with
+                          * its own BatchNorm batch statistics: prototypes.py:418-450 runs the student on the source-replay and
+                          * on the target batch): the schedule then keeps the tile that straddles the boundary out of the
+                          * stream-K remainder, so that onda_bn_finalize_l2 can split its statistics row (csrc/norm_l2.hip) */
 } OndaConv;
 
 /* Number of float partials conv_fwd writes when `stats` != NULL: tiles_m * 2 * Cout, where
@@ -150,6 +154,8 @@ int onda_conv_l2_variant(int64_t M, int Cout);  /* tile shape used for an (M, Co
  * at most 32 K-steps per tile: the continuous K-step stream); bench.py names its per-kernel figures after this */
 int onda_conv_l2_kernel_id(int64_t M, int Cout, int taps, int Cin);
 int onda_conv_l2_tiles_m(int64_t M, int Cout, int taps, int Cin);  /* rows of the `stats` partials the conv writes for this problem */
+/* the same with a row-group boundary (OndaConv.stat_split); *tile_rows (optional) receives the GEMM rows one partial row covers */
+int onda_conv_l2_tiles_m_split(int64_t M, int Cout, int taps, int Cin, int64_t stat_split, int* tile_rows);
 /* stats_rows: 2 = stats[tile][sum, sumsq][Cout] as onda_conv2d_fwd; 4 = also the per-channel min and max of the raw
  * output tile, from which onda_bn_finalize_l2 bounds max|BatchNorm output| before the apply pass writes limb planes */
 int onda_conv2d_fwd_l2(const void* xl, int64_t xplane, const float* xamax, const void* w2, const float* wamax, float* y,
@@ -164,17 +170,23 @@ int onda_conv2d_fwd_l2(const void* xl, int64_t xplane, const float* xamax, const
  *   the residual read from ITS limb planes; relu_mask (optional, M*C/8 bytes): bit (m*C+c) & 7 of byte (m*C+c) >> 3 =
  *   [out > 0], read by the backward passes instead of out's first limb (1/8 byte per element instead of 2).
  *   bwd: g = dout*[out>0] (relu_mask, or the sign of out's first limb when relu_mask is NULL), dres = g (fp32, optional),
- *   dx[2][M][C] limb planes of gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)), scaled by a bound folded into dx_amax. */
+ *   dx[2][M][C] limb planes of gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)), scaled by a bound folded into dx_amax.
+ *   ROW GROUPS (split > 0): rows [0, split) and [split, M) of the same tensor are two micro-batches normalised with their
+ *   own batch statistics in one pass (the student's source-replay and target batches, prototypes.py:418-450, with the
+ *   BN_POLICY "freeze" of adaptation_model.py:29-36: run_group = the group whose statistics move the running buffers, -1 =
+ *   none); mean / invstd / xhat_amax are then [2][C].  finalize splits the one partial row that straddles the boundary
+ *   with the conv output itself (y, row stride ldy; tile_rows = GEMM rows per partial row, onda_conv_l2_tiles_m_split). */
 int onda_bn_finalize_l2(const float* partials, int tiles, int C, int64_t count, float eps, float* mean, float* invstd,
                         float* running_mean, float* running_var, int64_t* nbt, float momentum, const float* gamma,
-                        const float* beta, const float* res_amax, int relu, float* xhat_amax, float* out_amax, onda_stream_t s);
+                        const float* beta, const float* res_amax, int relu, float* xhat_amax, float* out_amax, int64_t split,
+                        int tile_rows, int run_group, const float* y, int ldy, onda_stream_t s);
 int onda_bn_apply_l2(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
                      const void* res, int64_t res_plane, const float* res_amax, void* out, int64_t out_plane,
-                     const float* out_amax, int64_t M, int C, int relu, uint8_t* relu_mask, onda_stream_t s);
+                     const float* out_amax, int64_t M, int C, int relu, uint8_t* relu_mask, int64_t split, onda_stream_t s);
 int64_t onda_bn_bwd_l2_ws(int64_t M, int C);
 int onda_bn_bwd_l2(const float* dout, const void* out, int64_t out_plane, const float* x, const float* mean, const float* invstd,
                    const float* gamma, const float* xhat_amax, void* dx, int64_t dx_plane, float* dx_amax, float* dres, float* ws,
-                   int64_t M, int C, int relu, const uint8_t* relu_mask, onda_stream_t s);
+                   int64_t M, int C, int relu, const uint8_t* relu_mask, int64_t split, onda_stream_t s);
 
 /* onda_conv2d_wgrad slabs with both operands pre-split: [pixel][channel] limb planes in, LDS-DMA + transposed LDS reads
  * (ds_read_b64_tr_b16), tiles of 256 x 128 or 128 x 128 (output x input channels) per tap and pixel range */

@@ -1660,7 +1660,7 @@ bool l2_small_ring2() {
   return on != 0;
 }
 
-L2Schedule l2_schedule(long long M, int Cout, int taps, int Cin, bool have_ws) {
+L2Schedule l2_schedule(long long M, int Cout, int taps, int Cin, bool have_ws, long long stat_split = 0) {
   L2Schedule q;
   q.variant = onda_conv_l2_variant(M, Cout);
   q.BM = q.variant == 1 ? 128 : 256;
@@ -1681,6 +1681,11 @@ L2Schedule l2_schedule(long long M, int Cout, int taps, int Cin, bool have_ws) {
     if (force == 1 || !have_ws) q.balanced = false;
     else if (force == 2) q.balanced = q.rem != 0;
   }
+  // Two row groups with separate BatchNorm statistics (OndaConv.stat_split): the statistics row of the tile that straddles
+  // the boundary is split by onda_bn_finalize_l2, which needs that row to cover the WHOLE tile -- a stream-K remainder tile
+  // spreads its statistics over sub-block rows.  Remainder tiles are the last ones; keep the straddler out of their tile rows
+  // (only tiny problems -- fewer tiles than two rounds -- lose their balanced schedule to this).
+  if (q.balanced && stat_split > 0 && stat_split % q.BM != 0 && stat_split / q.BM >= (tiles - q.rem) / q.tilesN) q.balanced = false;
   return q;
 }
 }  // namespace
@@ -1689,6 +1694,11 @@ extern "C" {
 
 /* rows of the `stats` partials the conv will write for this problem (tile rows + the extra rows of a stream-K remainder) */
 int onda_conv_l2_tiles_m(int64_t M, int Cout, int taps, int Cin) { return l2_schedule(M, Cout, taps, Cin, true).stats_rows_total(); }
+int onda_conv_l2_tiles_m_split(int64_t M, int Cout, int taps, int Cin, int64_t stat_split, int* tile_rows) {
+  const L2Schedule q = l2_schedule(M, Cout, taps, Cin, true, stat_split);
+  if (tile_rows) *tile_rows = q.BM;
+  return q.stats_rows_total();
+}
 
 static int l2_fwd_impl(const void* xl, int64_t xplane, const float* xamax, const void* w2, const float* wamax, float* y,
                        const float* scale, const float* shift, const float* residual, float* stats, int stats_rows, float* ws,
@@ -1739,7 +1749,8 @@ static int l2_fwd_impl(const void* xl, int64_t xplane, const float* xamax, const
   k.M = (int)M;
   k.taps = c->kh * c->kw;
   k.kcper = c->Cin / 32;
-  const L2Schedule q = l2_schedule(M, c->Cout, k.taps, c->Cin, true);
+  ONDA_REQUIRE(c->stat_split >= 0 && c->stat_split < M);
+  const L2Schedule q = l2_schedule(M, c->Cout, k.taps, c->Cin, true, stats ? (long long)c->stat_split : 0);
   k.tilesM = q.tilesM;
   k.tilesN = q.tilesN;
   const size_t limb_elems = (size_t)c->Cout * k.taps * c->Cin;  // weight planes are [Cout][taps*Cin]

@@ -167,30 +167,68 @@ __device__ __forceinline__ void reduce_rows16(const float* __restrict__ partials
 
 // Tile partials [tiles][4][C] = (sum, sum of squares, min, max) -> mean, invstd, running statistics, xhat_amax[C] =
 // max|(x - mean) * invstd| (for the backward bound) and the bound of max|out| folded into out_amax.  16 channels per workgroup.
+//
+// ROW GROUPS (the student's source-replay and target micro-batches normalised in ONE pass, each with its own batch
+// statistics; blockIdx.y = group): the GEMM rows [0, split) are group 0, [split, M) group 1; mean / invstd / xhat_amax are
+// [2][C].  Partial row i covers the GEMM rows [i*bm, (i+1)*bm); the ONE row that straddles `split` (ts = split / bm, when
+// split is not a multiple of bm -- every feature grid of this network leaves 4 rows over) is counted whole with group 1
+// and corrected by the sums over its group-0 rows, read straight from the conv output y (a few rows x 16 channels per
+// workgroup): group 0 adds them, group 1 subtracts them.  Extrema only have to BOUND a group's: group 1 keeps the whole
+// row's.  (The host guarantees that the straddling tile is not a stream-K remainder tile: csrc/conv_l2.hip, l2_schedule.)
+// run_group: the group whose statistics move the running buffers (-1: none).
 __global__ __launch_bounds__(256) void bn_finalize_l2_kernel(const float* __restrict__ partials, int tiles, int C, double count, float eps,
                                                              float* mean, float* invstd, float* rmean, float* rvar, int64_t* nbt,
                                                              float momentum, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, const float* __restrict__ res_amax,
-                                                             int relu, float* __restrict__ xhat_amax, float* __restrict__ out_amax) {
-  if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) *nbt += 1;
+                                                             int relu, float* __restrict__ xhat_amax, float* __restrict__ out_amax,
+                                                             long long split, int bm, int run_group, const float* __restrict__ y,
+                                                             int ldy) {
+  const int g = blockIdx.y;
+  if (blockIdx.x == 0 && g == 0 && threadIdx.x == 0 && nbt) *nbt += 1;
+  int row0 = 0, nrows = tiles;
+  if (split > 0) {
+    const int ts = (int)(split / bm);
+    if (g == 0) nrows = ts; else row0 = ts, nrows = tiles - ts;
+    count = g == 0 ? (double)split : count - (double)split;
+  }
   double sum[2];
   float ext[2];
-  reduce_rows16<4, 2, true>(partials, tiles, C, blockIdx.x * 16, sum, ext);
+  reduce_rows16<4, 2, true>(partials + (size_t)row0 * 4 * C, nrows, C, blockIdx.x * 16, sum, ext);
   const int ch = blockIdx.x * 16 + threadIdx.x;
   float bound = 0.f;
   if (threadIdx.x < 16 && ch < C) {
+    if (split > 0 && split % bm != 0) {  // the group-0 rows of the straddling tile
+      double c1 = 0.0, c2 = 0.0;
+      float mn = 3.0e38f, mx = -3.0e38f;
+      for (long long r = split - split % bm; r < split; ++r) {
+        const float v = y[(size_t)r * ldy + ch];
+        c1 += (double)v;
+        c2 += (double)v * (double)v;
+        mn = fminf(mn, v);
+        mx = fmaxf(mx, v);
+      }
+      if (g == 0) {
+        sum[0] += c1;
+        sum[1] += c2;
+        ext[0] = fminf(ext[0], mn);
+        ext[1] = fmaxf(ext[1], mx);
+      } else {
+        sum[0] -= c1;
+        sum[1] -= c2;
+      }
+    }
     const double mu = sum[0] / count;
     double var = sum[1] / count - mu * mu;
     if (var < 0.0) var = 0.0;
     const float muf = (float)mu, is = (float)(1.0 / sqrt(var + (double)eps));
     const float lo = (ext[0] - muf) * is, hi = (ext[1] - muf) * is;
-    const float g = gamma[ch], b = beta[ch];
-    const float f_lo = lo * g + b, f_hi = hi * g + b;
+    const float gm = gamma[ch], b = beta[ch];
+    const float f_lo = lo * gm + b, f_hi = hi * gm + b;
     bound = relu ? fmaxf(0.f, fmaxf(f_lo, f_hi)) : fmaxf(fabsf(f_lo), fabsf(f_hi));  // behind a ReLU only the positive side counts
-    mean[ch] = muf;
-    invstd[ch] = is;
-    xhat_amax[ch] = fmaxf(fabsf(lo), fabsf(hi));
-    if (rmean) {
+    mean[g * C + ch] = muf;
+    invstd[g * C + ch] = is;
+    xhat_amax[g * C + ch] = fmaxf(fabsf(lo), fabsf(hi));
+    if (rmean && (split <= 0 || g == run_group)) {
       const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
       rmean[ch] = (1.f - momentum) * rmean[ch] + momentum * muf;
       rvar[ch] = (1.f - momentum) * rvar[ch] + momentum * (float)unbiased;
@@ -202,14 +240,16 @@ __global__ __launch_bounds__(256) void bn_finalize_l2_kernel(const float* __rest
   amax_update_block(out_amax, bound, red);
 }
 
-// out limbs = [relu]( (x - mean)*invstd*gamma + beta [+ residual limbs] ), 8 channels per thread
+// out limbs = [relu]( (x - mean)*invstd*gamma + beta [+ residual limbs] ), 8 channels per thread.
+// group1_at > 0: two row groups -- 8-channel items [0, group1_at) normalise with the statistics at mean / invstd, the others with
+// those at mean + C / invstd + C (gamma / beta are shared).
 __global__ __launch_bounds__(256) void bn_apply_l2_kernel(const float* __restrict__ x, const float* __restrict__ mean,
                                                           const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, const _Float16* __restrict__ res,
                                                           size_t res_plane, const float* __restrict__ res_amax,
                                                           _Float16* __restrict__ out, size_t out_plane,
                                                           const float* __restrict__ out_amax, size_t total8, int C, int relu,
-                                                          unsigned char* __restrict__ mask) {
+                                                          unsigned char* __restrict__ mask, size_t group1_at) {
   const int c8 = C / 8;
   const float so = scale_of(out_amax).s;
   const float ri = res ? scale_of(res_amax).inv : 0.f;
@@ -217,11 +257,16 @@ __global__ __launch_bounds__(256) void bn_apply_l2_kernel(const float* __restric
   // a thread stays on its 8 channels, so their parameters are loaded once
   const size_t e0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int col = (int)(e0 % c8) * 8;
-  const f32x4 sc0 = LD4(invstd + col) * LD4(gamma + col), sc1 = LD4(invstd + col + 4) * LD4(gamma + col + 4);
+  const f32x4 ga0 = LD4(gamma + col), ga1 = LD4(gamma + col + 4);
+  const f32x4 sc0 = LD4(invstd + col) * ga0, sc1 = LD4(invstd + col + 4) * ga1;
   const f32x4 mu0 = LD4(mean + col), mu1 = LD4(mean + col + 4), be0 = LD4(beta + col), be1 = LD4(beta + col + 4);
+  const int g1 = group1_at > 0 ? C : 0;  // (one group: the second set is the first)
+  const f32x4 tc0 = LD4(invstd + g1 + col) * ga0, tc1 = LD4(invstd + g1 + col + 4) * ga1;
+  const f32x4 nu0 = LD4(mean + g1 + col), nu1 = LD4(mean + g1 + col + 4);
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   auto one = [&](size_t e, f32x4 x0, f32x4 x1, u32x4 r1, u32x4 r2) {
-    f32x4 v0 = (x0 - mu0) * sc0 + be0, v1 = (x1 - mu1) * sc1 + be1;
+    const bool second = group1_at > 0 && e >= group1_at;
+    f32x4 v0 = (x0 - (second ? nu0 : mu0)) * (second ? tc0 : sc0) + be0, v1 = (x1 - (second ? nu1 : mu1)) * (second ? tc1 : sc1) + be1;
     if (res) {
       f32x4 q0, q1;
       join8(r1, r2, q0, q1);
@@ -315,23 +360,27 @@ __device__ __forceinline__ f32x4 relu_mask4(const _Float16* __restrict__ out, co
   return g;
 }
 
+// Row groups (split > 0): chunks [0, chunks0) walk the rows [0, split) with the statistics of group 0, the others the rows
+// [split, M) with those at mean + C / invstd + C -- a chunk never crosses the boundary.
 __global__ __launch_bounds__(256) void bn_bwd_reduce_l2_kernel(const float* __restrict__ dout, const _Float16* __restrict__ out,
                                                                size_t out_plane, const float* __restrict__ x,
                                                                const float* __restrict__ mean, const float* __restrict__ invstd,
                                                                float* __restrict__ dres, int64_t M, int C, int relu, int cx,
                                                                int64_t rows_per_chunk, float* __restrict__ partials,
-                                                               const unsigned char* __restrict__ mask) {
+                                                               const unsigned char* __restrict__ mask, int64_t split, int chunks0) {
   __shared__ f32x4 red[3][256];
   const int t = threadIdx.x;
   const int ry_n = 256 / cx;
   const int tx = t % cx, ty = t / cx;
   const int col = (blockIdx.x * cx + tx) * 4;
   const int chunk = blockIdx.y;
-  const int64_t r0 = (int64_t)chunk * rows_per_chunk;
-  const int64_t r1 = min(M, r0 + rows_per_chunk);
+  const bool second = split > 0 && chunk >= chunks0;
+  const int64_t r0 = second ? split + (int64_t)(chunk - chunks0) * rows_per_chunk : (int64_t)chunk * rows_per_chunk;
+  const int64_t r1 = min(split > 0 && !second ? split : M, r0 + rows_per_chunk);
   f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f}, s3 = {0.f, 0.f, 0.f, 0.f};
   if (col < C) {
-    const f32x4 mu = LD4(mean + col), is = LD4(invstd + col);
+    const int gofs = second ? C : 0;
+    const f32x4 mu = LD4(mean + gofs + col), is = LD4(invstd + gofs + col);
     for (int64_t r = r0 + ty; r < r1; r += ry_n) {
       const size_t o = (size_t)r * C + col;
       f32x4 g = LD4(dout + o);
@@ -363,57 +412,71 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_l2_kernel(const float* __re
   }
 }
 
-// pass 2: chunk partials [chunks][3][C] -> sums[2][C] and the bound of max|dx| into dx_amax; 16 channels per workgroup
-__global__ __launch_bounds__(256) void bn_bwd_sums_l2_kernel(const float* __restrict__ partials, int chunks, int C, double inv_m,
-                                                             const float* __restrict__ gamma, const float* __restrict__ invstd,
-                                                             const float* __restrict__ xhat_amax, float* __restrict__ sums,
-                                                             float* __restrict__ dx_amax) {
+// pass 2: chunk partials [chunks][3][C] -> sums[2][C] and the bound of max|dx| into dx_amax; 16 channels per workgroup.
+// Row groups: blockIdx.y = group; its chunk rows are [0, chunks0) / [chunks0, chunks), its results go to sums + g*2*C, its
+// statistics sit at invstd + g*C / xhat_amax + g*C.
+__global__ __launch_bounds__(256) void bn_bwd_sums_l2_kernel(const float* __restrict__ partials, int chunks, int C, double inv_m0,
+                                                             double inv_m1, const float* __restrict__ gamma,
+                                                             const float* __restrict__ invstd, const float* __restrict__ xhat_amax,
+                                                             float* __restrict__ sums, float* __restrict__ dx_amax, int chunks0) {
+  const int g = blockIdx.y;
+  const int row0 = g == 0 ? 0 : chunks0, nrows = gridDim.y == 1 ? chunks : (g == 0 ? chunks0 : chunks - chunks0);
+  const double inv_m = g == 0 ? inv_m0 : inv_m1;
   double sum[2];
   float ext[1];
-  reduce_rows16<3, 2, false>(partials, chunks, C, blockIdx.x * 16, sum, ext);
+  reduce_rows16<3, 2, false>(partials + (size_t)row0 * 3 * C, nrows, C, blockIdx.x * 16, sum, ext);
   const int ch = blockIdx.x * 16 + threadIdx.x;
   float bound = 0.f;
   if (threadIdx.x < 16 && ch < C) {
-    sums[ch] = (float)sum[0];
-    sums[C + ch] = (float)sum[1];
-    bound = fabsf(gamma[ch] * invstd[ch]) * (ext[0] + (float)(fabs(sum[0]) * inv_m) + xhat_amax[ch] * (float)(fabs(sum[1]) * inv_m));
+    sums[g * 2 * C + ch] = (float)sum[0];
+    sums[g * 2 * C + C + ch] = (float)sum[1];
+    bound = fabsf(gamma[ch] * invstd[g * C + ch]) *
+            (ext[0] + (float)(fabs(sum[0]) * inv_m) + xhat_amax[g * C + ch] * (float)(fabs(sum[1]) * inv_m));
   }
   bound *= 1.000001f;
   __shared__ float red[4];
   amax_update_block(dx_amax, bound, red);
 }
 
-// pass 3: dx limbs
+// pass 3: dx limbs.  group1_at > 0: the 8-channel items from there on belong to row group 1 (statistics at + C, sums at + 2C,
+// 1 / M of that group)
 __global__ __launch_bounds__(256) void bn_bwd_apply_l2_kernel(const float* __restrict__ dout, const _Float16* __restrict__ out,
                                                               size_t out_plane, const float* __restrict__ x,
                                                               const float* __restrict__ mean, const float* __restrict__ invstd,
                                                               const float* __restrict__ gamma, const float* __restrict__ sums,
                                                               _Float16* __restrict__ dx, size_t dx_plane,
                                                               const float* __restrict__ dx_amax, size_t total8, int C, float inv_m,
-                                                              int relu, const unsigned char* __restrict__ mask) {
+                                                              int relu, const unsigned char* __restrict__ mask, size_t group1_at,
+                                                              float inv_m1) {
   const int c8 = C / 8;
   const float sd = scale_of(dx_amax).s;
   const size_t e0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int col = (int)(e0 % c8) * 8;  // fixed per thread (see bn_apply_l2_kernel)
-  f32x4 is[2], mu[2], gi[2], m1[2], m2[2];
+  f32x4 is[2][2], mu[2][2], gi[2][2], m1[2][2], m2[2][2];
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const int cc = col + 4 * h;
-    is[h] = LD4(invstd + cc);
-    mu[h] = LD4(mean + cc);
-    gi[h] = LD4(gamma + cc) * is[h];
-    m1[h] = LD4(sums + cc) * inv_m;
-    m2[h] = LD4(sums + C + cc) * inv_m;
+  for (int g = 0; g < 2; ++g) {
+    const int go = g && group1_at > 0 ? C : 0;
+    const float im = g && group1_at > 0 ? inv_m1 : inv_m;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int cc = col + 4 * h;
+      is[g][h] = LD4(invstd + go + cc);
+      mu[g][h] = LD4(mean + go + cc);
+      gi[g][h] = LD4(gamma + cc) * is[g][h];
+      m1[g][h] = LD4(sums + 2 * go + cc) * im;
+      m2[g][h] = LD4(sums + 2 * go + C + cc) * im;
+    }
   }
   for (size_t e = e0; e < total8; e += (size_t)gridDim.x * blockDim.x) {
+    const bool second = group1_at > 0 && e >= group1_at;
     f32x4 v[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const size_t o = e * 8 + 4 * h;
       f32x4 g = LD4S(dout + o);
       if (relu) g = relu_mask4(out, mask, o, g);
-      const f32x4 xh = (LD4S(x + o) - mu[h]) * is[h];
-      v[h] = gi[h] * (g - m1[h] - xh * m2[h]);
+      const f32x4 xh = (LD4S(x + o) - (second ? mu[1][h] : mu[0][h])) * (second ? is[1][h] : is[0][h]);
+      v[h] = (second ? gi[1][h] : gi[0][h]) * (g - (second ? m1[1][h] : m1[0][h]) - xh * (second ? m2[1][h] : m2[0][h]));
     }
     u32x4 l1, l2;
     split8(v[0] * sd, v[1] * sd, l1, l2);
@@ -438,49 +501,67 @@ extern "C" {
 
 int onda_bn_finalize_l2(const float* partials, int tiles, int C, int64_t count, float eps, float* mean, float* invstd,
                         float* running_mean, float* running_var, int64_t* nbt, float momentum, const float* gamma,
-                        const float* beta, const float* res_amax, int relu, float* xhat_amax, float* out_amax, onda_stream_t s) {
+                        const float* beta, const float* res_amax, int relu, float* xhat_amax, float* out_amax, int64_t split,
+                        int tile_rows, int run_group, const float* y, int ldy, onda_stream_t s) {
   ONDA_REQUIRE(partials && mean && invstd && gamma && beta && xhat_amax && out_amax && tiles >= 1 && C >= 4 && C % 4 == 0 && count >= 1);
+  ONDA_REQUIRE(split >= 0 && split < count && (split == 0 || (tile_rows > 0 && y && ldy >= C && split / tile_rows < tiles)));
   if (!ONDA_ALIGNED16(partials)) return ONDA_EALIGN;
-  hipLaunchKernelGGL(bn_finalize_l2_kernel, dim3((C + 15) / 16), dim3(256), 0, ONDA_STREAM(s), partials, tiles, C, (double)count, eps,
-                     mean, invstd, running_mean, running_var, nbt, momentum, gamma, beta, res_amax, relu, xhat_amax, out_amax);
+  hipLaunchKernelGGL(bn_finalize_l2_kernel, dim3((C + 15) / 16, split > 0 ? 2 : 1), dim3(256), 0, ONDA_STREAM(s), partials, tiles, C,
+                     (double)count, eps, mean, invstd, running_mean, running_var, nbt, momentum, gamma, beta, res_amax, relu, xhat_amax,
+                     out_amax, (long long)split, tile_rows > 0 ? tile_rows : 1, run_group, y, ldy);
   return ONDA_LAUNCH_RESULT();
 }
 
 int onda_bn_apply_l2(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
                      const void* res, int64_t res_plane, const float* res_amax, void* out, int64_t out_plane,
-                     const float* out_amax, int64_t M, int C, int relu, uint8_t* relu_mask, onda_stream_t s) {
+                     const float* out_amax, int64_t M, int C, int relu, uint8_t* relu_mask, int64_t split, onda_stream_t s) {
   ONDA_REQUIRE(x && mean && invstd && gamma && beta && out && out_amax && C % 8 == 0 && out_plane % 8 == 0 && (!res || res_amax));
   ONDA_REQUIRE(256 % (C / 8) == 0 || (C / 8) % 256 == 0);  // a thread keeps its channel group across the grid stride
+  ONDA_REQUIRE(split >= 0 && split < M);
   if (!ONDA_ALIGNED16(x) || !ONDA_ALIGNED16(out) || (res && !ONDA_ALIGNED16(res))) return ONDA_EALIGN;
   const size_t total8 = (size_t)M * C / 8;
   hipLaunchKernelGGL(bn_apply_l2_kernel, dim3(ew_grid(total8)), dim3(256), 0, ONDA_STREAM(s), x, mean, invstd, gamma, beta,
                      static_cast<const _Float16*>(res), (size_t)res_plane, res_amax, static_cast<_Float16*>(out), (size_t)out_plane,
-                     out_amax, total8, C, relu, relu_mask);
+                     out_amax, total8, C, relu, relu_mask, (size_t)split * C / 8);
   return ONDA_LAUNCH_RESULT();
+}
+
+// chunk rows of the backward reduction with row groups: group 0 first, then group 1 (a chunk never crosses `split`)
+static inline void bwd_chunks(const ColPlan3& p, int64_t M, int64_t split, int& chunks0, int& chunks) {
+  if (split <= 0) {
+    chunks0 = chunks = p.chunks;
+    return;
+  }
+  chunks0 = (int)((split + p.rows_per_chunk - 1) / p.rows_per_chunk);
+  chunks = chunks0 + (int)((M - split + p.rows_per_chunk - 1) / p.rows_per_chunk);
 }
 
 int64_t onda_bn_bwd_l2_ws(int64_t M, int C) {
   const ColPlan3 p = col_plan3(M, C);
-  return (int64_t)p.chunks * 3 * C + 2 * C;
+  return (int64_t)(p.chunks + 1) * 3 * C + 4 * C;  // (+1 chunk row: two row groups round up separately; sums[2][2][C])
 }
 
 int onda_bn_bwd_l2(const float* dout, const void* out, int64_t out_plane, const float* x, const float* mean, const float* invstd,
                    const float* gamma, const float* xhat_amax, void* dx, int64_t dx_plane, float* dx_amax, float* dres, float* ws,
-                   int64_t M, int C, int relu, const uint8_t* relu_mask, onda_stream_t s) {
+                   int64_t M, int C, int relu, const uint8_t* relu_mask, int64_t split, onda_stream_t s) {
   ONDA_REQUIRE(dout && x && mean && invstd && gamma && xhat_amax && dx && dx_amax && ws && C % 8 == 0 && (!relu || out || relu_mask));
   ONDA_REQUIRE(256 % (C / 8) == 0 || (C / 8) % 256 == 0);
+  ONDA_REQUIRE(split >= 0 && split < M);
   if (!ONDA_ALIGNED16(dout) || !ONDA_ALIGNED16(x) || !ONDA_ALIGNED16(dx) || (out && !ONDA_ALIGNED16(out))) return ONDA_EALIGN;
   const ColPlan3 p = col_plan3(M, C);
-  float* sums = ws + (size_t)p.chunks * 3 * C;
+  int chunks0, chunks;
+  bwd_chunks(p, M, split, chunks0, chunks);
+  float* sums = ws + (size_t)(p.chunks + 1) * 3 * C;
   hipStream_t st = ONDA_STREAM(s);
-  hipLaunchKernelGGL(bn_bwd_reduce_l2_kernel, dim3(p.gridx, p.chunks), dim3(256), 0, st, dout, static_cast<const _Float16*>(out),
-                     (size_t)out_plane, x, mean, invstd, dres, M, C, relu, p.cx, p.rows_per_chunk, ws, relu_mask);
-  hipLaunchKernelGGL(bn_bwd_sums_l2_kernel, dim3((C + 15) / 16), dim3(256), 0, st, ws, p.chunks, C, 1.0 / (double)M, gamma, invstd,
-                     xhat_amax, sums, dx_amax);
+  hipLaunchKernelGGL(bn_bwd_reduce_l2_kernel, dim3(p.gridx, chunks), dim3(256), 0, st, dout, static_cast<const _Float16*>(out),
+                     (size_t)out_plane, x, mean, invstd, dres, M, C, relu, p.cx, p.rows_per_chunk, ws, relu_mask, split, chunks0);
+  const double inv_m0 = 1.0 / (double)(split > 0 ? split : M), inv_m1 = 1.0 / (double)(M - split);
+  hipLaunchKernelGGL(bn_bwd_sums_l2_kernel, dim3((C + 15) / 16, split > 0 ? 2 : 1), dim3(256), 0, st, ws, chunks, C, inv_m0, inv_m1,
+                     gamma, invstd, xhat_amax, sums, dx_amax, chunks0);
   const size_t total8 = (size_t)M * C / 8;
   hipLaunchKernelGGL(bn_bwd_apply_l2_kernel, dim3(ew_grid(total8)), dim3(256), 0, st, dout, static_cast<const _Float16*>(out),
                      (size_t)out_plane, x, mean, invstd, gamma, sums, static_cast<_Float16*>(dx), (size_t)dx_plane, dx_amax, total8,
-                     C, (float)(1.0 / (double)M), relu, relu_mask);
+                     C, (float)inv_m0, relu, relu_mask, (size_t)split * C / 8, (float)inv_m1);
   return ONDA_LAUNCH_RESULT();
 }
 

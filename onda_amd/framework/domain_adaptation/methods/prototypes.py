@@ -35,6 +35,15 @@ from onda_amd.framework.model import deeplabv2
 from onda_amd.framework.utils.monitoring import Monitor
 
 
+import os
+
+# the student's source-replay pass and its target pass as ONE pass over both batches (ops.row_groups); 0 = one after the
+# other, as the reference orders them.  PAIR_MAX_PIXELS: image pixels of both batches together up to which the paired pass
+# is used (both autograd graphs are alive at once; 1024x2048 batches of 4 + 4 do not fit beside the four models)
+PAIR_STUDENT = os.environ.get("ONDA_PAIR_STUDENT", "1") != "0"
+PAIR_MAX_PIXELS = int(os.environ.get("ONDA_PAIR_MAX_PIXELS", str(6 << 20)))
+
+
 def regular_loss(regularizer, activation):
     """"MRKLD": -mean(log_softmax(activation)) over every element (reference :35-38)."""
     if regularizer == "MRKLD":
@@ -400,14 +409,15 @@ class online_proDA(da_model):
         t["image"], t["student_mask"] = image, student_mask
         return t
 
-    def _target_finish(self, batch, t, deferred, fetch=None):
+    def _target_finish(self, batch, t, deferred, fetch=None, out=None):
         """Second half: the student's forward pass (launched BEFORE the switch scalars are read: `fetch`, given for the
-        first micro-batch of a step), prior mixing, pseudo-labels, the losses.  The prototype EMA and the monitor
-        entries stay pending (``_settle``)."""
+        first micro-batch of a step; `out`: its logits when the paired pass has already produced them), prior mixing,
+        pseudo-labels, the losses.  The prototype EMA and the monitor entries stay pending (``_settle``)."""
         image = t["image"]
-        if t["student_mask"] is not None:
-            deeplabv2.force_mask(t["student_mask"])
-        out = self.model(image)[1]["out"]
+        if out is None:
+            if t["student_mask"] is not None:
+                deeplabv2.force_mask(t["student_mask"])
+            out = self.model(image)[1]["out"]
         with torch.no_grad():
             conf_model, _, cls_model = ops.softmax_stats(out, want_argmax=True)
             deferred.put("model", conf_model)
@@ -538,6 +548,45 @@ class online_proDA(da_model):
             self.bn.exchange()
         return log
 
+    # ---- the student's two passes as one ---------------------------------------------------------------------------------
+    def _pairable(self, batches_source, batch_target):
+        """Can the student's source-replay pass and its target pass run as ONE pass over both batches (row groups:
+        ops.row_groups)?  The reference runs them one after the other through the same weights (:418-450), each with its
+        own BatchNorm batch statistics, the source pass with frozen running statistics (BN_POLICY "freeze"): the kernels
+        keep exactly that per group, so the result is the same arithmetic with every launch covering twice the rows."""
+        if not (PAIR_STUDENT and ops.row_groups_supported() and self.cfg_spec.BN_POLICY == "freeze"
+                and len(batches_source) == 1 and self.cfg.TRAINING.REPLAY_BUFFER > 0 and self.model.training
+                and not self.model.multi_level):  # (the auxiliary head would draw its Dropout2d mask in another order)
+            return False
+        src, trg = batches_source[0]["image"], batch_target["image"]
+        if tuple(src.shape[1:]) != tuple(trg.shape[1:]):
+            return False
+        # (both graphs are alive at once: 2 x 16 GB of activations + as much in limb planes at 512x1024, bs 4 + 4)
+        return (src.shape[0] + trg.shape[0]) * src.shape[2] * src.shape[3] <= PAIR_MAX_PIXELS
+
+    def _source_mask(self, batch):
+        """The Dropout2d mask of the source pass, drawn where the reference's source forward draws it (first in a step)."""
+        image = batch["image"]
+        return deeplabv2.draw_mask(self.model, image.shape[0], self.device)
+
+    def _student_pair(self, batch_source, src_mask, batch_target, t, deferred, fetch):
+        """Both student passes as one: returns (source log entries, target loss entries); the caller sums the two totals
+        and runs ONE backward pass."""
+        src_image = batch_source["image"].to(self.device, non_blocking=True)
+        n_src = src_image.shape[0]
+        image = torch.cat([src_image, t["image"]], 0)
+        masks = [m for m in (src_mask, t["student_mask"]) if m is not None]
+        if masks:
+            deeplabv2.force_mask(torch.cat(masks, 0))
+        with ops.row_groups(n_src):
+            out = self.model(image)[1]["out"]
+        out_src, out_trg = out[:n_src], out[n_src:]
+        label = batch_source["stored_predictions"] if "stored_predictions" in batch_source.keys() else batch_source["label_res"]
+        w_ce, w_rce = _positive(self.cfg_spec.BUFF_CE), _positive(self.cfg_spec.BUFF_RCE)
+        total, ce, rc, _ = ops.seg_losses(out_src, label.long().to(self.device), w_ce, w_rce, 0.0)
+        src_log = {"buff_ce_loss": ce if w_ce > 0 else 0, "buff_rce_loss": rc if w_rce > 0 else 0, "buff_loss": total}
+        return src_log, self._target_finish(batch_target, t, deferred, fetch, out=out_trg)
+
     def step(self, batches_source, batch_target):
         """One adaptation step: source replay fwd+bwd (BN statistics frozen), teacher / static fwd, target fwd, (dynamic
         fwd), pseudo-labels, target bwd, prototype EMA, optimizer step."""
@@ -551,12 +600,19 @@ class online_proDA(da_model):
         n = len(shards)
         scale = 1.0 / n
         deferred, src_log, prepared = _Scalars(), {}, []
+        # the student's source and target passes of a micro-batch as ONE pass over both batches, where the method's settings
+        # allow it (every micro-batch of a step the same way)
+        paired = all(self._pairable(bs, bt) for bs, bt in shards)
+        src_masks = []
         # source replay (gradients accumulate) and the no-grad teacher / static passes of every micro-batch; per
         # micro-batch the Dropout2d masks are drawn in the reference's order: source student, target student, teacher
         for i, (batches_source, batch_target) in enumerate(shards):
-            log = self._source_replay(batches_source, scale)
-            if i == 0:
-                src_log = log
+            if paired:
+                src_masks.append(self._source_mask(batches_source[0]))
+            else:
+                log = self._source_replay(batches_source, scale)
+                if i == 0:
+                    src_log = log
             prepared.append(self._target_prepare(batch_target))
         fetch = self._switch_scalars(prepared)  # ONE decision per step, from the mean over micro-batches and ranks
         run0 = None
@@ -568,10 +624,17 @@ class online_proDA(da_model):
         for i, ((_, batch_target), t) in enumerate(zip(shards, prepared)):
             if run0 is not None:
                 torch._foreach_copy_(bufs, run0)
-            losses = self._target_finish(batch_target, t, deferred, fetch if i == 0 else None)
+            if paired:
+                log, losses = self._student_pair(shards[i][0][0], src_masks[i], batch_target, t, deferred, fetch if i == 0 else None)
+                if i == 0:
+                    src_log = log
+                both = log["buff_loss"] + losses["Total target loss"]  # the reference's two backward passes, summed
+            else:
+                losses = self._target_finish(batch_target, t, deferred, fetch if i == 0 else None)
+                both = losses["Total target loss"]
             if i == n - 1:
                 self._grad_sync.arm()  # buckets go out as the last backward pass completes them
-            (losses["Total target loss"] if n == 1 else losses["Total target loss"] * scale).backward()
+            (both if n == 1 else both * scale).backward()
             if i == 0:
                 first_log = losses
             if run0 is not None:

@@ -148,9 +148,41 @@ def predicates_supported():
     return CONV_MODE == "f16x2" and H2_PATH == "dma"
 
 
-def _desc(B, Hi, Wi, Cin, Ho, Wo, Cout, k, stride, dil, pad, ldx, ldy, ldr=0, out_os=1, Hf=None, Wf=None, relu=0):
+def _desc(B, Hi, Wi, Cin, Ho, Wo, Cout, k, stride, dil, pad, ldx, ldy, ldr=0, out_os=1, Hf=None, Wf=None, relu=0, split=0):
     return OndaConv(B, Hi, Wi, Cin, Ho, Wo, Cout, k, k, stride, dil, pad, ldx, ldy, ldr, out_os,
-                    Ho if Hf is None else Hf, Wo if Wf is None else Wf, int(relu), _p(PREDICATE))
+                    Ho if Hf is None else Hf, Wo if Wf is None else Wf, int(relu), _p(PREDICATE), int(split))
+
+
+# Row groups: inside ``with ops.row_groups(n):`` the first n images of every batch that passes a train-mode BatchNorm are
+# one micro-batch and the rest another -- each normalised with its OWN batch statistics, only the second one moving the
+# running statistics (the student's source-replay pass under BN_POLICY "freeze" and its target pass, prototypes.py:418-450,
+# as ONE pass over both batches: every convolution, every weight gradient and every BatchNorm reduction is launched once
+# instead of twice).  Only the pre-split kernels know about groups; the other paths raise.
+ROW_GROUPS = 0
+
+
+class row_groups:
+    def __init__(self, first_images):
+        self.first = int(first_images)
+
+    def __enter__(self):
+        global ROW_GROUPS
+        self.old, ROW_GROUPS = ROW_GROUPS, self.first
+        return self
+
+    def __exit__(self, *exc):
+        global ROW_GROUPS
+        ROW_GROUPS = self.old
+        return False
+
+
+def row_groups_supported():
+    return CONV_MODE == "f16x2" and H2_PATH == "dma" and LIMB_ONLY
+
+
+def _group_split(B, H, W):
+    """GEMM row at which the second row group of a [B,H,W,*] activation starts (0: one group)."""
+    return ROW_GROUPS * H * W if 0 < ROW_GROUPS < B else 0
 
 
 _CONV_WS = {}
@@ -427,10 +459,15 @@ def conv_forward(x, wp, k, stride, dil, pad, cout, out=None, scale=None, shift=N
     if not l2 and is_limb_only(x):
         raise RuntimeError("onda_amd: a limb-only activation reached a conv that does not take limb planes")
     stats_rows = 4 if (l2 and want_stats == 4) else 2  # 4: + per-channel min / max, for the limb-writing BatchNorm
+    split = 0
     if want_stats:
-        tiles = query("onda_conv_l2_tiles_m", B * Ho * Wo, cout, k * k, Cin) if l2 else query("onda_conv_tiles_m", B * Ho * Wo)
+        split = _group_split(B, Ho, Wo)
+        if split and stats_rows != 4:
+            raise RuntimeError("onda_amd: row groups (ops.row_groups) need the pre-split conv + limb-writing BatchNorm path")
+        tiles = (query("onda_conv_l2_tiles_m_split", B * Ho * Wo, cout, k * k, Cin, split, None) if l2
+                 else query("onda_conv_tiles_m", B * Ho * Wo))
         stats = torch.empty(tiles, stats_rows, cout, device=x.device, dtype=torch.float32)
-    d = _desc(B, Hi, Wi, Cin, Ho, Wo, cout, k, stride, dil, pad, ldx, ldy, ldr, relu=relu)
+    d = _desc(B, Hi, Wi, Cin, Ho, Wo, cout, k, stride, dil, pad, ldx, ldy, ldr, relu=relu, split=split)
     if l2:
         xl = limbs_of(x)
         d.ldx = xl.ld
@@ -826,6 +863,8 @@ class BNTrainFn(torch.autograd.Function):
     def forward(ctx, y, stats, gamma, beta, residual, relu, running, momentum):
         B, H, W, C = y.shape
         M = B * H * W
+        if _group_split(B, H, W):
+            raise RuntimeError("onda_amd: row groups (ops.row_groups) need the limb-writing BatchNorm path")
         mean = torch.empty(C, device=y.device, dtype=torch.float32)
         invstd = torch.empty_like(mean)
         rm, rv, nbt = running if running is not None else (None, None, None)
@@ -888,7 +927,9 @@ class BNTrainLimbFn(torch.autograd.Function):
         B, H, W, C = y.shape
         M = B * H * W
         dev = y.device
-        mean = torch.empty(C, device=dev, dtype=torch.float32)
+        # two row groups (ops.row_groups): statistics [2][C]; only the second group moves the running statistics
+        split = _group_split(B, H, W)
+        mean = torch.empty((2 if split else 1) * C, device=dev, dtype=torch.float32)
         invstd = torch.empty_like(mean)
         xhat_amax = torch.empty_like(mean)
         rm, rv, nbt = running if running is not None else (None, None, None)
@@ -896,9 +937,10 @@ class BNTrainLimbFn(torch.autograd.Function):
         if res is not None and (res.ld != C or tuple(residual.shape) != (B, H, W, C)):
             raise RuntimeError("onda_amd: residual of a BatchNorm must be a dense [B,H,W,C] activation")
         out_amax = amax_slot(dev)
+        tile_rows = (128 if query("onda_conv_l2_variant", M, C) == 1 else 256) if split else 0
         call("onda_bn_finalize_l2", _p(stats), stats.shape[0], C, M, BN_EPS, _p(mean), _p(invstd), _p(rm), _p(rv), _p(nbt),
              float(momentum), _p(gamma), _p(beta), _p(res.amax) if res is not None else None, int(relu), _p(xhat_amax),
-             _p(out_amax), _stream())
+             _p(out_amax), split, tile_rows, 1, _p(y) if split else None, nhwc_ld(y) if split else 0, _stream())
         if running is not None:
             for t in running:
                 torch.autograd.graph.increment_version(t)
@@ -907,8 +949,9 @@ class BNTrainLimbFn(torch.autograd.Function):
         mask = torch.empty(M * C // 8, device=dev, dtype=torch.uint8) if relu and RELU_BITMASK and any(ctx.needs_input_grad) else None
         call("onda_bn_apply_l2", _p(y), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(res.planes) if res is not None else None,
              res.plane if res is not None else 0, _p(res.amax) if res is not None else None, _p(planes), M * C, _p(out_amax),
-             M, C, int(relu), _p(mask), _stream())
+             M, C, int(relu), _p(mask), split, _stream())
         lb = Limbs(planes, out_amax, C, M * C)
+        ctx.split = split
         ctx.save_for_backward(y, mean, invstd, gamma, xhat_amax)
         ctx.out_limbs = lb if relu and mask is None else None
         ctx.relu_mask = mask
@@ -935,7 +978,7 @@ class BNTrainLimbFn(torch.autograd.Function):
         ol = ctx.out_limbs
         call("onda_bn_bwd_l2", _p(dout), _p(ol.planes) if ol is not None else None, ol.plane if ol is not None else 0, _p(y),
              _p(mean), _p(invstd), _p(gamma), _p(xhat_amax), _p(planes), M * C, _p(dx_amax),
-             _p(dres) if (need_res and ctx.relu) else None, _p(ws), M, C, int(ctx.relu), _p(ctx.relu_mask), _stream())
+             _p(dres) if (need_res and ctx.relu) else None, _p(ws), M, C, int(ctx.relu), _p(ctx.relu_mask), ctx.split, _stream())
         dx = limb_only((B, H, W, C), dev, Limbs(planes, dx_amax, C, M * C))
         if need_res:
             dres = _sink_give(ctx.res_sink, dres, ctx.relu)

@@ -398,6 +398,66 @@ def test_batchnorm_train_limb_planes(C, H, W, relu, res, track):
         assert int(nbt) == 1
 
 
+@pytest.mark.parametrize("C,H,W,B,first,relu,res", [(256, 65, 129, 4, 2, True, True), (64, 33, 41, 5, 2, True, False),
+                                                    (128, 16, 16, 4, 2, False, True), (256, 9, 17, 4, 1, True, False)])
+def test_batchnorm_row_groups(C, H, W, B, first, relu, res):
+    """Two micro-batches through conv -> BatchNorm (+residual, +ReLU) -> conv as ONE launch train (ops.row_groups: the
+    student's source-replay and target batches, prototypes.py:418-450): each row group is normalised with its own batch
+    statistics, only the second one moves the running statistics -- against fp32 torch on the CPU running the two batches
+    one after the other (frozen / tracked), forward, all gradients and the running buffers.  Sizes: group boundaries inside
+    a 256-row and inside a 128-row tile (the statistics row finalize has to split), tile-aligned ones, whole rounds of tiles
+    with a stream-K remainder (4 x 65 x 129)."""
+    from onda_amd import ops
+    if not ops.row_groups_supported():
+        pytest.skip("row groups exist in the f16x2 / dma configuration only")
+    g = torch.Generator().manual_seed(C + H + B)
+    Cin = 64
+    x = torch.randn(B, Cin, H, W, generator=g)
+    x[first:] = x[first:] * 1.7 + 0.4  # the two groups have visibly different statistics
+    w1 = torch.randn(C, Cin, 1, 1, generator=g) / Cin ** 0.5
+    w2 = torch.randn(64, C, 3, 3, generator=g) / (9 * C) ** 0.5
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    r = torch.randn(B, C, H, W, generator=g) * 3 if res else None
+    rm, rv = torch.randn(C, generator=g) * 0.1, torch.rand(C, generator=g) + 0.5
+    xr, w1r, w2r = (t.clone().requires_grad_(True) for t in (x, w1, w2))
+    rr = r.clone().requires_grad_(True) if res else None
+    rm_r, rv_r = rm.clone(), rv.clone()
+    y1 = F.conv2d(xr, w1r)
+    z = torch.cat([F.batch_norm(y1[:first], None, None, gamma, beta, True, 0.1, 1e-5),
+                   F.batch_norm(y1[first:], rm_r, rv_r, gamma, beta, True, 0.1, 1e-5)], 0)
+    if res:
+        z = z + rr
+    if relu:
+        z = F.relu(z)
+    y2 = F.conv2d(z, w2r, None, 1, 2, 2)
+    gy = torch.randn(y2.shape, generator=g)
+    y2.backward(gy)
+
+    xd = nhwc(x).to(DEV).requires_grad_(True)
+    w1d, w2d = w1.to(DEV).requires_grad_(True), w2.to(DEV).requires_grad_(True)
+    rd = nhwc(r).to(DEV).requires_grad_(True) if res else None
+    rm_d, rv_d, nbt = rm.to(DEV), rv.to(DEV), torch.zeros((), dtype=torch.int64, device=DEV)
+    with ops.row_groups(first):
+        yd, stats = ops.Conv2dFn.apply(xd, w1d, None, ops._PackCache(), 1, 1, 0, 4, None)
+        zd = ops.BNTrainLimbFn.apply(yd, stats, gamma.to(DEV), beta.to(DEV), rd, relu, (rm_d, rv_d, nbt), 0.1)
+    assert ops.is_limb_only(zd) and zd.shape == (B, H, W, C)
+    lb = ops.limbs_of(zd)
+    bound, true_max = float(lb.amax.max()), float(z.detach().abs().max())
+    assert true_max <= bound * (1 + 1e-6), (bound, true_max)
+    close(nchw(ops.materialize(zd)), z, 2e-5, "bn fwd (two row groups)")
+    y2d, _ = ops.Conv2dFn.apply(zd, w2d, None, ops._PackCache(), 1, 2, 2, False, None)
+    close(nchw(y2d), y2, 3e-5, "conv on limb planes")
+    y2d.backward(nhwc(gy).to(DEV))
+    close(nchw(xd.grad), xr.grad, 2e-4, "dx through the grouped BN")
+    close(w2d.grad, w2r.grad, 1e-4, "wgrad (second conv)")
+    close(w1d.grad, w1r.grad, 2e-4, "wgrad through the grouped BN")
+    if res:
+        close(nchw(rd.grad), rr.grad, 1e-4, "bn dres")
+    close(rm_d, rm_r, 1e-5, "running mean: moved by the second group only")
+    close(rv_d, rv_r, 1e-5, "running var: moved by the second group only")
+    assert int(nbt) == 1
+
+
 def test_bn_fold_matches_eval_batchnorm():
     from onda_amd import ops
     g = torch.Generator().manual_seed(9)

@@ -1079,3 +1079,68 @@ def test_train_loop_golden(golden, tmp_path):
                 den += ((row - init[k]) ** 2).sum()
         assert (den > 0) == (who != "static.") and num ** 0.5 <= tol * den ** 0.5, (who, num ** 0.5, den ** 0.5)
     print("g14 worst relative deviations:", {k: round(v, 6) for k, v in sorted(worst.items(), key=lambda kv: -kv[1])[:8]})
+
+
+def test_paired_student_pass_matches_the_two_passes(tmp_path):
+    """The student's source-replay and target passes as ONE pass over both batches (row groups) against the same step with
+    the two passes one after the other (ONDA_PAIR_STUDENT=0: the reference's order): same kernels, same batch statistics per
+    group -- logs, prototypes, running statistics and the weight update agree to summation-order noise at step 0 (and the
+    second step, on weights that differ in their last bits, to the usual amplification)."""
+    from onda_amd import ops
+    from onda_amd.config import hybrid_switch_cfg
+    from onda_amd.framework.domain_adaptation.methods import prototypes as pmod
+    from onda_amd.framework.domain_adaptation.methods.adaptation_model import switch_batch_statistics
+    from onda_amd.framework.handlers import get_adapt_method, get_model
+    from onda_amd.framework.model import deeplabv2
+    from onda_amd.synthetic import fill_state_dict, synth_batch
+    from oracle import model as omodel
+    if not ops.row_groups_supported():
+        pytest.skip("row groups exist in the f16x2 / dma configuration only")
+
+    def run(paired):
+        old, pmod.PAIR_STUDENT = pmod.PAIR_STUDENT, paired
+        try:
+            cfg, spec = hybrid_switch_cfg(256, 128, DEV, str(tmp_path), batch_size=2)
+            model = get_model(cfg, 19)
+            fill_state_dict(model, 1, 40.0)
+            da = get_adapt_method(cfg)(model, cfg, spec)
+            src = [synth_batch(2, 128, 256, seed=100 + i) for i in range(2)]
+            trg = [synth_batch(2, 128, 256, seed=200 + i) for i in range(2)]
+            torch.manual_seed(123)
+            masks = iter([omodel.draw_drop_mask(2) for _ in range(8)])
+            deeplabv2.drop_mask_fn = lambda B, C, p, dev: next(masks).to(dev)
+            try:
+                da.update_dynamic()
+                switch_batch_statistics(da.model, False)
+                da.calculate_prototypes(src, save=False)
+                switch_batch_statistics(da.model, True)
+                da.optimizer.zero_grad()
+                states, logs = [{k: v.detach().double().cpu().clone() for k, v in da.model.state_dict().items()}], []
+                for s_ in range(2):
+                    da.adjust_learning_rate(s_, 6)
+                    log = da.step([src[s_]], trg[s_])
+                    da.update_ema()
+                    logs.append({k: float(v) for k, v in log.items() if not isinstance(v, dict)})
+                    states.append({k: v.detach().double().cpu().clone() for k, v in da.model.state_dict().items()})
+                return states, logs, da.prototypes.prototypes.cpu().clone()
+            finally:
+                deeplabv2.drop_mask_fn = deeplabv2._default_drop_mask
+        finally:
+            pmod.PAIR_STUDENT = old
+
+    sa, la, pa = run(True)
+    sb, lb, pb = run(False)
+    for s_ in range(2):
+        assert la[s_].keys() == lb[s_].keys()
+        for k in la[s_]:
+            a, b = la[s_][k], lb[s_][k]
+            assert (np.isnan(a) and np.isnan(b)) or abs(a - b) <= (2e-5 if s_ == 0 else 5e-3) * max(abs(b), 1e-3), (s_, k, a, b)
+        num = den = 0.0
+        for k in sa[0]:
+            if sa[0][k].is_floating_point() and sa[0][k].dim() > 0:
+                num += float(((sa[s_ + 1][k] - sb[s_ + 1][k]) ** 2).sum())
+                den += float(((sb[s_ + 1][k] - sb[s_][k]) ** 2).sum())
+        rel = (num / den) ** 0.5
+        print("paired vs two passes, step", s_, "update rel-L2", rel)
+        assert rel <= (1e-4 if s_ == 0 else 0.6), (s_, rel)
+    assert (pa - pb).abs().max() <= 1e-4 * pb.abs().max()
