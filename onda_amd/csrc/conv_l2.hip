@@ -1685,7 +1685,9 @@ L2Schedule l2_schedule(long long M, int Cout, int taps, int Cin, bool have_ws, l
   // the boundary is split by onda_bn_finalize_l2, which needs that row to cover the WHOLE tile -- a stream-K remainder tile
   // spreads its statistics over sub-block rows.  Remainder tiles are the last ones; keep the straddler out of their tile rows
   // (only tiny problems -- fewer tiles than two rounds -- lose their balanced schedule to this).
-  if (q.balanced && stat_split > 0 && stat_split % q.BM != 0 && stat_split / q.BM >= (tiles - q.rem) / q.tilesN) q.balanced = false;
+  // (the same when the boundary falls BETWEEN two tile rows: the remainder's extra statistic rows sit behind all regular
+  //  rows, where the BatchNorm kernels count them with group 1 -- every remainder tile must lie in group 1)
+  if (q.balanced && stat_split > 0 && (stat_split + q.BM - 1) / q.BM > (tiles - q.rem) / q.tilesN) q.balanced = false;
   return q;
 }
 }  // namespace

@@ -462,8 +462,8 @@ def conv_forward(x, wp, k, stride, dil, pad, cout, out=None, scale=None, shift=N
     split = 0
     if want_stats:
         split = _group_split(B, Ho, Wo)
-        if split and stats_rows != 4:
-            raise RuntimeError("onda_amd: row groups (ops.row_groups) need the pre-split conv + limb-writing BatchNorm path")
+        if split and not l2:
+            raise RuntimeError("onda_amd: row groups (ops.row_groups) need the pre-split conv path")
         tiles = (query("onda_conv_l2_tiles_m_split", B * Ho * Wo, cout, k * k, Cin, split, None) if l2
                  else query("onda_conv_tiles_m", B * Ho * Wo))
         stats = torch.empty(tiles, stats_rows, cout, device=x.device, dtype=torch.float32)
@@ -857,35 +857,60 @@ def stem_eval(x_nchw, weight, cache, scale, shift):
 
 class BNTrainFn(torch.autograd.Function):
     """Batch-statistics BatchNorm (+residual, +ReLU) on a conv output whose sum / sum-of-squares
-    partials came out of the conv epilogue.  Affine parameters are frozen (no dgamma/dbeta)."""
+    partials came out of the conv epilogue.  Affine parameters are frozen (no dgamma/dbeta).
+    Under ``ops.row_groups`` (the stem's BatchNorm in the paired student pass) the two row groups are normalised one
+    after the other on their row ranges of the same buffers; only the second group moves the running statistics."""
+
+    @staticmethod
+    def _groups(B, H, W):
+        split, M = _group_split(B, H, W), B * H * W
+        return [(0, M)] if not split else [(0, split), (split, M - split)]
 
     @staticmethod
     def forward(ctx, y, stats, gamma, beta, residual, relu, running, momentum):
         B, H, W, C = y.shape
-        M = B * H * W
-        if _group_split(B, H, W):
-            raise RuntimeError("onda_amd: row groups (ops.row_groups) need the limb-writing BatchNorm path")
-        mean = torch.empty(C, device=y.device, dtype=torch.float32)
+        groups = BNTrainFn._groups(B, H, W)
+        G = len(groups)
+        mean = torch.empty(G, C, device=y.device, dtype=torch.float32)
         invstd = torch.empty_like(mean)
-        rm, rv, nbt = running if running is not None else (None, None, None)
-        call("onda_bn_finalize", _p(stats), stats.shape[0], C, M, BN_EPS, _p(mean), _p(invstd), _p(rm), _p(rv), _p(nbt),
-             float(momentum), _stream())
+        out = torch.empty_like(y)
+        res = as_nhwc(residual) if residual is not None else None
+        if res is not None and nhwc_ld(res) != C:
+            res = res.contiguous()
+        if G > 1 and (nhwc_ld(y) != C or not y.is_contiguous()):
+            raise RuntimeError("onda_amd: row groups need a dense conv output")
+        amax = amax_slot(y.device) if CONV_MODE == "f16x2" else None  # the output feeds a conv: leave max|out| behind
+        for g, (r0, rows) in enumerate(groups):
+            part, nrows = stats, stats.shape[0]
+            if G > 1:
+                # the conv's partial rows cover 256 (128) GEMM rows each: a group takes its own rows when the boundary falls
+                # between two of them (every power-of-two image size), one reduction pass over its rows of y otherwise
+                bm = 128 if query("onda_conv_l2_variant", B * H * W, C) == 1 else 256
+                if groups[1][0] % bm == 0 and stats.shape[1] == 2:
+                    ts = groups[1][0] // bm
+                    part = stats[:ts] if g == 0 else stats[ts:]
+                    nrows = part.shape[0]
+                else:
+                    part = torch.empty(query("onda_bn_bwd_ws", rows, C), device=y.device, dtype=torch.float32)
+                    n = ctypes.c_int(0)
+                    call("onda_bn_stats", y.data_ptr() + 4 * r0 * C, rows, C, C, _p(part), byref(n), _stream())
+                    nrows = n.value
+            run = running if (running is not None and g == G - 1) else None
+            rm, rv, nbt = run if run is not None else (None, None, None)
+            call("onda_bn_finalize", _p(part), nrows, C, rows, BN_EPS, _p(mean[g]), _p(invstd[g]), _p(rm), _p(rv), _p(nbt),
+                 float(momentum), _stream())
+            off = 4 * r0 * C
+            call("onda_bn_apply", y.data_ptr() + off, _p(mean[g]), _p(invstd[g]), _p(gamma), _p(beta),
+                 res.data_ptr() + off if res is not None else None, out.data_ptr() + off, rows, C, int(relu), _p(amax), _stream())
         if running is not None:
             # the kernel wrote the running buffers through raw pointers: tell torch, so that everything keyed on
             # their version (HipBatchNorm2d.folded) sees the new statistics
             for t in running:
                 torch.autograd.graph.increment_version(t)
-        out = torch.empty_like(y)
-        res = as_nhwc(residual) if residual is not None else None
-        if res is not None and nhwc_ld(res) != C:
-            res = res.contiguous()
-        amax = amax_slot(y.device) if CONV_MODE == "f16x2" else None  # the output feeds a conv: leave max|out| behind
-        call("onda_bn_apply", _p(y), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(res), _p(out), M, C, int(relu),
-             _p(amax), _stream())
         if amax is not None:
             tag_amax(out, amax)
         ctx.save_for_backward(y, out if relu else None, mean, invstd, gamma)
-        ctx.relu, ctx.has_res = relu, residual is not None
+        ctx.relu, ctx.has_res, ctx.groups = relu, residual is not None, groups
         ctx.res_sink = _sink_of(residual) if (residual is not None and ctx.needs_input_grad[4]) else None
         return out
 
@@ -893,17 +918,19 @@ class BNTrainFn(torch.autograd.Function):
     def backward(ctx, dout):
         y, out, mean, invstd, gamma = ctx.saved_tensors
         B, H, W, C = y.shape
-        M = B * H * W
         dout = dout.contiguous()
-        ws = torch.empty(query("onda_bn_bwd_ws", M, C), device=y.device, dtype=torch.float32)
         dx = torch.empty_like(y)
         amax = amax_slot(y.device) if CONV_MODE == "f16x2" else None
         need_res = ctx.has_res and ctx.needs_input_grad[4]
         dres = None
         if need_res:
             dres = torch.empty_like(y) if ctx.relu else dout
-        call("onda_bn_bwd", _p(dout), _p(out), _p(y), _p(mean), _p(invstd), _p(gamma), _p(dx),
-             _p(dres) if (need_res and ctx.relu) else None, _p(ws), M, C, int(ctx.relu), _p(amax), _stream())
+        for g, (r0, rows) in enumerate(ctx.groups):
+            ws = torch.empty(query("onda_bn_bwd_ws", rows, C), device=y.device, dtype=torch.float32)
+            off = 4 * r0 * C
+            call("onda_bn_bwd", dout.data_ptr() + off, out.data_ptr() + off if out is not None else None, y.data_ptr() + off,
+                 _p(mean[g]), _p(invstd[g]), _p(gamma), dx.data_ptr() + off,
+                 dres.data_ptr() + off if (need_res and ctx.relu) else None, _p(ws), rows, C, int(ctx.relu), _p(amax), _stream())
         if amax is not None:
             tag_amax(dx, amax)  # dx is the dy of the conv below: data gradient and weight gradient read it
         if need_res:
