@@ -41,6 +41,10 @@ import os
 # other, as the reference orders them.  PAIR_MAX_PIXELS: image pixels of both batches together up to which the paired pass
 # is used (both autograd graphs are alive at once; 1024x2048 batches of 4 + 4 do not fit beside the four models)
 PAIR_STUDENT = os.environ.get("ONDA_PAIR_STUDENT", "1") != "0"
+# the no-grad passes of a step (teacher; static -> switch -> dynamic) on two side streams, beside the student's forward
+# pass on the main stream: three independent chains of launches, so one chain's latency-bound kernels (statistics
+# finalisation, stream-K fix-ups, 264-tiles-on-256-CUs tails) are covered by another chain's convolutions.  0 = one stream
+SIDE_STREAMS = os.environ.get("ONDA_SIDE_STREAMS", "1") != "0"
 PAIR_MAX_PIXELS = int(os.environ.get("ONDA_PAIR_MAX_PIXELS", str(6 << 20)))
 
 
@@ -409,6 +413,60 @@ class online_proDA(da_model):
         t["image"], t["student_mask"] = image, student_mask
         return t
 
+    # ---- the no-grad passes beside the student's forward pass -------------------------------------------------------------
+    def _concurrent_ok(self, n_shards):
+        """Sub-classes whose switch decision never visits the host (hybrid_proDA with the device-side switch) say yes."""
+        return False
+
+    def _side_streams(self):
+        st = self.__dict__.get("_side")
+        if st is None or st[0] != str(self.device):
+            st = self.__dict__["_side"] = (str(self.device), torch.cuda.Stream(device=self.device), torch.cuda.Stream(device=self.device))
+        return st[1], st[2]
+
+    def _target_prepare_concurrent(self, batch, deferred):
+        """``_target_prepare`` + the switch + the dynamic pass + the prior, issued on two side streams: stream 1 runs the
+        teacher, stream 2 the static model, then (behind the teacher's confidence) the switch step and the predicated dynamic
+        pass.  Returns at once; the caller launches the student's forward pass on the main stream and then ``_join``s."""
+        image = self._device_image(batch)
+        student_mask = deeplabv2.draw_mask(self.model, image.shape[0], image.device)
+        teacher_mask = deeplabv2.draw_mask(self.ema_model, image.shape[0], image.device)
+        # everything the passes share is made on the main stream first: the stem's patch matrix (cached on the image tensor)
+        # and enough zeroed max|x| slots for the whole step (a refill inside a side stream would race the other streams)
+        ops.stem_prefetch(image)
+        ops.reserve_amax_slots(image.device, 1024)
+        main = torch.cuda.current_stream()
+        s1, s2 = self._side_streams()
+        s1.wait_stream(main)
+        s2.wait_stream(main)
+        t = {"image": image, "student_mask": student_mask}
+        with torch.no_grad():
+            with torch.cuda.stream(s1):
+                t["pred"], prior_ema, t["conf_ema"], t["cls"] = self._forward_prior(self.ema_model, image, True, teacher_mask)
+            with torch.cuda.stream(s2):
+                t["conf_static"] = None
+                prior_static = None
+                if self.cfg_spec.STATIC_LAMBDA > 0:
+                    _, prior_static, t["conf_static"], _ = self._forward_prior(self.static_model, image)
+                s2.wait_stream(s1)  # the teacher's confidence and prior
+                t["prior"] = self.cfg_spec.EMA_LAMBDA * prior_ema
+                if prior_static is not None:
+                    t["prior"] += self.cfg_spec.STATIC_LAMBDA * prior_static
+                t["fetch"] = self._switch_scalars([t])
+                t["mixed_prior"] = self._mixed_prior(t, image, deferred)
+        t["streams"] = (s1, s2)
+        return t
+
+    def _join(self, t, deferred, fetch):
+        """The main stream waits for the side streams; what they produced is handed over to it (caching allocator)."""
+        main = torch.cuda.current_stream()
+        for s_ in t.pop("streams"):
+            main.wait_stream(s_)
+        keep = [t["pred"]["feat"], t["pred"]["out"], t["conf_ema"], t["cls"], t["prior"], t["mixed_prior"], t["conf_static"], fetch]
+        for v in keep + list(deferred.values):
+            if torch.is_tensor(v) and v.is_cuda:
+                v.record_stream(main)
+
     def _target_finish(self, batch, t, deferred, fetch=None, out=None):
         """Second half: the student's forward pass (launched BEFORE the switch scalars are read: `fetch`, given for the
         first micro-batch of a step; `out`: its logits when the paired pass has already produced them), prior mixing,
@@ -418,12 +476,15 @@ class online_proDA(da_model):
             if t["student_mask"] is not None:
                 deeplabv2.force_mask(t["student_mask"])
             out = self.model(image)[1]["out"]
+        if "streams" in t:
+            self._join(t, deferred, fetch)  # (the student's forward pass is in the main stream's queue by now)
         with torch.no_grad():
             conf_model, _, cls_model = ops.softmax_stats(out, want_argmax=True)
             deferred.put("model", conf_model)
             if fetch is not None:
                 self._record_switch_scalars(t, fetch)
-            proto_pred = self._labels(t, self._mixed_prior(t, image, deferred), deferred)
+            prior = t["mixed_prior"] if "mixed_prior" in t else self._mixed_prior(t, image, deferred)
+            proto_pred = self._labels(t, prior, deferred)
         losses = self._target_losses(out, proto_pred, cls_model)
         b, k, w, h = out.size()
         batch["stored_predictions"] = proto_pred["soft_predictions"].reshape(b, w, h, k).permute(0, 3, 1, 2)
@@ -603,6 +664,7 @@ class online_proDA(da_model):
         # the student's source and target passes of a micro-batch as ONE pass over both batches, where the method's settings
         # allow it (every micro-batch of a step the same way)
         paired = all(self._pairable(bs, bt) for bs, bt in shards)
+        concurrent = SIDE_STREAMS and self._concurrent_ok(n) and torch.device(self.device).type == "cuda"
         src_masks = []
         # source replay (gradients accumulate) and the no-grad teacher / static passes of every micro-batch; per
         # micro-batch the Dropout2d masks are drawn in the reference's order: source student, target student, teacher
@@ -613,8 +675,9 @@ class online_proDA(da_model):
                 log = self._source_replay(batches_source, scale)
                 if i == 0:
                     src_log = log
-            prepared.append(self._target_prepare(batch_target))
-        fetch = self._switch_scalars(prepared)  # ONE decision per step, from the mean over micro-batches and ranks
+            prepared.append(self._target_prepare_concurrent(batch_target, deferred) if concurrent else self._target_prepare(batch_target))
+        # ONE decision per step, from the mean over micro-batches and ranks
+        fetch = prepared[0].pop("fetch") if concurrent else self._switch_scalars(prepared)
         run0 = None
         if n > 1:  # every micro-batch starts from the same running statistics; their results are averaged
             bufs = self._float_buffers()

@@ -105,6 +105,11 @@ class hybrid_proDA(online_proDA):
             self.model_select.device_switch = self._dsw
             self.intensity_ma.gated.add("prior dynamic")
 
+    def _concurrent_ok(self, n_shards):
+        # the decision stays on the device and the dynamic pass is predicated: nothing between the static model's pass and
+        # the dynamic model's waits for the host, so the whole chain can sit on a side stream
+        return self._dsw is not None and n_shards == 1 and ops.predicates_supported() and not self.intensity_ma.freeze
+
     # ---- the switch on the device ------------------------------------------------------------------------------------
     def _switch_scalars(self, ts):
         if self._dsw is None:

@@ -211,6 +211,7 @@ _AMAX_POOL = {}
 
 
 AMAX_SLOTS = 2048  # ONDA_AMAX_FLOATS (include/onda_hip.h): 64 slots, one 128-byte line apart
+AMAX_POOL_TENSORS = 8192  # tensors served by one zero-filled pool (64 MB)
 
 
 def amax_slot(device):
@@ -219,10 +220,18 @@ def amax_slot(device):
     key = str(device)
     pool = _AMAX_POOL.get(key)
     if pool is None or pool[1] + AMAX_SLOTS > pool[0].numel():
-        pool = _AMAX_POOL[key] = [torch.zeros(2048 * AMAX_SLOTS, device=device, dtype=torch.float32), 0]
+        pool = _AMAX_POOL[key] = [torch.zeros(AMAX_POOL_TENSORS * AMAX_SLOTS, device=device, dtype=torch.float32), 0]
     i = pool[1]
     pool[1] = i + AMAX_SLOTS
     return pool[0][i:i + AMAX_SLOTS]
+
+
+def reserve_amax_slots(device, n):
+    """Make sure the next `n` amax_slot() calls are served from a pool that already exists (and whose zero-fill is ordered
+    before everything launched from now on): call on the main stream before work is spread over side streams."""
+    pool = _AMAX_POOL.get(str(device))
+    if pool is None or pool[1] + n * AMAX_SLOTS > pool[0].numel():
+        _AMAX_POOL[str(device)] = [torch.zeros(AMAX_POOL_TENSORS * AMAX_SLOTS, device=device, dtype=torch.float32), 0]
 
 
 def tag_amax(t, slot):
@@ -807,6 +816,14 @@ def stem_patches(x_nchw, Ho, Wo, l2):
     except AttributeError:
         pass
     return col
+
+
+def stem_prefetch(x_nchw):
+    """Build (and cache on the tensor) the stem's patch matrix of an image batch now, on the current stream: several passes
+    that read the same batch from different streams then all find it."""
+    B, _, H, W = x_nchw.shape
+    l2 = CONV_MODE == "f16x2" and H2_PATH == "dma" and STEM_K % 32 == 0
+    return stem_patches(x_nchw, conv_out_size(H, 7, 2, 1, 3), conv_out_size(W, 7, 2, 1, 3), l2)
 
 
 class StemConvFn(torch.autograd.Function):

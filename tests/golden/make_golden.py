@@ -513,6 +513,13 @@ def g13():
     _full_step("g13_step_1024x2048", 2048, 1024, 2, 40.0, seeds=(1300, 2300))
 
 
+def g13b():
+    """The same at batch 4 -- BASELINE config 5's own batch, the one bench.py's config-5 line runs: ~45 GB and ~15 minutes on the
+    CPU of the 64 GB build container with nothing else resident (run under `ulimit -v` so that a shortfall raises instead
+    of taking the container down)."""
+    _full_step("g13_step_1024x2048_bs4", 2048, 1024, 4, 40.0, seeds=(1300, 2300))
+
+
 def g11():
     """Eval-mode forward of one full-resolution frame of BASELINE config 5 (1 x 3 x 1024 x 2048): class map of
     interp(out).softmax.argmax, its tie mask, the logits on a 4-pixel grid and digests."""
