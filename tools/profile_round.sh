@@ -4,7 +4,7 @@
 # run, with --kernel-trace only, as MI355X_MICROARCH.md prescribes), per-shape conv rates.
 #   tools/profile_round.sh r03_a      -> gpurun_out/r03_a_*
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
-tag=${1:-r03_x}; G=gpurun_out; mkdir -p $G
+tag=${1:-r04_x}; G=gpurun_out; mkdir -p $G
 common="--no-cpu-baseline --no-eager --no-other-configs"
 python3 bench.py --steps 20 --warmup 5 > $G/${tag}_bench_line.json 2> $G/${tag}_bench_line.err
 python3 bench.py --steps 10 --warmup 3 --branch static $common --no-exact-f32 > $G/${tag}_bench_line_static_branch.json 2>/dev/null

@@ -6,6 +6,7 @@ sys.path.insert(0, ROOT)
 import torch
 from onda_amd import ops
 
+BATCH = int(os.environ.get("SWEEP_BATCH", "4"))  # 8: the paired student pass
 SHAPES = [  # (B,H,W,Cin,Cout,k,dil)
     (4, 65, 129, 512, 512, 3, 4), (4, 65, 129, 2048, 256, 3, 12), (4, 65, 129, 256, 256, 3, 2), (4, 65, 129, 1280, 256, 3, 1),
     (4, 65, 129, 2048, 512, 1, 1), (4, 65, 129, 512, 2048, 1, 1), (4, 65, 129, 1024, 2048, 1, 1), (4, 65, 129, 1024, 256, 1, 1),
@@ -16,7 +17,8 @@ SHAPES = [  # (B,H,W,Cin,Cout,k,dil)
 N = 8
 ops.H2_PATH = "dma"
 heur = ops._wgrad_splitk
-for (B, H, W, Cin, Cout, k, dil) in SHAPES:
+for (_b, H, W, Cin, Cout, k, dil) in SHAPES:
+    B = BATCH
     x = torch.randn(B, H, W, Cin, device="cuda")
     dy = torch.randn(B, H, W, Cout, device="cuda")
     pad = dil * (k - 1) // 2
