@@ -265,6 +265,131 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restri
   }
 }
 
+// ---- loss_calc(interp(logits), label): bilinear upsample (align_corners) -> cross-entropy, without the upsampled tensor ----
+// The supervised step (segmentation.py:70-80) upsamples the [B,K,h,w] logits to the label resolution (159 MB at 512x1024,
+// batch 4) only to reduce them to one scalar, and its backward pass writes and re-reads a gradient of the same size.  Here
+// every output pixel's K logits are interpolated in registers from the low-resolution rows (4.3 MB: cache-resident) in both
+// directions; only the labels (1 byte per pixel) are streamed.
+constexpr int UCE_KMAX = 32;
+
+// one thread per output pixel: -log softmax(v)[label] for valid labels; per-block partial (sum, count) into ws[block][2]
+__global__ __launch_bounds__(256) void upsample_ce_fwd_kernel(const float* __restrict__ logits, int ldl,
+                                                              const uint8_t* __restrict__ labels, float* __restrict__ ws, int B,
+                                                              int h, int w, int K, int H, int W, float sy, float sx) {
+  __shared__ float red[4];
+  const size_t total = (size_t)B * H * W;
+  float ce = 0.f, nv = 0.f;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const int tl = labels[e];
+    if (tl >= K) continue;  // 255 = ignore (loss.py:22-31)
+    const int X = (int)(e % W);
+    const size_t q = e / W;
+    const int Y = (int)(q % H), b = (int)(q / H);
+    const Lerp ly = lerp_index(Y, sy, h), lx = lerp_index(X, sx, w);
+    const float* p00 = logits + (((size_t)b * h + ly.i0) * w + lx.i0) * ldl;
+    const float* p01 = logits + (((size_t)b * h + ly.i0) * w + lx.i1) * ldl;
+    const float* p10 = logits + (((size_t)b * h + ly.i1) * w + lx.i0) * ldl;
+    const float* p11 = logits + (((size_t)b * h + ly.i1) * w + lx.i1) * ldl;
+    float v[UCE_KMAX], m = -INFINITY, vt = 0.f;
+#pragma unroll
+    for (int k = 0; k < UCE_KMAX; ++k)
+      if (k < K) {
+        v[k] = ly.l0 * (lx.l0 * p00[k] + lx.l1 * p01[k]) + ly.l1 * (lx.l0 * p10[k] + lx.l1 * p11[k]);  // = upsample_kernel
+        m = fmaxf(m, v[k]);
+        if (k == tl) vt = v[k];
+      }
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < UCE_KMAX; ++k)
+      if (k < K) sum += expf(v[k] - m);
+    ce += m + logf(sum) - vt;
+    nv += 1.f;
+  }
+  float r = block_sum_256(ce, red);
+  if (threadIdx.x == 0) ws[(size_t)blockIdx.x * 2] = r;
+  r = block_sum_256(nv, red);
+  if (threadIdx.x == 0) ws[(size_t)blockIdx.x * 2 + 1] = r;
+}
+
+__global__ void upsample_ce_finalize_kernel(const float* __restrict__ ws, int nblocks, float* __restrict__ result) {
+  if (threadIdx.x != 0) return;
+  double s = 0.0, n = 0.0;
+  for (int b = 0; b < nblocks; ++b) {  // fixed order: deterministic
+    s += (double)ws[(size_t)b * 2];
+    n += (double)ws[(size_t)b * 2 + 1];
+  }
+  result[0] = (float)(s / n);  // mean over the kept pixels; 0/0 = NaN as in the reference (loss.py:38 never fires)
+  result[1] = (float)n;
+}
+
+// Gradient with respect to the LOW-resolution logits, gather form (deterministic): one wave per low-resolution pixel, its
+// lanes walk the output pixels whose interpolation reads it (about (2 H/h)^2 of them), each recomputes that pixel's softmax
+// and contributes weight * (p - onehot); a wave reduction per class.  dl rows of stride ldl (columns >= K are zeroed).
+__global__ __launch_bounds__(256) void upsample_ce_bwd_kernel(const float* __restrict__ logits, int ldl,
+                                                              const uint8_t* __restrict__ labels,
+                                                              const float* __restrict__ result, const float* __restrict__ gscale,
+                                                              float w_ce, float* __restrict__ dl, int B, int h, int w, int K, int H,
+                                                              int W, float sy, float sx, float inv_sy, float inv_sx) {
+  const int lane = threadIdx.x & 63;
+  const size_t npix = (size_t)B * h * w;
+  const float nvalid = result[1];
+  const float a_ce = nvalid > 0.f ? (gscale ? gscale[0] : 1.f) * w_ce / nvalid : 0.f;
+  for (size_t pix = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6); pix < npix; pix += (size_t)gridDim.x * 4) {
+    const int x = (int)(pix % w);
+    const size_t q = pix / w;
+    const int y = (int)(q % h), b = (int)(q / h);
+    // destination rows / columns whose source coordinate falls in (y-1, y+1) / (x-1, x+1), with one of slack (upsample_bwd_kernel)
+    int Y0 = (int)floorf((float)(y - 1) * inv_sy) - 1, Y1 = (int)ceilf((float)(y + 1) * inv_sy) + 1;
+    int X0 = (int)floorf((float)(x - 1) * inv_sx) - 1, X1 = (int)ceilf((float)(x + 1) * inv_sx) + 1;
+    Y0 = max(Y0, 0);
+    X0 = max(X0, 0);
+    Y1 = min(Y1, H - 1);
+    X1 = min(X1, W - 1);
+    const int nx = X1 - X0 + 1, cnt = (Y1 - Y0 + 1) * nx;
+    float acc[UCE_KMAX];
+#pragma unroll
+    for (int k = 0; k < UCE_KMAX; ++k) acc[k] = 0.f;
+    for (int idx = lane; idx < cnt; idx += 64) {
+      const int Y = Y0 + idx / nx, X = X0 + idx % nx;
+      const Lerp ly = lerp_index(Y, sy, h), lx = lerp_index(X, sx, w);
+      const float wy = (ly.i0 == y ? ly.l0 : 0.f) + (ly.i1 == y ? ly.l1 : 0.f);
+      const float wx = (lx.i0 == x ? lx.l0 : 0.f) + (lx.i1 == x ? lx.l1 : 0.f);
+      const float wgt = wy * wx;
+      if (wgt == 0.f) continue;
+      const int tl = labels[((size_t)b * H + Y) * W + X];
+      if (tl >= K) continue;
+      const float* p00 = logits + (((size_t)b * h + ly.i0) * w + lx.i0) * ldl;
+      const float* p01 = logits + (((size_t)b * h + ly.i0) * w + lx.i1) * ldl;
+      const float* p10 = logits + (((size_t)b * h + ly.i1) * w + lx.i0) * ldl;
+      const float* p11 = logits + (((size_t)b * h + ly.i1) * w + lx.i1) * ldl;
+      float v[UCE_KMAX], m = -INFINITY;
+#pragma unroll
+      for (int k = 0; k < UCE_KMAX; ++k)
+        if (k < K) {
+          v[k] = ly.l0 * (lx.l0 * p00[k] + lx.l1 * p01[k]) + ly.l1 * (lx.l0 * p10[k] + lx.l1 * p11[k]);
+          m = fmaxf(m, v[k]);
+        }
+      float sum = 0.f;
+#pragma unroll
+      for (int k = 0; k < UCE_KMAX; ++k)
+        if (k < K) {
+          v[k] = expf(v[k] - m);
+          sum += v[k];
+        }
+      const float sc = wgt * a_ce, inv = 1.f / sum;
+#pragma unroll
+      for (int k = 0; k < UCE_KMAX; ++k)
+        if (k < K) acc[k] += sc * (v[k] * inv - (k == tl ? 1.f : 0.f));
+    }
+    float* out = dl + pix * ldl;
+#pragma unroll
+    for (int k = 0; k < UCE_KMAX; ++k) {  // (fully unrolled: acc[] stays in registers)
+      const float r = wave_sum(acc[k]);
+      if (lane == 0 && k < ldl) out[k] = k < K ? r : 0.f;
+    }
+  }
+}
+
 static inline unsigned ew_grid(size_t total) {
   size_t g = (total + 255) / 256;
   if (g > 16384) g = 16384;
@@ -352,6 +477,29 @@ int onda_upsample_argmax_hist(const float* logits, int ldl, const uint8_t* label
   hipLaunchKernelGGL((upsample_kernel<true>), dim3(ew_grid((size_t)B * H * W)), dim3(256), 0, ONDA_STREAM(s), logits,
                      ldl, (float*)nullptr, cls, labels, reinterpret_cast<unsigned long long*>(hist), B, h, w, K, H, W,
                      ac_scale(h, H), ac_scale(w, W));
+  return ONDA_LAUNCH_RESULT();
+}
+
+int64_t onda_upsample_ce_ws(int B, int H, int W) { return 2 * (int64_t)ew_grid((size_t)B * H * W); }
+
+int onda_upsample_ce_fwd(const float* logits, int ldl, const uint8_t* labels, float* result, float* ws, int B, int h, int w, int K,
+                         int H, int W, onda_stream_t s) {
+  ONDA_REQUIRE(logits && labels && result && ws && K <= ldl && K <= UCE_KMAX && h > 1 && w > 1 && H > 1 && W > 1);
+  const unsigned nb = ew_grid((size_t)B * H * W);
+  hipLaunchKernelGGL(upsample_ce_fwd_kernel, dim3(nb), dim3(256), 0, ONDA_STREAM(s), logits, ldl, labels, ws, B, h, w, K, H, W,
+                     ac_scale(h, H), ac_scale(w, W));
+  hipLaunchKernelGGL(upsample_ce_finalize_kernel, dim3(1), dim3(64), 0, ONDA_STREAM(s), ws, (int)nb, result);
+  return ONDA_LAUNCH_RESULT();
+}
+
+int onda_upsample_ce_bwd(const float* logits, int ldl, const uint8_t* labels, const float* result, const float* gscale, float w_ce,
+                         float* dlogits, int B, int h, int w, int K, int H, int W, onda_stream_t s) {
+  ONDA_REQUIRE(logits && labels && result && dlogits && K <= ldl && ldl <= UCE_KMAX && h > 1 && w > 1 && H > 1 && W > 1);
+  const float sy = ac_scale(h, H), sx = ac_scale(w, W);
+  const size_t npix = (size_t)B * h * w;
+  const unsigned nb = (unsigned)((npix + 3) / 4 > 16384 ? 16384 : (npix + 3) / 4);
+  hipLaunchKernelGGL(upsample_ce_bwd_kernel, dim3(nb), dim3(256), 0, ONDA_STREAM(s), logits, ldl, labels, result, gscale, w_ce,
+                     dlogits, B, h, w, K, H, W, sy, sx, 1.f / sy, 1.f / sx);
   return ONDA_LAUNCH_RESULT();
 }
 

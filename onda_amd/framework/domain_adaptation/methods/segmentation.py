@@ -56,7 +56,9 @@ class SegmentationTrainer:
             if p is None:
                 continue
             logits = p["out"] if isinstance(p, dict) else p
-            part = ops.seg_losses(ops.UpsampleFn.apply(logits, self.size), label, 1.0, 0.0, 0.0)[0]
+            if tuple(label.shape[1:]) != tuple(self.size):
+                raise RuntimeError(f"onda_amd: labels of {tuple(label.shape[1:])} for SCHEME.RESOLUTION {self.size}")
+            part = ops.upsample_ce(logits, label)  # interp -> cross-entropy without the upsampled tensor
             total = weight * part if total is None else total + weight * part
         return total
 

@@ -1256,6 +1256,38 @@ class UpsampleFn(torch.autograd.Function):
         return dl[..., :K].permute(0, 3, 1, 2), None
 
 
+class UpsampleCEFn(torch.autograd.Function):
+    """loss_calc(interp(out), label): bilinear upsample (align_corners) to the label resolution -> cross-entropy over the
+    pixels whose label is not 255, as ONE pass in each direction -- the upsampled logits (and their gradient) exist in
+    registers only (csrc/pointwise.hip)."""
+
+    @staticmethod
+    def forward(ctx, out, labels):
+        rows, ld, _, K = logits_rows(out)
+        B, _, h, w = out.shape
+        labels = labels.to(device=out.device, dtype=torch.uint8).contiguous()
+        H, W = labels.shape[1:]
+        result = torch.empty(2, device=out.device, dtype=torch.float32)
+        ws = torch.empty(query("onda_upsample_ce_ws", B, H, W), device=out.device, dtype=torch.float32)
+        call("onda_upsample_ce_fwd", _p(rows), ld, _p(labels), _p(result), _p(ws), B, h, w, K, H, W, _stream())
+        ctx.save_for_backward(rows, labels, result)
+        ctx.meta = (ld, B, h, w, K, H, W)
+        return result[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        rows, labels, result = ctx.saved_tensors
+        ld, B, h, w, K, H, W = ctx.meta
+        dl = torch.empty(B, h, w, ld, device=rows.device, dtype=torch.float32)
+        call("onda_upsample_ce_bwd", _p(rows), ld, _p(labels), _p(result), _p(g.reshape(1).float().contiguous()), 1.0, _p(dl),
+             B, h, w, K, H, W, _stream())
+        return dl[..., :K].permute(0, 3, 1, 2), None
+
+
+def upsample_ce(out, labels):
+    return UpsampleCEFn.apply(out, labels)
+
+
 def upsample_argmax(out, size):
     """Fused evaluation tail: class map u8[B,H,W] of interp(out).softmax(1).argmax(1)."""
     rows, ld, _, K = logits_rows(out)

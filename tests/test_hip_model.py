@@ -790,8 +790,11 @@ def test_segmentation_step_config2(golden):
         _, pred = m(b["image"].to(DEV))
     finally:
         deeplabv2.drop_mask_fn = deeplabv2._default_drop_mask
-    up = ops.UpsampleFn.apply(pred["out"], (64, 128))
-    loss = ops.seg_losses(up, b["label"].to(DEV), 1.0, 0.0, 0.0)[0]
+    with torch.no_grad():
+        up = ops.UpsampleFn.apply(pred["out"], (64, 128))
+    loss = ops.upsample_ce(pred["out"], b["label"].to(DEV))
+    # a batch without a single kept pixel: mean over nothing = NaN, as the reference
+    assert torch.isnan(ops.upsample_ce(pred["out"].detach(), torch.full_like(b["label"], 255).to(DEV)))
     loss.backward()
     # oracle
     sd = {k: synth_tensor(k, torch.empty(shape, dtype=dt), 1, 3.0).to(dt) for k, shape, dt in omodel.state_spec()}
@@ -836,23 +839,21 @@ def test_segmentation_step_config2_full_size(conv_mode):
     m = build_model(1, 3.0).train()
     tr = SegmentationTrainer(m, cfg, spec)
     seen = {}
-    real_up = ops.UpsampleFn.apply
+    real_head = ops.upsample_ce
 
-    class _Spy:
-        @staticmethod
-        def apply(logits, size):
-            seen["out"] = logits
-            logits.retain_grad()
-            return real_up(logits, size)
+    def _spy(logits, labels):  # the trainer's loss head (interp -> cross-entropy as one fused pass each way)
+        seen["out"] = logits
+        logits.retain_grad()
+        return real_head(logits, labels)
     torch.manual_seed(5)
     mask4 = omodel.draw_drop_mask(4)
     deeplabv2.drop_mask_fn = lambda B, C, p, dev: mask4.to(dev)
     before = {k: v.detach().clone() for k, v in m.named_parameters() if v.requires_grad}
-    ops.UpsampleFn, keep = _Spy, ops.UpsampleFn
+    ops.upsample_ce = _spy
     try:
         loss4 = tr.step({k: v.to(DEV) for k, v in b4.items()}, 1000)
     finally:
-        ops.UpsampleFn = keep
+        ops.upsample_ce = real_head
         deeplabv2.drop_mask_fn = deeplabv2._default_drop_mask
     out = seen["out"]
     assert out.shape == (4, 19, 65, 129)
@@ -862,8 +863,14 @@ def test_segmentation_step_config2_full_size(conv_mode):
     assert loss4.item() == pytest.approx(ref_loss.item(), rel=1e-5)
     # the head alone on two images: forward value and the gradient that reaches the logits
     two = out.detach()[:2].clone().requires_grad_(True)
-    l2 = ops.seg_losses(ops.UpsampleFn.apply(two, (H, W)), b4["label"][:2].to(DEV), 1.0, 0.0, 0.0)[0]
+    l2 = ops.upsample_ce(two, b4["label"][:2].to(DEV))
     l2.backward()
+    # ... and the same head as two passes through the materialised upsampled tensor (the evaluation-side kernels)
+    two_b = out.detach()[:2].clone().requires_grad_(True)
+    l2b = ops.seg_losses(ops.UpsampleFn.apply(two_b, (H, W)), b4["label"][:2].to(DEV), 1.0, 0.0, 0.0)[0]
+    l2b.backward()
+    assert l2.item() == pytest.approx(l2b.item(), rel=1e-6)
+    assert (two.grad - two_b.grad).abs().max() <= 2e-6 * two_b.grad.abs().max()
     o2 = out.detach()[:2].cpu().clone().requires_grad_(True)
     r2 = losses.ce_hard(F.interpolate(o2, size=(H, W), mode="bilinear", align_corners=True), b4["label"][:2])
     (g2,) = torch.autograd.grad(r2, o2)
@@ -882,8 +889,9 @@ def test_segmentation_step_config2_full_size(conv_mode):
         _, pred = m(b2["image"].to(DEV))
     finally:
         deeplabv2.drop_mask_fn = deeplabv2._default_drop_mask
-    up = ops.UpsampleFn.apply(pred["out"], (H, W))
-    loss = ops.seg_losses(up, b2["label"].to(DEV), 1.0, 0.0, 0.0)[0]
+    with torch.no_grad():
+        up = ops.UpsampleFn.apply(pred["out"], (H, W))
+    loss = ops.upsample_ce(pred["out"], b2["label"].to(DEV))
     loss.backward()
     sd = {k: synth_tensor(k, torch.empty(shape, dtype=dt), 1, 3.0).to(dt) for k, shape, dt in omodel.state_spec()}
     names = ["layer6.head.1.weight", "layer6.bottleneck.2.weight", "layer6.bottleneck.2.bias", "layer6.bottleneck.1.bias"]
