@@ -286,12 +286,13 @@ int onda_upsample_bwd(const float* dout_nchw, float* dlogits, int ldl, int B, in
 /* fused supervised-loss head: loss_calc(interp(logits), label) (segmentation.py:70-80 -> func.py:35-42 -> loss.py:16-45) without
  * the upsampled tensor.  labels u8[B,H,W] (values >= K, i.e. 255, are ignored); result[0] = mean CE over the kept pixels (NaN
  * when none is kept, as the reference), result[1] = their number; ws: onda_upsample_ce_ws floats.  bwd: dlogits[B,h,w] rows of
- * stride ldl <= 32 (columns >= K zeroed) = gscale[0] (or 1) * w_ce * d result[0] / d logits, gather form, deterministic. */
+ * stride ldl (columns >= K zeroed) = gscale[0] (or 1) * w_ce * d result[0] / d logits: two separable gather passes, deterministic. */
 int64_t onda_upsample_ce_ws(int B, int H, int W);
 int onda_upsample_ce_fwd(const float* logits, int ldl, const uint8_t* labels, float* result, float* ws, int B, int h, int w, int K,
                          int H, int W, onda_stream_t s);
+int64_t onda_upsample_ce_bwd_ws(int B, int w, int K, int H);  /* floats of `ws` for the backward pass */
 int onda_upsample_ce_bwd(const float* logits, int ldl, const uint8_t* labels, const float* result, const float* gscale, float w_ce,
-                         float* dlogits, int B, int h, int w, int K, int H, int W, onda_stream_t s);
+                         float* dlogits, float* ws, int B, int h, int w, int K, int H, int W, onda_stream_t s);
 /* fused evaluation tail: upsample -> (softmax) -> argmax class map u8[B,H,W]
  * (adaptation_model.py:145-153) without materialising the upsampled tensor */
 int onda_upsample_argmax(const float* logits, int ldl, uint8_t* cls, int B, int h, int w, int K, int H, int W,

@@ -101,7 +101,8 @@ SIGNATURES = {
     "onda_upsample_argmax": (I, [P, I, P, I, I, I, I, I, I, P]),
     "onda_upsample_ce_ws": (L, [I, I, I]),
     "onda_upsample_ce_fwd": (I, [P, I, P, P, P, I, I, I, I, I, I, P]),
-    "onda_upsample_ce_bwd": (I, [P, I, P, P, P, F, P, I, I, I, I, I, I, P]),
+    "onda_upsample_ce_bwd_ws": (L, [I, I, I, I]),
+    "onda_upsample_ce_bwd": (I, [P, I, P, P, P, F, P, P, I, I, I, I, I, I, P]),
     "onda_upsample_argmax_hist": (I, [P, I, P, P, P, I, I, I, I, I, I, P]),
     "onda_softmax_stats": (I, [P, I, P, I, P, P, P, L, I, P]),
     "onda_seg_loss_fwd": (I, [P, I, P, P, P, L, I, P]),

@@ -311,82 +311,143 @@ __global__ __launch_bounds__(256) void upsample_ce_fwd_kernel(const float* __res
   if (threadIdx.x == 0) ws[(size_t)blockIdx.x * 2 + 1] = r;
 }
 
-__global__ void upsample_ce_finalize_kernel(const float* __restrict__ ws, int nblocks, float* __restrict__ result) {
-  if (threadIdx.x != 0) return;
+__global__ __launch_bounds__(256) void upsample_ce_finalize_kernel(const float* __restrict__ ws, int nblocks, float* __restrict__ result) {
+  // fixed order: thread t sums the blocks t, t + 256, ... in double, then a fixed tree over the 256 threads
+  __shared__ double sh[2][256];
+  const int t = threadIdx.x;
   double s = 0.0, n = 0.0;
-  for (int b = 0; b < nblocks; ++b) {  // fixed order: deterministic
+  for (int b = t; b < nblocks; b += 256) {
     s += (double)ws[(size_t)b * 2];
     n += (double)ws[(size_t)b * 2 + 1];
   }
-  result[0] = (float)(s / n);  // mean over the kept pixels; 0/0 = NaN as in the reference (loss.py:38 never fires)
-  result[1] = (float)n;
+  sh[0][t] = s;
+  sh[1][t] = n;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (t < o) {
+      sh[0][t] += sh[0][t + o];
+      sh[1][t] += sh[1][t + o];
+    }
+    __syncthreads();
+  }
+  if (t == 0) {
+    result[0] = (float)(sh[0][0] / sh[1][0]);  // mean over the kept pixels; 0/0 = NaN as in the reference (loss.py:38 never fires)
+    result[1] = (float)sh[1][0];
+  }
 }
 
-// Gradient with respect to the LOW-resolution logits, gather form (deterministic): one wave per low-resolution pixel, its
-// lanes walk the output pixels whose interpolation reads it (about (2 H/h)^2 of them), each recomputes that pixel's softmax
-// and contributes weight * (p - onehot); a wave reduction per class.  dl rows of stride ldl (columns >= K are zeroed).
-__global__ __launch_bounds__(256) void upsample_ce_bwd_kernel(const float* __restrict__ logits, int ldl,
-                                                              const uint8_t* __restrict__ labels,
-                                                              const float* __restrict__ result, const float* __restrict__ gscale,
-                                                              float w_ce, float* __restrict__ dl, int B, int h, int w, int K, int H,
-                                                              int W, float sy, float sx, float inv_sy, float inv_sx) {
-  const int lane = threadIdx.x & 63;
-  const size_t npix = (size_t)B * h * w;
+// Gradient with respect to the LOW-resolution logits.  The interpolation weights are separable, so
+//     dl[y][x][k] = sum_Y wy(Y, y) * ( sum_X wx(X, x) * g[Y][X][k] ),   g = a * (softmax(v) - onehot) at the kept pixels,
+// is taken in two gather passes (fixed summation order: deterministic), each output pixel's softmax evaluated about once:
+//   pass A, one workgroup per (image, output row Y, block of CW low-resolution columns): the row's interpolated low-res
+//     rows r[x][k] = ly.l0 * p[y0][x][k] + ly.l1 * p[y1][x][k] go to LDS once, every output pixel of the block's span then
+//     needs two of them (no global loads per pixel); its g[X][k] goes to LDS; threads (x, k) gather over their ~2 W/w
+//     columns -> t[b][Y][x][k];
+//   pass B, one thread per (b, y, x, k): gathers t over its ~2 H/h rows -> dl.
+constexpr int UCE_SPAN = 640;  // output pixels of one pass-A workgroup (LDS: UCE_SPAN * K floats of g)
+
+__global__ __launch_bounds__(256) void upsample_ce_bwd_rows_kernel(const float* __restrict__ logits, int ldl,
+                                                                   const uint8_t* __restrict__ labels,
+                                                                   const float* __restrict__ result,
+                                                                   const float* __restrict__ gscale, float w_ce,
+                                                                   float* __restrict__ tmp, int B, int h, int w, int K, int H, int W,
+                                                                   float sy, float sx, float inv_sx, int CW) {
+  extern __shared__ float uce_lds[];
+  float* r = uce_lds;                    // [CW + 2][K]
+  float* g = r + (CW + 2) * K;           // [UCE_SPAN][K]
+  float* lw = g + UCE_SPAN * K;          // [UCE_SPAN]: l1 of the pixel's column interpolation
+  int* li = reinterpret_cast<int*>(lw + UCE_SPAN);  // [UCE_SPAN]: its i0 (i1 = i0 + 1, or i0 at the right edge: l1 = 0 there)
+  const int t = threadIdx.x;
+  const int xb = blockIdx.x * CW, xe = min(w, xb + CW);  // low-resolution columns of this workgroup
+  const int Y = blockIdx.y % H, b = blockIdx.y / H;
   const float nvalid = result[1];
   const float a_ce = nvalid > 0.f ? (gscale ? gscale[0] : 1.f) * w_ce / nvalid : 0.f;
-  for (size_t pix = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6); pix < npix; pix += (size_t)gridDim.x * 4) {
-    const int x = (int)(pix % w);
-    const size_t q = pix / w;
+  const Lerp ly = lerp_index(Y, sy, h);
+  // output columns that read a column of [xb, xe): source coordinate in (xb - 1, xe), with one of slack on either side
+  int X0 = (int)floorf((float)(xb - 1) * inv_sx) - 1, X1 = (int)ceilf((float)xe * inv_sx) + 1;
+  X0 = max(X0, 0);
+  X1 = min(X1, W - 1);
+  const int span = X1 - X0 + 1;          // <= UCE_SPAN (the host picks CW)
+  const int x_lo = max(xb - 1, 0), nxr = min(w, xe + 1) - x_lo;  // low-res columns those pixels interpolate between
+  const float* p0 = logits + ((size_t)b * h + ly.i0) * w * ldl;
+  const float* p1 = logits + ((size_t)b * h + ly.i1) * w * ldl;
+  for (int idx = t; idx < nxr * K; idx += 256) {
+    const int x = idx / K, k = idx - x * K;
+    r[idx] = ly.l0 * p0[(size_t)(x_lo + x) * ldl + k] + ly.l1 * p1[(size_t)(x_lo + x) * ldl + k];
+  }
+  __syncthreads();
+  for (int i = t; i < span; i += 256) {
+    const int X = X0 + i;
+    const Lerp lx = lerp_index(X, sx, w);
+    li[i] = lx.i0;
+    lw[i] = lx.i1 != lx.i0 ? lx.l1 : 0.f;
+    float* gi = g + i * K;
+    const int tl = labels[((size_t)b * H + Y) * W + X];
+    const bool inside = lx.i0 >= x_lo && lx.i1 < x_lo + nxr;  // (slack pixels outside the block's rows contribute nothing)
+    if (tl >= K || !inside) {
+      for (int k = 0; k < K; ++k) gi[k] = 0.f;
+      continue;
+    }
+    const float* r0 = r + (lx.i0 - x_lo) * K;
+    const float* r1 = r + (lx.i1 - x_lo) * K;
+    float v[UCE_KMAX], m = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < UCE_KMAX; ++k)
+      if (k < K) {
+        v[k] = lx.l0 * r0[k] + lx.l1 * r1[k];
+        m = fmaxf(m, v[k]);
+      }
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < UCE_KMAX; ++k)
+      if (k < K) {
+        v[k] = expf(v[k] - m);
+        sum += v[k];
+      }
+    const float inv = a_ce / sum;
+#pragma unroll
+    for (int k = 0; k < UCE_KMAX; ++k)
+      if (k < K) gi[k] = v[k] * inv - (k == tl ? a_ce : 0.f);
+  }
+  __syncthreads();
+  float* out = tmp + (((size_t)b * H + Y) * w) * K;
+  for (int idx = t; idx < (xe - xb) * K; idx += 256) {
+    const int xr = idx / K, k = idx - xr * K, x = xb + xr;
+    int A0 = (int)floorf((float)(x - 1) * inv_sx) - 1, A1 = (int)ceilf((float)(x + 1) * inv_sx) + 1;
+    A0 = max(A0, X0);
+    A1 = min(A1, X1);
+    float acc = 0.f;
+    for (int X = A0; X <= A1; ++X) {
+      const int i = X - X0, i0 = li[i];
+      const float l1 = lw[i];
+      const float wx = i0 == x ? 1.f - l1 : (i0 + 1 == x ? l1 : 0.f);
+      acc += wx * g[i * K + k];
+    }
+    out[(size_t)x * K + k] = acc;
+  }
+}
+
+__global__ __launch_bounds__(256) void upsample_ce_bwd_cols_kernel(const float* __restrict__ tmp, float* __restrict__ dl, int ldl, int B,
+                                                                   int h, int w, int K, int H, float sy, float inv_sy) {
+  const size_t total = (size_t)B * h * w * ldl;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const int k = (int)(e % ldl);
+    size_t q = e / ldl;
+    const int x = (int)(q % w);
+    q /= w;
     const int y = (int)(q % h), b = (int)(q / h);
-    // destination rows / columns whose source coordinate falls in (y-1, y+1) / (x-1, x+1), with one of slack (upsample_bwd_kernel)
-    int Y0 = (int)floorf((float)(y - 1) * inv_sy) - 1, Y1 = (int)ceilf((float)(y + 1) * inv_sy) + 1;
-    int X0 = (int)floorf((float)(x - 1) * inv_sx) - 1, X1 = (int)ceilf((float)(x + 1) * inv_sx) + 1;
-    Y0 = max(Y0, 0);
-    X0 = max(X0, 0);
-    Y1 = min(Y1, H - 1);
-    X1 = min(X1, W - 1);
-    const int nx = X1 - X0 + 1, cnt = (Y1 - Y0 + 1) * nx;
-    float acc[UCE_KMAX];
-#pragma unroll
-    for (int k = 0; k < UCE_KMAX; ++k) acc[k] = 0.f;
-    for (int idx = lane; idx < cnt; idx += 64) {
-      const int Y = Y0 + idx / nx, X = X0 + idx % nx;
-      const Lerp ly = lerp_index(Y, sy, h), lx = lerp_index(X, sx, w);
-      const float wy = (ly.i0 == y ? ly.l0 : 0.f) + (ly.i1 == y ? ly.l1 : 0.f);
-      const float wx = (lx.i0 == x ? lx.l0 : 0.f) + (lx.i1 == x ? lx.l1 : 0.f);
-      const float wgt = wy * wx;
-      if (wgt == 0.f) continue;
-      const int tl = labels[((size_t)b * H + Y) * W + X];
-      if (tl >= K) continue;
-      const float* p00 = logits + (((size_t)b * h + ly.i0) * w + lx.i0) * ldl;
-      const float* p01 = logits + (((size_t)b * h + ly.i0) * w + lx.i1) * ldl;
-      const float* p10 = logits + (((size_t)b * h + ly.i1) * w + lx.i0) * ldl;
-      const float* p11 = logits + (((size_t)b * h + ly.i1) * w + lx.i1) * ldl;
-      float v[UCE_KMAX], m = -INFINITY;
-#pragma unroll
-      for (int k = 0; k < UCE_KMAX; ++k)
-        if (k < K) {
-          v[k] = ly.l0 * (lx.l0 * p00[k] + lx.l1 * p01[k]) + ly.l1 * (lx.l0 * p10[k] + lx.l1 * p11[k]);
-          m = fmaxf(m, v[k]);
-        }
-      float sum = 0.f;
-#pragma unroll
-      for (int k = 0; k < UCE_KMAX; ++k)
-        if (k < K) {
-          v[k] = expf(v[k] - m);
-          sum += v[k];
-        }
-      const float sc = wgt * a_ce, inv = 1.f / sum;
-#pragma unroll
-      for (int k = 0; k < UCE_KMAX; ++k)
-        if (k < K) acc[k] += sc * (v[k] * inv - (k == tl ? 1.f : 0.f));
+    float acc = 0.f;
+    if (k < K) {
+      int Y0 = (int)floorf((float)(y - 1) * inv_sy) - 1, Y1 = (int)ceilf((float)(y + 1) * inv_sy) + 1;
+      Y0 = max(Y0, 0);
+      Y1 = min(Y1, H - 1);
+      for (int Y = Y0; Y <= Y1; ++Y) {
+        const Lerp ly = lerp_index(Y, sy, h);
+        const float wy = (ly.i0 == y ? ly.l0 : 0.f) + (ly.i1 == y ? ly.l1 : 0.f);
+        if (wy != 0.f) acc += wy * tmp[(((size_t)b * H + Y) * w + x) * K + k];
+      }
     }
-    float* out = dl + pix * ldl;
-#pragma unroll
-    for (int k = 0; k < UCE_KMAX; ++k) {  // (fully unrolled: acc[] stays in registers)
-      const float r = wave_sum(acc[k]);
-      if (lane == 0 && k < ldl) out[k] = k < K ? r : 0.f;
-    }
+    dl[e] = acc;  // (columns >= K: zero)
   }
 }
 
@@ -488,18 +549,26 @@ int onda_upsample_ce_fwd(const float* logits, int ldl, const uint8_t* labels, fl
   const unsigned nb = ew_grid((size_t)B * H * W);
   hipLaunchKernelGGL(upsample_ce_fwd_kernel, dim3(nb), dim3(256), 0, ONDA_STREAM(s), logits, ldl, labels, ws, B, h, w, K, H, W,
                      ac_scale(h, H), ac_scale(w, W));
-  hipLaunchKernelGGL(upsample_ce_finalize_kernel, dim3(1), dim3(64), 0, ONDA_STREAM(s), ws, (int)nb, result);
+  hipLaunchKernelGGL(upsample_ce_finalize_kernel, dim3(1), dim3(256), 0, ONDA_STREAM(s), ws, (int)nb, result);
   return ONDA_LAUNCH_RESULT();
 }
 
+int64_t onda_upsample_ce_bwd_ws(int B, int w, int K, int H) { return (int64_t)B * H * w * K; }
+
 int onda_upsample_ce_bwd(const float* logits, int ldl, const uint8_t* labels, const float* result, const float* gscale, float w_ce,
-                         float* dlogits, int B, int h, int w, int K, int H, int W, onda_stream_t s) {
-  ONDA_REQUIRE(logits && labels && result && dlogits && K <= ldl && ldl <= UCE_KMAX && h > 1 && w > 1 && H > 1 && W > 1);
+                         float* dlogits, float* ws, int B, int h, int w, int K, int H, int W, onda_stream_t s) {
+  ONDA_REQUIRE(logits && labels && result && dlogits && ws && K <= ldl && K <= UCE_KMAX && h > 1 && w > 1 && H > 1 && W > 1);
   const float sy = ac_scale(h, H), sx = ac_scale(w, W);
-  const size_t npix = (size_t)B * h * w;
-  const unsigned nb = (unsigned)((npix + 3) / 4 > 16384 ? 16384 : (npix + 3) / 4);
-  hipLaunchKernelGGL(upsample_ce_bwd_kernel, dim3(nb), dim3(256), 0, ONDA_STREAM(s), logits, ldl, labels, result, gscale, w_ce,
-                     dlogits, B, h, w, K, H, W, sy, sx, 1.f / sy, 1.f / sx);
+  // low-resolution columns per pass-A workgroup: as many as keep its output span within UCE_SPAN pixels
+  int CW = (int)((UCE_SPAN - 6) * sx) - 2;
+  if (CW > 64) CW = 64;
+  ONDA_REQUIRE(CW >= 1);
+  const size_t lds = ((size_t)(CW + 2) * K + (size_t)UCE_SPAN * K + 2 * UCE_SPAN) * sizeof(float);
+  ONDA_REQUIRE(lds <= 64 * 1024);  // (19 classes: 59 KB)
+  hipLaunchKernelGGL(upsample_ce_bwd_rows_kernel, dim3((w + CW - 1) / CW, B * H), dim3(256), lds, ONDA_STREAM(s), logits, ldl, labels,
+                     result, gscale, w_ce, ws, B, h, w, K, H, W, sy, sx, 1.f / sx, CW);
+  hipLaunchKernelGGL(upsample_ce_bwd_cols_kernel, dim3(ew_grid((size_t)B * h * w * ldl)), dim3(256), 0, ONDA_STREAM(s), ws, dlogits,
+                     ldl, B, h, w, K, H, sy, 1.f / sy);
   return ONDA_LAUNCH_RESULT();
 }
 

@@ -1279,8 +1279,9 @@ class UpsampleCEFn(torch.autograd.Function):
         rows, labels, result = ctx.saved_tensors
         ld, B, h, w, K, H, W = ctx.meta
         dl = torch.empty(B, h, w, ld, device=rows.device, dtype=torch.float32)
+        ws = torch.empty(query("onda_upsample_ce_bwd_ws", B, w, K, H), device=rows.device, dtype=torch.float32)
         call("onda_upsample_ce_bwd", _p(rows), ld, _p(labels), _p(result), _p(g.reshape(1).float().contiguous()), 1.0, _p(dl),
-             B, h, w, K, H, W, _stream())
+             _p(ws), B, h, w, K, H, W, _stream())
         return dl[..., :K].permute(0, 3, 1, 2), None
 
 
