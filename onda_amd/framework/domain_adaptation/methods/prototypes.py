@@ -434,11 +434,15 @@ class online_proDA(da_model):
         # everything the passes share is made on the main stream first: the stem's patch matrix (cached on the image tensor)
         # and enough zeroed max|x| slots for the whole step (a refill inside a side stream would race the other streams)
         ops.stem_prefetch(image)
-        ops.reserve_amax_slots(image.device, 1024)
+        ops.reserve_amax_slots(image.device, 4096)  # (a step takes ~1 000: four forward passes, two backward passes, two repacks)
         main = torch.cuda.current_stream()
         s1, s2 = self._side_streams()
         s1.wait_stream(main)
         s2.wait_stream(main)
+        if teacher_mask is not None:
+            # made on the main stream, dropped by the host as soon as the teacher's head has been ENQUEUED on stream 1: the
+            # main stream (busy with the student meanwhile) must not get its memory back before stream 1 has read it
+            teacher_mask.record_stream(s1)
         t = {"image": image, "student_mask": student_mask}
         with torch.no_grad():
             with torch.cuda.stream(s1):
@@ -591,16 +595,19 @@ class online_proDA(da_model):
             torch._foreach_copy_(plan["ints_k"], plan["ints_q"])
 
     # -------------------------------------------------------------------------------------------------------- step
-    def _source_replay(self, batches_source, scale=1.0):
-        """Source replay with the BatchNorm policy of the config around it; returns the last batch's log entries."""
+    def _source_replay(self, batches_source, scale=1.0, masks=None):
+        """Source replay with the BatchNorm policy of the config around it; returns the last batch's log entries.
+        `masks`: the Dropout2d masks of these passes when they were drawn ahead of time (one per batch, in order)."""
         policy = self.cfg_spec.BN_POLICY
         if policy == "freeze":
             switch_batch_statistics(self.model, False, self._bn_modules())
         elif policy == "double":
             self.bn.exchange()
         log = {}
-        for batch in batches_source:
+        for i, batch in enumerate(batches_source):
             if self.cfg.TRAINING.REPLAY_BUFFER > 0:
+                if masks is not None and masks[i] is not None:
+                    deeplabv2.force_mask(masks[i])
                 log = self.supervised_loss(batch)
                 (log["buff_loss"] if scale == 1.0 else log["buff_loss"] * scale).backward()
         if policy == "freeze":
@@ -671,6 +678,13 @@ class online_proDA(da_model):
         for i, (batches_source, batch_target) in enumerate(shards):
             if paired:
                 src_masks.append(self._source_mask(batches_source[0]))
+            elif concurrent and self.cfg.TRAINING.REPLAY_BUFFER > 0 and not self.model.multi_level:
+                # the no-grad passes go to their side streams FIRST and run beside the source-replay pass as well; the
+                # source passes' masks are drawn before theirs, as the reference's order of draws has it
+                masks = [self._source_mask(b) for b in batches_source]
+                prepared.append(self._target_prepare_concurrent(batch_target, deferred))
+                src_log = self._source_replay(batches_source, scale, masks)
+                continue
             else:
                 log = self._source_replay(batches_source, scale)
                 if i == 0:

@@ -211,27 +211,42 @@ _AMAX_POOL = {}
 
 
 AMAX_SLOTS = 2048  # ONDA_AMAX_FLOATS (include/onda_hip.h): 64 slots, one 128-byte line apart
-AMAX_POOL_TENSORS = 8192  # tensors served by one zero-filled pool (64 MB)
+AMAX_POOL_TENSORS = 16384  # tensors served by one zero-filled pool (128 MB)
+
+
+def _new_amax_pool(device):
+    buf = torch.zeros(AMAX_POOL_TENSORS * AMAX_SLOTS, device=device, dtype=torch.float32)
+    if buf.is_cuda:  # the zero-fill runs on the creating stream: any other stream that takes slices waits for it once
+        done = torch.cuda.Event()
+        done.record()
+        return [buf, 0, done, {torch.cuda.current_stream().cuda_stream}]
+    return [buf, 0, None, None]
 
 
 def amax_slot(device):
     """Zeroed device floats for a tensor's running max|x| (slices of a zero-filled pool: one fill kernel per
-    2048 tensors instead of one per tensor; a slice is written by exactly one producer and never reused)."""
+    16384 tensors instead of one per tensor; a slice is written by exactly one producer and never reused)."""
     key = str(device)
     pool = _AMAX_POOL.get(key)
     if pool is None or pool[1] + AMAX_SLOTS > pool[0].numel():
-        pool = _AMAX_POOL[key] = [torch.zeros(AMAX_POOL_TENSORS * AMAX_SLOTS, device=device, dtype=torch.float32), 0]
+        pool = _AMAX_POOL[key] = _new_amax_pool(device)
+    if pool[2] is not None:
+        cur = torch.cuda.current_stream()
+        if cur.cuda_stream not in pool[3]:
+            cur.wait_event(pool[2])
+            pool[3].add(cur.cuda_stream)
     i = pool[1]
     pool[1] = i + AMAX_SLOTS
     return pool[0][i:i + AMAX_SLOTS]
 
 
 def reserve_amax_slots(device, n):
-    """Make sure the next `n` amax_slot() calls are served from a pool that already exists (and whose zero-fill is ordered
-    before everything launched from now on): call on the main stream before work is spread over side streams."""
+    """Make sure the next `n` amax_slot() calls are served from a pool that already exists: call on the main stream before
+    work is spread over side streams (a refill is safe on any stream -- the others wait for its zero-fill -- but it then
+    costs them that wait)."""
     pool = _AMAX_POOL.get(str(device))
     if pool is None or pool[1] + n * AMAX_SLOTS > pool[0].numel():
-        _AMAX_POOL[str(device)] = [torch.zeros(AMAX_POOL_TENSORS * AMAX_SLOTS, device=device, dtype=torch.float32), 0]
+        _AMAX_POOL[str(device)] = _new_amax_pool(device)
 
 
 def tag_amax(t, slot):
