@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
 
 #include "onda_hip.h"
 
@@ -18,10 +20,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // Argument check at the top of every entry point.  It also drops any stale error another
 // library left in this thread's HIP error slot, so that the hipGetLastError() after our own
 // launches reports our launches only.
-#define ONDA_REQUIRE(cond)           \
-  do {                               \
-    (void)hipGetLastError();         \
-    if (!(cond)) return ONDA_EINVAL; \
+#define ONDA_REQUIRE(cond)                                                                              \
+  do {                                                                                                  \
+    (void)hipGetLastError();                                                                            \
+    if (!(cond)) {                                                                                      \
+      if (getenv("ONDA_DEBUG_REQUIRE")) fprintf(stderr, "onda_hip: %s:%d: requirement failed: %s\n", __FILE__, __LINE__, #cond); \
+      return ONDA_EINVAL;                                                                               \
+    }                                                                                                   \
   } while (0)
 #define ONDA_ALIGNED16(p) ((reinterpret_cast<uintptr_t>(p) & 15u) == 0)
 #define ONDA_LAUNCH_RESULT() static_cast<int>(hipGetLastError())

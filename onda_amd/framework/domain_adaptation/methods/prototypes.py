@@ -33,19 +33,22 @@ from onda_amd.framework.domain_adaptation.methods.adaptation_model import da_mod
 from onda_amd.framework.domain_adaptation.methods.prototype_handler import prototype_handler
 from onda_amd.framework.model import deeplabv2
 from onda_amd.framework.utils.monitoring import Monitor
+from onda_amd.synthetic import feature_hw as synthetic_feature_hw
 
 
 import os
 
 # the student's source-replay pass and its target pass as ONE pass over both batches (ops.row_groups); 0 = one after the
-# other, as the reference orders them.  PAIR_MAX_PIXELS: image pixels of both batches together up to which the paired pass
-# is used (both autograd graphs are alive at once; 1024x2048 batches of 4 + 4 do not fit beside the four models)
+# other, as the reference orders them.  PAIR_MAX_ROWS: feature-grid pixels of both batches together up to which the paired
+# pass is used -- the kernels address an operand with 32-bit byte offsets, and the widest activation (layer4's 2048 channels,
+# two f16 limb planes) passes 2 GiB at 262 143 rows: 4 + 4 images of 512x1024 (67 080 rows, 22 GB peak with both autograd
+# graphs alive) pair, 4 + 4 images of 1024x2048 (265 224 rows) run one pass after the other
 PAIR_STUDENT = os.environ.get("ONDA_PAIR_STUDENT", "1") != "0"
+PAIR_MAX_ROWS = int(os.environ.get("ONDA_PAIR_MAX_ROWS", str(0x7FFFF000 // (2048 * 4))))
 # the no-grad passes of a step (teacher; static -> switch -> dynamic) on two side streams, beside the student's forward
 # pass on the main stream: three independent chains of launches, so one chain's latency-bound kernels (statistics
 # finalisation, stream-K fix-ups, 264-tiles-on-256-CUs tails) are covered by another chain's convolutions.  0 = one stream
 SIDE_STREAMS = os.environ.get("ONDA_SIDE_STREAMS", "1") != "0"
-PAIR_MAX_PIXELS = int(os.environ.get("ONDA_PAIR_MAX_PIXELS", str(6 << 20)))
 
 
 def regular_loss(regularizer, activation):
@@ -629,8 +632,8 @@ class online_proDA(da_model):
         src, trg = batches_source[0]["image"], batch_target["image"]
         if tuple(src.shape[1:]) != tuple(trg.shape[1:]):
             return False
-        # (both graphs are alive at once: 2 x 16 GB of activations + as much in limb planes at 512x1024, bs 4 + 4)
-        return (src.shape[0] + trg.shape[0]) * src.shape[2] * src.shape[3] <= PAIR_MAX_PIXELS
+        h, w = synthetic_feature_hw(src.shape[2], src.shape[3])
+        return (src.shape[0] + trg.shape[0]) * h * w <= PAIR_MAX_ROWS
 
     def _source_mask(self, batch):
         """The Dropout2d mask of the source pass, drawn where the reference's source forward draws it (first in a step)."""

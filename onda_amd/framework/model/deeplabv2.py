@@ -317,11 +317,25 @@ class ResNetMulti(nn.Module):
     def _stem(self, x):
         bn = self.bn1
         if bn.training:
-            y, stats = ops.StemConvFn.apply(x, self.conv1.weight, self.conv1._pack, True)
-            running = (bn.running_mean, bn.running_var, bn.num_batches_tracked) if bn.track_running_stats else None
-            y = ops.BNTrainFn.apply(y, stats, bn.weight, bn.bias, None, True, running, bn.momentum)
-        else:
-            y = ops.stem_eval(x, self.conv1.weight, self.conv1._pack, *bn.folded())
+            first = ops.ROW_GROUPS
+            if 0 < first < x.shape[0] and ops.stem_patch_rows(x) > ops.STEM_MAX_ROWS:
+                # two row groups whose patch matrix together passes the kernels' 32-bit offsets (1024x2048, 4 + 4 images):
+                # the stem runs once per group -- the first with frozen running statistics, as the source pass has them --
+                # and the groups meet again behind the pool
+                with ops.row_groups(0):
+                    parts = [self._stem_train(x[:first], None), self._stem_train(x[first:], self._running(bn))]
+                return torch.cat(parts, 0)
+            return self._stem_train(x, self._running(bn))
+        return ops.MaxPoolFn.apply(ops.stem_eval(x, self.conv1.weight, self.conv1._pack, *bn.folded()))
+
+    @staticmethod
+    def _running(bn):
+        return (bn.running_mean, bn.running_var, bn.num_batches_tracked) if bn.track_running_stats else None
+
+    def _stem_train(self, x, running):
+        bn = self.bn1
+        y, stats = ops.StemConvFn.apply(x, self.conv1.weight, self.conv1._pack, True)
+        y = ops.BNTrainFn.apply(y, stats, bn.weight, bn.bias, None, True, running, bn.momentum)
         return ops.MaxPoolFn.apply(y)
 
     def forward(self, x):

@@ -833,6 +833,14 @@ def stem_patches(x_nchw, Ho, Wo, l2):
     return col
 
 
+STEM_MAX_ROWS = 0x7FFFF000 // (STEM_K * 4)  # rows of a patch matrix the kernels' 32-bit byte offsets reach (two f16 planes)
+
+
+def stem_patch_rows(x_nchw):
+    B, _, H, W = x_nchw.shape
+    return B * conv_out_size(H, 7, 2, 1, 3) * conv_out_size(W, 7, 2, 1, 3)
+
+
 def stem_prefetch(x_nchw):
     """Build (and cache on the tensor) the stem's patch matrix of an image batch now, on the current stream: several passes
     that read the same batch from different streams then all find it."""

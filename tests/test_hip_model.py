@@ -366,7 +366,7 @@ def test_full_resolution_step_golden(golden, tmp_path, conv_mode, batch, name):
     """One adaptation step at BASELINE config 5's resolution, 1024x2048 (feature grid 129x257): at batch 2 (fixture G13) and at
     batch 4 -- config 5's own batch, the one bench.py's config-5 line runs; the reference's CPU run of the batch-4 step takes
     30 GB and eight minutes in the build container (make_golden.py::g13b).  At this size the student's two passes run one
-    after the other (PAIR_MAX_PIXELS: both graphs alive at once do not fit beside the four models)."""
+    after the other (PAIR_MAX_ROWS: the 2048-channel activations of 4 + 4 such images pass the kernels' 32-bit byte offsets)."""
     if conv_mode != "f16x2":
         pytest.skip("full-size step: default conv mode only (the small-size step runs in both)")
     _full_size_step_against(golden, tmp_path, name, 2048, 1024, batch, 40.0, seeds=(1300, 2300))
