@@ -50,6 +50,9 @@ typedef struct OndaConv {
                           * its own BatchNorm batch statistics: prototypes.py:418-450 runs the student on the source-replay and
                           * on the target batch): the schedule then keeps the tile that straddles the boundary out of the
                           * stream-K remainder, so that onda_bn_finalize_l2 can split its statistics row (csrc/norm_l2.hip) */
+  int32_t plain_schedule; /* != 0: one tile per workgroup, no stream-K remainder (a launch that shares the GPU with launches of
+                           * other streams: its short last round is filled by them, the remainder's partial tiles and fix-up
+                           * launch are not worth their traffic) */
 } OndaConv;
 
 /* Number of float partials conv_fwd writes when `stats` != NULL: tiles_m * 2 * Cout, where
@@ -154,8 +157,9 @@ int onda_conv_l2_variant(int64_t M, int Cout);  /* tile shape used for an (M, Co
  * at most 32 K-steps per tile: the continuous K-step stream); bench.py names its per-kernel figures after this */
 int onda_conv_l2_kernel_id(int64_t M, int Cout, int taps, int Cin);
 int onda_conv_l2_tiles_m(int64_t M, int Cout, int taps, int Cin);  /* rows of the `stats` partials the conv writes for this problem */
-/* the same with a row-group boundary (OndaConv.stat_split); *tile_rows (optional) receives the GEMM rows one partial row covers */
-int onda_conv_l2_tiles_m_split(int64_t M, int Cout, int taps, int Cin, int64_t stat_split, int* tile_rows);
+/* the same for a launch with a row-group boundary (OndaConv.stat_split) and / or OndaConv.plain_schedule; *tile_rows (optional)
+ * receives the GEMM rows one partial row covers */
+int onda_conv_l2_tiles_m_split(int64_t M, int Cout, int taps, int Cin, int64_t stat_split, int plain_schedule, int* tile_rows);
 /* stats_rows: 2 = stats[tile][sum, sumsq][Cout] as onda_conv2d_fwd; 4 = also the per-channel min and max of the raw
  * output tile, from which onda_bn_finalize_l2 bounds max|BatchNorm output| before the apply pass writes limb planes */
 int onda_conv2d_fwd_l2(const void* xl, int64_t xplane, const float* xamax, const void* w2, const float* wamax, float* y,

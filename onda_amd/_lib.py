@@ -16,7 +16,7 @@ I, L, F = c_int, c_int64, c_float
 
 class OndaConv(Structure):
     _fields_ = [(n, c_int) for n in ("B Hi Wi Cin Ho Wo Cout kh kw stride dil pad ldx ldy ldr out_os Hf Wf relu").split()] + \
-               [("run_if", c_void_p), ("stat_split", c_int64)]
+               [("run_if", c_void_p), ("stat_split", c_int64), ("plain_schedule", c_int)]
 
 
 class OndaSwitchCfg(Structure):
@@ -67,7 +67,7 @@ SIGNATURES = {
     "onda_conv_l2_variant": (I, [L, I]),
     "onda_conv_l2_kernel_id": (I, [L, I, I, I]),
     "onda_conv_l2_tiles_m": (I, [L, I, I, I]),
-    "onda_conv_l2_tiles_m_split": (I, [L, I, I, I, L, POINTER(c_int)]),
+    "onda_conv_l2_tiles_m_split": (I, [L, I, I, I, L, I, POINTER(c_int)]),
     "onda_conv_wgrad_l2_variant": (I, [I, I]),
     "onda_conv2d_wgrad_l2": (I, [P, L, P, P, L, P, P, I, I, POINTER(OndaConv), P]),
     "onda_conv2d_fwd_l2": (I, [P, L, P, P, P, P, P, P, P, P, I, P, P, POINTER(OndaConv), P]),

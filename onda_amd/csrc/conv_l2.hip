@@ -1660,7 +1660,7 @@ bool l2_small_ring2() {
   return on != 0;
 }
 
-L2Schedule l2_schedule(long long M, int Cout, int taps, int Cin, bool have_ws, long long stat_split = 0) {
+L2Schedule l2_schedule(long long M, int Cout, int taps, int Cin, bool have_ws, long long stat_split = 0, bool plain = false) {
   L2Schedule q;
   q.variant = onda_conv_l2_variant(M, Cout);
   q.BM = q.variant == 1 ? 128 : 256;
@@ -1677,6 +1677,7 @@ L2Schedule l2_schedule(long long M, int Cout, int taps, int Cin, bool have_ws, l
   const double fix_us = 6.0 + (q.G + 2.0 * q.rem) * (q.BM * q.BN / 16384.0) * 0.02;  // partial tiles written + read
   q.balanced = have_ws && q.rem != 0 && KT >= 4 && t_tile_us * (1.0 - (double)q.rem / q.G) > fix_us &&
                (size_t)q.G * 2 * q.BM * q.BN <= (size_t)onda_conv_ws_floats() && q.G <= 1024;
+  if (plain) q.balanced = false;  // OndaConv.plain_schedule
   if (const int force = conv_sched_override()) {  // ONDA_CONV_SCHED: 1 tile-per-workgroup, 2 hybrid
     if (force == 1 || !have_ws) q.balanced = false;
     else if (force == 2) q.balanced = q.rem != 0;
@@ -1696,8 +1697,8 @@ extern "C" {
 
 /* rows of the `stats` partials the conv will write for this problem (tile rows + the extra rows of a stream-K remainder) */
 int onda_conv_l2_tiles_m(int64_t M, int Cout, int taps, int Cin) { return l2_schedule(M, Cout, taps, Cin, true).stats_rows_total(); }
-int onda_conv_l2_tiles_m_split(int64_t M, int Cout, int taps, int Cin, int64_t stat_split, int* tile_rows) {
-  const L2Schedule q = l2_schedule(M, Cout, taps, Cin, true, stat_split);
+int onda_conv_l2_tiles_m_split(int64_t M, int Cout, int taps, int Cin, int64_t stat_split, int plain_schedule, int* tile_rows) {
+  const L2Schedule q = l2_schedule(M, Cout, taps, Cin, true, stat_split, plain_schedule != 0);
   if (tile_rows) *tile_rows = q.BM;
   return q.stats_rows_total();
 }
@@ -1752,7 +1753,7 @@ static int l2_fwd_impl(const void* xl, int64_t xplane, const float* xamax, const
   k.taps = c->kh * c->kw;
   k.kcper = c->Cin / 32;
   ONDA_REQUIRE(c->stat_split >= 0 && c->stat_split < M);
-  const L2Schedule q = l2_schedule(M, c->Cout, k.taps, c->Cin, true, stats ? (long long)c->stat_split : 0);
+  const L2Schedule q = l2_schedule(M, c->Cout, k.taps, c->Cin, true, stats ? (long long)c->stat_split : 0, c->plain_schedule != 0);
   k.tilesM = q.tilesM;
   k.tilesN = q.tilesN;
   const size_t limb_elems = (size_t)c->Cout * k.taps * c->Cin;  // weight planes are [Cout][taps*Cin]

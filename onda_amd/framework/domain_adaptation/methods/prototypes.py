@@ -49,6 +49,11 @@ PAIR_MAX_ROWS = int(os.environ.get("ONDA_PAIR_MAX_ROWS", str(0x7FFFF000 // (2048
 # pass on the main stream: three independent chains of launches, so one chain's latency-bound kernels (statistics
 # finalisation, stream-K fix-ups, 264-tiles-on-256-CUs tails) are covered by another chain's convolutions.  0 = one stream
 SIDE_STREAMS = os.environ.get("ONDA_SIDE_STREAMS", "1") != "0"
+# ... and their convolutions without the stream-K remainder (ops.plain_schedule), on the idea that the other streams fill a
+# short last round: measured WORSE (104.5 against 102.6 ms per step, A/B on one box) -- the balanced schedule keeps every
+# workgroup of a launch on the same K position (one weight slice shared in L2), a second round beside another stream's
+# kernel does not.  Off; the switch stays for measurements.
+SIDE_PLAIN = os.environ.get("ONDA_SIDE_PLAIN", "0") != "0"
 
 
 def regular_loss(regularizer, activation):
@@ -447,7 +452,7 @@ class online_proDA(da_model):
             # main stream (busy with the student meanwhile) must not get its memory back before stream 1 has read it
             teacher_mask.record_stream(s1)
         t = {"image": image, "student_mask": student_mask}
-        with torch.no_grad():
+        with torch.no_grad(), ops.plain_schedule(SIDE_PLAIN):
             with torch.cuda.stream(s1):
                 t["pred"], prior_ema, t["conf_ema"], t["cls"] = self._forward_prior(self.ema_model, image, True, teacher_mask)
             with torch.cuda.stream(s2):

@@ -150,7 +150,28 @@ def predicates_supported():
 
 def _desc(B, Hi, Wi, Cin, Ho, Wo, Cout, k, stride, dil, pad, ldx, ldy, ldr=0, out_os=1, Hf=None, Wf=None, relu=0, split=0):
     return OndaConv(B, Hi, Wi, Cin, Ho, Wo, Cout, k, k, stride, dil, pad, ldx, ldy, ldr, out_os,
-                    Ho if Hf is None else Hf, Wo if Wf is None else Wf, int(relu), _p(PREDICATE), int(split))
+                    Ho if Hf is None else Hf, Wo if Wf is None else Wf, int(relu), _p(PREDICATE), int(split), int(PLAIN_SCHEDULE))
+
+
+# ``with ops.plain_schedule():`` -- convolutions launched inside run one tile per workgroup without the stream-K remainder:
+# for passes that share the GPU with other streams' launches (the no-grad passes of an adaptation step, on side streams),
+# whose short last round of tiles is filled by those.
+PLAIN_SCHEDULE = False
+
+
+class plain_schedule:
+    def __init__(self, on=True):
+        self.on = bool(on)
+
+    def __enter__(self):
+        global PLAIN_SCHEDULE
+        self.old, PLAIN_SCHEDULE = PLAIN_SCHEDULE, self.on
+        return self
+
+    def __exit__(self, *exc):
+        global PLAIN_SCHEDULE
+        PLAIN_SCHEDULE = self.old
+        return False
 
 
 # Row groups: inside ``with ops.row_groups(n):`` the first n images of every batch that passes a train-mode BatchNorm are
@@ -488,7 +509,7 @@ def conv_forward(x, wp, k, stride, dil, pad, cout, out=None, scale=None, shift=N
         split = _group_split(B, Ho, Wo)
         if split and not l2:
             raise RuntimeError("onda_amd: row groups (ops.row_groups) need the pre-split conv path")
-        tiles = (query("onda_conv_l2_tiles_m_split", B * Ho * Wo, cout, k * k, Cin, split, None) if l2
+        tiles = (query("onda_conv_l2_tiles_m_split", B * Ho * Wo, cout, k * k, Cin, split, int(PLAIN_SCHEDULE), None) if l2
                  else query("onda_conv_tiles_m", B * Ho * Wo))
         stats = torch.empty(tiles, stats_rows, cout, device=x.device, dtype=torch.float32)
     d = _desc(B, Hi, Wi, Cin, Ho, Wo, cout, k, stride, dil, pad, ldx, ldy, ldr, relu=relu, split=split)
