@@ -150,11 +150,21 @@ def measure_roofline(step_fn, steps_done, record=True):
     stream).  Reported for the dominant family.  Every rank runs the two instrumented steps (they contain the step's
     collectives); only the recording rank keeps events."""
     from onda_amd import ops
-    if record:
-        ops.PROFILE = []
-    step_fn(steps_done)
-    step_fn(steps_done + 1)
-    torch.cuda.synchronize()
+    from onda_amd.framework.domain_adaptation.methods import prototypes as pmod
+    # A kernel's roofline fraction is a property of the kernel: the instrumented steps run with the no-grad passes back on
+    # the main stream (ONDA_SIDE_STREAMS=0), so that an event pair brackets ONE kernel that has the GPU to itself -- beside
+    # other streams' launches the pair would also time the wait for the CUs they hold (and rocprof's per-kernel durations
+    # stretch the same way).  The matching rocprofv3 summary is profiles/*_bench_kernel_stats_one_stream.csv.
+    side, pmod.SIDE_STREAMS = pmod.SIDE_STREAMS, False
+    try:
+        step_fn(steps_done)  # (not recorded: the first step after the switch re-allocates workspaces on the main stream)
+        if record:
+            ops.PROFILE = []
+        step_fn(steps_done + 1)
+        step_fn(steps_done + 2)
+        torch.cuda.synchronize()
+    finally:
+        pmod.SIDE_STREAMS = side
     if not record:
         return None
     fam = {}
@@ -179,6 +189,7 @@ def measure_roofline(step_fn, steps_done, record=True):
         products, what = 0, "fp32 MFMA (v_mfma_f32_32x32x2_f32)"
     peak = F16_MFMA_PEAK_TFLOPS / products if products else FP32_MFMA_PEAK_TFLOPS
     roof = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+            "measured": "HIP events around every launch of two extra steps with ONDA_SIDE_STREAMS=0 (each kernel alone on the GPU)",
             "frac": round(achieved / peak, 4), "traffic": None, "launches_per_step": n // 2,
             "avg_launch_ms": round(secs / n * 1e3, 4), "avg_launch_gflop": round(flops / n / 1e9, 3), "families": detail,
             "all_fwd_dgrad_tflops": round(sum(v[0] for v in fwd) / max(sum(v[1] for v in fwd), 1e-12) / 1e12, 2) if fwd else None,

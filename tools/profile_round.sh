@@ -17,10 +17,14 @@ python3 tools/conv_shapes.py > $G/${tag}_conv_shapes.txt 2>&1
 rm -rf $G/prof_$tag && mkdir -p $G/prof_$tag
 rocprofv3 --kernel-trace --stats -d $G/prof_$tag/kt -- python3 bench.py --steps 10 --warmup 3 $common --no-exact-f32 --no-roofline > $G/${tag}_profiled_bench_line.json 2> $G/prof_$tag/kt.err
 python3 tools/kstats.py $G/prof_$tag/kt > $G/${tag}_bench_kernel_stats.csv
+# the same command with every pass on ONE stream: per-kernel durations of kernels that have the GPU to themselves (what the
+# bench line's `roofline` is measured on; beside other streams' launches a kernel's duration stretches)
+ONDA_SIDE_STREAMS=0 rocprofv3 --kernel-trace --stats -d $G/prof_$tag/kt1 -- python3 bench.py --steps 10 --warmup 3 $common --no-exact-f32 --no-roofline > $G/${tag}_profiled_bench_line_one_stream.json 2> $G/prof_$tag/kt1.err
+python3 tools/kstats.py $G/prof_$tag/kt1 > $G/${tag}_bench_kernel_stats_one_stream.csv
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $G/prof_$tag/fetch -- python3 tools/one_pass.py > /dev/null 2> $G/prof_$tag/fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $G/prof_$tag/write -- python3 tools/one_pass.py > /dev/null 2> $G/prof_$tag/write.err
 python3 tools/pmc_summary.py $G/prof_$tag/fetch $G/prof_$tag/write $G/${tag}_hbm_traffic.json > $G/${tag}_hbm_traffic_top.txt
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $G/prof_$tag/sq -o sq -- python3 tools/one_pass.py > /dev/null 2> $G/prof_$tag/sq.err
 python3 tools/sq_summary.py $(find $G/prof_$tag/sq -name "*counter_collection.csv" | head -1) 12 > $G/${tag}_sq_counters.txt 2>&1
-rm -rf $G/prof_$tag/fetch $G/prof_$tag/write $G/prof_$tag/sq $G/prof_$tag/kt   # (raw traces: hundreds of MB)
+rm -rf $G/prof_$tag/fetch $G/prof_$tag/write $G/prof_$tag/sq $G/prof_$tag/kt $G/prof_$tag/kt1   # (raw traces: hundreds of MB)
 head -c 400 $G/${tag}_bench_line.json; echo; head -12 $G/${tag}_bench_kernel_stats.csv; cat $G/${tag}_sq_counters.txt | head -8
