@@ -325,6 +325,11 @@ def _full_size_step_against(golden, tmp_path, name, width, height, batch, head_s
     tie = np.unpackbits(g["tie_mask"])[: labels.size].reshape(labels.shape).astype(bool)
     wrong = (labels != g["labels"]) & ~tie
     assert wrong.sum() == 0, int(wrong.sum())
+    # the tie mask (pixels whose two best soft probabilities are within 2e-3 in the reference's own run) must not absorb a
+    # regression: only a small part of the masked pixels may actually come out differently
+    inside = int(((labels != g["labels"]) & tie).sum())
+    print(f"{name}: {int(tie.sum())} of {labels.size} pixels in the reference's tie mask ({tie.mean():.4%}), {inside} of them differ")
+    assert inside <= max(2, 0.02 * tie.sum()), (inside, int(tie.sum()))  # (measured: none of G10 / G12 / G13's masked pixels differ)
     assert np.abs(soft.max(1)[0].numpy() - g["soft_max"].astype(np.float32)).max() < 3e-3
     for k, v in json.loads(str(g["log_json"])).items():
         mine = log[k]
@@ -581,7 +586,7 @@ def test_step_sharded_matches_the_oracle_emulation_of_two_ranks(tmp_path, conv_m
     # reference's own fp32 noise through a train-mode pass (its step-0 update moves by 0.3 % with its thread count); the
     # same-kernel comparison of the two layouts is test_multirank_gpu.py (1e-4)
     print("step_sharded vs oracle emulation, update rel-L2:", (num / den) ** 0.5)
-    assert (num / den) ** 0.5 <= 0.01, (num / den) ** 0.5
+    assert (num / den) ** 0.5 <= 5e-3, (num / den) ** 0.5  # (measured: 1.2e-3)
 
 
 def test_eval_forward_1024x2048_golden(golden, conv_mode):
