@@ -254,6 +254,7 @@ int onda_bn_bwd(const float* dout, const float* out, const float* x, const float
 int64_t onda_gn_ws(int B, int64_t HW, int C);
 int onda_gn_fwd(const float* x, int ldx, const float* gamma, const float* beta, const float* chmul, float* out, int ldo,
                 float* mean, float* rstd, float* ws, int B, int64_t HW, int C, int groups, float eps, int relu,
+                float* amax /* NULL, or the running max|out| of a tensor that feeds a convolution (f16x2 section) */,
                 onda_stream_t s);
 int onda_gn_bwd(const float* dout, int lddo, const float* out, int ldo, const float* x, int ldx, const float* gamma,
                 const float* chmul, const float* mean, const float* rstd, float* dx, float* dgamma, float* dbeta,
@@ -279,6 +280,10 @@ int onda_se_fc_bwd(const float* dgate, const float* pooled, const float* hidden,
 /* out[b][px][c] = x[b][px][c] * gate[b][c] (+ add[b][c] if add != NULL) */
 int onda_chan_scale(const float* x, const float* gate, const float* add, float* out, int B, int64_t HW, int C,
                     onda_stream_t s);
+/* the SE gate applied and the result written as the NEXT conv's operand: out[2][B*HW][C] f16 limb planes of x * gate scaled by
+ * the scale of x_amax (= max|x|: a sigmoid gate cannot raise it) -- no fp32 copy, no max pass, no split pass */
+int onda_chan_scale_limbs(const float* x, const float* gate, void* out, int64_t out_plane, const float* x_amax, int B, int64_t HW,
+                          int C, onda_stream_t s);
 
 /* ---- bilinear upsample, align_corners=True (adaptation_model.py:94-98) -------------------
  * logits NHWC [B,h,w] rows of stride ldl holding K classes -> NCHW f32[B,K,H,W]. */

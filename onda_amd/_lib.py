@@ -87,7 +87,7 @@ SIGNATURES = {
     "onda_bn_bwd_ws": (L, [L, I]),
     "onda_bn_bwd": (I, [P, P, P, P, P, P, P, P, P, L, I, I, P, P]),
     "onda_gn_ws": (L, [I, L, I]),
-    "onda_gn_fwd": (I, [P, I, P, P, P, P, I, P, P, P, I, L, I, I, F, I, P]),
+    "onda_gn_fwd": (I, [P, I, P, P, P, P, I, P, P, P, I, L, I, I, F, I, P, P]),
     "onda_gn_bwd": (I, [P, I, P, I, P, I, P, P, P, P, P, P, P, P, I, L, I, I, I, P]),
     "onda_maxpool_fwd": (I, [P, P, P, I, I, I, I, I, I, P]),
     "onda_maxpool_bwd": (I, [P, P, P, I, I, I, I, I, I, P]),
@@ -96,6 +96,7 @@ SIGNATURES = {
     "onda_se_fc_fwd": (I, [P, P, P, P, P, P, P, I, I, I, P]),
     "onda_se_fc_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, P, F, I, I, I, P]),
     "onda_chan_scale": (I, [P, P, P, P, I, L, I, P]),
+    "onda_chan_scale_limbs": (I, [P, P, P, L, P, I, L, I, P]),
     "onda_upsample_fwd": (I, [P, I, P, I, I, I, I, I, I, P]),
     "onda_upsample_bwd": (I, [P, P, I, I, I, I, I, I, I, P]),
     "onda_upsample_argmax": (I, [P, I, P, I, I, I, I, I, I, P]),

@@ -291,8 +291,9 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
                                                        const float* __restrict__ chmul, float* __restrict__ out,
                                                        int ldo, const float* __restrict__ mean,
                                                        const float* __restrict__ rstd, int64_t HW, int C, int groups,
-                                                       size_t total4, int relu) {
+                                                       size_t total4, int relu, float* __restrict__ amax) {
   const int c4 = C / 4, cpg = C / groups;
+  float mx = 0.f;
   for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total4; e += (size_t)gridDim.x * blockDim.x) {
     const int col = (int)(e % c4) * 4;
     const size_t row = e / c4;
@@ -305,7 +306,9 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
     }
     if (chmul) v *= LD4(chmul + (size_t)b * C + col);
     *reinterpret_cast<f32x4*>(out + row * ldo + col) = v;
+    mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
   }
+  if (amax != nullptr) amax_update(amax, mx);  // the output feeds a convolution (directly, or through the SE gate): leave max|out| behind
 }
 
 // partials[b][chunk][2][C] -> AB[b][2][C] (one wave per (b,c))
@@ -469,7 +472,7 @@ int64_t onda_gn_ws(int B, int64_t HW, int C) {
 }
 
 int onda_gn_fwd(const float* x, int ldx, const float* gamma, const float* beta, const float* chmul, float* out, int ldo,
-                float* mean, float* rstd, float* ws, int B, int64_t HW, int C, int groups, float eps, int relu,
+                float* mean, float* rstd, float* ws, int B, int64_t HW, int C, int groups, float eps, int relu, float* amax,
                 onda_stream_t s) {
   ONDA_REQUIRE(x && gamma && beta && out && mean && rstd && ws);
   ONDA_REQUIRE(C % groups == 0 && (C / groups) % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0);
@@ -481,7 +484,7 @@ int onda_gn_fwd(const float* x, int ldx, const float* gamma, const float* beta, 
                      C, groups, (double)HW * (C / groups), eps, mean, rstd);
   const size_t total4 = (size_t)B * HW * C / 4;
   hipLaunchKernelGGL(gn_apply_kernel, dim3(ew_grid(total4)), dim3(256), 0, ONDA_STREAM(s), x, ldx, gamma, beta, chmul,
-                     out, ldo, mean, rstd, HW, C, groups, total4, relu);
+                     out, ldo, mean, rstd, HW, C, groups, total4, relu, amax);
   return ONDA_LAUNCH_RESULT();
 }
 

@@ -485,6 +485,25 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_l2_kernel(const float* __res
   }
 }
 
+// SE gate applied to the ASPP concat, written as the bottleneck conv's OPERAND: out limbs = x * gate[b][c] scaled by the
+// scale of max|x| (the gate is a sigmoid: |out| <= |x|, so the input's maximum bounds the output's).  No fp32 copy, no
+// max pass, no split pass (framework/model/deeplabv2.py:99-114 -> :244).
+__global__ __launch_bounds__(256) void chan_scale_limbs_kernel(const float* __restrict__ x, const float* __restrict__ gate,
+                                                               _Float16* __restrict__ out, size_t plane,
+                                                               const float* __restrict__ amax, int64_t HW, int C, size_t total8) {
+  const int c8 = C / 8;
+  const float so = scale_of(amax).s;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total8; e += (size_t)gridDim.x * blockDim.x) {
+    const int col = (int)(e % c8) * 8;
+    const size_t b = (e / c8) / HW;
+    const f32x4 v0 = LD4S(x + e * 8) * LD4(gate + b * C + col), v1 = LD4S(x + e * 8 + 4) * LD4(gate + b * C + col + 4);
+    u32x4 l1, l2;
+    split8(v0 * so, v1 * so, l1, l2);
+    st_stream(reinterpret_cast<u32x4*>(out + e * 8), l1);
+    st_stream(reinterpret_cast<u32x4*>(out + plane + e * 8), l2);
+  }
+}
+
 static inline unsigned ew_grid(size_t total) {
   size_t g = (total + 255) / 256;
 #ifndef ONDA_EW_GRID_CAP
@@ -509,6 +528,16 @@ int onda_bn_finalize_l2(const float* partials, int tiles, int C, int64_t count, 
   hipLaunchKernelGGL(bn_finalize_l2_kernel, dim3((C + 15) / 16, split > 0 ? 2 : 1), dim3(256), 0, ONDA_STREAM(s), partials, tiles, C,
                      (double)count, eps, mean, invstd, running_mean, running_var, nbt, momentum, gamma, beta, res_amax, relu, xhat_amax,
                      out_amax, (long long)split, tile_rows > 0 ? tile_rows : 1, run_group, y, ldy);
+  return ONDA_LAUNCH_RESULT();
+}
+
+int onda_chan_scale_limbs(const float* x, const float* gate, void* out, int64_t out_plane, const float* x_amax, int B, int64_t HW,
+                          int C, onda_stream_t s) {
+  ONDA_REQUIRE(x && gate && out && x_amax && C % 8 == 0 && out_plane % 8 == 0 && B > 0 && HW > 0);
+  if (!ONDA_ALIGNED16(x) || !ONDA_ALIGNED16(out) || !ONDA_ALIGNED16(gate)) return ONDA_EALIGN;
+  const size_t total8 = (size_t)B * HW * C / 8;
+  hipLaunchKernelGGL(chan_scale_limbs_kernel, dim3(ew_grid(total8)), dim3(256), 0, ONDA_STREAM(s), x, gate,
+                     static_cast<_Float16*>(out), (size_t)out_plane, x_amax, HW, C, total8);
   return ONDA_LAUNCH_RESULT();
 }
 

@@ -1102,6 +1102,9 @@ class MaxPoolFn(torch.autograd.Function):
         idx = torch.empty(B, Ho, Wo, C, device=x.device, dtype=torch.uint8)
         x = x.contiguous()
         call("onda_maxpool_fwd", _p(x), _p(y), _p(idx), B, Hi, Wi, C, Ho, Wo, _stream())
+        slot = known_amax(x)
+        if slot is not None:  # a max over windows of x >= 0 (behind the stem's ReLU) cannot pass max|x|: no max pass over y
+            tag_amax(y, slot)
         ctx.save_for_backward(idx)
         ctx.in_shape = (B, Hi, Wi, C)
         return y
@@ -1129,15 +1132,19 @@ class GNConcatFn(torch.autograd.Function):
         HW = H * W
         cat = torch.empty(B, H, W, C * n, device=ys[0].device, dtype=torch.float32)
         ws = torch.empty(query("onda_gn_ws", B, HW, C), device=cat.device, dtype=torch.float32)
+        # the buffer feeds a convolution (through the SE gate, or directly: the class head): the apply passes leave max|cat|
+        amax = amax_slot(cat.device) if CONV_MODE == "f16x2" else None
         means, rstds = [], []
         for i in range(n):
             mean = torch.empty(B * GN_GROUPS, device=cat.device, dtype=torch.float32)
             rstd = torch.empty_like(mean)
             sl = cat[..., i * C:(i + 1) * C]
             call("onda_gn_fwd", _p(ys[i]), nhwc_ld(ys[i]), _p(gammas[i]), _p(betas[i]), _p(chmul), _p(sl), C * n,
-                 _p(mean), _p(rstd), _p(ws), B, HW, C, GN_GROUPS, GN_EPS, int(relu), _stream())
+                 _p(mean), _p(rstd), _p(ws), B, HW, C, GN_GROUPS, GN_EPS, int(relu), _p(amax), _stream())
             means.append(mean)
             rstds.append(rstd)
+        if amax is not None:
+            tag_amax(cat, amax)
         ctx.save_for_backward(cat, chmul, *ys, *gammas, *means, *rstds)
         ctx.n, ctx.relu = n, relu
         return cat
@@ -1168,6 +1175,9 @@ class GNConcatFn(torch.autograd.Function):
         return (None, None, *dys, *dgs, *dbs)
 
 
+SE_LIMBS = os.environ.get("ONDA_SE_LIMBS", "1") != "0"  # measurement knob: 0 = the gated concat as fp32 + max pass + split pass
+
+
 class SEScaleFn(torch.autograd.Function):
     """SEBlock: x * sigmoid(W2 relu(W1 mean_px(x) + b1) + b2)."""
 
@@ -1179,8 +1189,16 @@ class SEScaleFn(torch.autograd.Function):
         hidden = torch.empty(B, R, device=x.device, dtype=torch.float32)
         gate = torch.empty(B, C, device=x.device, dtype=torch.float32)
         call("onda_se_fc_fwd", _p(pooled), _p(w1), _p(b1), _p(w2), _p(b2), _p(hidden), _p(gate), B, C, R, _stream())
-        out = torch.empty_like(x)
-        call("onda_chan_scale", _p(x), _p(gate), None, _p(out), B, H * W, C, _stream())
+        slot = known_amax(x)
+        if SE_LIMBS and slot is not None and limb_mode(C) and x.is_contiguous():
+            # the result feeds the bottleneck conv only: written as that conv's operand (limb planes scaled by max|x|, which
+            # the sigmoid gate cannot raise) -- no fp32 copy, no max pass, no split pass over the 1280-channel buffer
+            planes = torch.empty(2, B * H * W, C, device=x.device, dtype=torch.float16)
+            call("onda_chan_scale_limbs", _p(x), _p(gate), _p(planes), B * H * W * C, _p(slot), B, H * W, C, _stream())
+            out = limb_only((B, H, W, C), x.device, Limbs(planes, slot, C, B * H * W * C))
+        else:
+            out = torch.empty_like(x)
+            call("onda_chan_scale", _p(x), _p(gate), None, _p(out), B, H * W, C, _stream())
         ctx.save_for_backward(x, pooled, hidden, gate, w1, w2)
         return out
 

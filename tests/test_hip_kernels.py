@@ -520,7 +520,8 @@ def test_maxpool_ceil(H, W):
     assert torch.equal(nchw(xd.grad).cpu(), xr.grad)
 
 
-def test_se_block():
+@pytest.mark.parametrize("known_scale", [False, True])
+def test_se_block(known_scale):
     from onda_amd import ops
     g = torch.Generator().manual_seed(3)
     B, C, R, H, W = 2, 1280, 80, 9, 17
@@ -533,8 +534,11 @@ def test_se_block():
     gy = torch.randn(ref.shape, generator=g)
     ref.backward(gy)
     ds = [nhwc(x).to(DEV).requires_grad_(True)] + [t.to(DEV).requires_grad_(True) for t in (w1, b1, w2, b2)]
+    if known_scale:  # the producer left max|x| behind (GroupNorm apply does): the gated result exists as limb planes only
+        ops.activation_scale(ds[0])
     out = ops.SEScaleFn.apply(*ds)
-    close(nchw(out), ref, 2e-5, "se fwd")
+    assert ops.is_limb_only(out) == (known_scale and ops.limb_mode(C))
+    close(nchw(ops.materialize(out)), ref, 2e-5, "se fwd")
     out.backward(nhwc(gy).to(DEV))
     close(nchw(ds[0].grad), ps[0].grad, 1e-4, "se dx")
     for i, name in enumerate(("dw1", "db1", "dw2", "db2"), 1):
