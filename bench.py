@@ -273,7 +273,7 @@ def point_miopen_at_tree():
     """MIOpen reads these when its first handle is created (the first eager convolution; the HIP path never calls
     MIOpen).  The directory must be writable: a miss makes MIOpen search and append."""
     os.makedirs(MIOPEN_DB, exist_ok=True)
-    os.environ.setdefault("MIOPEN_USER_DB_PATH", MIOPEN_DB)
+    os.environ.setdefault("MIOPEN_USER_DB_PATH", MIOPEN_DB)  # (honoured by a child only if it does not set its own: eager_rocm_boxed)
     os.environ.setdefault("MIOPEN_CUSTOM_CACHE_DIR", os.path.join(MIOPEN_DB, "cache"))
 
 
@@ -320,6 +320,13 @@ def eager_rocm_boxed(args):
     cmd = [sys.executable, os.path.abspath(__file__), "--eager-only", "--batch", str(args.batch), "--height", str(args.height),
            "--width", str(args.width), "--branch", args.branch]
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    # MIOpen appends to its user db and kernel cache whenever it meets something new: the child works on a COPY of the tracked
+    # directory (1.7 MB), so that a measurement run never dirties the tree (`python bench.py --eager` is the run that fills it)
+    import shutil
+    scratch = tempfile.mkdtemp(prefix="onda_miopen_")
+    shutil.copytree(MIOPEN_DB, os.path.join(scratch, "db"))
+    env["MIOPEN_USER_DB_PATH"] = os.path.join(scratch, "db")
+    env["MIOPEN_CUSTOM_CACHE_DIR"] = os.path.join(scratch, "db", "cache")
     child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
     try:
         out, _ = child.communicate(timeout=budget)
@@ -327,6 +334,8 @@ def eager_rocm_boxed(args):
         child.kill()  # (this exact child, by handle)
         child.communicate()
         return None, f"the eager leg did not finish within {budget:.0f} s (MIOpen searching: tools/miopen_db does not match this box)"
+    finally:
+        shutil.rmtree(scratch, ignore_errors=True)
     lines = [ln for ln in out.decode().splitlines() if ln.startswith("{")]
     if child.returncode != 0 or not lines:
         return None, f"the eager leg's process ended with code {child.returncode}"
