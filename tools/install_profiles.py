@@ -1,30 +1,32 @@
-"""Move one evidence run from gpurun_out/ (scratch) into profiles/ (tracked): bench lines of every configuration, kernel
-stats, PMC traffic, SQ counters, per-shape conv rates; stamps each file with the library source hash the run used and
-points the bench lines' roofline.traffic at the PMC summary of the same run.
-usage: python tools/install_profiles.py r02_n <library_src> [old_tag_to_remove]"""
+"""Move one evidence run of tools/profile_round.sh from gpurun_out/ (scratch) into profiles/ (tracked): bench lines of every
+configuration, kernel stats (default command and one-stream), PMC traffic, SQ counters, per-shape conv rates; stamps each file
+with the library source hash the run used and points the bench lines' roofline.traffic at the PMC summary of the same run.
+usage: python tools/install_profiles.py r04_c [old_tag_to_remove]"""
 import glob, json, os, shutil, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-tag, src = sys.argv[1], sys.argv[2]
-old = sys.argv[3] if len(sys.argv) > 3 else None
+tag = sys.argv[1]
+old = sys.argv[2] if len(sys.argv) > 2 else None
 G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
-names = {"default": "bench_line.json", "static": "bench_line_static_branch.json", "c1": "bench_line_config1.json",
-         "c2": "bench_line_config2.json", "c5": "bench_line_config5.json", "gb32": "bench_line_strong_gb32_n1.json"}
+src = json.load(open(os.path.join(G, f"{tag}_bench_line.json")))["config"]["library"]["library_src"]
+if old:
+    for f in glob.glob(os.path.join(P, f"{old}_*")):
+        subprocess.run(["git", "rm", "-q", "-f", f], cwd=ROOT)
 t = json.load(open(os.path.join(G, f"{tag}_hbm_traffic.json")))
 t["library_src"] = src
 t["command"] = ("rocprofv3 --pmc FETCH_SIZE (and, separately, WRITE_SIZE) --kernel-trace --output-format csv -- python3 "
                 "tools/one_pass.py; tools/pmc_summary.py")
-if old:
-    for f in glob.glob(os.path.join(P, f"{old}_*")):
-        subprocess.run(["git", "rm", "-q", "-f", f], cwd=ROOT)
 json.dump(t, open(os.path.join(P, f"{tag}_hbm_traffic.json"), "w"), indent=1)
 import bench  # noqa: E402  (committed_traffic reads the file just written)
-for k, n in names.items():
-    line = open(os.path.join(G, f"m_{k}.log")).read().strip().splitlines()[-1]
-    j = json.loads(line)
-    j["roofline"].update(bench.committed_traffic(j["roofline"]["kernel"]))
+lines = sorted(glob.glob(os.path.join(G, f"{tag}_bench_line*.json"))) + [os.path.join(G, f"{tag}_profiled_bench_line.json"),
+                                                                         os.path.join(G, f"{tag}_profiled_bench_line_one_stream.json")]
+for f in lines:
+    j = json.load(open(f))
+    if j.get("roofline"):
+        j["roofline"].update(bench.committed_traffic(j["roofline"]["kernel"]))
     j["library_src"] = src
-    open(os.path.join(P, f"{tag}_{n}"), "w").write(json.dumps(j) + "\n")
-    print(k, j["value"], j["ms_per_step"], j["roofline"]["frac"], j["roofline"]["traffic_source"])
-for a, b in (("kstats.csv", "bench_kernel_stats.csv"), ("sq_counters.txt", "sq_counters.txt"), ("conv_shapes.txt", "conv_shapes.txt")):
-    shutil.copy(os.path.join(G, f"{tag}_{a}"), os.path.join(P, f"{tag}_{b}"))
+    open(os.path.join(P, os.path.basename(f)), "w").write(json.dumps(j) + "\n")
+    print(os.path.basename(f), j["ms_per_step"], j["value"], (j.get("roofline") or {}).get("frac"))
+for n in ("bench_kernel_stats.csv", "bench_kernel_stats_one_stream.csv", "sq_counters.txt", "conv_shapes.txt", "hbm_traffic_top.txt"):
+    shutil.copy(os.path.join(G, f"{tag}_{n}"), os.path.join(P, f"{tag}_{n}"))
+print("library_src", src)
