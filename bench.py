@@ -168,37 +168,61 @@ def measure_roofline(step_fn, steps_done, record=True):
     if not record:
         return None
     fam = {}
-    for name, flops, e0, e1, _tag in ops.profile_entries(ops.PROFILE):
-        f = fam.setdefault(name, [0.0, 0.0, 0])
+    for name, flops, e0, e1, tag, issued in ops.profile_entries(ops.PROFILE):
+        f = fam.setdefault(name, [0.0, 0.0, 0, 0.0, 0.0])
         f[0] += flops
         f[1] += e0.elapsed_time(e1) * 1e-3
         f[2] += 1
+        f[3] += issued
+        f[4] += algorithmic_bytes(tag)
     ops.PROFILE = None
-    name, (flops, secs, n) = max(fam.items(), key=lambda kv: kv[1][1])
+    name, (flops, secs, n, issued, abytes) = max(fam.items(), key=lambda kv: kv[1][1])
     achieved = flops / secs / 1e12
-    detail = {k: {"launches": v[2], "ms_total": round(v[1] * 1e3, 3), "tflops": round(v[0] / v[1] / 1e12, 2)} for k, v in fam.items()}
+    detail = {k: {"launches": v[2], "ms_total": round(v[1] * 1e3, 3), "tflops": round(v[0] / v[1] / 1e12, 2),
+                  "issued_share": round(v[3] / v[0], 4)} for k, v in fam.items()}
     fwd = [v for k, v in fam.items() if "wgrad" not in k]
     wg = [v for k, v in fam.items() if "wgrad" in k]
     # The roofline of a kernel is the matrix pipe it executes on: `peak` = that pipe's dense peak divided by the MFMA
-    # products the evaluation spends per fp32 product (f16x2: 3, f32: the fp32 MFMA itself), so `frac` =
-    # executed MFMA flops / pipe peak.  The fp32 matrix peak (what an unsplit fp32 kernel could reach at most) is
-    # reported next to it.
+    # products the evaluation spends per fp32 product (f16x2: 3, f32: the fp32 MFMA itself).  `achieved` / `frac` are in
+    # ALGORITHMIC flops (2 M Cout taps Cin per launch); the kernels skip K-steps that only multiply padding
+    # (dead taps of the dilated branches), so the matrix pipe itself executes `pipe.executed_tflops` =
+    # products x ISSUED flops / time (< products x achieved).  The fp32 matrix peak (what an unsplit fp32 kernel could
+    # reach at most) is reported next to it.
     if "l2" in name or "h2" in name:
         products, what = 3, "f16 MFMA (v_mfma_f32_16x16x32_f16), 3 limb products per fp32 product, fp32 accumulate"
     else:
         products, what = 0, "fp32 MFMA (v_mfma_f32_32x32x2_f32)"
     peak = F16_MFMA_PEAK_TFLOPS / products if products else FP32_MFMA_PEAK_TFLOPS
+    pipe_peak = F16_MFMA_PEAK_TFLOPS if products else FP32_MFMA_PEAK_TFLOPS
+    executed = (products or 1) * issued / secs / 1e12
     roof = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
             "measured": "HIP events around every launch of two extra steps with ONDA_SIDE_STREAMS=0 (each kernel alone on the GPU)",
+            "schedule": "one_stream (a per-kernel property; ms_per_step / value come from the default multi-stream schedule)",
             "frac": round(achieved / peak, 4), "traffic": None, "launches_per_step": n // 2,
-            "avg_launch_ms": round(secs / n * 1e3, 4), "avg_launch_gflop": round(flops / n / 1e9, 3), "families": detail,
+            "avg_launch_ms": round(secs / n * 1e3, 4), "avg_launch_gflop": round(flops / n / 1e9, 3),
+            "avg_launch_algorithmic_bytes": round(abytes / n), "families": detail,
             "all_fwd_dgrad_tflops": round(sum(v[0] for v in fwd) / max(sum(v[1] for v in fwd), 1e-12) / 1e12, 2) if fwd else None,
             "all_wgrad_tflops": round(sum(v[0] for v in wg) / max(sum(v[1] for v in wg), 1e-12) / 1e12, 2) if wg else None,
-            "pipe": {"what": what, "pipe_peak_tflops": F16_MFMA_PEAK_TFLOPS if products else FP32_MFMA_PEAK_TFLOPS,
-                     "executed_tflops": round((products or 1) * achieved, 1)},
+            "pipe": {"what": what, "pipe_peak_tflops": pipe_peak, "issued_share_of_algorithmic_flops": round(issued / flops, 4),
+                     "executed_tflops": round(executed, 1), "executed_frac_of_pipe_peak": round(executed / pipe_peak, 4)},
             "vs_fp32_matrix_peak": {"peak": FP32_MFMA_PEAK_TFLOPS, "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4)}}
     roof.update(committed_traffic(name))
+    if roof.get("traffic"):
+        # bytes that crossed the L2's memory side per launch / bytes the launch has to touch once (operands + output):
+        # > 1 = re-reads (the nine taps of a 3x3 convolution re-streaming their input rows through a 4 MB L2)
+        roof["traffic_over_algorithmic_bytes"] = round(roof["traffic"] / max(roof["avg_launch_algorithmic_bytes"], 1), 3)
     return roof
+
+
+def algorithmic_bytes(tag):
+    """Bytes a conv launch has to touch once: its operands (limb planes: 4 bytes per element, like fp32) and its output.
+    tag = (kind, M, Cout, Cin, k, stride, dil[, splitk]) as ops records it; M = GEMM rows of the launch."""
+    if not tag:
+        return 0.0
+    kind, M, co, ci, k = tag[0], tag[1], tag[2], tag[3], tag[4]
+    if kind == "wgrad":
+        return 4.0 * (M * ci + M * co) + 4.0 * tag[7] * co * k * k * ci
+    return 4.0 * (M * ci + co * k * k * ci + M * co)
 
 
 def committed_traffic(kernel_family):
@@ -220,7 +244,9 @@ def committed_traffic(kernel_family):
             tot = sum(v["hbm_bytes_per_launch"] * v["launches"] for _, v in rows)
             n = sum(v["launches"] for _, v in rows)
             best = {"traffic": round(tot / n), "traffic_unit": "bytes per launch (HBM + Infinity-Cache side of L2)",
-                    "traffic_source": os.path.relpath(path, ROOT), "traffic_library_src": blob.get("library_src")}
+                    "traffic_source": os.path.relpath(path, ROOT), "traffic_library_src": blob.get("library_src"),
+                    "traffic_workload": blob.get("workload", "tools/one_pass.py (one bs-4 forward+backward pass; NOT the bench step)"),
+                    "traffic_avg_launch_us_profiled": round(sum(v["avg_launch_us_profiled"] * v["launches"] for _, v in rows) / n, 1)}
     return best or {}
 
 

@@ -160,6 +160,11 @@ int onda_conv_l2_tiles_m(int64_t M, int Cout, int taps, int Cin);  /* rows of th
 /* the same for a launch with a row-group boundary (OndaConv.stat_split) and / or OndaConv.plain_schedule; *tile_rows (optional)
  * receives the GEMM rows one partial row covers */
 int onda_conv_l2_tiles_m_split(int64_t M, int Cout, int taps, int Cin, int64_t stat_split, int plain_schedule, int* tile_rows);
+/* Measurement helpers (bench.py `roofline.pipe`): the share of a problem's K-steps the kernels really issue -- whole tiles of
+ * onda_conv2d_fwd_l2 skip filter taps that only see padding (dilated ASPP branches, deeplabv2.py:147-167), the weight
+ * gradient skips 32-pixel steps whose rows are all padding for its tap; 1.0 = nothing skipped.  Host arithmetic only. */
+double onda_conv_l2_live_fraction(const OndaConv* c, int with_stats);
+double onda_conv_wgrad_l2_live_fraction(const OndaConv* c, int splitk);
 /* stats_rows: 2 = stats[tile][sum, sumsq][Cout] as onda_conv2d_fwd; 4 = also the per-channel min and max of the raw
  * output tile, from which onda_bn_finalize_l2 bounds max|BatchNorm output| before the apply pass writes limb planes */
 int onda_conv2d_fwd_l2(const void* xl, int64_t xplane, const float* xamax, const void* w2, const float* wamax, float* y,

@@ -68,6 +68,8 @@ SIGNATURES = {
     "onda_conv_l2_kernel_id": (I, [L, I, I, I]),
     "onda_conv_l2_tiles_m": (I, [L, I, I, I]),
     "onda_conv_l2_tiles_m_split": (I, [L, I, I, I, L, I, POINTER(c_int)]),
+    "onda_conv_l2_live_fraction": (ctypes.c_double, [POINTER(OndaConv), I]),
+    "onda_conv_wgrad_l2_live_fraction": (ctypes.c_double, [POINTER(OndaConv), I]),
     "onda_conv_wgrad_l2_variant": (I, [I, I]),
     "onda_conv2d_wgrad_l2": (I, [P, L, P, P, L, P, P, I, I, POINTER(OndaConv), P]),
     "onda_conv2d_fwd_l2": (I, [P, L, P, P, P, P, P, P, P, P, I, P, P, POINTER(OndaConv), P]),

@@ -17,6 +17,7 @@
 // 16-byte chunk index XOR-ed with a function of the row (swz_row) on the DMA's source side and in the
 // fragment read: conflict-free ds_read_b128.
 #include "conv_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -1056,6 +1057,441 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_l2x_kernel(const ConvK
   }
 }
 
+// ---- the short-K convolutions as a PRODUCER / CONSUMER workgroup ----------------------------------------------------------
+// conv_l2x_kernel above streams its K-steps across tile boundaries, but every tile still ends with an epilogue during which
+// the matrix pipe idles: 12 000-13 500 cycles per 256 x 128 tile whatever the shape (statistics 2 400, transposition + stores
+// 5 000, barrier + cross-wave reduction 3 400; profiles/r03_l2x_stamps.txt) against a K loop of 21 500 cycles at 256 input
+// channels.  The eight waves of that kernel all hold accumulators (232 registers each): nobody has room to keep a finished
+// tile while the next one is being multiplied, and LDS (144 KB of ring) has none either.
+// Here the workgroup's eight waves have three ROLES on a 128 x 128 tile:
+//   waves 0-3  CONSUMERS (one per SIMD): 64 x 64 each, fragments from the ring, MFMAs, nothing else -- no global memory
+//              instruction, no vmcnt wait.  At the end of a tile they add the two accumulator sets and drop the tile into
+//              the HOLD area of LDS (64 KB) in ~500 cycles, and go on with the next tile's K loop;
+//   waves 4-5  PRODUCERS: all LDS-DMA of the workgroup (16 instructions each per K-step), two K-steps ahead across tile
+//              boundaries, counted vmcnt waits (they issue nothing else, so the count is exact);
+//   waves 6-7  EPILOGUE: read the held tile back row-wise (4 rows x 64 columns per instruction), statistics / scale /
+//              shift / residual / ReLU / limb split, 256-byte row segments to global memory -- spread over the K-steps of
+//              the NEXT tile, 32 chunks per tile and wave, beside the consumers' MFMAs.
+// LDS: ring of three 32 KB stages (96 KB) + 64 KB hold = all 160 KB of a CU.  One s_barrier per K-step for everybody: the
+// producers arrive with the step's DMAs landed, the consumers with the previous stage's fragments in registers; hold is
+// handed over by the same barriers (a tile is dropped behind barrier first(t+1) and read behind first(t+1)+1 ..
+// first(t+1)+KT-1; the next drop comes behind first(t+2)).  Consumers pre-fetch the next step's fragments beside the
+// current step's MFMAs (PIPE): a1 / b1 of the next step into registers of their own, b2 / a2 into the registers the current
+// step has finished with -- 224 registers, no copies (the loop body exists twice, roles of the two a1 / b1 sets swapped).
+// 128 x 128 tiles move a third more bytes L2 -> LDS per MFMA than 256 x 128: the price of the hold area.  No stream-K:
+// a problem has four times the tiles of the 256-row kernels, the last round's loss is ~3 %.
+template <bool LIMB, bool AFFINE>
+__device__ __forceinline__ void l2p_chunk(const ConvK& a, const float* __restrict__ hold, int e, int lane, int ch, int m0, int n0,
+                                          f32x4 sc, f32x4 sh, float so, float ri, bool plain, float (&st)[4][4], float& mx) {
+  const OndaConv& c = a.c;
+  const int r = 4 * ch + (lane >> 4), cg = lane & 15;
+  const int m = m0 + r, n = n0 + 64 * e + 4 * cg;
+  const int sw = ((r >> 2) & 3) << 4;  // (the consumers' drop XORs the 16-column block with the row group: conflict-free both ways)
+  f32x4 v = *reinterpret_cast<const f32x4*>(hold + r * 128 + ((64 * e + 4 * cg) ^ sw));
+  const bool live = m < a.M && n < c.Cout;
+  if (a.stats != nullptr) {  // raw sums of the tile's rows (rows past M hold zeros: only have to be BOUNDED by the extrema)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      st[j][0] += v[j];
+      st[j][1] += v[j] * v[j];
+      st[j][2] = fminf(st[j][2], v[j]);
+      st[j][3] = fmaxf(st[j][3], v[j]);
+    }
+  }
+  if constexpr (LIMB) {
+    v = v * sc + sh;
+    if (a.resl != nullptr && live) {
+      const _Float16* p = a.resl + (size_t)m * c.ldr + n;
+      const u32x2 q1 = *reinterpret_cast<const u32x2*>(p), q2 = *reinterpret_cast<const u32x2*>(p + a.resplane);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const f32x2 p1 = unpack2h(q1[h]), p2 = unpack2h(q2[h]);
+        v[2 * h] += (p1[0] + p2[0] * LIMB2_UNSCALE) * ri;
+        v[2 * h + 1] += (p1[1] + p2[1] * LIMB2_UNSCALE) * ri;
+      }
+    }
+    if (c.relu) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
+    }
+    if (live) {
+      mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+      const f32x4 w = v * so;
+      u32x2 l1, l2;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const unsigned pk = cvt2h(w[2 * h], w[2 * h + 1]);
+        const f32x2 f = unpack2h(pk);
+        l1[h] = pk;
+        l2[h] = cvt2h((w[2 * h] - f[0]) * LIMB2_SCALE, (w[2 * h + 1] - f[1]) * LIMB2_SCALE);
+      }
+      _Float16* dst = a.yl + (size_t)m * c.ldy + n;
+      store_out(reinterpret_cast<u32x2*>(dst), l1);
+      store_out(reinterpret_cast<u32x2*>(dst + a.yplane), l2);
+    }
+  } else {
+    if constexpr (AFFINE) {
+      v = v * sc + sh;
+      if (a.res && live) v += *reinterpret_cast<const f32x4*>(a.res + (size_t)m * c.ldr + n);
+      if (c.relu) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
+      }
+    } else {
+      v = v * sc;
+    }
+    if (live) {
+      size_t orow = (size_t)m;
+      if (!plain) {  // scattered rows (stride-2 data gradient)
+        const int wo = m % c.Wo, tq = m / c.Wo;
+        const int ho = tq % c.Ho, b = tq / c.Ho;
+        orow = ((size_t)b * c.Hf + (size_t)ho * c.out_os) * c.Wf + (size_t)wo * c.out_os;
+      }
+      store_out(reinterpret_cast<f32x4*>(a.y + orow * c.ldy + n), v);
+      if (a.amax != nullptr) mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    }
+  }
+}
+
+template <bool PIPE>
+__global__ __launch_bounds__(512, 2) void conv_l2p_kernel(const ConvK a, unsigned xplane, unsigned wplane, unsigned x_bytes,
+                                                          unsigned w_bytes, const float* __restrict__ xamax,
+                                                          const float* __restrict__ wamax) {
+  if (a.c.run_if != nullptr && *a.c.run_if == 0) return;  // predicated launch (onda_switch_step decided on the device)
+  constexpr int BM = 128, BN = 128;
+  constexpr int PLANE = BM * 64;  // one limb plane of A (or of B) in a stage: 64-byte rows
+  constexpr int A_BYTES = 2 * PLANE, STAGE = 4 * PLANE, RING = 3 * STAGE, HOLD = BM * BN * 4;
+  constexpr int DPW = 16;    // LDS-DMA instructions per producer wave and K-step
+  constexpr int NCH = 32;    // 4-row chunks of a tile per epilogue wave
+  static_assert(RING + HOLD == 160 * 1024, "all of a CU's LDS");
+  __shared__ __attribute__((aligned(16))) unsigned char lds[RING + HOLD];
+
+  const OndaConv& c = a.c;
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int nblk = gridDim.x, bid = blockIdx.x;
+  const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
+  const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  const int KT = a.taps * a.kcper;  // >= 2 (host)
+  const int tiles = a.tilesM * a.tilesN;
+  const int ntiles = (tiles - swz + nblk - 1) / nblk;  // this workgroup's tiles: swz, swz + nblk, ...  (>= 1: grid <= tiles)
+  const int G = ntiles * KT;                           // its K-steps = its barriers B_0 .. B_{G-1}
+  auto next_stage = [](int s_) { return s_ + STAGE == RING ? 0 : s_ + STAGE; };
+
+  if (wave < 4) {
+    // ---------------------------------------------------------------------------------------------------- consumers
+    const int wm = wave >> 1, wn = wave & 1;
+    const int frag = (lane & 15) * 64 + (((lane >> 4) ^ swz_row(lane & 15)) << 4);
+    f32x4 acc[4][4], accx[4][4];
+    auto zero = [&]() {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[i][j][e] = accx[i][j][e] = 0.f;
+    };
+    zero();
+    float* hold = reinterpret_cast<float*>(lds + RING);
+    const int hbase = (wm * 64 + 4 * (lane >> 4)) * 128, hcol = (wn * 64 + (lane & 15)) ^ ((lane >> 4) << 4);
+    auto tile_end = [&]() {  // both product classes back into one set (exact: a power of two), the tile into the hold area
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const f32x4 v = acc[i][j] + accx[i][j] * LIMB2_UNSCALE;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) hold[hbase + (i * 16 + e) * 128 + (hcol ^ (j << 4))] = v[e];
+        }
+      zero();
+    };
+    f16x8 a1[2][4], b1[2][4], a2[4], b2[4];
+    int st_read = 0;
+    const unsigned char *Ab, *Bb;
+    auto open_stage = [&]() {
+      Ab = lds + st_read + wm * 64 * 64 + frag;
+      Bb = lds + st_read + A_BYTES + wn * 64 * 64 + frag;
+      st_read = next_stage(st_read);
+    };
+    auto mfma3 = [&](const f16x8 (&A1)[4], const f16x8 (&B1)[4], int which) {
+      if (which == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) accx[i][ZZ(i, jj)] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A1[i], b2[ZZ(i, jj)], accx[i][ZZ(i, jj)], 0, 0, 0);
+      } else if (which == 1) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) accx[i][ZZ(i, jj)] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2[i], B1[ZZ(i, jj)], accx[i][ZZ(i, jj)], 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) acc[i][ZZ(i, jj)] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A1[i], B1[ZZ(i, jj)], acc[i][ZZ(i, jj)], 0, 0, 0);
+      }
+    };
+    if constexpr (!PIPE) {
+      for (int it = 0; it < ntiles; ++it) {
+        for (int kt = 0; kt < KT; ++kt) {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (a tile dropped in the last step is in LDS before the barrier publishes it)
+          __builtin_amdgcn_s_barrier();  // B_g: stage g landed
+          open_stage();
+#pragma unroll
+          for (int i = 0; i < 4; ++i) a1[0][i] = *reinterpret_cast<const f16x8*>(Ab + i * 1024);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) b2[j] = *reinterpret_cast<const f16x8*>(Bb + PLANE + j * 1024);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) a2[i] = *reinterpret_cast<const f16x8*>(Ab + PLANE + i * 1024);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) b1[0][j] = *reinterpret_cast<const f16x8*>(Bb + j * 1024);
+          mfma3(a1[0], b1[0], 0);
+          mfma3(a1[0], b1[0], 1);
+          mfma3(a1[0], b1[0], 2);
+        }
+        tile_end();
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();  // B_G (nothing to publish: the others count it)
+    } else {
+      __builtin_amdgcn_s_barrier();  // B_0
+      open_stage();
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a1[0][i] = *reinterpret_cast<const f16x8*>(Ab + i * 1024);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b2[j] = *reinterpret_cast<const f16x8*>(Bb + PLANE + j * 1024);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a2[i] = *reinterpret_cast<const f16x8*>(Ab + PLANE + i * 1024);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b1[0][j] = *reinterpret_cast<const f16x8*>(Bb + j * 1024);
+      // one K-step: MFMAs on the fragments of step g (set P) while the fragments of step g + 1 arrive (a1 / b1 into set 1 - P;
+      // b2 / a2 in place, each behind the MFMA group that last reads it).  No branch in here: behind the workgroup's last
+      // K-step the reads fetch a stage nobody filled, into registers nobody uses.
+      auto body = [&](auto P_) {
+        constexpr int P = decltype(P_)::value;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this step's fragments (and a dropped tile) are where they belong
+        __builtin_amdgcn_s_barrier();  // B_{g+1}: stage g + 1 landed; everybody holds the fragments of stage g
+        open_stage();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a1[1 - P][i] = *reinterpret_cast<const f16x8*>(Ab + i * 1024);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b1[1 - P][j] = *reinterpret_cast<const f16x8*>(Bb + j * 1024);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma3(a1[P], b1[P], 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b2[j] = *reinterpret_cast<const f16x8*>(Bb + PLANE + j * 1024);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma3(a1[P], b1[P], 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a2[i] = *reinterpret_cast<const f16x8*>(Ab + PLANE + i * 1024);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma3(a1[P], b1[P], 2);
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      for (int it = 0; it < ntiles; ++it) {  // (KT is even: a tile starts on set 0)
+        for (int kp = 0; kp < KT; kp += 2) {
+          body(std::integral_constant<int, 0>{});
+          body(std::integral_constant<int, 1>{});
+        }
+        tile_end();
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // T: the last tile is in the hold area
+    return;
+  }
+
+  if (wave < 6) {
+    // ---------------------------------------------------------------------------------------------------- producers
+    const int d = wave - 4;
+    const int wstride = a.taps * c.Cin;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, x_bytes), rw = make_rsrc(a.w, w_bytes);
+    const int lrow = lane >> 2;
+    const unsigned cq16 = (unsigned)(((lane & 3) ^ swz_row(lrow)) << 4);
+    int hi0[4], wi0[4], bH[4], tap_i = 0, c0_i = 0;
+    unsigned bofs[4], aofs[4];
+    int it_i = 0, i_left = 0, st_issue = 0, issued = 0;
+    auto set_tap = [&](int tp) {
+      const int rr = tp / c.kw, ss = tp - rr * c.kw;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int hi = hi0[k] + rr * c.dil, wi = wi0[k] + ss * c.dil;
+        const bool ok = (unsigned)hi < (unsigned)c.Hi && (unsigned)wi < (unsigned)c.Wi;
+        aofs[k] = ok ? (unsigned)(((bH[k] + hi) * c.Wi + wi) * c.ldx) * 2u + cq16 : OOB;
+      }
+    };
+    auto open_item = [&]() {
+      const int tile = swz + it_i * nblk;
+      ++it_i;
+      i_left = KT;
+      const int m0 = (tile / a.tilesN) * BM, n0 = (tile % a.tilesN) * BN;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int m = m0 + (d * 4 + k) * 16 + lrow;
+        const bool vm = m < a.M;
+        const int mm = vm ? m : 0;
+        const int wo = mm % c.Wo, tq = mm / c.Wo;
+        const int ho = tq % c.Ho, b = tq / c.Ho;
+        hi0[k] = vm ? ho * c.stride - c.pad : -(1 << 28);
+        wi0[k] = wo * c.stride - c.pad;
+        bH[k] = b * c.Hi;
+        const int n = n0 + (d * 4 + k) * 16 + lrow;
+        bofs[k] = n < c.Cout ? (unsigned)n * wstride * 2u + cq16 : OOB;
+      }
+      tap_i = 0;
+      c0_i = 0;
+      set_tap(0);
+    };
+    auto issue_step = [&]() {
+      if (i_left == 0) {
+        if (it_i >= ntiles) return;
+        open_item();
+      }
+#if defined(__HIP_DEVICE_COMPILE__)
+      const int sa = c0_i * 2, sb = (tap_i * c.Cin + c0_i) * 2;
+#pragma unroll
+      for (int l = 0; l < 2; ++l) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          unsigned char* dst = lds + st_issue + l * PLANE + (d * 4 + k) * 1024;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)dst, 16, aofs[k], sa + l * xplane, 0, 0);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          unsigned char* dst = lds + st_issue + A_BYTES + l * PLANE + (d * 4 + k) * 1024;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)dst, 16, bofs[k], sb + l * wplane, 0, 0);
+        }
+      }
+#endif
+      st_issue = next_stage(st_issue);
+      ++issued;
+      --i_left;
+      c0_i += BK;
+      if (c0_i == c.Cin) {
+        c0_i = 0;
+        ++tap_i;
+        if (i_left > 0) set_tap(tap_i);
+      }
+    };
+    issue_step();
+    issue_step();
+    for (int g = 0; g < G; ++g) {
+      // the DMAs of step g have landed; those of step g + 1 (if issued: the 16 youngest) may still fly
+      if (issued > g + 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPW) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();  // B_g: publishes stage g; the consumers are done with stage g - 1
+      issue_step();                  // step g + 2 -> the stage of step g - 1
+    }
+    __builtin_amdgcn_s_barrier();  // B_G
+    __builtin_amdgcn_s_barrier();  // T
+    return;
+  }
+
+  // -------------------------------------------------------------------------------------------------------- epilogue
+  {
+    const int e = wave - 6;
+    const float* hold = reinterpret_cast<const float*>(lds + RING);
+    const Scale2 sx = scale_of(xamax), sw = scale_of(wamax);
+    const float ua = sx.inv, ub = sw.inv;  // always applied one after the other: their product may leave the normal range
+    const bool limb = a.yl != nullptr;
+    const bool affine = a.scale != nullptr || a.shift != nullptr || a.res != nullptr || c.relu;
+    const bool plain = (c.out_os == 1 && c.Hf == c.Ho && c.Wf == c.Wo);
+    const int SR = a.stats_rows;
+    float so = 1.f, ri = 0.f;
+    if (limb) {
+      const float bound = limb_out_bound(a);
+      so = scale_from(bound).s;
+      if (wave == 6 && lane == 0) a.ybound[(blockIdx.x & (ONDA_AMAX_SLOTS - 1)) * AMAX_STRIDE] = bound;
+      ri = a.resl != nullptr ? scale_of(a.res_amax).inv : 0.f;
+    }
+    const int cpi = (NCH + KT - 2) / (KT - 1);  // chunks per barrier interval: a tile is gone within KT - 1 intervals
+    float st[4][4];
+    float mx = 0.f;
+    int chunk = NCH;  // next chunk of the tile being written out (NCH: none pending)
+    int m0 = 0, n0 = 0, tile_m = 0;
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    auto open_tile = [&](int seq) {
+      const int tile = swz + seq * nblk;
+      tile_m = tile / a.tilesN;
+      m0 = tile_m * BM;
+      n0 = (tile % a.tilesN) * BN;
+      chunk = 0;
+      mx = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        st[j][0] = st[j][1] = 0.f;
+        st[j][2] = 3.0e38f;
+        st[j][3] = -3.0e38f;
+      }
+      const int n = n0 + 64 * e + 4 * (lane & 15);
+      sc = f32x4{1.f, 1.f, 1.f, 1.f};
+      sh = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (n < c.Cout && a.scale) sc = *reinterpret_cast<const f32x4*>(a.scale + n);
+      if (n < c.Cout && a.shift) sh = *reinterpret_cast<const f32x4*>(a.shift + n);
+      sc = (sc * ua) * ub;
+    };
+    auto close_tile = [&]() {  // column statistics over the tile's 128 rows: this wave holds all of them, no cross-wave step
+      if (a.stats != nullptr) {
+        f32x4 o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          rows_reduce4(st[j][0], st[j][1], st[j][2], st[j][3]);
+          o[0][j] = (st[j][0] * ua) * ub;
+          o[1][j] = (((st[j][1] * ua) * ub) * ua) * ub;
+          o[2][j] = (st[j][2] * ua) * ub;
+          o[3][j] = (st[j][3] * ua) * ub;
+        }
+        const int n = n0 + 64 * e + 4 * lane;
+        if (lane < 16 && n < c.Cout) {
+          float* dst = a.stats + (size_t)tile_m * SR * c.Cout + n;
+          *reinterpret_cast<f32x4*>(dst) = o[0];
+          *reinterpret_cast<f32x4*>(dst + c.Cout) = o[1];
+          if (SR == 4) {
+            *reinterpret_cast<f32x4*>(dst + 2 * c.Cout) = o[2];
+            *reinterpret_cast<f32x4*>(dst + 3 * c.Cout) = o[3];
+          }
+        }
+      }
+      if (a.amax != nullptr) {
+        const float m = wave_max(mx);
+        if (lane == 0 && m > 0.f)
+          atomicMax(reinterpret_cast<unsigned*>(a.amax) + ((blockIdx.x * 2 + e) & (ONDA_AMAX_SLOTS - 1)) * AMAX_STRIDE, __float_as_uint(m));
+      }
+    };
+    auto work = [&](int n_chunks) {
+      for (int k = 0; k < n_chunks && chunk < NCH; ++k, ++chunk) {
+        if (limb) l2p_chunk<true, true>(a, hold, e, lane, chunk, m0, n0, sc, sh, so, ri, plain, st, mx);
+        else if (affine) l2p_chunk<false, true>(a, hold, e, lane, chunk, m0, n0, sc, sh, so, ri, plain, st, mx);
+        else l2p_chunk<false, false>(a, hold, e, lane, chunk, m0, n0, sc, sh, so, ri, plain, st, mx);
+        if (chunk == NCH - 1) close_tile();
+      }
+    };
+    int it = 0, kt = 0;  // where the consumers stand at barrier B_g: K-step kt of their tile number it
+    for (int g = 0; g < G; ++g) {
+      __builtin_amdgcn_s_barrier();  // B_g
+      // tile it - 1 lies in the hold area: dropped behind B_first(it) (PIPE) / before it (not PIPE), replaced behind
+      // B_first(it + 1) / B_last(it)
+      if (it > 0) {
+        const bool may = PIPE ? kt >= 1 : kt <= KT - 2;
+        if (may) {
+          if (chunk == NCH && kt == (PIPE ? 1 : 0)) open_tile(it - 1);
+          work(cpi);
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the chunk reads are done before the next barrier lets a drop in
+        }
+      }
+      if (++kt == KT) {
+        kt = 0;
+        ++it;
+      }
+    }
+    __builtin_amdgcn_s_barrier();  // B_G
+    __builtin_amdgcn_s_barrier();  // T: the last tile
+    open_tile(ntiles - 1);
+    work(NCH);
+  }
+}
+
 // ---- stream-K remainder: partial tiles -> output, in ONE wide launch ---------------------------------------------------
 // A remainder tile was cut into pieces by the workgroups of conv_l2_kernel<.., SK = true> (raw accumulators in `ws`).
 // One workgroup per 8 rows of a remainder tile sums that tile's pieces in ascending-workgroup order (fixed order:
@@ -1640,7 +2076,12 @@ int onda_conv_l2_variant(int64_t M, int Cout) {
 int onda_conv_l2_kernel_id(int64_t M, int Cout, int taps, int Cin) {
   const int variant = onda_conv_l2_variant(M, Cout);
   static const int xt = getenv("ONDA_L2_XT") ? atoi(getenv("ONDA_L2_XT")) : 1;
-  const bool short_k = taps * (Cin / 32) <= 32 || xt == 2;
+  static const int l2p = getenv("ONDA_L2P") ? atoi(getenv("ONDA_L2P")) : 1;  // 0: off, 1: on, 2: on without the fragment pre-fetch
+  const int KT = taps * (Cin / 32);
+  const bool short_k = KT <= 32 || xt == 2;
+  // 4 = conv_l2p_kernel: the producer / consumer form (128 x 128 tiles, the epilogue under the next tile's K loop) takes the
+  // continuous-stream kernel's problems when a tile has at least two K-steps to spread the previous tile's epilogue over
+  if (variant == 0 && xt && KT <= 32 && KT >= 2 && KT % 2 == 0 && l2p) return 4;
   return variant == 0 && xt && short_k ? 3 : variant;
 }
 
@@ -1652,6 +2093,7 @@ namespace {
 struct L2Schedule {
   int variant, BM, BN, tilesM, tilesN, G, rem, sub;
   bool balanced;
+  bool p128 = false;  // conv_l2p_kernel (128 x 128 tiles, whole tiles only)
   int rem_rows() const { return tilesM - (tilesM * tilesN - rem) / tilesN; }  // tile rows that hold remainder tiles
   int stats_rows_total() const { return tilesM + (balanced ? rem_rows() * (sub - 1) : 0); }
 };
@@ -1663,6 +2105,17 @@ bool l2_small_ring2() {
 L2Schedule l2_schedule(long long M, int Cout, int taps, int Cin, bool have_ws, long long stat_split = 0, bool plain = false) {
   L2Schedule q;
   q.variant = onda_conv_l2_variant(M, Cout);
+  if (onda_conv_l2_kernel_id(M, Cout, taps, Cin) == 4) {
+    q.p128 = true;
+    q.BM = q.BN = 128;
+    q.tilesM = (int)((M + 127) / 128);
+    q.tilesN = (Cout + 127) / 128;
+    q.G = conv_resident_workgroups() / 2;  // all of a CU's LDS: one workgroup per CU
+    q.rem = 0;
+    q.sub = 1;
+    q.balanced = false;
+    return q;
+  }
   q.BM = q.variant == 1 ? 128 : 256;
   q.BN = q.variant == 2 ? 64 : 128;
   q.tilesM = (int)((M + q.BM - 1) / q.BM);
@@ -1701,6 +2154,60 @@ int onda_conv_l2_tiles_m_split(int64_t M, int Cout, int taps, int Cin, int64_t s
   const L2Schedule q = l2_schedule(M, Cout, taps, Cin, true, stat_split, plain_schedule != 0);
   if (tile_rows) *tile_rows = q.BM;
   return q.stats_rows_total();
+}
+
+/* Measurement helpers (bench.py's `pipe.executed_tflops`): the share of a problem's K-steps the kernel really issues.
+ * conv_l2_kernel skips, per whole tile, the filter taps that only see padding; the continuous-stream kernel and stream-K
+ * pieces run the full K range; the weight gradient skips dead 32-pixel steps per tap.  Same arithmetic as the kernels. */
+double onda_conv_l2_live_fraction(const OndaConv* c, int with_stats) {
+  if (!c) return 1.0;
+  const long long M = (long long)c->B * c->Ho * c->Wo;
+  const int taps = c->kh * c->kw, kcper = c->Cin / 32;
+  if (M <= 0 || taps <= 1 || kcper <= 0) return 1.0;
+  const L2Schedule q = l2_schedule(M, c->Cout, taps, c->Cin, true, with_stats ? (long long)c->stat_split : 0, c->plain_schedule != 0);
+  if (onda_conv_l2_kernel_id(M, c->Cout, taps, c->Cin) == 3) return 1.0;
+  const int tiles = q.tilesM * q.tilesN, tiles_dp = q.balanced ? tiles - q.rem : tiles;
+  long long live_steps = (long long)(tiles - tiles_dp) * taps * kcper;
+  for (int tile_m = 0; tile_m * q.tilesN < tiles_dp; ++tile_m) {
+    const int n_dp = tiles_dp - tile_m * q.tilesN < q.tilesN ? tiles_dp - tile_m * q.tilesN : q.tilesN;
+    const long long m0 = (long long)tile_m * q.BM, m_last = (M < m0 + q.BM ? M : m0 + q.BM) - 1;
+    const long long r0 = m0 / c->Wo, r1 = m_last / c->Wo;
+    int live = 0;
+    for (int tp = 0; tp < taps; ++tp) {
+      const int dh = (tp / c->kw) * c->dil - c->pad;
+      bool alive = false;
+      for (long long r = r0; r <= r1 && !alive; ++r) alive = (unsigned)((int)(r % c->Ho) * c->stride + dh) < (unsigned)c->Hi;
+      live += alive;
+    }
+    if (live == 0) live = 1;
+    live_steps += (long long)n_dp * live * kcper;
+  }
+  return (double)live_steps / ((double)tiles * taps * kcper);
+}
+
+double onda_conv_wgrad_l2_live_fraction(const OndaConv* c, int splitk) {
+  if (!c || splitk < 1) return 1.0;
+  const long long M = (long long)c->B * c->Ho * c->Wo;
+  const int taps = c->kh * c->kw;
+  if (M <= 0 || taps <= 1) return 1.0;
+  const long long mchunk = ((M + splitk - 1) / splitk + 31) / 32 * 32;
+  long long live = 0, all = 0;
+  for (int ks = 0; ks < splitk; ++ks) {
+    const long long mbeg = ks * mchunk, mend = M < mbeg + mchunk ? M : mbeg + mchunk;
+    const long long KT = mend > mbeg ? (mend - mbeg + 31) / 32 : 0;
+    all += KT * taps;
+    for (int tp = 0; tp < taps; ++tp) {
+      const int dh = (tp / c->kw) * c->dil - c->pad;
+      for (long long kt = 0; kt < KT; ++kt) {
+        const long long m_first = mbeg + kt * 32, m_last = (mend < m_first + 32 ? mend : m_first + 32) - 1;
+        bool alive = false;
+        for (long long r = m_first / c->Wo; r <= m_last / c->Wo && !alive; ++r)
+          alive = (unsigned)((int)(r % c->Ho) * c->stride + dh) < (unsigned)c->Hi;
+        live += alive;
+      }
+    }
+  }
+  return all > 0 ? (double)live / (double)all : 1.0;
 }
 
 static int l2_fwd_impl(const void* xl, int64_t xplane, const float* xamax, const void* w2, const float* wamax, float* y,
@@ -1782,6 +2289,16 @@ static int l2_fwd_impl(const void* xl, int64_t xplane, const float* xamax, const
   // short K loops (1 x 1 convolutions up to 1024 input channels) gain 6-17 % from the continuous stream; long ones lose
   // ~4 % against the slot-staggered kernel, whose per-tile start / end they amortise anyway (measured per shape, one process)
   const bool short_k = k.taps * k.kcper <= 32 || xt == 2;
+  if (q.p128) {
+    static const int l2p = getenv("ONDA_L2P") ? atoi(getenv("ONDA_L2P")) : 1;
+    k.tiles_dp = tiles;
+    const int grid = tiles < q.G ? tiles : q.G;
+    if (l2p == 2)
+      hipLaunchKernelGGL((conv_l2p_kernel<false>), dim3(grid), dim3(512), 0, st, k, xpl, wpl, x_bytes, w_bytes, xamax, wamax);
+    else
+      hipLaunchKernelGGL((conv_l2p_kernel<true>), dim3(grid), dim3(512), 0, st, k, xpl, wpl, x_bytes, w_bytes, xamax, wamax);
+    return ONDA_LAUNCH_RESULT();
+  }
   if (xt && short_k && q.variant == 0 && y_total < 0x7FFFF000ll) {
     if (!q.balanced) k.tiles_dp = tiles;  // persistent either way: whole tiles only
     const int grid = tiles < q.G ? tiles : q.G;

@@ -564,7 +564,18 @@ int onda_upsample_ce_bwd(const float* logits, int ldl, const uint8_t* labels, co
   if (CW > 64) CW = 64;
   ONDA_REQUIRE(CW >= 1);
   const size_t lds = ((size_t)(CW + 2) * K + (size_t)UCE_SPAN * K + 2 * UCE_SPAN) * sizeof(float);
-  ONDA_REQUIRE(lds <= 64 * 1024);  // (19 classes: 59 KB)
+  // 19 classes: 59 KB.  Every K the forward accepts (<= UCE_KMAX = 32: 95 KB) has to run backward as well (round-4 advisor): above
+  // the default 64 KB limit of dynamic LDS the kernel asks for its size once (a CU of gfx950 has 160 KB)
+  ONDA_REQUIRE(lds <= 160 * 1024);
+  if (lds > 64 * 1024) {
+    static size_t granted = 0;
+    if (lds > granted) {
+      const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(upsample_ce_bwd_rows_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return (int)e;
+      granted = lds;
+    }
+  }
   hipLaunchKernelGGL(upsample_ce_bwd_rows_kernel, dim3((w + CW - 1) / CW, B * H), dim3(256), lds, ONDA_STREAM(s), logits, ldl, labels,
                      result, gscale, w_ce, ws, B, h, w, K, H, W, sy, sx, 1.f / sx, CW);
   hipLaunchKernelGGL(upsample_ce_bwd_cols_kernel, dim3(ew_grid((size_t)B * h * w * ldl)), dim3(256), 0, ONDA_STREAM(s), ws, dlogits,

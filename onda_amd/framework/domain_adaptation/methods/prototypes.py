@@ -461,6 +461,12 @@ class online_proDA(da_model):
                 if self.cfg_spec.STATIC_LAMBDA > 0:
                     _, prior_static, t["conf_static"], _ = self._forward_prior(self.static_model, image)
                 s2.wait_stream(s1)  # the teacher's confidence and prior
+                # allocated on stream 1, read on stream 2 from here on (the switch scalars, the prior mix): tell the caching
+                # allocator, so that a later piece of stream-1 work in this step cannot be handed their blocks while stream 2
+                # still reads them (round-4 advisor: until now only the step's shape guaranteed that)
+                for v in (prior_ema, t["conf_ema"], t["cls"]):
+                    if torch.is_tensor(v) and v.is_cuda:
+                        v.record_stream(s2)
                 t["prior"] = self.cfg_spec.EMA_LAMBDA * prior_ema
                 if prior_static is not None:
                     t["prior"] += self.cfg_spec.STATIC_LAMBDA * prior_static

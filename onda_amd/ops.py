@@ -54,7 +54,7 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-_L2_KERNELS = ("conv_l2_kernel<4,2>", "conv_l2_kernel<2,2>", "conv_l2_kernel<4,1>", "conv_l2x_kernel<4,2>")
+_L2_KERNELS = ("conv_l2_kernel<4,2>", "conv_l2_kernel<2,2>", "conv_l2_kernel<4,1>", "conv_l2x_kernel<4,2>", "conv_l2p_kernel")
 
 
 def _l2_name(M, cout, taps, cin):
@@ -62,7 +62,9 @@ def _l2_name(M, cout, taps, cin):
     return _L2_KERNELS[query("onda_conv_l2_kernel_id", M, cout, taps, cin)] if PROFILE is not None else ""
 
 
-def _launch(name, flops, fn_name, *args, tag=None):
+def _launch(name, flops, fn_name, *args, tag=None, issued=None):
+    """`issued` (profiling only): a callable returning the share of `flops` the kernel really issues (dead taps / dead
+    pixel steps skipped: onda_conv_l2_live_fraction); None = all of them."""
     if PROFILE is None:
         return call(fn_name, *args)
     # a launch under a device predicate does its work only while the flag is set: the flag's value at this point of the
@@ -72,11 +74,12 @@ def _launch(name, flops, fn_name, *args, tag=None):
     e0.record()
     call(fn_name, *args)
     e1.record()
-    PROFILE.append((name, flops, e0, e1, tag, live))
+    PROFILE.append((name, flops, e0, e1, tag, live, flops * (issued() if issued is not None else 1.0)))
 
 
 def profile_entries(entries):
-    """(name, flops, e0, e1, tag) of the recorded launches that executed (call after a device synchronize)."""
+    """(name, algorithmic flops, e0, e1, tag, issued flops) of the recorded launches that executed (call after a device
+    synchronize).  `issued` <= algorithmic: the kernels skip K-steps that only multiply padding."""
     flags = [e[5] for e in entries if e[5] is not None]
     on = torch.stack([f.reshape(()) for f in flags]).ne(0).tolist() if flags else []
     out, i = [], 0
@@ -85,7 +88,7 @@ def profile_entries(entries):
             i += 1
             if not on[i - 1]:
                 continue
-        out.append(e[:5])
+        out.append(e[:5] + (e[6],))
     return out
 
 
@@ -235,8 +238,11 @@ AMAX_SLOTS = 2048  # ONDA_AMAX_FLOATS (include/onda_hip.h): 64 slots, one 128-by
 AMAX_POOL_TENSORS = 16384  # tensors served by one zero-filled pool (128 MB)
 
 
-def _new_amax_pool(device):
-    buf = torch.zeros(AMAX_POOL_TENSORS * AMAX_SLOTS, device=device, dtype=torch.float32)
+WEIGHT_POOL_TENSORS = 256  # pools that serve LONG-LIVED scales (packed weights): 2 MB each
+
+
+def _new_amax_pool(device, tensors=AMAX_POOL_TENSORS):
+    buf = torch.zeros(tensors * AMAX_SLOTS, device=device, dtype=torch.float32)
     if buf.is_cuda:  # the zero-fill runs on the creating stream: any other stream that takes slices waits for it once
         done = torch.cuda.Event()
         done.record()
@@ -244,13 +250,16 @@ def _new_amax_pool(device):
     return [buf, 0, None, None]
 
 
-def amax_slot(device):
+def amax_slot(device, long_lived=False):
     """Zeroed device floats for a tensor's running max|x| (slices of a zero-filled pool: one fill kernel per
-    16384 tensors instead of one per tensor; a slice is written by exactly one producer and never reused)."""
-    key = str(device)
+    16384 tensors instead of one per tensor; a slice is written by exactly one producer and never reused).
+    long_lived: scales that outlive a step (the max|w| of packed weights: a frozen static / dynamic model keeps its slices
+    for the whole run) come from small pools of their own -- a pool is freed only when every slice of it has died, and one
+    long-lived slice used to pin a whole 128 MB activation pool (round-4 advisor)."""
+    key = (str(device), bool(long_lived))
     pool = _AMAX_POOL.get(key)
     if pool is None or pool[1] + AMAX_SLOTS > pool[0].numel():
-        pool = _AMAX_POOL[key] = _new_amax_pool(device)
+        pool = _AMAX_POOL[key] = _new_amax_pool(device, WEIGHT_POOL_TENSORS if long_lived else AMAX_POOL_TENSORS)
     if pool[2] is not None:
         cur = torch.cuda.current_stream()
         if cur.cuda_stream not in pool[3]:
@@ -265,9 +274,9 @@ def reserve_amax_slots(device, n):
     """Make sure the next `n` amax_slot() calls are served from a pool that already exists: call on the main stream before
     work is spread over side streams (a refill is safe on any stream -- the others wait for its zero-fill -- but it then
     costs them that wait)."""
-    pool = _AMAX_POOL.get(str(device))
+    pool = _AMAX_POOL.get((str(device), False))
     if pool is None or pool[1] + n * AMAX_SLOTS > pool[0].numel():
-        _AMAX_POOL[str(device)] = _new_amax_pool(device)
+        _AMAX_POOL[(str(device), False)] = _new_amax_pool(device)
 
 
 def tag_amax(t, slot):
@@ -381,7 +390,7 @@ def _pack_h2(weight, rows_pad, kp, dgrad, cout_pad):
     w = weight.detach().contiguous()
     slot = known_amax(weight)  # the forward and the data-gradient packing of one weight version share max|w|
     if slot is None:
-        slot = amax_slot(weight.device)
+        slot = amax_slot(weight.device, long_lived=True)
         call("onda_absmax", _p(w), 1, w.numel(), w.numel(), _p(slot), _stream())  # the whole tensor as one row
         tag_amax(weight, slot)
     dst = torch.empty(2, rows_pad, kp, device=weight.device, dtype=torch.float16)
@@ -489,7 +498,8 @@ def conv_forward(x, wp, k, stride, dil, pad, cout, out=None, scale=None, shift=N
                          _p(res.amax) if res is not None else None, _p(res.true_amax) if res is not None else None)
         _launch(_l2_name(M, cout, k * k, Cin), 2.0 * M * cout * k * k * Cin,
                 "onda_conv2d_fwd_l2_limbs", _p(xl.planes), xl.plane, _p(xl.amax), _p(wp.limbs), _p(wp.amax), _p(scale), _p(shift),
-                byref(lo), _p(_conv_ws(dev)), byref(d), _stream(), tag=("fwd", M, cout, Cin, k, stride, dil))
+                byref(lo), _p(_conv_ws(dev)), byref(d), _stream(), tag=("fwd", M, cout, Cin, k, stride, dil),
+                issued=lambda: query("onda_conv_l2_live_fraction", byref(d), 0))
         return limb_only((B, Ho, Wo, cout), dev, Limbs(planes, bound, cout, M * cout, true_amax=true)), None, 0
     if out is None:
         out = torch.empty(B, Ho, Wo, cout, device=x.device, dtype=torch.float32)
@@ -520,7 +530,8 @@ def conv_forward(x, wp, k, stride, dil, pad, cout, out=None, scale=None, shift=N
         _launch(_l2_name(B * Ho * Wo, cout, k * k, Cin), 2.0 * B * Ho * Wo * cout * k * k * Cin,
                 "onda_conv2d_fwd_l2", _p(xl.planes), xl.plane, _p(xl.amax), _p(wp.limbs), _p(wp.amax), _p(out), _p(scale),
                 _p(shift), _p(residual), _p(stats), stats_rows, _p(_conv_ws(x.device)), _p(yamax), byref(d), _stream(),
-                tag=("fwd", B * Ho * Wo, cout, Cin, k, stride, dil))
+                tag=("fwd", B * Ho * Wo, cout, Cin, k, stride, dil),
+                issued=lambda: query("onda_conv_l2_live_fraction", byref(d), int(stats is not None)))
         if yamax is not None:
             tag_amax(out, yamax)
         return out, stats, tiles
@@ -559,7 +570,8 @@ def conv_dgrad(dy, wpd, k, stride, dil, pad, cin, in_hw, accumulate=None):
         _launch(_l2_name(B * Hi * Wi, cin, k * k, Co), 2.0 * B * Ho * Wo * cin * k * k * Co,
                 "onda_conv2d_fwd_l2", _p(dyl.planes), dyl.plane, _p(dyl.amax), _p(wpd.limbs), _p(wpd.amax), _p(accumulate), None,
                 None, _p(accumulate), None, 2, _p(_conv_ws(dy.device)), None, byref(d), _stream(),
-                tag=("dgrad", B * Hi * Wi, cin, Co, k, stride, dil))
+                tag=("dgrad", B * Hi * Wi, cin, Co, k, stride, dil),
+                issued=lambda: query("onda_conv_l2_live_fraction", byref(d), 0))
         return accumulate
     if stride == 1:
         dx = torch.empty(B, Hi, Wi, cin, device=dy.device, dtype=torch.float32)
@@ -576,7 +588,7 @@ def conv_dgrad(dy, wpd, k, stride, dil, pad, cin, in_hw, accumulate=None):
         _launch(_l2_name(Mo, cin, k * k, Co), 2.0 * B * Ho * Wo * cin * k * k * Co,
                 "onda_conv2d_fwd_l2", _p(dyl.planes), dyl.plane, _p(dyl.amax), _p(wpd.limbs), _p(wpd.amax), _p(dx), None, None,
                 None, None, 2, _p(_conv_ws(dy.device)), None, byref(d), _stream(),
-                tag=("dgrad", Mo, cin, Co, k, stride, dil))
+                tag=("dgrad", Mo, cin, Co, k, stride, dil), issued=lambda: query("onda_conv_l2_live_fraction", byref(d), 0))
         return dx
     if is_limb_only(dy):
         raise RuntimeError("onda_amd: a limb-only gradient reached a data-gradient kernel that does not take limb planes")
@@ -642,7 +654,8 @@ def conv_wgrad(x, dy, k, stride, dil, pad, cout_real, cin_real, flat_k=0, into=N
         d.ldx = xl.ld
         _launch("conv_wgrad_l2_kernel<%d>" % query("onda_conv_wgrad_l2_variant", Co, Cin), 2.0 * M * Co * taps * Cin,
                 "onda_conv2d_wgrad_l2", _p(xl.planes), xl.plane, _p(xl.amax), _p(dyl.planes), dyl.plane, _p(dyl.amax), _p(slabs),
-                dyl.ld, sk, byref(d), _stream(), tag=("wgrad", M, Co, Cin, k, stride, dil, sk))
+                dyl.ld, sk, byref(d), _stream(), tag=("wgrad", M, Co, Cin, k, stride, dil, sk),
+                issued=lambda: query("onda_conv_wgrad_l2_live_fraction", byref(d), sk))
     elif CONV_MODE == "f16x2" and Cin % 4 == 0 and Co % 4 == 0:
         xs = xscale if xscale is not None else activation_scale(x)
         _launch("conv_wgrad_h2_kernel<%s>" % ("128,128" if (Co > 64 and Cin > 64) else "64,64"), 2.0 * M * Co * taps * Cin,
@@ -751,7 +764,7 @@ class ModelPacker:
             if buf is None or buf[0].device != w.device:
                 buf = self.bufs[id(c)] = (torch.empty(2, cout, kh * kw * cin, device=w.device, dtype=torch.float16),
                                           torch.empty(2, cin, kh * kw * cout, device=w.device, dtype=torch.float16))
-            slot = amax_slot(w.device)
+            slot = amax_slot(w.device, long_lived=True)
             tag_amax(c.weight, slot)
             cache = c._pack
             cache.fwd, cache.key_f = H2Weight(buf[0], slot), key
@@ -1321,7 +1334,11 @@ class UpsampleFn(torch.autograd.Function):
 class UpsampleCEFn(torch.autograd.Function):
     """loss_calc(interp(out), label): bilinear upsample (align_corners) to the label resolution -> cross-entropy over the
     pixels whose label is not 255, as ONE pass in each direction -- the upsampled logits (and their gradient) exist in
-    registers only (csrc/pointwise.hip)."""
+    registers only (csrc/pointwise.hip).
+    Label contract: integer class maps with values in [0, K) or the ignore value 255; they travel as uint8, so any value >= K
+    (a negative one wraps to >= 128) is IGNORED, as F.cross_entropy(ignore_index=255) ignores 255.  A batch without a single
+    kept pixel returns NaN like the reference's mean over zero pixels (utils/loss.py:88-112), and its gradient is all zeros --
+    what torch's own nll_loss backward produces for total_weight == 0 -- not NaN: the caller sees the NaN loss."""
 
     @staticmethod
     def forward(ctx, out, labels):

@@ -214,3 +214,71 @@ def test_parameters_that_signal_twice_count_once():
     for i in range(6):
         assert torch.allclose(a0[i], (l0[i] + l1[i]) / 2, rtol=1e-6, atol=1e-7), i
         assert torch.equal(a0[i], a1[i])
+
+
+def _world8_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from onda_amd import dist as od
+    od.init_from_env("gloo")
+    torch.set_num_threads(1)
+    torch.manual_seed(0)  # same weights on every rank
+    net = torch.nn.Sequential(torch.nn.Linear(48, 40), torch.nn.ReLU(), torch.nn.Linear(40, 24), torch.nn.ReLU(),
+                              torch.nn.Linear(24, 8), torch.nn.Linear(8, 4))
+    idle = torch.nn.Parameter(torch.zeros(5))  # a parameter that gets NO gradient in any pass (the unused-but-registered case)
+    holder = torch.nn.ModuleList([net])
+    holder.register_parameter("idle", idle)
+    import copy
+    twin = copy.deepcopy(net)  # this rank's own gradients come from a copy: a bucket that left early is summed IN PLACE
+    sync = od.GradSync(holder, tail_floats=7, bucket_floats=200)
+    sizes = [e - s for s, e, _ in sync.buckets]
+    assert len(sync.buckets) >= 4 and sizes[-1] >= 7, sizes  # >= 3 full buckets + the one that carries the tail
+    # the tail travels with the LAST bucket, behind the last gradients
+    assert sync.buckets[-1][1] == sync.flat.numel() and sync.tail.data_ptr() == sync.flat.data_ptr() + 4 * (sync.flat.numel() - 7)
+    g = torch.Generator().manual_seed(100 + rank)  # every rank its own micro-batch
+    steps = []
+    for step in range(2):
+        sync.zero()
+        x = torch.randn(12, 48, generator=g)
+        net(x).sum().backward()                      # first backward pass of the step (source replay): nothing leaves
+        assert not sync._pending
+        sync.arm()
+        net(x * 0.5).pow(2).sum().backward()         # last backward pass: full buckets leave from the hooks
+        early = sum(sync._launched)
+        sync.tail.copy_(torch.arange(7.0) + rank)
+        twin.zero_grad()
+        twin(x).sum().backward()
+        twin(x * 0.5).pow(2).sum().backward()
+        local = [p.grad.detach().clone() for p in twin.parameters()]
+        n = sync.finish(mean=False)                  # rank SUMS: the division by the world size happens inside the SGD kernel
+        sums = [p.grad.detach().clone() for p in net.parameters()]
+        # what ReplaySGD does with them on the way in (onda_sgd_multi's grad_scale = 1 / world): one multiply per element
+        scaled = [s * (1.0 / world) for s in sums]
+        steps.append((n, early, local, sums, scaled, sync.tail.clone(), idle.grad.clone()))
+    out[rank] = steps
+    dist.destroy_process_group()
+
+
+def test_gradient_exchange_with_eight_ranks():
+    """BASELINE config 4's world size (8 ranks) through GradSync: several buckets that leave during the last backward pass, the
+    tail in the last bucket, a parameter that never receives a gradient, rank SUMS scaled by 1 / world on the way into SGD
+    (`finish(mean=False)` + `ReplaySGD.grad_scale`): every rank ends with the same buffer and with the mean of the eight
+    ranks' own gradients."""
+    world = 8
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_world8_worker, args=(world, port, out), nprocs=world, join=True)
+    nparams = 48 * 40 + 40 + 40 * 24 + 24 + 24 * 8 + 8 + 8 * 4 + 4 + 5
+    for step in range(2):
+        n0, early0, _, sums0, scaled0, tail0, idle0 = out[0][step]
+        assert n0 == nparams + 7
+        assert early0 >= 3                                         # at least three buckets overlapped with the backward pass
+        assert torch.equal(tail0, torch.arange(7.0) * world + sum(range(world)))  # the tail comes back as the rank SUM
+        assert torch.equal(idle0, torch.zeros(5))                  # no gradient anywhere: zeros exchanged, zeros back
+        for r in range(1, world):
+            for a, b in zip(sums0, out[r][step][3]):
+                assert torch.equal(a, b), (step, r)               # replicas hold bit-identical buffers
+            assert torch.equal(tail0, out[r][step][5])
+        for i in range(len(sums0)):
+            ref = sum(out[r][step][2][i].double() for r in range(world)) / world
+            assert (scaled0[i].double() - ref).abs().max() <= 2e-6 * ref.abs().max(), (step, i)  # fp32 sums of eight terms

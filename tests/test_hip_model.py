@@ -523,10 +523,12 @@ def test_a_step_never_stops_the_host(tmp_path, conv_mode):
         torch.cuda.empty_cache()
 
 
-def test_step_sharded_matches_the_oracle_emulation_of_two_ranks(tmp_path, conv_mode):
-    """``step_sharded`` with two micro-batches (= what two data-parallel ranks compute: rank-local batch statistics,
-    averaged gradients, one switch decision from averaged confidences, summed prototype statistics, averaged running
-    statistics) against the oracle's sequential emulation on the CPU (oracle/step.py step_sharded)."""
+@pytest.mark.parametrize("nshards", [2, 4, 8])
+def test_step_sharded_matches_the_oracle_emulation_of_two_ranks(tmp_path, conv_mode, nshards):
+    """``step_sharded`` with `nshards` micro-batches (= what that many data-parallel ranks compute: rank-local batch
+    statistics, averaged gradients, one switch decision from averaged confidences, summed prototype statistics, averaged
+    running statistics) against the oracle's sequential emulation on the CPU (oracle/step.py step_sharded).  8 and 4 are
+    the micro-batch counts `bench.py --global-batch 32` runs per rank at N = 1 and N = 2 (BASELINE config 4's shapes)."""
     if conv_mode != "f16x2":
         pytest.skip("default conv mode only")
     from onda_amd.config import hybrid_switch_cfg
@@ -541,9 +543,10 @@ def test_step_sharded_matches_the_oracle_emulation_of_two_ranks(tmp_path, conv_m
     fill_state_dict(model, 1, 40.0)
     da = get_adapt_method(cfg)(model, cfg, spec)
     proto_src = [synth_batch(2, 64, 128, seed=100 + i) for i in range(2)]
-    shards = [({k: v for k, v in synth_batch(2, 64, 128, seed=300 + r).items()}, synth_batch(2, 64, 128, seed=400 + r)) for r in range(2)]
+    shards = [({k: v for k, v in synth_batch(2, 64, 128, seed=300 + r).items()}, synth_batch(2, 64, 128, seed=400 + r))
+              for r in range(nshards)]
     torch.manual_seed(123)
-    masks = [omodel.draw_drop_mask(2) for _ in range(2 + 6)]
+    masks = [omodel.draw_drop_mask(2) for _ in range(2 + 3 * nshards)]
     it = iter(masks)
     deeplabv2.drop_mask_fn = lambda B, C, p, dev: next(it).to(dev)
     try:
@@ -564,7 +567,7 @@ def test_step_sharded_matches_the_oracle_emulation_of_two_ranks(tmp_path, conv_m
     ad.refresh_dynamic()
     torch.manual_seed(123)
     ad.proto = ad.initial_prototypes(proto_src)  # draws the same two masks
-    rank_masks = [tuple(masks[2 + 3 * r: 5 + 3 * r]) for r in range(2)]
+    rank_masks = [tuple(masks[2 + 3 * r: 5 + 3 * r]) for r in range(nshards)]
     ref = ad.step_sharded(shards, rank_masks)
     assert ad.switch.current == da.model_select.current
     for key in ("buff_loss", "Total target loss", "ce_loss", "rce_loss", "regularization_loss", "pseudolabel_pixel_num",
@@ -585,7 +588,7 @@ def test_step_sharded_matches_the_oracle_emulation_of_two_ranks(tmp_path, conv_m
     # post-step weights (running statistics included), as updates.  This is HIP against torch-CPU fp32: the floor is the
     # reference's own fp32 noise through a train-mode pass (its step-0 update moves by 0.3 % with its thread count); the
     # same-kernel comparison of the two layouts is test_multirank_gpu.py (1e-4)
-    print("step_sharded vs oracle emulation, update rel-L2:", (num / den) ** 0.5)
+    print(f"step_sharded ({nshards} shards) vs oracle emulation, update rel-L2:", (num / den) ** 0.5)
     assert (num / den) ** 0.5 <= 5e-3, (num / den) ** 0.5  # (measured: 1.2e-3)
 
 

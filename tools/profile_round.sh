@@ -4,7 +4,7 @@
 # run, with --kernel-trace only, as MI355X_MICROARCH.md prescribes), per-shape conv rates.
 #   tools/profile_round.sh r03_a      -> gpurun_out/r03_a_*
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
-tag=${1:-r04_x}; G=gpurun_out; mkdir -p $G
+tag=${1:-r05_x}; G=gpurun_out; mkdir -p $G
 common="--no-cpu-baseline --no-eager --no-other-configs"
 python3 bench.py --steps 20 --warmup 5 > $G/${tag}_bench_line.json 2> $G/${tag}_bench_line.err
 python3 bench.py --steps 10 --warmup 3 --branch static $common --no-exact-f32 > $G/${tag}_bench_line_static_branch.json 2>/dev/null
@@ -21,9 +21,12 @@ python3 tools/kstats.py $G/prof_$tag/kt > $G/${tag}_bench_kernel_stats.csv
 # bench line's `roofline` is measured on; beside other streams' launches a kernel's duration stretches)
 ONDA_SIDE_STREAMS=0 rocprofv3 --kernel-trace --stats -d $G/prof_$tag/kt1 -- python3 bench.py --steps 10 --warmup 3 $common --no-exact-f32 --no-roofline > $G/${tag}_profiled_bench_line_one_stream.json 2> $G/prof_$tag/kt1.err
 python3 tools/kstats.py $G/prof_$tag/kt1 > $G/${tag}_bench_kernel_stats_one_stream.csv
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $G/prof_$tag/fetch -- python3 tools/one_pass.py > /dev/null 2> $G/prof_$tag/fetch.err
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $G/prof_$tag/write -- python3 tools/one_pass.py > /dev/null 2> $G/prof_$tag/write.err
-python3 tools/pmc_summary.py $G/prof_$tag/fetch $G/prof_$tag/write $G/${tag}_hbm_traffic.json > $G/${tag}_hbm_traffic_top.txt
+# HBM-side traffic ON THE BENCH STEP ITSELF (round-4 verdict: bytes and flops per launch of one `roofline` block must describe the
+# same launches), every pass on one stream as the roofline leg measures it; separate --pmc passes with --kernel-trace only
+pmc_cmd="bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-eager --no-other-configs --no-exact-f32 --no-roofline"
+ONDA_SIDE_STREAMS=0 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $G/prof_$tag/fetch -- python3 $pmc_cmd > /dev/null 2> $G/prof_$tag/fetch.err
+ONDA_SIDE_STREAMS=0 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $G/prof_$tag/write -- python3 $pmc_cmd > /dev/null 2> $G/prof_$tag/write.err
+python3 tools/pmc_summary.py $G/prof_$tag/fetch $G/prof_$tag/write $G/${tag}_hbm_traffic.json "ONDA_SIDE_STREAMS=0 python3 $pmc_cmd (the bench step: 5 steps + set-up passes)" > $G/${tag}_hbm_traffic_top.txt
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $G/prof_$tag/sq -o sq -- python3 tools/one_pass.py > /dev/null 2> $G/prof_$tag/sq.err
 python3 tools/sq_summary.py $(find $G/prof_$tag/sq -name "*counter_collection.csv" | head -1) 12 > $G/${tag}_sq_counters.txt 2>&1
 rm -rf $G/prof_$tag/fetch $G/prof_$tag/write $G/prof_$tag/sq $G/prof_$tag/kt $G/prof_$tag/kt1   # (raw traces: hundreds of MB)
