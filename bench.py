@@ -398,8 +398,7 @@ def arithmetic():
     """(dtype label, note) of the convolution arithmetic in force."""
     from onda_amd import ops
     if ops.CONV_MODE == "f16x2":
-        path = ("both operands pre-split into limb planes, LDS-DMA only (conv_l2.hip)" if ops.H2_PATH == "dma"
-                else "activations split in-kernel (conv_h2.hip)")
+        path = "both operands pre-split into limb rows in HBM, LDS-DMA only (conv_l2.hip)"
         return ("f32 (f16x2 split emulation)",
                 "f16x2: fp32 operands scaled by a per-tensor power of two and split into 2 f16 limbs (22 significant bits), 3 limb "
                 "products on the f16 MFMA pipe, fp32 accumulation; 1-3e-7 relative L2 against fp64 = the accuracy of an fp32 FMA "

@@ -79,18 +79,20 @@ int onda_conv2d_fwd(const float* x, const float* w, float* y, const float* scale
  * A tensor's scale travels as `amax`: ONDA_AMAX_FLOATS device floats whose maximum is max|x| (producers spread
  * their atomicMax over ONDA_AMAX_SLOTS slots, one cache line apart); every consumer derives 2^e (max * 2^e in
  * [2^14, 2^15)) from it in-kernel.  amax buffers must be ZERO before their producer runs; producers are
- * onda_absmax below, or -- fused, no extra pass -- onda_bn_apply / onda_bn_bwd / onda_conv2d_fwd_h2 (their
+ * onda_absmax below, or -- fused, no extra pass -- onda_bn_apply / onda_bn_bwd / onda_conv2d_fwd_l2 (their
  * `amax` / `yamax` argument, may be NULL).  onda_absmax: x[rows][ld] with C valid channels, C and ld multiples of
  * 4; a flat tensor (rows == 1) may have any length. */
 #define ONDA_AMAX_SLOTS 64     /* slots, one 128-byte line apart */
 #define ONDA_AMAX_FLOATS 2048  /* floats per amax buffer */
 int onda_absmax(const float* x, int64_t rows, int C, int ld, float* amax, onda_stream_t s);
-/* OIHW fp32 weights -> dst[2][rows_pad][Kp] f16 limbs of w * 2^e(amax): limb planes with rows = Cout and K = taps*Cin
- * (dgrad=0: row n, k = tap*Cin + c; dgrad=1: row c, k = tap'*Cout_pad + n, taps flipped -- the data-gradient operand) */
+/* OIHW fp32 weights -> dst[rows_pad][Kp / 32][2][32] f16 LIMB ROWS of w * 2^e(amax) (the operand format of the pre-split
+ * kernels, below: per block of 32 K indices a row holds the 32 first limbs, then the 32 second limbs), rows = Cout and
+ * K = taps*Cin (dgrad=0: row n, k = tap*Cin + c; Kp a multiple of 32) or rows = Cin and K = taps*Cout_pad (dgrad=1: row c,
+ * k = tap'*Cout_pad + n, taps flipped -- the data-gradient operand) */
 int onda_pack_weight_h2(const float* w_oihw, void* dst, int Cout, int Cin, int taps, int rows_pad, int Kp, int dgrad,
                         int Cout_pad, const float* amax, onda_stream_t s);
 /* All conv weights of a model at once: a device table of OIHW tensors -> per tensor max|w| into `amax` (zeroed) and the
- * forward limb planes fwd[2][Cout][taps*Cin] (+ the data-gradient planes dgrad[2][Cin][taps*Cout], taps flipped, unless
+ * forward limb rows fwd[Cout][taps*Cin/32][2][32] (+ the data-gradient rows dgrad[Cin][taps*Cout/32][2][32], taps flipped, unless
  * dgrad is NULL); two launches for the whole table instead of two or three per tensor. */
 typedef struct {
   const float* w;
@@ -102,19 +104,18 @@ typedef struct {
 } OndaPackEntry;
 int onda_pack_blocks(int Cout, int Cin, int taps); /* workgroups one entry takes in the two launches */
 int onda_pack_weights_h2_multi(const OndaPackEntry* table, int n, int64_t total_blocks, onda_stream_t s);
-/* onda_conv2d_fwd with the activations split in-kernel (xamax = max|x|) and the weights pre-split (w2 / wamax
- * from onda_pack_weight_h2); same epilogue, workspace and schedule.  yamax (optional, zeroed): max|y| */
-int onda_conv2d_fwd_h2(const float* x, const float* xamax, const void* w2, const float* wamax, float* y,
-                       const float* scale, const float* shift, const float* residual, float* stats, float* ws,
-                       float* yamax, const OndaConv* c, onda_stream_t s);
-
-/* ---- "f16x2" with BOTH operands pre-split (csrc/conv_l2.hip): activations travel as limb planes
- *   xl[2][rows][ldx] f16:  xl[0] = f16(x * 2^e),  xl[1] = f16((x * 2^e - xl[0]) * 2^11),  e from xamax (as above),
+/* ---- "f16x2" with BOTH operands pre-split (csrc/conv_l2.hip): activations travel as LIMB ROWS
+ *   xl[rows][ldx / 32][2][32] f16:  first limbs l1 = f16(x * 2^e), second limbs l2 = f16((x * 2^e - l1) * 2^11),  e from
+ *   xamax (as above); element (row r, channel c) has its first limb at f16 index r * 2*ldx + (c/32)*64 + c%32 and its second
+ *   limb 32 further: the 128 bytes a K-step of 32 channels reads of a row are ONE cache line (round 5; until then two planes
+ *   xl[2][rows][ldx] = two half lines per row and K-step, and the kernels' K loops were bound by line requests per CU:
+ *   tools/micro/dma_rate.hip).  ldx is a multiple of 32.  The `*plane` arguments of the entry points below date from the
+ *   two-plane format and are ignored.
  * 4 bytes per element like fp32, written by the kernel that produces the tensor or by onda_split_h2 from an fp32
  * tensor whose max|x| is known.  The conv kernel then moves both operands HBM/L2 -> LDS by LDS-DMA only (no VALU,
  * no LDS stores in the K loop), 256 x 128 tiles on a 3-stage ring filled two K-steps ahead.
  * Replaces the same F.conv2d call sites as onda_conv2d_fwd (deeplabv2.py:53-68, :243-257); c->ldx counts f16
- * elements of a plane row, xplane the f16 elements between the two planes. */
+ * elements (channels) of a row. */
 int onda_split_h2(const float* x, int64_t rows, int C, int ldx, void* dst, int ldo, int64_t plane, const float* amax,
                   onda_stream_t s);
 /* onda_conv2d_fwd_l2 whose OUTPUT is limb planes as well: eval-mode conv + folded BatchNorm (scale, shift) [+ residual
@@ -202,10 +203,6 @@ int onda_bn_bwd_l2(const float* dout, const void* out, int64_t out_plane, const 
 int onda_conv_wgrad_l2_variant(int Cout, int Cin);
 int onda_conv2d_wgrad_l2(const void* xl, int64_t xplane, const float* xamax, const void* dyl, int64_t dyplane, const float* dyamax,
                          float* slabs, int lddy, int splitk, const OndaConv* c, onda_stream_t s);
-
-/* onda_conv2d_wgrad slabs from the two-limb f16 evaluation; xamax / dyamax = max|x| / max|dy| */
-int onda_conv2d_wgrad_h2(const float* x, const float* xamax, const float* dy, const float* dyamax, float* slabs, int lddy,
-                         int splitk, const OndaConv* c, onda_stream_t s);
 
 /* Weight gradient, split over `splitk` pixel ranges: slabs[ks][Cout][kh*kw][Cin] partial
  * sums of dy[m][n] * x[pix(m,tap)][c]  (autograd of F.conv2d w.r.t. weight).  Then

@@ -53,8 +53,6 @@ SIGNATURES = {
     "onda_pack_weight_h2": (I, [P, P, I, I, I, I, I, I, I, P, P]),
     "onda_pack_weights_h2_multi": (I, [P, I, L, P]),
     "onda_pack_blocks": (I, [I, I, I]),
-    "onda_conv2d_fwd_h2": (I, [P, P, P, P, P, P, P, P, P, P, P, POINTER(OndaConv), P]),
-    "onda_conv2d_wgrad_h2": (I, [P, P, P, P, P, I, I, POINTER(OndaConv), P]),
     "onda_split_h2": (I, [P, L, I, I, P, I, L, P, P]),
     "onda_stem_im2col_l2": (I, [P, P, P, L, I, I, I, I, I, I, P]),
     "onda_debug_stamps": (None, [P]),

@@ -16,6 +16,19 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// LIMB ROWS (round 5): how an operand of the pre-split convolutions lies in memory.  Row r -- a pixel of an activation, an
+// output channel of a packed weight -- holds, for every block of 32 channels, the 32 FIRST limbs followed by the 32 SECOND
+// limbs: 128 bytes = one cache line per (row, K-step of 32 channels).  Until round 4 the two limbs were separate planes
+// ([2][rows][ld]); a K-step then fetched two HALF lines per row, and tools/micro/dma_rate.hip shows what that costs: the
+// convolutions' LDS-DMA stream alone (no MFMA, no fragment read) takes as long as the whole 1024 -> 256 1x1 kernel, bound
+// by cache-line REQUESTS per CU, and runs 22-30 % faster with the same bytes as whole lines.
+//   f16 index of (row r, channel c, first limb) = r * 2 * ld + (c / 32) * 64 + c % 32;  second limb: + LIMB2_OFS
+// ld = channels per row (a multiple of 32); a row is 2 * ld f16 = 4 * ld bytes, like an fp32 row.
+constexpr int LIMB2_OFS = 32;
+__host__ __device__ __forceinline__ size_t limb_at(size_t row, int c, int ld) {
+  return row * 2 * (size_t)ld + (size_t)((c >> 5) << 6) + (size_t)(c & 31);
+}
+
 #define ONDA_STREAM(s) (reinterpret_cast<hipStream_t>(s))
 // Argument check at the top of every entry point.  It also drops any stale error another
 // library left in this thread's HIP error slot, so that the hipGetLastError() after our own

@@ -3,19 +3,21 @@
 // no ds_write in the K loop (the register-split kernel of conv_h2.hip spends its K-step between two
 // barriers on exactly those, beside the other wave's MFMA stream that starves them).
 //
-// Operand format ("limb planes", the same for activations and weights):
-//   L[2][rows][ld] f16,  L[0] = f16(x * s),  L[1] = f16((x * s - L[0]) * 2^11),  s = 2^e from the tensor's max|x|
-// (conv_h2.hip explains the arithmetic).  Activation planes are written by the kernel that produces the
-// tensor (BatchNorm / GroupNorm apply, BatchNorm backward, pooling, the stem's patch kernel) or by
-// split_h2_kernel below from an fp32 tensor whose max|x| is known; 4 bytes per element, like fp32.
+// Operand format ("limb rows", the same for activations and weights; common.h limb_at):
+//   row r, block of 32 channels b:  [32 x l1][32 x l2] f16,  l1 = f16(x * s),  l2 = f16((x * s - l1) * 2^11),  s = 2^e from max|x|
+// (conv_h2.hip explains the arithmetic): the 128 bytes a K-step needs of a row are ONE cache line (until round 4 the limbs
+// were separate planes, two half lines per row and K-step: the kernels' K loops were bound by line requests per CU,
+// tools/micro/dma_rate.hip).  Activation rows are written by the kernel that produces the tensor (BatchNorm apply /
+// backward, eval-mode conv epilogue, SE gate, the stem's patch kernel) or by split_h2_kernel below from an fp32 tensor
+// whose max|x| is known; 4 bytes per element, like fp32.
 //
 // Geometry: WM x WN waves, each a 64 x 64 output (4 x 4 MFMA tiles of 16 x 16, two accumulator sets), K-step 32
 // channels of one filter tap, a ring of STAGES LDS stages filled two K-steps ahead:
 //   s_waitcnt vmcnt(own DMAs of the next step)  ->  s_barrier  ->  issue the DMAs of step k+2  ->  fragments + MFMAs
 // one barrier per K-step, never vmcnt(0) inside the loop.  256 x 128 tiles (8 waves, 144 KB, one workgroup per
-// CU) halve the L2 -> LDS bytes per MFMA of the 128 x 128 kernel.  LDS image: 64-byte rows per limb plane,
-// 16-byte chunk index XOR-ed with a function of the row (swz_row) on the DMA's source side and in the
-// fragment read: conflict-free ds_read_b128.
+// CU) halve the L2 -> LDS bytes per MFMA of the 128 x 128 kernel.  LDS image: 128-byte rows (both limbs of the K-step's
+// 32 channels, as they lie in memory: one LDS-DMA instruction = 8 rows x 128 B), the 16-byte chunk index XOR-ed with a
+// function of the row (swz8) on the DMA's source side and in the fragment read: conflict-free ds_read_b128.
 #include "conv_common.h"
 #include <type_traits>
 
@@ -52,9 +54,36 @@ constexpr unsigned OOB = 0x80000000u;  // every operand is < 2 GiB - 4 KiB (chec
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
 }
-__device__ __forceinline__ int swz_row(int row) {
-  const int q = (row >> 2) & 3;
-  return q ^ ((q & 1) << 1) ^ ((row >> 1) & 1);
+// LDS image of an operand tile: 128-byte rows = 8 chunks of 16 bytes (source chunks 0-3: first limb's channels 0-31, 4-7: second
+// limb's).  Chunk c of row r sits at position c ^ swz8(r).  A fragment read takes rows 0-15 of a 16-row block at one chunk
+// per 16 lanes: rows r and r + 2 start 256 bytes = one pass over the 64 banks apart, so the eight rows of one parity need
+// eight different positions: swz8(r) = (r & 15) >> 1.
+__device__ __forceinline__ int swz8(int row) { return (row & 15) >> 1; }
+// source side of an LDS-DMA piece (8 rows x 128 B; lane L lands at byte 16 L of the piece = row L >> 3, position L & 7):
+// the byte offset inside the row's line this lane has to fetch; `odd` = the piece holds rows 8..15 of a 16-row block
+__device__ __forceinline__ unsigned dma_chunk16(int lane, int odd) { return (unsigned)(((lane & 7) ^ (4 * odd + (lane >> 4))) << 4); }
+// fragment read: lane l takes row l & 15 of a 16-row block, K chunk l >> 4 (8 channels) of limb `limb`
+__device__ __forceinline__ int frag_ofs(int lane, int limb) {
+  return (lane & 15) * 128 + ((((limb << 2) | (lane >> 4)) ^ swz8(lane & 15)) << 4);
+}
+// a tile row's (input row, input column, image row base) for tap (0, 0), packed: set_tap unpacks it once per filter tap
+struct RowPos {
+  int hw;  // (hi0 & 0xFFFF) | wi0 << 16;  hi0 = -32768: the row does not exist (past M)
+  int bH;
+};
+__device__ __forceinline__ RowPos row_pos(int m, int M, const OndaConv& c) {
+  const bool vm = m < M;
+  const int mm = vm ? m : 0;
+  const int wo = mm % c.Wo, tq = mm / c.Wo;
+  const int ho = tq % c.Ho, b = tq / c.Ho;
+  const int hi0 = vm ? ho * c.stride - c.pad : -32768, wi0 = wo * c.stride - c.pad;
+  return RowPos{(int)((unsigned)(hi0 & 0xFFFF) | ((unsigned)wi0 << 16)), b * c.Hi};
+}
+// byte offset of the row's 128-byte block 0 for filter tap (rr, ss), or OOB (padding / no such row)
+__device__ __forceinline__ unsigned row_tap_ofs(const RowPos& p, int rr, int ss, const OndaConv& c, unsigned chunk16) {
+  const int hi = (int)(short)(p.hw & 0xFFFF) + rr * c.dil, wi = (p.hw >> 16) + ss * c.dil;
+  const bool ok = (unsigned)hi < (unsigned)c.Hi && (unsigned)wi < (unsigned)c.Wi;
+  return ok ? (unsigned)(((p.bH + hi) * c.Wi + wi) * c.ldx) * 4u + chunk16 : 0x80000000u;
 }
 
 struct Scale2 {
@@ -80,7 +109,7 @@ __device__ __forceinline__ f32x2 unpack2h(unsigned p) {
   return __builtin_convertvector(__builtin_bit_cast(f16x2, p), f32x2);
 }
 
-// x[rows][ldx] fp32 (C valid channels) -> limb planes dst[2][rows][ldo] f16 with the scale of *amax
+// x[rows][ldx] fp32 (C valid channels) -> limb rows dst[rows][ldo / 32][2][32] f16 with the scale of *amax
 __global__ __launch_bounds__(256) void split_h2_kernel(const float* __restrict__ x, long long rows, int C, int ldx,
                                                        _Float16* __restrict__ dst, int ldo, long long plane,
                                                        const float* __restrict__ amax) {
@@ -101,8 +130,9 @@ __global__ __launch_bounds__(256) void split_h2_kernel(const float* __restrict__
       l1[h] = p;
       l2[h] = cvt2h((a - f[0]) * LIMB2_SCALE, (b - f[1]) * LIMB2_SCALE);
     }
-    *reinterpret_cast<u32x4*>(dst + row * ldo + ch) = l1;
-    *reinterpret_cast<u32x4*>(dst + plane + row * ldo + ch) = l2;
+    _Float16* o = dst + limb_at((size_t)row, ch, ldo);
+    *reinterpret_cast<u32x4*>(o) = l1;
+    *reinterpret_cast<u32x4*>(o + LIMB2_OFS) = l2;
   }
 }
 
@@ -142,8 +172,9 @@ __global__ __launch_bounds__(256) void stem_im2col_l2_kernel(const float* __rest
       l1[h] = pk;
       l2[h] = cvt2h((v[2 * h] - f[0]) * LIMB2_SCALE, (v[2 * h + 1] - f[1]) * LIMB2_SCALE);
     }
-    *reinterpret_cast<u32x4*>(dst + m * Kp + k0) = l1;
-    *reinterpret_cast<u32x4*>(dst + plane + m * Kp + k0) = l2;
+    _Float16* o = dst + limb_at((size_t)m, k0, Kp);
+    *reinterpret_cast<u32x4*>(o) = l1;
+    *reinterpret_cast<u32x4*>(o + LIMB2_OFS) = l2;
   }
 }
 
@@ -402,13 +433,13 @@ __device__ __forceinline__ void l2_epilogue_limbs(const ConvK& a, const f32x4 (&
       for (int r = 0; r < 4; ++r) {
         const int m = mw + i * 16 + 4 * r;
         const bool live = m < a.M && vn;
-        const _Float16* p = a.resl + (size_t)(live ? m : 0) * c.ldr + (live ? n : 0);
+        const _Float16* p = a.resl + limb_at((size_t)(live ? m : 0), live ? n : 0, c.ldr);
         r1[i][r] = live ? *reinterpret_cast<const u32x2*>(p) : u32x2{0u, 0u};
-        r2[i][r] = live ? *reinterpret_cast<const u32x2*>(p + a.resplane) : u32x2{0u, 0u};
+        r2[i][r] = live ? *reinterpret_cast<const u32x2*>(p + LIMB2_OFS) : u32x2{0u, 0u};
       }
   }
   float mx = 0.f;
-  const size_t plane_bytes = (size_t)a.M * c.ldy * 2;  // one plane as a buffer: rows past M fall outside
+  const size_t out_bytes = (size_t)a.M * c.ldy * 4;  // the output's limb rows as a buffer: rows past M fall outside
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -447,14 +478,14 @@ __device__ __forceinline__ void l2_epilogue_limbs(const ConvK& a, const f32x4 (&
       }
       if constexpr (COUNTED) {
 #if defined(__HIP_DEVICE_COMPILE__)
-        const unsigned off = vn ? (unsigned)(((size_t)m * c.ldy + n) * 2) : OOB;  // rows past M: past the plane's end
-        __builtin_amdgcn_raw_buffer_store_b64(l1, make_rsrc(a.yl, (unsigned)plane_bytes), off, 0, NT_AUX);
-        __builtin_amdgcn_raw_buffer_store_b64(l2, make_rsrc(a.yl + a.yplane, (unsigned)plane_bytes), off, 0, NT_AUX);
+        const unsigned off = vn ? (unsigned)(limb_at((size_t)m, n, c.ldy) * 2) : OOB;  // rows past M: past the buffer's end
+        __builtin_amdgcn_raw_buffer_store_b64(l1, make_rsrc(a.yl, (unsigned)out_bytes), off, 0, NT_AUX);
+        __builtin_amdgcn_raw_buffer_store_b64(l2, make_rsrc(a.yl, (unsigned)out_bytes), off, 2 * LIMB2_OFS, NT_AUX);
 #endif
       } else if (live) {
-        _Float16* dst = a.yl + (size_t)m * c.ldy + n;
+        _Float16* dst = a.yl + limb_at((size_t)m, n, c.ldy);
         store_out(reinterpret_cast<u32x2*>(dst), l1);
-        store_out(reinterpret_cast<u32x2*>(dst + a.yplane), l2);
+        store_out(reinterpret_cast<u32x2*>(dst + LIMB2_OFS), l2);
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -486,11 +517,10 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_l2_kernel(const ConvK 
   if (a.c.run_if != nullptr && *a.c.run_if == 0) return;  // predicated launch (onda_switch_step decided on the device)
   constexpr int NW = WM * WN;
   constexpr int BM = 64 * WM, BN = 64 * WN;
-  constexpr int PLANE_A = BM * 64, PLANE_B = BN * 64;  // one limb plane of a stage: 64-byte rows
-  constexpr int A_BYTES = 2 * PLANE_A, STAGE = A_BYTES + 2 * PLANE_B;
-  constexpr int APW = (BM / 16) / NW, BPW = (BN / 16) / NW;  // 16-row blocks (2 limbs x 1 KiB) per wave and stage
-  static_assert((BM / 16) % NW == 0 && (BN / 16) % NW == 0, "whole blocks per wave");
-  constexpr int DPW = 2 * (APW + BPW);  // LDS-DMA instructions per wave per K-step
+  constexpr int A_BYTES = BM * 128, STAGE = A_BYTES + BN * 128;  // 128-byte rows: both limbs of the K-step's 32 channels
+  constexpr int APW = (BM / 8) / NW, BPW = (BN / 8) / NW;        // 8-row pieces (1 KiB: one LDS-DMA instruction) per wave and stage
+  static_assert((BM / 8) % NW == 0 && (BN / 8) % NW == 0 && APW % 2 == 0 && BPW % 2 == 0, "whole 16-row blocks per wave");
+  constexpr int DPW = APW + BPW;  // LDS-DMA instructions per wave per K-step
   static_assert(STAGES >= 2, "ring: one stage being read, STAGES - 1 in flight");
   constexpr int AHEAD = STAGES >= 3 ? 2 : 1;     // K-steps in flight beyond the one being read
   constexpr bool STAGGER = NW == 8 && DBG != 6;  // two waves per SIMD: the second half of the workgroup runs half a step late
@@ -518,10 +548,9 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_l2_kernel(const ConvK 
   const Scale2 sx = scale_of(xamax), sw = scale_of(wamax);
   const float unscale_a = sx.inv, unscale_b = sw.inv;  // applied one after the other: their product may underflow
 
-  const int lrow = lane >> 2;                          // row inside a 16-row block
-  const unsigned cq16 = (unsigned)(((lane & 3) ^ swz_row(lrow)) << 4);  // source chunk of this lane's LDS slot
-  // fragment read: lane l takes row l & 15 of each 16-row block, data chunk l >> 4
-  const int frag = (lane & 15) * 64 + (((lane >> 4) ^ swz_row(lane & 15)) << 4);
+  const int lrow = lane >> 3;                                                // row inside an 8-row piece
+  const unsigned cq[2] = {dma_chunk16(lane, 0), dma_chunk16(lane, 1)};       // source chunk of this lane's LDS slot (even / odd piece)
+  const int fr0 = frag_ofs(lane, 0), fr1 = frag_ofs(lane, 1);                // fragment reads: first / second limb
 
   unsigned long long tk_setup = 0, tk_loop = 0, tk_epi = 0, tk_mark = DBG == 5 ? __builtin_amdgcn_s_memtime() : 0;
   const unsigned long long tk_start = tk_mark;
@@ -540,23 +569,14 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_l2_kernel(const ConvK 
     const int tile_n = tile % a.tilesN, tile_m = tile / a.tilesN;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
-    int hi0[APW], wi0[APW], bH[APW];
+    RowPos rp[APW];
 #pragma unroll
-    for (int d = 0; d < APW; ++d) {
-      const int m = m0 + (wave * APW + d) * 16 + lrow;
-      const bool vm = m < a.M;
-      const int mm = vm ? m : 0;
-      const int wo = mm % c.Wo, tq = mm / c.Wo;
-      const int ho = tq % c.Ho, b = tq / c.Ho;
-      hi0[d] = vm ? ho * c.stride - c.pad : -(1 << 28);
-      wi0[d] = wo * c.stride - c.pad;
-      bH[d] = b * c.Hi;
-    }
+    for (int d = 0; d < APW; ++d) rp[d] = row_pos(m0 + (wave * APW + d) * 8 + lrow, a.M, c);
     unsigned bofs[BPW];
 #pragma unroll
     for (int d = 0; d < BPW; ++d) {
-      const int n = n0 + (wave * BPW + d) * 16 + lrow;
-      bofs[d] = n < c.Cout ? (unsigned)n * wstride * 2u + cq16 : OOB;
+      const int n = n0 + (wave * BPW + d) * 8 + lrow;
+      bofs[d] = n < c.Cout ? (unsigned)n * wstride * 4u + cq[d & 1] : OOB;  // a weight row: 2 * K f16
     }
 
     // Filter taps whose input rows all lie outside the image for EVERY output row of this tile (whole image rows of a
@@ -589,28 +609,21 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_l2_kernel(const ConvK 
     auto set_tap = [&](int tp) {
       const int rr = tp / c.kw, ss = tp - rr * c.kw;
 #pragma unroll
-      for (int d = 0; d < APW; ++d) {
-        const int hi = hi0[d] + rr * c.dil, wi = wi0[d] + ss * c.dil;
-        const bool ok = (unsigned)hi < (unsigned)c.Hi && (unsigned)wi < (unsigned)c.Wi;
-        aofs[d] = ok ? (unsigned)(((bH[d] + hi) * c.Wi + wi) * c.ldx) * 2u + cq16 : OOB;
-      }
+      for (int d = 0; d < APW; ++d) aofs[d] = row_tap_ofs(rp[d], rr, ss, c, cq[d & 1]);
     };
     auto issue = [&](int stage_off) {
 #if defined(__HIP_DEVICE_COMPILE__)
-      const int sa = c0_i * 2;
-      const int sb = (tap_i * c.Cin + c0_i) * 2;
+      const int sa = c0_i * 4;                       // the row's 128-byte block of channels c0 .. c0 + 31
+      const int sb = (tap_i * c.Cin + c0_i) * 4;
 #pragma unroll
-      for (int l = 0; l < (DBG == 9 ? 1 : 2); ++l) {  // (DBG 9, ablation: the first limb planes only = half of the DMA instructions)
+      for (int d = 0; d < (DBG == 9 ? APW / 2 : APW); ++d) {  // (DBG 9, ablation: half of the DMA instructions)
+        unsigned char* dst = lds + stage_off + (wave * APW + d) * 1024;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)dst, 16, aofs[d], sa, 0, 0);
+      }
 #pragma unroll
-        for (int d = 0; d < APW; ++d) {
-          unsigned char* dst = lds + stage_off + l * PLANE_A + (wave * APW + d) * 1024;
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)dst, 16, aofs[d], sa + l * xplane, 0, 0);
-        }
-#pragma unroll
-        for (int d = 0; d < BPW; ++d) {
-          unsigned char* dst = lds + stage_off + A_BYTES + l * PLANE_B + (wave * BPW + d) * 1024;
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)dst, 16, bofs[d], sb + l * wplane, 0, 0);
-        }
+      for (int d = 0; d < (DBG == 9 ? BPW / 2 : BPW); ++d) {
+        unsigned char* dst = lds + stage_off + A_BYTES + (wave * BPW + d) * 1024;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)dst, 16, bofs[d], sb, 0, 0);
       }
 #else
       (void)stage_off;
@@ -663,28 +676,30 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_l2_kernel(const ConvK 
         bf[i] = b1[i] = f16x8{(_Float16)0.25f, (_Float16)2.f, (_Float16)lane, 0, 0, 0, 0, 0};
       }
     }
-    const unsigned char *Ab, *Bb;
+    const unsigned char *Ab, *Ab2, *Bb, *Bb2;  // this wave's 16-row blocks of the stage being read: first / second limb
     auto prepare = [&]() {  // "P": first fragments of the stage at st_read (ALL of them when the halves are staggered)
-      Ab = lds + st_read + wm * 64 * 64 + frag;
-      Bb = lds + st_read + A_BYTES + wn * 64 * 64 + frag;
+      Ab = lds + st_read + wm * 64 * 128 + fr0;
+      Ab2 = lds + st_read + wm * 64 * 128 + fr1;
+      Bb = lds + st_read + A_BYTES + wn * 64 * 128 + fr0;
+      Bb2 = lds + st_read + A_BYTES + wn * 64 * 128 + fr1;
       st_read = st_read + STAGE == STAGES * STAGE ? 0 : st_read + STAGE;
       if constexpr (DBG == 8 || DBG >= 10) return;  // ablation: no fragment reads at all (the MFMAs run on whatever the registers hold)
       if constexpr (DBG == 7) {        // ablation: half of the fragment reads (first limbs only, used for every product)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) af[i][1] = af[i][0] = *reinterpret_cast<const f16x8*>(Ab + i * 1024);
+        for (int i = 0; i < 4; ++i) af[i][1] = af[i][0] = *reinterpret_cast<const f16x8*>(Ab + i * 2048);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) b1[j] = bf[j] = *reinterpret_cast<const f16x8*>(Bb + j * 1024);
+        for (int j = 0; j < 4; ++j) b1[j] = bf[j] = *reinterpret_cast<const f16x8*>(Bb + j * 2048);
         return;
       }
 #pragma unroll
-      for (int l = 0; l < 2; ++l)
+      for (int i = 0; i < 4; ++i) af[i][0] = *reinterpret_cast<const f16x8*>(Ab + i * 2048);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) af[i][l] = *reinterpret_cast<const f16x8*>(Ab + l * PLANE_A + i * 1024);
+      for (int i = 0; i < 4; ++i) af[i][1] = *reinterpret_cast<const f16x8*>(Ab2 + i * 2048);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) bf[j] = *reinterpret_cast<const f16x8*>(Bb + PLANE_B + j * 1024);
+      for (int j = 0; j < 4; ++j) bf[j] = *reinterpret_cast<const f16x8*>(Bb2 + j * 2048);
       if constexpr (STAGGER) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) b1[j] = *reinterpret_cast<const f16x8*>(Bb + j * 1024);
+        for (int j = 0; j < 4; ++j) b1[j] = *reinterpret_cast<const f16x8*>(Bb + j * 2048);
       }
     };
     auto compute = [&]() {  // "C": 48 MFMAs (one wave per SIMD: the b1 fragments are fetched behind the first 16)
@@ -694,7 +709,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_l2_kernel(const ConvK 
         for (int jj = 0; jj < 4; ++jj) accx[i][ZZ(i, jj)] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][0], bf[ZZ(i, jj)], accx[i][ZZ(i, jj)], 0, 0, 0);
       if constexpr (!STAGGER && DBG != 7 && DBG != 8 && DBG < 10) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) b1[j] = *reinterpret_cast<const f16x8*>(Bb + j * 1024);
+        for (int j = 0; j < 4; ++j) b1[j] = *reinterpret_cast<const f16x8*>(Bb + j * 2048);
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -813,11 +828,10 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_l2x_kernel(const ConvK
   if (a.c.run_if != nullptr && *a.c.run_if == 0) return;  // predicated launch (onda_switch_step decided on the device)
   constexpr int NW = WM * WN;
   constexpr int BM = 64 * WM, BN = 64 * WN;
-  constexpr int PLANE_A = BM * 64, PLANE_B = BN * 64;
-  constexpr int A_BYTES = 2 * PLANE_A, STAGE = A_BYTES + 2 * PLANE_B;
-  constexpr int APW = (BM / 16) / NW, BPW = (BN / 16) / NW;
-  static_assert((BM / 16) % NW == 0 && (BN / 16) % NW == 0, "whole blocks per wave");
-  constexpr int DPW = 2 * (APW + BPW);
+  constexpr int A_BYTES = BM * 128, STAGE = A_BYTES + BN * 128;  // 128-byte rows: both limbs (see conv_l2_kernel)
+  constexpr int APW = (BM / 8) / NW, BPW = (BN / 8) / NW;        // 8-row pieces per wave and stage
+  static_assert((BM / 8) % NW == 0 && (BN / 8) % NW == 0 && APW % 2 == 0 && BPW % 2 == 0, "whole 16-row blocks per wave");
+  constexpr int DPW = APW + BPW;
   constexpr int EST = 16;  // buffer stores every wave issues per epilogue (l2_epilogue<.., true>)
   static_assert(STAGES == 3 && DPW + EST <= 63, "ring of three; vmcnt holds 6 bits");
   __shared__ __attribute__((aligned(16))) unsigned char lds[STAGES * STAGE];
@@ -836,9 +850,9 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_l2x_kernel(const ConvK
   const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, x_bytes), rw = make_rsrc(a.w, w_bytes);
   const Scale2 sx = scale_of(xamax), sw = scale_of(wamax);
   const float unscale_a = sx.inv, unscale_b = sw.inv;
-  const int lrow = lane >> 2;
-  const unsigned cq16 = (unsigned)(((lane & 3) ^ swz_row(lrow)) << 4);
-  const int frag = (lane & 15) * 64 + (((lane >> 4) ^ swz_row(lane & 15)) << 4);
+  const int lrow = lane >> 3;
+  const unsigned cq[2] = {dma_chunk16(lane, 0), dma_chunk16(lane, 1)};
+  const int fr0 = frag_ofs(lane, 0), fr1 = frag_ofs(lane, 1);
 
   // ---- work items: (tile, k_begin, k_end); a cursor is (whole tile index, stream-K unit) ------------------------------
   struct Cursor {
@@ -864,17 +878,14 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_l2x_kernel(const ConvK
   // ---- issue side ------------------------------------------------------------------------------------------------------
   Cursor ci{swz, u_begin};
   int i_left = 0;  // K-steps of the issue item still to be issued
-  int hi0[APW], wi0[APW], bH[APW], tap_i = 0, c0_i = 0;
+  RowPos rp[APW];
+  int tap_i = 0, c0_i = 0;
   unsigned bofs[BPW], aofs[APW];
   int st_issue = 0, st_read = 0, in_flight = 0;  // in_flight: issued steps whose DMAs have not been waited for
   auto set_tap = [&](int tp) {
     const int rr = tp / c.kw, ss = tp - rr * c.kw;
 #pragma unroll
-    for (int d = 0; d < APW; ++d) {
-      const int hi = hi0[d] + rr * c.dil, wi = wi0[d] + ss * c.dil;
-      const bool ok = (unsigned)hi < (unsigned)c.Hi && (unsigned)wi < (unsigned)c.Wi;
-      aofs[d] = ok ? (unsigned)(((bH[d] + hi) * c.Wi + wi) * c.ldx) * 2u + cq16 : OOB;
-    }
+    for (int d = 0; d < APW; ++d) aofs[d] = row_tap_ofs(rp[d], rr, ss, c, cq[d & 1]);
   };
   auto open_issue_item = [&]() {  // row decomposition of the item at `ci` (the VALU work that used to start every tile)
     int tile, k_begin, k_end;
@@ -882,20 +893,11 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_l2x_kernel(const ConvK
     i_left = k_end - k_begin;
     const int m0 = (tile / a.tilesN) * BM, n0 = (tile % a.tilesN) * BN;
 #pragma unroll
-    for (int d = 0; d < APW; ++d) {
-      const int m = m0 + (wave * APW + d) * 16 + lrow;
-      const bool vm = m < a.M;
-      const int mm = vm ? m : 0;
-      const int wo = mm % c.Wo, tq = mm / c.Wo;
-      const int ho = tq % c.Ho, b = tq / c.Ho;
-      hi0[d] = vm ? ho * c.stride - c.pad : -(1 << 28);
-      wi0[d] = wo * c.stride - c.pad;
-      bH[d] = b * c.Hi;
-    }
+    for (int d = 0; d < APW; ++d) rp[d] = row_pos(m0 + (wave * APW + d) * 8 + lrow, a.M, c);
 #pragma unroll
     for (int d = 0; d < BPW; ++d) {
-      const int n = n0 + (wave * BPW + d) * 16 + lrow;
-      bofs[d] = n < c.Cout ? (unsigned)n * wstride * 2u + cq16 : OOB;
+      const int n = n0 + (wave * BPW + d) * 8 + lrow;
+      bofs[d] = n < c.Cout ? (unsigned)n * wstride * 4u + cq[d & 1] : OOB;
     }
     tap_i = k_begin / a.kcper;
     c0_i = (k_begin - tap_i * a.kcper) * BK;
@@ -908,19 +910,16 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_l2x_kernel(const ConvK
       open_issue_item();
     }
 #if defined(__HIP_DEVICE_COMPILE__)
-    const int sa = c0_i * 2, sb = (tap_i * c.Cin + c0_i) * 2;
+    const int sa = c0_i * 4, sb = (tap_i * c.Cin + c0_i) * 4;
 #pragma unroll
-    for (int l = 0; l < 2; ++l) {
+    for (int d = 0; d < APW; ++d) {
+      unsigned char* dst = lds + st_issue + (wave * APW + d) * 1024;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)dst, 16, aofs[d], sa, 0, 0);
+    }
 #pragma unroll
-      for (int d = 0; d < APW; ++d) {
-        unsigned char* dst = lds + st_issue + l * PLANE_A + (wave * APW + d) * 1024;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)dst, 16, aofs[d], sa + l * xplane, 0, 0);
-      }
-#pragma unroll
-      for (int d = 0; d < BPW; ++d) {
-        unsigned char* dst = lds + st_issue + A_BYTES + l * PLANE_B + (wave * BPW + d) * 1024;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)dst, 16, bofs[d], sb + l * wplane, 0, 0);
-      }
+    for (int d = 0; d < BPW; ++d) {
+      unsigned char* dst = lds + st_issue + A_BYTES + (wave * BPW + d) * 1024;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)dst, 16, bofs[d], sb, 0, 0);
     }
 #endif
     st_issue = st_issue + STAGE == STAGES * STAGE ? 0 : st_issue + STAGE;
@@ -936,17 +935,19 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_l2x_kernel(const ConvK
 
   // ---- compute side ----------------------------------------------------------------------------------------------------
   f16x8 af[4][2], bf[4];
-  const unsigned char *Ab, *Bb;
+  const unsigned char *Ab, *Ab2, *Bb, *Bb2;
   auto prepare = [&]() {
-    Ab = lds + st_read + wm * 64 * 64 + frag;
-    Bb = lds + st_read + A_BYTES + wn * 64 * 64 + frag;
+    Ab = lds + st_read + wm * 64 * 128 + fr0;
+    Ab2 = lds + st_read + wm * 64 * 128 + fr1;
+    Bb = lds + st_read + A_BYTES + wn * 64 * 128 + fr0;
+    Bb2 = lds + st_read + A_BYTES + wn * 64 * 128 + fr1;
     st_read = st_read + STAGE == STAGES * STAGE ? 0 : st_read + STAGE;
 #pragma unroll
-    for (int l = 0; l < 2; ++l)
+    for (int i = 0; i < 4; ++i) af[i][0] = *reinterpret_cast<const f16x8*>(Ab + i * 2048);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) af[i][l] = *reinterpret_cast<const f16x8*>(Ab + l * PLANE_A + i * 1024);
+    for (int i = 0; i < 4; ++i) af[i][1] = *reinterpret_cast<const f16x8*>(Ab2 + i * 2048);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) bf[j] = *reinterpret_cast<const f16x8*>(Bb + PLANE_B + j * 1024);
+    for (int j = 0; j < 4; ++j) bf[j] = *reinterpret_cast<const f16x8*>(Bb2 + j * 2048);
   };
   int stores_young = 0;  // waits during which an epilogue's stores are still younger than the DMAs waited for
   const bool limb_out = a.yl != nullptr;  // limb-plane output: two 8-byte stores where the fp32 output has one of 16 bytes
@@ -1003,7 +1004,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_l2x_kernel(const ConvK
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) accx[i][ZZ(i, jj)] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][0], bf[ZZ(i, jj)], accx[i][ZZ(i, jj)], 0, 0, 0);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) bf[j] = *reinterpret_cast<const f16x8*>(Bb + j * 1024);
+      for (int j = 0; j < 4; ++j) bf[j] = *reinterpret_cast<const f16x8*>(Bb + j * 2048);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -1101,8 +1102,8 @@ __device__ __forceinline__ void l2p_chunk(const ConvK& a, const float* __restric
   if constexpr (LIMB) {
     v = v * sc + sh;
     if (a.resl != nullptr && live) {
-      const _Float16* p = a.resl + (size_t)m * c.ldr + n;
-      const u32x2 q1 = *reinterpret_cast<const u32x2*>(p), q2 = *reinterpret_cast<const u32x2*>(p + a.resplane);
+      const _Float16* p = a.resl + limb_at((size_t)m, n, c.ldr);
+      const u32x2 q1 = *reinterpret_cast<const u32x2*>(p), q2 = *reinterpret_cast<const u32x2*>(p + LIMB2_OFS);
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const f32x2 p1 = unpack2h(q1[h]), p2 = unpack2h(q2[h]);
@@ -1125,9 +1126,9 @@ __device__ __forceinline__ void l2p_chunk(const ConvK& a, const float* __restric
         l1[h] = pk;
         l2[h] = cvt2h((w[2 * h] - f[0]) * LIMB2_SCALE, (w[2 * h + 1] - f[1]) * LIMB2_SCALE);
       }
-      _Float16* dst = a.yl + (size_t)m * c.ldy + n;
+      _Float16* dst = a.yl + limb_at((size_t)m, n, c.ldy);
       store_out(reinterpret_cast<u32x2*>(dst), l1);
-      store_out(reinterpret_cast<u32x2*>(dst + a.yplane), l2);
+      store_out(reinterpret_cast<u32x2*>(dst + LIMB2_OFS), l2);
     }
   } else {
     if constexpr (AFFINE) {
@@ -1159,8 +1160,7 @@ __global__ __launch_bounds__(512, 2) void conv_l2p_kernel(const ConvK a, unsigne
                                                           const float* __restrict__ wamax) {
   if (a.c.run_if != nullptr && *a.c.run_if == 0) return;  // predicated launch (onda_switch_step decided on the device)
   constexpr int BM = 128, BN = 128;
-  constexpr int PLANE = BM * 64;  // one limb plane of A (or of B) in a stage: 64-byte rows
-  constexpr int A_BYTES = 2 * PLANE, STAGE = 4 * PLANE, RING = 3 * STAGE, HOLD = BM * BN * 4;
+  constexpr int A_BYTES = BM * 128, STAGE = A_BYTES + BN * 128, RING = 3 * STAGE, HOLD = BM * BN * 4;  // 128-byte rows: both limbs
   constexpr int DPW = 16;    // LDS-DMA instructions per producer wave and K-step
   constexpr int NCH = 32;    // 4-row chunks of a tile per epilogue wave
   static_assert(RING + HOLD == 160 * 1024, "all of a CU's LDS");
@@ -1180,7 +1180,7 @@ __global__ __launch_bounds__(512, 2) void conv_l2p_kernel(const ConvK a, unsigne
   if (wave < 4) {
     // ---------------------------------------------------------------------------------------------------- consumers
     const int wm = wave >> 1, wn = wave & 1;
-    const int frag = (lane & 15) * 64 + (((lane >> 4) ^ swz_row(lane & 15)) << 4);
+    const int fr0 = frag_ofs(lane, 0), fr1 = frag_ofs(lane, 1);
     f32x4 acc[4][4], accx[4][4];
     auto zero = [&]() {
 #pragma unroll
@@ -1206,10 +1206,12 @@ __global__ __launch_bounds__(512, 2) void conv_l2p_kernel(const ConvK a, unsigne
     };
     f16x8 a1[2][4], b1[2][4], a2[4], b2[4];
     int st_read = 0;
-    const unsigned char *Ab, *Bb;
+    const unsigned char *Ab, *Ab2, *Bb, *Bb2;
     auto open_stage = [&]() {
-      Ab = lds + st_read + wm * 64 * 64 + frag;
-      Bb = lds + st_read + A_BYTES + wn * 64 * 64 + frag;
+      Ab = lds + st_read + wm * 64 * 128 + fr0;
+      Ab2 = lds + st_read + wm * 64 * 128 + fr1;
+      Bb = lds + st_read + A_BYTES + wn * 64 * 128 + fr0;
+      Bb2 = lds + st_read + A_BYTES + wn * 64 * 128 + fr1;
       st_read = next_stage(st_read);
     };
     auto mfma3 = [&](const f16x8 (&A1)[4], const f16x8 (&B1)[4], int which) {
@@ -1237,13 +1239,13 @@ __global__ __launch_bounds__(512, 2) void conv_l2p_kernel(const ConvK a, unsigne
           __builtin_amdgcn_s_barrier();  // B_g: stage g landed
           open_stage();
 #pragma unroll
-          for (int i = 0; i < 4; ++i) a1[0][i] = *reinterpret_cast<const f16x8*>(Ab + i * 1024);
+          for (int i = 0; i < 4; ++i) a1[0][i] = *reinterpret_cast<const f16x8*>(Ab + i * 2048);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) b2[j] = *reinterpret_cast<const f16x8*>(Bb + PLANE + j * 1024);
+          for (int j = 0; j < 4; ++j) b2[j] = *reinterpret_cast<const f16x8*>(Bb2 + j * 2048);
 #pragma unroll
-          for (int i = 0; i < 4; ++i) a2[i] = *reinterpret_cast<const f16x8*>(Ab + PLANE + i * 1024);
+          for (int i = 0; i < 4; ++i) a2[i] = *reinterpret_cast<const f16x8*>(Ab2 + i * 2048);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) b1[0][j] = *reinterpret_cast<const f16x8*>(Bb + j * 1024);
+          for (int j = 0; j < 4; ++j) b1[0][j] = *reinterpret_cast<const f16x8*>(Bb + j * 2048);
           mfma3(a1[0], b1[0], 0);
           mfma3(a1[0], b1[0], 1);
           mfma3(a1[0], b1[0], 2);
@@ -1256,13 +1258,13 @@ __global__ __launch_bounds__(512, 2) void conv_l2p_kernel(const ConvK a, unsigne
       __builtin_amdgcn_s_barrier();  // B_0
       open_stage();
 #pragma unroll
-      for (int i = 0; i < 4; ++i) a1[0][i] = *reinterpret_cast<const f16x8*>(Ab + i * 1024);
+      for (int i = 0; i < 4; ++i) a1[0][i] = *reinterpret_cast<const f16x8*>(Ab + i * 2048);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) b2[j] = *reinterpret_cast<const f16x8*>(Bb + PLANE + j * 1024);
+      for (int j = 0; j < 4; ++j) b2[j] = *reinterpret_cast<const f16x8*>(Bb2 + j * 2048);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) a2[i] = *reinterpret_cast<const f16x8*>(Ab + PLANE + i * 1024);
+      for (int i = 0; i < 4; ++i) a2[i] = *reinterpret_cast<const f16x8*>(Ab2 + i * 2048);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) b1[0][j] = *reinterpret_cast<const f16x8*>(Bb + j * 1024);
+      for (int j = 0; j < 4; ++j) b1[0][j] = *reinterpret_cast<const f16x8*>(Bb + j * 2048);
       // one K-step: MFMAs on the fragments of step g (set P) while the fragments of step g + 1 arrive (a1 / b1 into set 1 - P;
       // b2 / a2 in place, each behind the MFMA group that last reads it).  No branch in here: behind the workgroup's last
       // K-step the reads fetch a stage nobody filled, into registers nobody uses.
@@ -1272,19 +1274,19 @@ __global__ __launch_bounds__(512, 2) void conv_l2p_kernel(const ConvK a, unsigne
         __builtin_amdgcn_s_barrier();  // B_{g+1}: stage g + 1 landed; everybody holds the fragments of stage g
         open_stage();
 #pragma unroll
-        for (int i = 0; i < 4; ++i) a1[1 - P][i] = *reinterpret_cast<const f16x8*>(Ab + i * 1024);
+        for (int i = 0; i < 4; ++i) a1[1 - P][i] = *reinterpret_cast<const f16x8*>(Ab + i * 2048);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) b1[1 - P][j] = *reinterpret_cast<const f16x8*>(Bb + j * 1024);
+        for (int j = 0; j < 4; ++j) b1[1 - P][j] = *reinterpret_cast<const f16x8*>(Bb + j * 2048);
         __builtin_amdgcn_sched_barrier(0);
         mfma3(a1[P], b1[P], 0);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) b2[j] = *reinterpret_cast<const f16x8*>(Bb + PLANE + j * 1024);
+        for (int j = 0; j < 4; ++j) b2[j] = *reinterpret_cast<const f16x8*>(Bb2 + j * 2048);
         __builtin_amdgcn_sched_barrier(0);
         mfma3(a1[P], b1[P], 1);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) a2[i] = *reinterpret_cast<const f16x8*>(Ab + PLANE + i * 1024);
+        for (int i = 0; i < 4; ++i) a2[i] = *reinterpret_cast<const f16x8*>(Ab2 + i * 2048);
         __builtin_amdgcn_sched_barrier(0);
         mfma3(a1[P], b1[P], 2);
         __builtin_amdgcn_sched_barrier(0);
@@ -1307,19 +1309,16 @@ __global__ __launch_bounds__(512, 2) void conv_l2p_kernel(const ConvK a, unsigne
     const int d = wave - 4;
     const int wstride = a.taps * c.Cin;
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, x_bytes), rw = make_rsrc(a.w, w_bytes);
-    const int lrow = lane >> 2;
-    const unsigned cq16 = (unsigned)(((lane & 3) ^ swz_row(lrow)) << 4);
-    int hi0[4], wi0[4], bH[4], tap_i = 0, c0_i = 0;
-    unsigned bofs[4], aofs[4];
+    const int lrow = lane >> 3;
+    const unsigned cq[2] = {dma_chunk16(lane, 0), dma_chunk16(lane, 1)};
+    RowPos rp[8];  // this wave's eight 8-row pieces of A (rows 64 d .. 64 d + 63) and of B
+    int tap_i = 0, c0_i = 0;
+    unsigned bofs[8], aofs[8];
     int it_i = 0, i_left = 0, st_issue = 0, issued = 0;
     auto set_tap = [&](int tp) {
       const int rr = tp / c.kw, ss = tp - rr * c.kw;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int hi = hi0[k] + rr * c.dil, wi = wi0[k] + ss * c.dil;
-        const bool ok = (unsigned)hi < (unsigned)c.Hi && (unsigned)wi < (unsigned)c.Wi;
-        aofs[k] = ok ? (unsigned)(((bH[k] + hi) * c.Wi + wi) * c.ldx) * 2u + cq16 : OOB;
-      }
+      for (int k = 0; k < 8; ++k) aofs[k] = row_tap_ofs(rp[k], rr, ss, c, cq[k & 1]);
     };
     auto open_item = [&]() {
       const int tile = swz + it_i * nblk;
@@ -1327,17 +1326,10 @@ __global__ __launch_bounds__(512, 2) void conv_l2p_kernel(const ConvK a, unsigne
       i_left = KT;
       const int m0 = (tile / a.tilesN) * BM, n0 = (tile % a.tilesN) * BN;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int m = m0 + (d * 4 + k) * 16 + lrow;
-        const bool vm = m < a.M;
-        const int mm = vm ? m : 0;
-        const int wo = mm % c.Wo, tq = mm / c.Wo;
-        const int ho = tq % c.Ho, b = tq / c.Ho;
-        hi0[k] = vm ? ho * c.stride - c.pad : -(1 << 28);
-        wi0[k] = wo * c.stride - c.pad;
-        bH[k] = b * c.Hi;
-        const int n = n0 + (d * 4 + k) * 16 + lrow;
-        bofs[k] = n < c.Cout ? (unsigned)n * wstride * 2u + cq16 : OOB;
+      for (int k = 0; k < 8; ++k) {
+        rp[k] = row_pos(m0 + (d * 8 + k) * 8 + lrow, a.M, c);
+        const int n = n0 + (d * 8 + k) * 8 + lrow;
+        bofs[k] = n < c.Cout ? (unsigned)n * wstride * 4u + cq[k & 1] : OOB;
       }
       tap_i = 0;
       c0_i = 0;
@@ -1349,19 +1341,16 @@ __global__ __launch_bounds__(512, 2) void conv_l2p_kernel(const ConvK a, unsigne
         open_item();
       }
 #if defined(__HIP_DEVICE_COMPILE__)
-      const int sa = c0_i * 2, sb = (tap_i * c.Cin + c0_i) * 2;
+      const int sa = c0_i * 4, sb = (tap_i * c.Cin + c0_i) * 4;
 #pragma unroll
-      for (int l = 0; l < 2; ++l) {
+      for (int k = 0; k < 8; ++k) {
+        unsigned char* dst = lds + st_issue + (d * 8 + k) * 1024;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)dst, 16, aofs[k], sa, 0, 0);
+      }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          unsigned char* dst = lds + st_issue + l * PLANE + (d * 4 + k) * 1024;
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)dst, 16, aofs[k], sa + l * xplane, 0, 0);
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          unsigned char* dst = lds + st_issue + A_BYTES + l * PLANE + (d * 4 + k) * 1024;
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)dst, 16, bofs[k], sb + l * wplane, 0, 0);
-        }
+      for (int k = 0; k < 8; ++k) {
+        unsigned char* dst = lds + st_issue + A_BYTES + (d * 8 + k) * 1024;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)dst, 16, bofs[k], sb, 0, 0);
       }
 #endif
       st_issue = next_stage(st_issue);
@@ -1586,8 +1575,8 @@ __global__ __launch_bounds__(256) void conv_l2_fixup_kernel(const ConvK a, int G
       if (a.scale) o *= *reinterpret_cast<const f32x4*>(a.scale + n);
       if (a.shift) o += *reinterpret_cast<const f32x4*>(a.shift + n);
       if (a.resl != nullptr) {
-        const _Float16* p = a.resl + (size_t)m * c.ldr + n;
-        const u32x2 q1 = *reinterpret_cast<const u32x2*>(p), q2 = *reinterpret_cast<const u32x2*>(p + a.resplane);
+        const _Float16* p = a.resl + limb_at((size_t)m, n, c.ldr);
+        const u32x2 q1 = *reinterpret_cast<const u32x2*>(p), q2 = *reinterpret_cast<const u32x2*>(p + LIMB2_OFS);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const f32x2 p1 = unpack2h(q1[h]), p2 = unpack2h(q2[h]);
@@ -1609,9 +1598,9 @@ __global__ __launch_bounds__(256) void conv_l2_fixup_kernel(const ConvK a, int G
         l1[h] = pk;
         l2[h] = cvt2h((w[2 * h] - f[0]) * LIMB2_SCALE, (w[2 * h + 1] - f[1]) * LIMB2_SCALE);
       }
-      _Float16* dst = a.yl + (size_t)m * c.ldy + n;
+      _Float16* dst = a.yl + limb_at((size_t)m, n, c.ldy);
       *reinterpret_cast<u32x2*>(dst) = l1;
-      *reinterpret_cast<u32x2*>(dst + a.yplane) = l2;
+      *reinterpret_cast<u32x2*>(dst + LIMB2_OFS) = l2;
     }
     if (a.amax != nullptr) amax_update_block(a.amax, mx, reinterpret_cast<float*>(&red[0][0]));
     return;
@@ -1666,12 +1655,15 @@ __global__ __launch_bounds__(256) void conv_l2_fixup_kernel(const ConvK a, int G
 
 // ---- weight gradient ----------------------------------------------------------------------------------------------------
 // dw[n][tap][c] = sum over pixels m of dy[m][n] * x[pix(m, tap)][c]: the contraction index (pixels) is the SLOW memory axis
-// of both operands.  Both arrive as they lie in HBM -- [pixel][channel] rows of their limb planes, by LDS-DMA, 4 pixels x 128
-// channels per instruction -- and are read out of LDS TRANSPOSED by ds_read_b64_tr_b16 (4 pixels x 16 channels per 16 lanes,
-// each lane receives one channel's 4 pixels): two of them make the 8 consecutive k of a 16x16x32 MFMA operand.  No VALU
-// split, no register transposition, no LDS stores.  LDS image per limb and 128-channel half: [32 pixels][256 B] with the
-// 16-byte chunk index XOR-ed by ((row & 3) << 2 | (row >> 2) & 3) (conflict-free for the transposed reads), applied on the
-// DMA's source side.  Tile 64*WM output channels x 64*WN input channels per (tap, pixel range); ring and slot stagger as in
+// of both operands.  Both arrive as they lie in HBM -- [pixel][channel] limb rows, by LDS-DMA, 2 pixels x (128 channels x 2
+// limbs) = four whole cache lines per pixel and instruction -- and are read out of LDS TRANSPOSED by ds_read_b64_tr_b16 (4
+// pixels x 16 channels per 16 lanes, each lane receives one channel's 4 pixels): two of them make the 8 consecutive k of a
+// 16x16x32 MFMA operand.  No VALU split, no register transposition, no LDS stores.  LDS image per 128-channel half:
+// [32 pixels][512 B], a row = the 128 first limbs (256 B) then the 128 second limbs, each half with its 16-byte chunk index
+// XOR-ed by ((row & 3) << 2 | (row >> 2) & 3) (conflict-free for the transposed reads), applied on the DMA's source side.
+// An instruction's lanes 0-31 / 32-63 fetch pixels 4g + 2h and 4g + 2h + 2 ... no: pixels 4g + 2 lambda + h (lambda = lane >> 5,
+// h = the group's first / second instruction) into LDS rows 4g + 2h + lambda -- the middle two pixels of every four swap
+// rows, for BOTH operands alike (the contraction does not care), so that a lane's two pixels are neighbours (m, m + 1).  Tile 64*WM output channels x 64*WN input channels per (tap, pixel range); ring and slot stagger as in
 // conv_l2_kernel.  K-steps whose 32 pixels all fall into the padding for this tap are skipped (whole dead rows of a
 // dilated tap: up to half of the ASPP weight-gradient work).
 // The transposed reads are inline assembly: behind the builtin the compiler waits for vmcnt(0) -- every LDS-DMA in flight --
@@ -1697,8 +1689,8 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_wgrad_l2_kernel(const 
   constexpr int NW = WM * WN;
   constexpr int SA = (64 * WM) / 128, SB = (64 * WN) / 128;  // 128-channel sub-images of dy / x
   static_assert(SA >= 1 && SB >= 1, "tiles are multiples of 128 channels");
-  constexpr int SUB = 32 * 256;                              // one sub-image of one limb: 32 pixels x 256 B
-  constexpr int A_LIMB = SA * SUB, B_LIMB = SB * SUB, A_BYTES = 2 * A_LIMB, STAGE = A_BYTES + 2 * B_LIMB;
+  constexpr int SUB = 32 * 512;                              // one sub-image (128 channels, both limbs): 32 pixels x 512 B
+  constexpr int A_BYTES = SA * SUB, STAGE = A_BYTES + SB * SUB;
   constexpr int GPW = 8 / NW;                                // 4-pixel groups per wave
   static_assert(GPW >= 1 && 8 % NW == 0, "8 pixel groups per K-step");
   constexpr int DPW = GPW * (SA + SB) * 2;                   // LDS-DMA instructions per wave per K-step
@@ -1762,30 +1754,35 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_wgrad_l2_kernel(const 
   }
   auto live_at = [&](int i) -> int { return __builtin_amdgcn_readfirstlane((int)live_list[i]); };
 
-  // DMA roles: this wave moves pixel groups grp = wave*GPW + d (4 pixels each) of every K-step, both operands, both limbs
-  const int prow = lane >> 4;  // pixel inside the group
-  unsigned ch_dy[GPW][SA], ch_x[GPW][SB];
+  // DMA roles: this wave moves pixel groups grp = wave*GPW + d (4 pixels each) of every K-step, both operands: two
+  // instructions h = 0, 1 per group and 128-channel half, each 2 pixels x 512 B (lanes 0-31: one pixel, its 16 first-limb chunks
+  // then its 16 second-limb chunks)
+  const int lam = lane >> 5, limb = (lane >> 4) & 1;
+  unsigned ch_dy[GPW][2][SA], ch_x[GPW][2][SB];
 #pragma unroll
-  for (int d = 0; d < GPW; ++d) {
-    const int row = (wave * GPW + d) * 4 + prow;
-    const int swz = ((row & 3) << 2) | ((row >> 2) & 3);
-    const int ch = (lane & 15) ^ swz;  // data chunk (8 channels) that lands in this lane's LDS slot
+  for (int d = 0; d < GPW; ++d)
 #pragma unroll
-    for (int sI = 0; sI < SA; ++sI) {
-      const int n = n0 + sI * 128 + ch * 8;
-      ch_dy[d][sI] = n < c.Cout ? (unsigned)n * 2u : dy_bytes;  // past the buffer whatever pixel offset is added
+    for (int h = 0; h < 2; ++h) {
+      const int row = (wave * GPW + d) * 4 + 2 * h + lam;  // LDS row this lane fills
+      const int swz = ((row & 3) << 2) | ((row >> 2) & 3);
+      const int ch = (lane & 15) ^ swz;  // data chunk (8 channels) that lands in this lane's LDS slot
+#pragma unroll
+      for (int sI = 0; sI < SA; ++sI) {
+        const int n = n0 + sI * 128 + ch * 8;
+        ch_dy[d][h][sI] = n < c.Cout ? (unsigned)(limb_at(0, n, 0) + limb * LIMB2_OFS) * 2u : dy_bytes;  // past the buffer whatever pixel offset is added
+      }
+#pragma unroll
+      for (int sI = 0; sI < SB; ++sI) {
+        const int cc = c0 + sI * 128 + ch * 8;
+        ch_x[d][h][sI] = cc < c.Cin ? (unsigned)(limb_at(0, cc, 0) + limb * LIMB2_OFS) * 2u : x_bytes;
+      }
     }
-#pragma unroll
-    for (int sI = 0; sI < SB; ++sI) {
-      const int cc = c0 + sI * 128 + ch * 8;
-      ch_x[d][sI] = cc < c.Cin ? (unsigned)cc * 2u : x_bytes;
-    }
-  }
-  // this lane's pixel of each group: (image, output row, output column), advanced incrementally (no division in the loop)
+  // this lane's FIRST pixel of each group (its second one is the next pixel): (image, output row, output column), advanced
+  // incrementally (no division in the loop)
   int p_m[GPW], p_wo[GPW], p_ho[GPW], p_b[GPW];
 #pragma unroll
   for (int d = 0; d < GPW; ++d) {
-    const int m = mbeg + (wave * GPW + d) * 4 + prow;
+    const int m = mbeg + (wave * GPW + d) * 4 + 2 * lam;
     p_m[d] = m;
     p_wo[d] = m % c.Wo;
     const int tq = m / c.Wo;
@@ -1800,28 +1797,28 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_wgrad_l2_kernel(const 
   // barrier, its compute slot 768 of MFMA.  With the split: 2 550.  Tried and slower: reads issued before the DMAs
   // (2 950: the read issue itself blocks for 780 cycles and the DMAs behind it for 1 000), next step's offsets worked
   // out in the compute slot (3 190: branchy VALU code and an LDS lookup break the MFMA stream).
-  unsigned pdy_s[GPW], px_s[GPW];
+  unsigned pdy_s[GPW][2], px_s[GPW][2];
   int stage_s = 0;
-  auto issue_part = [&](int l) {
+  auto issue_part = [&](int h) {  // the h-th instruction of every group: LDS rows 4 grp + 2 h, + 1
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
     for (int d = 0; d < GPW; ++d) {
       const int grp = wave * GPW + d;
 #pragma unroll
       for (int sI = 0; sI < SA; ++sI) {
-        unsigned char* dst = lds + stage_s + l * A_LIMB + sI * SUB + grp * 1024;
-        const unsigned vo = pdy_s[d] + ch_dy[d][sI];  // OOB (2^31) + anything below 2^31 stays out of range, no wrap
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rdy, (__attribute__((address_space(3))) void*)dst, 16, vo, l * dyplane, 0, 0);
+        unsigned char* dst = lds + stage_s + sI * SUB + (grp * 2 + h) * 1024;
+        const unsigned vo = pdy_s[d][h] + ch_dy[d][h][sI];  // OOB (2^31) + anything below 2^31 stays out of range, no wrap
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rdy, (__attribute__((address_space(3))) void*)dst, 16, vo, 0, 0, 0);
       }
 #pragma unroll
       for (int sI = 0; sI < SB; ++sI) {
-        unsigned char* dst = lds + stage_s + A_BYTES + l * B_LIMB + sI * SUB + grp * 1024;
-        const unsigned vo = px_s[d] + ch_x[d][sI];
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)dst, 16, vo, l * xplane, 0, 0);
+        unsigned char* dst = lds + stage_s + A_BYTES + sI * SUB + (grp * 2 + h) * 1024;
+        const unsigned vo = px_s[d][h] + ch_x[d][h][sI];
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)dst, 16, vo, 0, 0, 0);
       }
     }
 #else
-    (void)l;
+    (void)h;
 #endif
   };
   auto issue_addr = [&](int kt, int stage_off) {  // the step's pixel offsets (kept for both parts)
@@ -1839,15 +1836,26 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_wgrad_l2_kernel(const 
           ++p_b[d];
         }
       }
-      const int m = p_m[d];
-      unsigned pdy = OOB, px = OOB;
-      if (m < mend) {
-        pdy = (unsigned)m * (unsigned)a.lddy * 2u;
-        const int hi = p_ho[d] * c.stride + dh, wi = p_wo[d] * c.stride + dw;
-        if ((unsigned)hi < (unsigned)c.Hi && (unsigned)wi < (unsigned)c.Wi) px = (unsigned)(((p_b[d] * c.Hi + hi) * c.Wi + wi) * c.ldx) * 2u;
+      int m = p_m[d], wo = p_wo[d], ho = p_ho[d], b = p_b[d];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {  // this lane's two pixels: m and m + 1
+        unsigned pdy = OOB, px = OOB;
+        if (m < mend) {
+          pdy = (unsigned)m * (unsigned)a.lddy * 4u;  // a limb row: 4 bytes per channel
+          const int hi = ho * c.stride + dh, wi = wo * c.stride + dw;
+          if ((unsigned)hi < (unsigned)c.Hi && (unsigned)wi < (unsigned)c.Wi) px = (unsigned)(((b * c.Hi + hi) * c.Wi + wi) * c.ldx) * 4u;
+        }
+        pdy_s[d][h] = pdy;
+        px_s[d][h] = px;
+        ++m;
+        if (++wo == c.Wo) {
+          wo = 0;
+          if (++ho == c.Ho) {
+            ho = 0;
+            ++b;
+          }
+        }
       }
-      pdy_s[d] = pdy;
-      px_s[d] = px;
     }
   };
   auto issue = [&](int kt, int stage_off) {
@@ -1868,8 +1876,8 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_wgrad_l2_kernel(const 
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int cha = (wm & 1) * 8 + 2 * i + (pp >> 1), chb = (wn & 1) * 8 + 2 * i + (pp >> 1);
-        fa[i][h] = (unsigned)((wm >> 1) * SUB + 256 * row + 16 * (cha ^ swz) + 8 * (pp & 1));
-        fb[i][h] = (unsigned)(A_BYTES + (wn >> 1) * SUB + 256 * row + 16 * (chb ^ swz) + 8 * (pp & 1));
+        fa[i][h] = (unsigned)((wm >> 1) * SUB + 512 * row + 16 * (cha ^ swz) + 8 * (pp & 1));  // (+ 256: the second limbs)
+        fb[i][h] = (unsigned)(A_BYTES + (wn >> 1) * SUB + 512 * row + 16 * (chb ^ swz) + 8 * (pp & 1));
       }
     }
   }
@@ -1933,9 +1941,9 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_wgrad_l2_kernel(const 
 #pragma unroll
     for (int l = 0; l < 2; ++l)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) af[i][l] = tr_read8(base + l * A_LIMB + fa[i][0], base + l * A_LIMB + fa[i][1]);
+      for (int i = 0; i < 4; ++i) af[i][l] = tr_read8(base + l * 256 + fa[i][0], base + l * 256 + fa[i][1]);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) bf[j] = tr_read8(base + B_LIMB + fb[j][0], base + B_LIMB + fb[j][1]);
+    for (int j = 0; j < 4; ++j) bf[j] = tr_read8(base + 256 + fb[j][0], base + 256 + fb[j][1]);
     if constexpr (STAGGER) {  // staggered halves: the compute slot reads nothing from LDS (see conv_l2_kernel)
 #pragma unroll
       for (int j = 0; j < 4; ++j) b1[j] = tr_read8(base + fb[j][0], base + fb[j][1]);
@@ -2076,7 +2084,7 @@ int onda_conv_l2_variant(int64_t M, int Cout) {
 int onda_conv_l2_kernel_id(int64_t M, int Cout, int taps, int Cin) {
   const int variant = onda_conv_l2_variant(M, Cout);
   static const int xt = getenv("ONDA_L2_XT") ? atoi(getenv("ONDA_L2_XT")) : 1;
-  static const int l2p = getenv("ONDA_L2P") ? atoi(getenv("ONDA_L2P")) : 1;  // 0: off, 1: on, 2: on without the fragment pre-fetch
+  static const int l2p = getenv("ONDA_L2P") ? atoi(getenv("ONDA_L2P")) : 0;  // 0: off (default: measured slower), 1: on, 2: on without the fragment pre-fetch
   const int KT = taps * (Cin / 32);
   const bool short_k = KT <= 32 || xt == 2;
   // 4 = conv_l2p_kernel: the producer / consumer form (128 x 128 tiles, the epilogue under the next tile's K loop) takes the
@@ -2215,14 +2223,15 @@ static int l2_fwd_impl(const void* xl, int64_t xplane, const float* xamax, const
                        float* yamax, const OndaConv* c, onda_stream_t s, const OndaLimbOut* lo) {
   ONDA_REQUIRE(xl && xamax && w2 && wamax && (y || lo) && c && ws && (stats_rows == 2 || stats_rows == 4));
   if (lo != nullptr) {  // limb-plane output: dense [M][ldy] planes, no statistics, residual (if any) as limb planes
-    ONDA_REQUIRE(lo->out && lo->out_bound && lo->kb && lo->xtrue && lo->out_plane > 0 && lo->out_plane % 8 == 0 && !stats && !residual);
-    ONDA_REQUIRE(c->out_os == 1 && c->Hf == c->Ho && c->Wf == c->Wo && c->ldy % 4 == 0 && c->ldy >= c->Cout);
-    ONDA_REQUIRE(!lo->res || (lo->res_amax && lo->res_plane > 0 && lo->res_plane % 8 == 0 && c->ldr % 4 == 0 && c->ldr >= c->Cout));
-    ONDA_REQUIRE((long long)c->B * c->Ho * c->Wo * c->ldy * 2 < 0x7FFFF000ll);
+    ONDA_REQUIRE(lo->out && lo->out_bound && lo->kb && lo->xtrue && !stats && !residual);
+    ONDA_REQUIRE(c->out_os == 1 && c->Hf == c->Ho && c->Wf == c->Wo && c->ldy % 32 == 0 && c->ldy >= c->Cout);
+    ONDA_REQUIRE(!lo->res || (lo->res_amax && c->ldr % 32 == 0 && c->ldr >= c->Cout));
+    ONDA_REQUIRE((long long)c->B * c->Ho * c->Wo * c->ldy * 4 < 0x7FFFF000ll);
     if (!ONDA_ALIGNED16(lo->out) || (lo->res && !ONDA_ALIGNED16(lo->res))) return ONDA_EALIGN;
   }
-  ONDA_REQUIRE(c->Cin > 0 && c->Cin % 32 == 0 && c->Cout > 0 && c->Cout % 4 == 0 && c->ldx % 8 == 0 && c->ldx >= c->Cin);
-  ONDA_REQUIRE(c->kh >= 1 && c->kw >= 1 && c->stride >= 1 && c->dil >= 1 && c->out_os >= 1 && xplane > 0 && xplane % 8 == 0);
+  ONDA_REQUIRE(c->Cin > 0 && c->Cin % 32 == 0 && c->Cout > 0 && c->Cout % 4 == 0 && c->ldx % 32 == 0 && c->ldx >= c->Cin);
+  ONDA_REQUIRE(c->kh >= 1 && c->kw >= 1 && c->stride >= 1 && c->dil >= 1 && c->out_os >= 1);
+  (void)xplane;  // (limb rows: the two limbs of a 32-channel block are 64 bytes apart inside the row; kept in the signature)
   if (!ONDA_ALIGNED16(xl) || !ONDA_ALIGNED16(w2)) return ONDA_EALIGN;
   // the epilogue stores (and reads the residual in) 16-byte vectors
   if (c->ldy % 4 != 0 || (y && !ONDA_ALIGNED16(y)) || (residual && (c->ldr % 4 != 0 || !ONDA_ALIGNED16(residual)))) return ONDA_EALIGN;
@@ -2254,7 +2263,7 @@ static int l2_fwd_impl(const void* xl, int64_t xplane, const float* xamax, const
   k.c = *c;
   const long long M = (long long)c->B * c->Ho * c->Wo;
   ONDA_REQUIRE(M > 0 && M < (1ll << 31));
-  const long long x_total = xplane * 2 + ((long long)c->B * c->Hi * c->Wi - 1) * c->ldx * 2 + c->Cin * 2;  // last byte of plane 1
+  const long long x_total = (long long)c->B * c->Hi * c->Wi * c->ldx * 4;  // limb rows: 4 bytes per element
   ONDA_REQUIRE(x_total < 0x7FFFF000ll);  // 32-bit byte offsets
   k.M = (int)M;
   k.taps = c->kh * c->kw;
@@ -2266,7 +2275,7 @@ static int l2_fwd_impl(const void* xl, int64_t xplane, const float* xamax, const
   const size_t limb_elems = (size_t)c->Cout * k.taps * c->Cin;  // weight planes are [Cout][taps*Cin]
   ONDA_REQUIRE(limb_elems * 4 < (1ull << 31));
   const unsigned x_bytes = (unsigned)x_total, w_bytes = (unsigned)(limb_elems * 4);
-  const unsigned xpl = (unsigned)(xplane * 2), wpl = (unsigned)(limb_elems * 2);
+  const unsigned xpl = 0, wpl = 0;  // (unused by the kernels since the limbs share a row)
   const int tiles = k.tilesM * k.tilesN;
   k.tiles_dp = tiles - q.rem;
   hipStream_t st = ONDA_STREAM(s);
@@ -2371,13 +2380,15 @@ int onda_conv_wgrad_l2_variant(int Cout, int Cin) {
 
 int onda_conv2d_wgrad_l2(const void* xl, int64_t xplane, const float* xamax, const void* dyl, int64_t dyplane, const float* dyamax,
                          float* slabs, int lddy, int splitk, const OndaConv* c, onda_stream_t s) {
-  ONDA_REQUIRE(xl && dyl && xamax && dyamax && slabs && c && splitk >= 1 && xplane > 0 && dyplane > 0);
-  ONDA_REQUIRE(c->Cin % 8 == 0 && c->Cout % 8 == 0 && c->ldx % 8 == 0 && lddy % 8 == 0 && xplane % 8 == 0 && dyplane % 8 == 0);
+  ONDA_REQUIRE(xl && dyl && xamax && dyamax && slabs && c && splitk >= 1);
+  ONDA_REQUIRE(c->Cin % 8 == 0 && c->Cout % 8 == 0 && c->ldx % 32 == 0 && lddy % 32 == 0);
+  (void)xplane;
+  (void)dyplane;  // (limb rows: kept in the signature)
   if (!ONDA_ALIGNED16(xl) || !ONDA_ALIGNED16(dyl) || !ONDA_ALIGNED16(slabs)) return ONDA_EALIGN;
   const long long M = (long long)c->B * c->Ho * c->Wo;
   ONDA_REQUIRE(M > 0 && M < (1ll << 31));
-  const long long x_total = xplane * 2 + ((long long)c->B * c->Hi * c->Wi - 1) * c->ldx * 2 + c->Cin * 2;
-  const long long dy_total = dyplane * 2 + (M - 1) * lddy * 2 + c->Cout * 2;
+  const long long x_total = (long long)c->B * c->Hi * c->Wi * c->ldx * 4;
+  const long long dy_total = M * lddy * 4;
   ONDA_REQUIRE(x_total < 0x7FFF0000ll && dy_total < 0x7FFF0000ll);
   WgradK k;
   k.x = static_cast<const float*>(xl); k.dy = static_cast<const float*>(dyl); k.slabs = slabs; k.c = *c;
@@ -2393,7 +2404,7 @@ int onda_conv2d_wgrad_l2(const void* xl, int64_t xplane, const float* xamax, con
   k.tilesN = (c->Cout + TN - 1) / TN;
   k.tilesC = (c->Cin + 127) / 128;
   const unsigned grid = (unsigned)(k.tilesN * k.tilesC * k.taps * splitk);
-  const unsigned xpl = (unsigned)(xplane * 2), dypl = (unsigned)(dyplane * 2);
+  const unsigned xpl = 0, dypl = 0;
   if (variant == 0)
     hipLaunchKernelGGL((conv_wgrad_l2_kernel<4, 2, 3, 2>), dim3(grid), dim3(512), 0, ONDA_STREAM(s), k, xpl, dypl, (unsigned)x_total,
                        (unsigned)dy_total, xamax, dyamax);

@@ -1,5 +1,6 @@
 // BatchNorm around the pre-split convolutions (conv_l2.hip): the kernels that PRODUCE a conv operand write it
-// as limb planes (out[2][M][C] f16, 4 bytes per element like fp32) instead of fp32 + a later split pass.
+// as limb rows (out[M][C / 32][2][32] f16: common.h limb_at; 4 bytes per element like fp32) instead of fp32 + a later
+// split pass.  ("limb planes" below: the same two limbs, which lay in two planes until round 4.)
 //
 // A limb plane needs its tensor's power-of-two scale BEFORE the first element is written, i.e. an upper bound
 // of max|out| from quantities that exist before the apply pass:
@@ -264,6 +265,9 @@ __global__ __launch_bounds__(256) void bn_apply_l2_kernel(const float* __restric
   const f32x4 tc0 = LD4(invstd + g1 + col) * ga0, tc1 = LD4(invstd + g1 + col + 4) * ga1;
   const f32x4 nu0 = LD4(mean + g1 + col), nu1 = LD4(mean + g1 + col + 4);
   const size_t stride = (size_t)gridDim.x * blockDim.x;
+  // item e = 8 channels `col` of row e / c8; in limb rows: first limbs at limb_at(row, col, C), second limbs 32 f16 further
+  const size_t lcol = limb_at(0, col, C);
+  auto lofs = [&](size_t e) { return (size_t)((unsigned)e / (unsigned)c8) * 2 * (size_t)C + lcol; };  // (items < 2^32: 32-bit division)
   auto one = [&](size_t e, f32x4 x0, f32x4 x1, u32x4 r1, u32x4 r2) {
     const bool second = group1_at > 0 && e >= group1_at;
     f32x4 v0 = (x0 - (second ? nu0 : mu0)) * (second ? tc0 : sc0) + be0, v1 = (x1 - (second ? nu1 : mu1)) * (second ? tc1 : sc1) + be1;
@@ -288,8 +292,9 @@ __global__ __launch_bounds__(256) void bn_apply_l2_kernel(const float* __restric
     }
     u32x4 l1, l2;
     split8(v0 * so, v1 * so, l1, l2);
-    st_stream(reinterpret_cast<u32x4*>(out + e * 8), l1);
-    st_stream(reinterpret_cast<u32x4*>(out + out_plane + e * 8), l2);
+    _Float16* o = out + lofs(e);
+    st_stream(reinterpret_cast<u32x4*>(o), l1);
+    st_stream(reinterpret_cast<u32x4*>(o + LIMB2_OFS), l2);
   };
   size_t e = e0;
   // two independent items per iteration: all loads of both are issued before the first is used
@@ -298,10 +303,10 @@ __global__ __launch_bounds__(256) void bn_apply_l2_kernel(const float* __restric
     const f32x4 a0 = LD4S(x + e * 8), a1 = LD4S(x + e * 8 + 4), b0 = LD4S(x + f * 8), b1 = LD4S(x + f * 8 + 4);
     u32x4 ra1 = {}, ra2 = {}, rb1 = {}, rb2 = {};
     if (res) {
-      ra1 = ld_stream(reinterpret_cast<const u32x4*>(res + e * 8));
-      ra2 = ld_stream(reinterpret_cast<const u32x4*>(res + res_plane + e * 8));
-      rb1 = ld_stream(reinterpret_cast<const u32x4*>(res + f * 8));
-      rb2 = ld_stream(reinterpret_cast<const u32x4*>(res + res_plane + f * 8));
+      ra1 = ld_stream(reinterpret_cast<const u32x4*>(res + lofs(e)));
+      ra2 = ld_stream(reinterpret_cast<const u32x4*>(res + lofs(e) + LIMB2_OFS));
+      rb1 = ld_stream(reinterpret_cast<const u32x4*>(res + lofs(f)));
+      rb2 = ld_stream(reinterpret_cast<const u32x4*>(res + lofs(f) + LIMB2_OFS));
     }
     one(e, a0, a1, ra1, ra2);
     one(f, b0, b1, rb1, rb2);
@@ -309,8 +314,8 @@ __global__ __launch_bounds__(256) void bn_apply_l2_kernel(const float* __restric
   if (e < total8) {
     u32x4 r1 = {}, r2 = {};
     if (res) {
-      r1 = *reinterpret_cast<const u32x4*>(res + e * 8);
-      r2 = *reinterpret_cast<const u32x4*>(res + res_plane + e * 8);
+      r1 = *reinterpret_cast<const u32x4*>(res + lofs(e));
+      r2 = *reinterpret_cast<const u32x4*>(res + lofs(e) + LIMB2_OFS);
     }
     one(e, LD4(x + e * 8), LD4(x + e * 8 + 4), r1, r2);
   }
@@ -343,14 +348,16 @@ static inline ColPlan3 col_plan3(int64_t M, int C) {
 // g * [out > 0] from the FIRST limb of out (2 bytes per element).  The first limb of a positive element is zero only below
 // 2^-40 of the tensor maximum (f16 subnormals reach 2^-24, the scale puts the maximum at 2^15): there the gradient is
 // dropped, at the kink of the ReLU.
-__device__ __forceinline__ f32x4 relu_mask4(const _Float16* __restrict__ out, const unsigned char* __restrict__ mask, size_t o, f32x4 g) {
+__device__ __forceinline__ f32x4 relu_mask4(const _Float16* __restrict__ out, const unsigned char* __restrict__ mask, size_t o, f32x4 g,
+                                            int C) {
   if (mask != nullptr) {  // the bit mask of the apply pass: 1/8 byte per element instead of the 2 bytes of the first limb
     const unsigned bits = (unsigned)mask[o >> 3] >> ((o & 4) ? 4 : 0);
 #pragma unroll
     for (int j = 0; j < 4; ++j) g[j] = (bits >> j) & 1u ? g[j] : 0.f;
     return g;
   }
-  const u32x2 h1 = *reinterpret_cast<const u32x2*>(out + o);
+  const unsigned orow = (unsigned)(o / (unsigned)C);  // (o = row * C + channel)
+  const u32x2 h1 = *reinterpret_cast<const u32x2*>(out + limb_at(orow, (int)(o - (size_t)orow * C), C));
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const f32x2 a = unpack2h(h1[j]);
@@ -384,7 +391,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_l2_kernel(const float* __re
     for (int64_t r = r0 + ty; r < r1; r += ry_n) {
       const size_t o = (size_t)r * C + col;
       f32x4 g = LD4(dout + o);
-      if (relu) g = relu_mask4(out, mask, o, g);
+      if (relu) g = relu_mask4(out, mask, o, g, C);
       if (dres) *reinterpret_cast<f32x4*>(dres + o) = g;
       const f32x4 xh = (LD4(x + o) - mu) * is;
       s1 += g;
@@ -474,14 +481,15 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_l2_kernel(const float* __res
     for (int h = 0; h < 2; ++h) {
       const size_t o = e * 8 + 4 * h;
       f32x4 g = LD4S(dout + o);
-      if (relu) g = relu_mask4(out, mask, o, g);
+      if (relu) g = relu_mask4(out, mask, o, g, C);
       const f32x4 xh = (LD4S(x + o) - (second ? mu[1][h] : mu[0][h])) * (second ? is[1][h] : is[0][h]);
       v[h] = (second ? gi[1][h] : gi[0][h]) * (g - (second ? m1[1][h] : m1[0][h]) - xh * (second ? m2[1][h] : m2[0][h]));
     }
     u32x4 l1, l2;
     split8(v[0] * sd, v[1] * sd, l1, l2);
-    st_stream(reinterpret_cast<u32x4*>(dx + e * 8), l1);
-    st_stream(reinterpret_cast<u32x4*>(dx + dx_plane + e * 8), l2);
+    _Float16* o = dx + (size_t)((unsigned)e / (unsigned)c8) * 2 * (size_t)C + limb_at(0, col, C);
+    st_stream(reinterpret_cast<u32x4*>(o), l1);
+    st_stream(reinterpret_cast<u32x4*>(o + LIMB2_OFS), l2);
   }
 }
 
@@ -499,8 +507,9 @@ __global__ __launch_bounds__(256) void chan_scale_limbs_kernel(const float* __re
     const f32x4 v0 = LD4S(x + e * 8) * LD4(gate + b * C + col), v1 = LD4S(x + e * 8 + 4) * LD4(gate + b * C + col + 4);
     u32x4 l1, l2;
     split8(v0 * so, v1 * so, l1, l2);
-    st_stream(reinterpret_cast<u32x4*>(out + e * 8), l1);
-    st_stream(reinterpret_cast<u32x4*>(out + plane + e * 8), l2);
+    _Float16* o = out + (size_t)((unsigned)e / (unsigned)c8) * 2 * (size_t)C + limb_at(0, col, C);
+    st_stream(reinterpret_cast<u32x4*>(o), l1);
+    st_stream(reinterpret_cast<u32x4*>(o + LIMB2_OFS), l2);
   }
 }
 
@@ -533,7 +542,8 @@ int onda_bn_finalize_l2(const float* partials, int tiles, int C, int64_t count, 
 
 int onda_chan_scale_limbs(const float* x, const float* gate, void* out, int64_t out_plane, const float* x_amax, int B, int64_t HW,
                           int C, onda_stream_t s) {
-  ONDA_REQUIRE(x && gate && out && x_amax && C % 8 == 0 && out_plane % 8 == 0 && B > 0 && HW > 0);
+  ONDA_REQUIRE(x && gate && out && x_amax && C % 32 == 0 && B > 0 && HW > 0);
+  (void)out_plane;
   if (!ONDA_ALIGNED16(x) || !ONDA_ALIGNED16(out) || !ONDA_ALIGNED16(gate)) return ONDA_EALIGN;
   const size_t total8 = (size_t)B * HW * C / 8;
   hipLaunchKernelGGL(chan_scale_limbs_kernel, dim3(ew_grid(total8)), dim3(256), 0, ONDA_STREAM(s), x, gate,
@@ -544,7 +554,7 @@ int onda_chan_scale_limbs(const float* x, const float* gate, void* out, int64_t 
 int onda_bn_apply_l2(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
                      const void* res, int64_t res_plane, const float* res_amax, void* out, int64_t out_plane,
                      const float* out_amax, int64_t M, int C, int relu, uint8_t* relu_mask, int64_t split, onda_stream_t s) {
-  ONDA_REQUIRE(x && mean && invstd && gamma && beta && out && out_amax && C % 8 == 0 && out_plane % 8 == 0 && (!res || res_amax));
+  ONDA_REQUIRE(x && mean && invstd && gamma && beta && out && out_amax && C % 32 == 0 && (!res || res_amax));
   ONDA_REQUIRE(256 % (C / 8) == 0 || (C / 8) % 256 == 0);  // a thread keeps its channel group across the grid stride
   ONDA_REQUIRE(split >= 0 && split < M);
   if (!ONDA_ALIGNED16(x) || !ONDA_ALIGNED16(out) || (res && !ONDA_ALIGNED16(res))) return ONDA_EALIGN;
@@ -573,7 +583,7 @@ int64_t onda_bn_bwd_l2_ws(int64_t M, int C) {
 int onda_bn_bwd_l2(const float* dout, const void* out, int64_t out_plane, const float* x, const float* mean, const float* invstd,
                    const float* gamma, const float* xhat_amax, void* dx, int64_t dx_plane, float* dx_amax, float* dres, float* ws,
                    int64_t M, int C, int relu, const uint8_t* relu_mask, int64_t split, onda_stream_t s) {
-  ONDA_REQUIRE(dout && x && mean && invstd && gamma && xhat_amax && dx && dx_amax && ws && C % 8 == 0 && (!relu || out || relu_mask));
+  ONDA_REQUIRE(dout && x && mean && invstd && gamma && xhat_amax && dx && dx_amax && ws && C % 32 == 0 && (!relu || out || relu_mask));
   ONDA_REQUIRE(256 % (C / 8) == 0 || (C / 8) % 256 == 0);
   ONDA_REQUIRE(split >= 0 && split < M);
   if (!ONDA_ALIGNED16(dout) || !ONDA_ALIGNED16(x) || !ONDA_ALIGNED16(dx) || (out && !ONDA_ALIGNED16(out))) return ONDA_EALIGN;

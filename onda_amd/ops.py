@@ -27,18 +27,17 @@ STEM_K = 160   # 7*7*3 = 147 patch values padded to a multiple of 32
 # How the convolutions (forward, data gradient, weight gradient) are evaluated:
 #   "f16x2" : fp32 operands scaled by a per-tensor power of two and split into two f16 limbs, three
 #             products on the f16 MFMA pipe with fp32 accumulation (the accuracy of an fp32 FMA chain at
-#             16/3 of the fp32-MFMA rate; csrc/conv_l2.hip, conv_h2.hip) -- the default;
+#             16/3 of the fp32-MFMA rate; csrc/conv_l2.hip; the arithmetic is described in conv_h2.hip) -- the default;
 #   "f32"   : v_mfma_f32_32x32x2_f32 (an exact fp32 fmaf chain; csrc/conv.hip) -- the strict-fp32 leg of bench.py and the
 #             yardstick of test_f16x2_steps_track_the_exact_f32_steps; also what a conv whose weight the f16x2 packers do not
 #             take (element count not a multiple of 4) runs on.
 # (The round-1 "bf16x3" mode -- three bf16 limbs, six products -- was retired in round 4: slower than f16x2, never re-tuned.)
 CONV_MODE = os.environ.get("ONDA_CONV_MODE", "f16x2")
 
-# "f16x2" only -- where the activation operand of forward / data gradient is split into its two limbs:
-#   "dma": beforehand, as limb planes in HBM (by the producing kernel or one split pass); the conv kernel moves both
-#          operands to LDS by LDS-DMA only (csrc/conv_l2.hip) -- the default;
-#   "reg": inside the conv kernel, in registers between two barriers (csrc/conv_h2.hip).
-H2_PATH = os.environ.get("ONDA_H2_PATH", "dma")
+# "f16x2": both operands are split into their two limbs BEFOREHAND, as limb rows in HBM (by the producing kernel or one split
+# pass); the conv kernels move them to LDS by LDS-DMA only (csrc/conv_l2.hip).  (The round-1 kernels that split the
+# activations inside the conv kernel -- ONDA_H2_PATH=reg -- were removed in round 5; the name stays for tools and tests.)
+H2_PATH = "dma"
 
 # the multi-GPU gradient exchange installs a callable here: called with the weight Parameter as soon as its gradient of the
 # current backward pass has been accumulated in place (autograd's post-accumulate hook fires for it as well, later: the
@@ -363,7 +362,7 @@ def limbs_of(x):
 
 def limb_mode(channels):
     """Do the BatchNorm kernels write their output as limb planes only (no fp32 copy)?"""
-    return CONV_MODE == "f16x2" and H2_PATH == "dma" and channels % 8 == 0 and LIMB_ONLY
+    return CONV_MODE == "f16x2" and channels % 32 == 0 and LIMB_ONLY
 
 
 LIMB_ONLY = os.environ.get("ONDA_LIMB_ONLY", "1") != "0"
@@ -375,7 +374,8 @@ def materialize(x):
         return x
     lb = limbs_of(x)
     B, H, W, C = x.shape
-    planes = lb.planes.reshape(2, B * H * W, lb.ld)[:, :, :C].float()
+    # limb rows [rows][ld / 32][2][32] -> the two limbs as [rows][ld]
+    planes = lb.planes.reshape(B * H * W, lb.ld // 32, 2, 32).permute(2, 0, 1, 3).reshape(2, B * H * W, lb.ld)[:, :, :C].float()
     amax = lb.amax.max()
     e = torch.where((amax > 0) & (amax < 3e38), 15 - torch.frexp(amax)[1], torch.zeros((), dtype=torch.int32, device=x.device))
     return ((planes[0] + planes[1] / query("onda_limb2_scale")) * torch.ldexp(torch.ones((), device=x.device), -e)).reshape(B, H, W, C)
@@ -403,8 +403,10 @@ def pack_weight_fwd(weight, cout_pad=None, kp=None):
     cout, cin, kh, kw = weight.shape
     taps = kh * kw
     cout_pad = cout_pad or cout
+    flat = kp is not None  # a flat, zero-padded K (the stem's patch matrix): consumed as a 1 x 1 conv over kp "channels"
     kp = kp or taps * cin
-    if CONV_MODE == "f16x2" and weight.numel() % 4 == 0:
+    # the pre-split kernels walk K in steps of 32 channels of one tap
+    if CONV_MODE == "f16x2" and (kp % 32 == 0 if flat else cin % 32 == 0):
         return _pack_h2(weight, cout_pad, kp, 0, cout_pad)
     dst = torch.empty(cout_pad, kp, device=weight.device, dtype=torch.float32)
     call("onda_pack_weight_fwd", _p(weight.detach().contiguous()), _p(dst), cout, cin, taps, cout_pad, kp, _stream())
@@ -415,7 +417,7 @@ def pack_weight_dgrad(weight, cout_pad=None):
     """OIHW -> [Cin][taps (flipped)][Cout_pad]: the data gradient of a stride-1 conv is a conv of dy with this."""
     cout, cin, kh, kw = weight.shape
     cout_pad = cout_pad or cout
-    if CONV_MODE == "f16x2" and weight.numel() % 4 == 0:
+    if CONV_MODE == "f16x2" and cout_pad % 32 == 0:  # (the data gradient's K runs over the output channels)
         return _pack_h2(weight, cin, kh * kw * cout_pad, 1, cout_pad)
     dst = torch.empty(cin, kh * kw, cout_pad, device=weight.device, dtype=torch.float32)
     call("onda_pack_weight_dgrad", _p(weight.detach().contiguous()), _p(dst), cout, cin, kh * kw, cout_pad, _stream())
@@ -519,9 +521,12 @@ def conv_forward(x, wp, k, stride, dil, pad, cout, out=None, scale=None, shift=N
         split = _group_split(B, Ho, Wo)
         if split and not l2:
             raise RuntimeError("onda_amd: row groups (ops.row_groups) need the pre-split conv path")
-        tiles = (query("onda_conv_l2_tiles_m_split", B * Ho * Wo, cout, k * k, Cin, split, int(PLAIN_SCHEDULE), None) if l2
+        tile_rows = ctypes.c_int(0)
+        tiles = (query("onda_conv_l2_tiles_m_split", B * Ho * Wo, cout, k * k, Cin, split, int(PLAIN_SCHEDULE), byref(tile_rows)) if l2
                  else query("onda_conv_tiles_m", B * Ho * Wo))
         stats = torch.empty(tiles, stats_rows, cout, device=x.device, dtype=torch.float32)
+        if l2:  # GEMM rows one partial row covers: depends on the kernel the problem runs on (the BatchNorm row groups need it)
+            stats._onda_tile_rows = tile_rows.value
     d = _desc(B, Hi, Wi, Cin, Ho, Wo, cout, k, stride, dil, pad, ldx, ldy, ldr, relu=relu, split=split)
     if l2:
         xl = limbs_of(x)
@@ -536,15 +541,7 @@ def conv_forward(x, wp, k, stride, dil, pad, cout, out=None, scale=None, shift=N
             tag_amax(out, yamax)
         return out, stats, tiles
     if isinstance(wp, H2Weight):
-        # a folded-BN (+ReLU) output is the next conv's input: let the epilogue leave its max|y| behind
-        yamax = amax_slot(x.device) if (scale is not None or relu) else None
-        _launch("conv_fwd_h2_kernel<128,%d>" % (128 if cout > 64 else 64), 2.0 * B * Ho * Wo * cout * k * k * Cin,
-                "onda_conv2d_fwd_h2", _p(x), _p(activation_scale(x)), _p(wp.limbs), _p(wp.amax), _p(out), _p(scale), _p(shift),
-                _p(residual), _p(stats), _p(_conv_ws(x.device)), _p(yamax), byref(d), _stream(),
-                tag=("fwd", B * Ho * Wo, cout, Cin, k, stride, dil))
-        if yamax is not None:
-            tag_amax(out, yamax)
-        return out, stats, tiles
+        raise RuntimeError("onda_amd: a pre-split weight reached a conv the pre-split kernels do not take (Cin % 32 != 0)")
     _launch("conv_fwd_kernel<128,%d>" % (128 if cout > 64 else 64), 2.0 * B * Ho * Wo * cout * k * k * Cin, "onda_conv2d_fwd",
             _p(x), _p(wp), _p(out), _p(scale), _p(shift), _p(residual), _p(stats), _p(_conv_ws(x.device)), byref(d), _stream(),
             tag=("fwd", B * Ho * Wo, cout, Cin, k, stride, dil))
@@ -593,11 +590,7 @@ def conv_dgrad(dy, wpd, k, stride, dil, pad, cin, in_hw, accumulate=None):
     if is_limb_only(dy):
         raise RuntimeError("onda_amd: a limb-only gradient reached a data-gradient kernel that does not take limb planes")
     if isinstance(wpd, H2Weight):
-        _launch("conv_fwd_h2_kernel<128,%d>" % (128 if cin > 64 else 64), 2.0 * B * Ho * Wo * cin * k * k * Co,
-                "onda_conv2d_fwd_h2", _p(dy), _p(activation_scale(dy)), _p(wpd.limbs), _p(wpd.amax), _p(dx), None, None, None,
-                None, _p(_conv_ws(dy.device)), None, byref(d), _stream(),
-                tag=("dgrad", B * Ho * Wo if stride != 1 else B * Hi * Wi, cin, Co, k, stride, dil))
-        return dx
+        raise RuntimeError("onda_amd: a pre-split weight reached a data gradient the pre-split kernels do not take (Cout % 32 != 0)")
     _launch("conv_fwd_kernel<128,%d>" % (128 if cin > 64 else 64), 2.0 * B * Ho * Wo * cin * k * k * Co, "onda_conv2d_fwd",
             _p(dy), _p(wpd), _p(dx), None, None, None, None, _p(_conv_ws(dy.device)), byref(d), _stream(),
             tag=("dgrad", B * Ho * Wo if stride != 1 else B * Hi * Wi, cin, Co, k, stride, dil))
@@ -642,7 +635,7 @@ def conv_wgrad(x, dy, k, stride, dil, pad, cout_real, cin_real, flat_k=0, into=N
     _, Ho, Wo, Co = dy.shape
     taps = k * k
     M = B * Ho * Wo
-    l2 = CONV_MODE == "f16x2" and H2_PATH == "dma" and Cin % 8 == 0 and Co % 8 == 0
+    l2 = CONV_MODE == "f16x2" and Cin % 32 == 0 and Co % 32 == 0
     sk = _wgrad_splitk(M, Co, Cin, taps, l2)
     slabs = torch.empty(sk, Co, taps, Cin, device=x.device, dtype=torch.float32)
     d = _desc(B, Hi, Wi, Cin, Ho, Wo, Co, k, stride, dil, pad, 0 if is_limb_only(x) else nhwc_ld(x), Co)
@@ -656,11 +649,6 @@ def conv_wgrad(x, dy, k, stride, dil, pad, cout_real, cin_real, flat_k=0, into=N
                 "onda_conv2d_wgrad_l2", _p(xl.planes), xl.plane, _p(xl.amax), _p(dyl.planes), dyl.plane, _p(dyl.amax), _p(slabs),
                 dyl.ld, sk, byref(d), _stream(), tag=("wgrad", M, Co, Cin, k, stride, dil, sk),
                 issued=lambda: query("onda_conv_wgrad_l2_live_fraction", byref(d), sk))
-    elif CONV_MODE == "f16x2" and Cin % 4 == 0 and Co % 4 == 0:
-        xs = xscale if xscale is not None else activation_scale(x)
-        _launch("conv_wgrad_h2_kernel<%s>" % ("128,128" if (Co > 64 and Cin > 64) else "64,64"), 2.0 * M * Co * taps * Cin,
-                "onda_conv2d_wgrad_h2", _p(x), _p(xs), _p(dy), _p(activation_scale(dy)), _p(slabs), nhwc_ld(dy), sk, byref(d),
-                _stream(), tag=("wgrad", M, Co, Cin, k, stride, dil, sk))
     else:
         _wgrad_other(x, dy, slabs, sk, d, M, Co, taps, Cin, k, stride, dil)
     return _wgrad_finish(slabs, into, sk, Co, taps, Cin, cout_real, cin_real, flat_k, k, x.device)
@@ -739,7 +727,7 @@ class ModelPacker:
     fresh zeroed max|w| slots.  Convolutions with padded layouts (stem, class head) keep their own _PackCache path."""
 
     def __init__(self, convs):
-        self.convs = [c for c in convs if c.weight.numel() % 4 == 0]
+        self.convs = [c for c in convs if c.weight.shape[0] % 32 == 0 and c.weight.shape[1] % 32 == 0]
         self.bufs = {}
 
     def refresh(self, need_dgrad):
@@ -959,7 +947,7 @@ class BNTrainFn(torch.autograd.Function):
             if G > 1:
                 # the conv's partial rows cover 256 (128) GEMM rows each: a group takes its own rows when the boundary falls
                 # between two of them (every power-of-two image size), one reduction pass over its rows of y otherwise
-                bm = 128 if query("onda_conv_l2_variant", B * H * W, C) == 1 else 256
+                bm = getattr(stats, "_onda_tile_rows", None) or (128 if query("onda_conv_l2_variant", B * H * W, C) == 1 else 256)
                 if groups[1][0] % bm == 0 and stats.shape[1] == 2:
                     ts = groups[1][0] // bm
                     part = stats[:ts] if g == 0 else stats[ts:]
@@ -1038,7 +1026,7 @@ class BNTrainLimbFn(torch.autograd.Function):
         if res is not None and (res.ld != C or tuple(residual.shape) != (B, H, W, C)):
             raise RuntimeError("onda_amd: residual of a BatchNorm must be a dense [B,H,W,C] activation")
         out_amax = amax_slot(dev)
-        tile_rows = (128 if query("onda_conv_l2_variant", M, C) == 1 else 256) if split else 0
+        tile_rows = (getattr(stats, "_onda_tile_rows", None) or (128 if query("onda_conv_l2_variant", M, C) == 1 else 256)) if split else 0
         call("onda_bn_finalize_l2", _p(stats), stats.shape[0], C, M, BN_EPS, _p(mean), _p(invstd), _p(rm), _p(rv), _p(nbt),
              float(momentum), _p(gamma), _p(beta), _p(res.amax) if res is not None else None, int(relu), _p(xhat_amax),
              _p(out_amax), split, tile_rows, 1, _p(y) if split else None, nhwc_ld(y) if split else 0, _stream())
