@@ -32,6 +32,8 @@ struct ConvK {
   unsigned long long* stamps = nullptr;  // diagnostics (ONDA_L2X_STAMP=1, tools/l2x_stamps.py): s_memtime per workgroup,
                                          // [32] each: start, then (end of K loop, end of epilogue) per work item
   int stats_rows = 2;     // 2: stats[tile][sum, sumsq][Cout]; 4: also the per-channel min and max of the raw tile (conv_l2.hip)
+  long long x_total = 0;  // conv_l2.hip: bytes of the whole input operand.  A tile addresses it with 32-bit offsets RELATIVE to the
+                          // first image its rows touch (a window of < 2 GiB), so the operand itself may be larger
 };
 
 struct WgradK {
@@ -40,6 +42,7 @@ struct WgradK {
   float* slabs;
   OndaConv c;
   int M, lddy, splitk, mchunk, tilesN, tilesC, taps;
+  long long x_total = 0, dy_total = 0;  // bytes of the operands: a workgroup addresses them relative to its pixel range's start
   unsigned long long* stamps = nullptr;  // diagnostics (onda_debug_stamps, tools/wgrad_stamps.py): [8] s_memtime per workgroup
 };
 

@@ -19,7 +19,6 @@
 // 32 channels, as they lie in memory: one LDS-DMA instruction = 8 rows x 128 B), the 16-byte chunk index XOR-ed with a
 // function of the row (swz8) on the DMA's source side and in the fragment read: conflict-free ds_read_b128.
 #include "conv_common.h"
-#include <type_traits>
 
 namespace {
 
@@ -71,13 +70,23 @@ struct RowPos {
   int hw;  // (hi0 & 0xFFFF) | wi0 << 16;  hi0 = -32768: the row does not exist (past M)
   int bH;
 };
-__device__ __forceinline__ RowPos row_pos(int m, int M, const OndaConv& c) {
+// (b0: the image the offsets are relative to -- the first one the tile touches, see x_window)
+__device__ __forceinline__ RowPos row_pos(int m, int M, const OndaConv& c, int b0) {
   const bool vm = m < M;
   const int mm = vm ? m : 0;
   const int wo = mm % c.Wo, tq = mm / c.Wo;
   const int ho = tq % c.Ho, b = tq / c.Ho;
   const int hi0 = vm ? ho * c.stride - c.pad : -32768, wi0 = wo * c.stride - c.pad;
-  return RowPos{(int)((unsigned)(hi0 & 0xFFFF) | ((unsigned)wi0 << 16)), b * c.Hi};
+  return RowPos{(int)((unsigned)(hi0 & 0xFFFF) | ((unsigned)wi0 << 16)), (vm ? b - b0 : 0) * c.Hi};
+}
+// The input operand as a tile sees it: a buffer that starts at the first image its rows touch.  32-bit byte offsets then only
+// have to span the images of ONE tile (two, for images of at least a tile's rows), not the tensor: 4 + 4 images of
+// 1024 x 2048 put layer4's 2048-channel activations at 2.17 GB.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t x_window(const ConvK& a, int m0, int& b0) {
+  const OndaConv& c = a.c;
+  b0 = m0 / (c.Ho * c.Wo);
+  const long long at = (long long)b0 * c.Hi * c.Wi * c.ldx * 4, left = a.x_total - at;
+  return make_rsrc(reinterpret_cast<const char*>(a.x) + at, (unsigned)(left < 0x7FFFF000ll ? left : 0x7FFFF000ll));
 }
 // byte offset of the row's 128-byte block 0 for filter tap (rr, ss), or OOB (padding / no such row)
 __device__ __forceinline__ unsigned row_tap_ofs(const RowPos& p, int rr, int ss, const OndaConv& c, unsigned chunk16) {
@@ -288,7 +297,12 @@ __device__ __forceinline__ void l2_epilogue(const ConvK& a, const f32x4 (&acc)[4
   const bool track = a.amax != nullptr;
   const bool full_rows = m0 + 64 * WM <= a.M;
   const int mw = m0 + wm * 64 + rl;  // this lane's output row for (i, r) = (0, 0)
-  const unsigned vbase = vn ? (unsigned)(((size_t)mw * c.ldy + n) * 4) : OOB;
+  // (buffer stores: the output as a buffer that starts at the tile's first row and ends behind row M - 1 -- 32-bit offsets
+  //  span one tile, the tensor may pass 2 GiB)
+  const unsigned vbase = vn ? (unsigned)(((size_t)(mw - m0) * c.ldy + n) * 4) : OOB;
+  const long long y_left = (long long)(a.M - m0) * c.ldy * 4;
+  const unsigned y_win = (unsigned)(y_left < 0x7FFFF000ll ? y_left : 0x7FFFF000ll);
+  float* const ytile = a.y + (size_t)m0 * c.ldy;
   float* const ybase = a.y + (size_t)mw * c.ldy + n;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -317,7 +331,7 @@ __device__ __forceinline__ void l2_epilogue(const ConvK& a, const f32x4 (&acc)[4
       if (plain) {
         if constexpr (COUNTED) {
 #if defined(__HIP_DEVICE_COMPILE__)
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), make_rsrc(a.y, y_bytes),
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), make_rsrc(ytile, y_win),
                                                  vbase + (unsigned)((i * 16 + 4 * r) * c.ldy * 4), 0, NT_AUX);
 #endif
         } else if (live) {
@@ -439,7 +453,10 @@ __device__ __forceinline__ void l2_epilogue_limbs(const ConvK& a, const f32x4 (&
       }
   }
   float mx = 0.f;
-  const size_t out_bytes = (size_t)a.M * c.ldy * 4;  // the output's limb rows as a buffer: rows past M fall outside
+  // the output's limb rows as a buffer from the tile's first row on: rows past M fall outside, offsets span one tile
+  const long long out_left = (long long)(a.M - m0) * c.ldy * 4;
+  const unsigned out_bytes = (unsigned)(out_left < 0x7FFFF000ll ? out_left : 0x7FFFF000ll);
+  _Float16* const ytile = a.yl + (size_t)m0 * 2 * c.ldy;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -478,9 +495,9 @@ __device__ __forceinline__ void l2_epilogue_limbs(const ConvK& a, const f32x4 (&
       }
       if constexpr (COUNTED) {
 #if defined(__HIP_DEVICE_COMPILE__)
-        const unsigned off = vn ? (unsigned)(limb_at((size_t)m, n, c.ldy) * 2) : OOB;  // rows past M: past the buffer's end
-        __builtin_amdgcn_raw_buffer_store_b64(l1, make_rsrc(a.yl, (unsigned)out_bytes), off, 0, NT_AUX);
-        __builtin_amdgcn_raw_buffer_store_b64(l2, make_rsrc(a.yl, (unsigned)out_bytes), off, 2 * LIMB2_OFS, NT_AUX);
+        const unsigned off = vn ? (unsigned)(limb_at((size_t)(m - m0), n, c.ldy) * 2) : OOB;  // rows past M: past the buffer's end
+        __builtin_amdgcn_raw_buffer_store_b64(l1, make_rsrc(ytile, out_bytes), off, 0, NT_AUX);
+        __builtin_amdgcn_raw_buffer_store_b64(l2, make_rsrc(ytile, out_bytes), off, 2 * LIMB2_OFS, NT_AUX);
 #endif
       } else if (live) {
         _Float16* dst = a.yl + limb_at((size_t)m, n, c.ldy);
@@ -544,7 +561,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_l2_kernel(const ConvK 
   const long long u_end = SK ? (swz + 1) * U / nblk : 0;
   int dp_tile = swz;
   const int wstride = a.taps * c.Cin;
-  const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, x_bytes), rw = make_rsrc(a.w, w_bytes);
+  const __amdgpu_buffer_rsrc_t rw = make_rsrc(a.w, w_bytes);
   const Scale2 sx = scale_of(xamax), sw = scale_of(wamax);
   const float unscale_a = sx.inv, unscale_b = sw.inv;  // applied one after the other: their product may underflow
 
@@ -569,9 +586,11 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_l2_kernel(const ConvK 
     const int tile_n = tile % a.tilesN, tile_m = tile / a.tilesN;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
+    int b0;
+    const __amdgpu_buffer_rsrc_t rx = x_window(a, m0, b0);
     RowPos rp[APW];
 #pragma unroll
-    for (int d = 0; d < APW; ++d) rp[d] = row_pos(m0 + (wave * APW + d) * 8 + lrow, a.M, c);
+    for (int d = 0; d < APW; ++d) rp[d] = row_pos(m0 + (wave * APW + d) * 8 + lrow, a.M, c, b0);
     unsigned bofs[BPW];
 #pragma unroll
     for (int d = 0; d < BPW; ++d) {
@@ -847,7 +866,8 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_l2x_kernel(const ConvK
   const long long U = (long long)(tiles_all - tiles_dp) * KT;
   const long long u_begin = swz * U / nblk, u_end = (swz + 1) * U / nblk;
   const int wstride = a.taps * c.Cin;
-  const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, x_bytes), rw = make_rsrc(a.w, w_bytes);
+  const __amdgpu_buffer_rsrc_t rw = make_rsrc(a.w, w_bytes);
+  __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, 0);  // (the window of the item being issued: open_issue_item)
   const Scale2 sx = scale_of(xamax), sw = scale_of(wamax);
   const float unscale_a = sx.inv, unscale_b = sw.inv;
   const int lrow = lane >> 3;
@@ -892,8 +912,10 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_l2x_kernel(const ConvK
     item_of(ci, tile, k_begin, k_end);
     i_left = k_end - k_begin;
     const int m0 = (tile / a.tilesN) * BM, n0 = (tile % a.tilesN) * BN;
+    int b0;
+    rx = x_window(a, m0, b0);
 #pragma unroll
-    for (int d = 0; d < APW; ++d) rp[d] = row_pos(m0 + (wave * APW + d) * 8 + lrow, a.M, c);
+    for (int d = 0; d < APW; ++d) rp[d] = row_pos(m0 + (wave * APW + d) * 8 + lrow, a.M, c, b0);
 #pragma unroll
     for (int d = 0; d < BPW; ++d) {
       const int n = n0 + (wave * BPW + d) * 8 + lrow;
@@ -1055,429 +1077,6 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_l2x_kernel(const ConvK
                                        lane, ua, ub, y_bytes);
     stores_young = 2;
     stamp();
-  }
-}
-
-// ---- the short-K convolutions as a PRODUCER / CONSUMER workgroup ----------------------------------------------------------
-// conv_l2x_kernel above streams its K-steps across tile boundaries, but every tile still ends with an epilogue during which
-// the matrix pipe idles: 12 000-13 500 cycles per 256 x 128 tile whatever the shape (statistics 2 400, transposition + stores
-// 5 000, barrier + cross-wave reduction 3 400; profiles/r03_l2x_stamps.txt) against a K loop of 21 500 cycles at 256 input
-// channels.  The eight waves of that kernel all hold accumulators (232 registers each): nobody has room to keep a finished
-// tile while the next one is being multiplied, and LDS (144 KB of ring) has none either.
-// Here the workgroup's eight waves have three ROLES on a 128 x 128 tile:
-//   waves 0-3  CONSUMERS (one per SIMD): 64 x 64 each, fragments from the ring, MFMAs, nothing else -- no global memory
-//              instruction, no vmcnt wait.  At the end of a tile they add the two accumulator sets and drop the tile into
-//              the HOLD area of LDS (64 KB) in ~500 cycles, and go on with the next tile's K loop;
-//   waves 4-5  PRODUCERS: all LDS-DMA of the workgroup (16 instructions each per K-step), two K-steps ahead across tile
-//              boundaries, counted vmcnt waits (they issue nothing else, so the count is exact);
-//   waves 6-7  EPILOGUE: read the held tile back row-wise (4 rows x 64 columns per instruction), statistics / scale /
-//              shift / residual / ReLU / limb split, 256-byte row segments to global memory -- spread over the K-steps of
-//              the NEXT tile, 32 chunks per tile and wave, beside the consumers' MFMAs.
-// LDS: ring of three 32 KB stages (96 KB) + 64 KB hold = all 160 KB of a CU.  One s_barrier per K-step for everybody: the
-// producers arrive with the step's DMAs landed, the consumers with the previous stage's fragments in registers; hold is
-// handed over by the same barriers (a tile is dropped behind barrier first(t+1) and read behind first(t+1)+1 ..
-// first(t+1)+KT-1; the next drop comes behind first(t+2)).  Consumers pre-fetch the next step's fragments beside the
-// current step's MFMAs (PIPE): a1 / b1 of the next step into registers of their own, b2 / a2 into the registers the current
-// step has finished with -- 224 registers, no copies (the loop body exists twice, roles of the two a1 / b1 sets swapped).
-// 128 x 128 tiles move a third more bytes L2 -> LDS per MFMA than 256 x 128: the price of the hold area.  No stream-K:
-// a problem has four times the tiles of the 256-row kernels, the last round's loss is ~3 %.
-template <bool LIMB, bool AFFINE>
-__device__ __forceinline__ void l2p_chunk(const ConvK& a, const float* __restrict__ hold, int e, int lane, int ch, int m0, int n0,
-                                          f32x4 sc, f32x4 sh, float so, float ri, bool plain, float (&st)[4][4], float& mx) {
-  const OndaConv& c = a.c;
-  const int r = 4 * ch + (lane >> 4), cg = lane & 15;
-  const int m = m0 + r, n = n0 + 64 * e + 4 * cg;
-  const int sw = ((r >> 2) & 3) << 4;  // (the consumers' drop XORs the 16-column block with the row group: conflict-free both ways)
-  f32x4 v = *reinterpret_cast<const f32x4*>(hold + r * 128 + ((64 * e + 4 * cg) ^ sw));
-  const bool live = m < a.M && n < c.Cout;
-  if (a.stats != nullptr) {  // raw sums of the tile's rows (rows past M hold zeros: only have to be BOUNDED by the extrema)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      st[j][0] += v[j];
-      st[j][1] += v[j] * v[j];
-      st[j][2] = fminf(st[j][2], v[j]);
-      st[j][3] = fmaxf(st[j][3], v[j]);
-    }
-  }
-  if constexpr (LIMB) {
-    v = v * sc + sh;
-    if (a.resl != nullptr && live) {
-      const _Float16* p = a.resl + limb_at((size_t)m, n, c.ldr);
-      const u32x2 q1 = *reinterpret_cast<const u32x2*>(p), q2 = *reinterpret_cast<const u32x2*>(p + LIMB2_OFS);
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const f32x2 p1 = unpack2h(q1[h]), p2 = unpack2h(q2[h]);
-        v[2 * h] += (p1[0] + p2[0] * LIMB2_UNSCALE) * ri;
-        v[2 * h + 1] += (p1[1] + p2[1] * LIMB2_UNSCALE) * ri;
-      }
-    }
-    if (c.relu) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
-    }
-    if (live) {
-      mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
-      const f32x4 w = v * so;
-      u32x2 l1, l2;
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const unsigned pk = cvt2h(w[2 * h], w[2 * h + 1]);
-        const f32x2 f = unpack2h(pk);
-        l1[h] = pk;
-        l2[h] = cvt2h((w[2 * h] - f[0]) * LIMB2_SCALE, (w[2 * h + 1] - f[1]) * LIMB2_SCALE);
-      }
-      _Float16* dst = a.yl + limb_at((size_t)m, n, c.ldy);
-      store_out(reinterpret_cast<u32x2*>(dst), l1);
-      store_out(reinterpret_cast<u32x2*>(dst + LIMB2_OFS), l2);
-    }
-  } else {
-    if constexpr (AFFINE) {
-      v = v * sc + sh;
-      if (a.res && live) v += *reinterpret_cast<const f32x4*>(a.res + (size_t)m * c.ldr + n);
-      if (c.relu) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
-      }
-    } else {
-      v = v * sc;
-    }
-    if (live) {
-      size_t orow = (size_t)m;
-      if (!plain) {  // scattered rows (stride-2 data gradient)
-        const int wo = m % c.Wo, tq = m / c.Wo;
-        const int ho = tq % c.Ho, b = tq / c.Ho;
-        orow = ((size_t)b * c.Hf + (size_t)ho * c.out_os) * c.Wf + (size_t)wo * c.out_os;
-      }
-      store_out(reinterpret_cast<f32x4*>(a.y + orow * c.ldy + n), v);
-      if (a.amax != nullptr) mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
-    }
-  }
-}
-
-template <bool PIPE>
-__global__ __launch_bounds__(512, 2) void conv_l2p_kernel(const ConvK a, unsigned xplane, unsigned wplane, unsigned x_bytes,
-                                                          unsigned w_bytes, const float* __restrict__ xamax,
-                                                          const float* __restrict__ wamax) {
-  if (a.c.run_if != nullptr && *a.c.run_if == 0) return;  // predicated launch (onda_switch_step decided on the device)
-  constexpr int BM = 128, BN = 128;
-  constexpr int A_BYTES = BM * 128, STAGE = A_BYTES + BN * 128, RING = 3 * STAGE, HOLD = BM * BN * 4;  // 128-byte rows: both limbs
-  constexpr int DPW = 16;    // LDS-DMA instructions per producer wave and K-step
-  constexpr int NCH = 32;    // 4-row chunks of a tile per epilogue wave
-  static_assert(RING + HOLD == 160 * 1024, "all of a CU's LDS");
-  __shared__ __attribute__((aligned(16))) unsigned char lds[RING + HOLD];
-
-  const OndaConv& c = a.c;
-  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int nblk = gridDim.x, bid = blockIdx.x;
-  const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
-  const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  const int KT = a.taps * a.kcper;  // >= 2 (host)
-  const int tiles = a.tilesM * a.tilesN;
-  const int ntiles = (tiles - swz + nblk - 1) / nblk;  // this workgroup's tiles: swz, swz + nblk, ...  (>= 1: grid <= tiles)
-  const int G = ntiles * KT;                           // its K-steps = its barriers B_0 .. B_{G-1}
-  auto next_stage = [](int s_) { return s_ + STAGE == RING ? 0 : s_ + STAGE; };
-
-  if (wave < 4) {
-    // ---------------------------------------------------------------------------------------------------- consumers
-    const int wm = wave >> 1, wn = wave & 1;
-    const int fr0 = frag_ofs(lane, 0), fr1 = frag_ofs(lane, 1);
-    f32x4 acc[4][4], accx[4][4];
-    auto zero = [&]() {
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) acc[i][j][e] = accx[i][j][e] = 0.f;
-    };
-    zero();
-    float* hold = reinterpret_cast<float*>(lds + RING);
-    const int hbase = (wm * 64 + 4 * (lane >> 4)) * 128, hcol = (wn * 64 + (lane & 15)) ^ ((lane >> 4) << 4);
-    auto tile_end = [&]() {  // both product classes back into one set (exact: a power of two), the tile into the hold area
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const f32x4 v = acc[i][j] + accx[i][j] * LIMB2_UNSCALE;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) hold[hbase + (i * 16 + e) * 128 + (hcol ^ (j << 4))] = v[e];
-        }
-      zero();
-    };
-    f16x8 a1[2][4], b1[2][4], a2[4], b2[4];
-    int st_read = 0;
-    const unsigned char *Ab, *Ab2, *Bb, *Bb2;
-    auto open_stage = [&]() {
-      Ab = lds + st_read + wm * 64 * 128 + fr0;
-      Ab2 = lds + st_read + wm * 64 * 128 + fr1;
-      Bb = lds + st_read + A_BYTES + wn * 64 * 128 + fr0;
-      Bb2 = lds + st_read + A_BYTES + wn * 64 * 128 + fr1;
-      st_read = next_stage(st_read);
-    };
-    auto mfma3 = [&](const f16x8 (&A1)[4], const f16x8 (&B1)[4], int which) {
-      if (which == 0) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int jj = 0; jj < 4; ++jj) accx[i][ZZ(i, jj)] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A1[i], b2[ZZ(i, jj)], accx[i][ZZ(i, jj)], 0, 0, 0);
-      } else if (which == 1) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int jj = 0; jj < 4; ++jj) accx[i][ZZ(i, jj)] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2[i], B1[ZZ(i, jj)], accx[i][ZZ(i, jj)], 0, 0, 0);
-      } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int jj = 0; jj < 4; ++jj) acc[i][ZZ(i, jj)] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A1[i], B1[ZZ(i, jj)], acc[i][ZZ(i, jj)], 0, 0, 0);
-      }
-    };
-    if constexpr (!PIPE) {
-      for (int it = 0; it < ntiles; ++it) {
-        for (int kt = 0; kt < KT; ++kt) {
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (a tile dropped in the last step is in LDS before the barrier publishes it)
-          __builtin_amdgcn_s_barrier();  // B_g: stage g landed
-          open_stage();
-#pragma unroll
-          for (int i = 0; i < 4; ++i) a1[0][i] = *reinterpret_cast<const f16x8*>(Ab + i * 2048);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) b2[j] = *reinterpret_cast<const f16x8*>(Bb2 + j * 2048);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) a2[i] = *reinterpret_cast<const f16x8*>(Ab2 + i * 2048);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) b1[0][j] = *reinterpret_cast<const f16x8*>(Bb + j * 2048);
-          mfma3(a1[0], b1[0], 0);
-          mfma3(a1[0], b1[0], 1);
-          mfma3(a1[0], b1[0], 2);
-        }
-        tile_end();
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();  // B_G (nothing to publish: the others count it)
-    } else {
-      __builtin_amdgcn_s_barrier();  // B_0
-      open_stage();
-#pragma unroll
-      for (int i = 0; i < 4; ++i) a1[0][i] = *reinterpret_cast<const f16x8*>(Ab + i * 2048);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) b2[j] = *reinterpret_cast<const f16x8*>(Bb2 + j * 2048);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) a2[i] = *reinterpret_cast<const f16x8*>(Ab2 + i * 2048);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) b1[0][j] = *reinterpret_cast<const f16x8*>(Bb + j * 2048);
-      // one K-step: MFMAs on the fragments of step g (set P) while the fragments of step g + 1 arrive (a1 / b1 into set 1 - P;
-      // b2 / a2 in place, each behind the MFMA group that last reads it).  No branch in here: behind the workgroup's last
-      // K-step the reads fetch a stage nobody filled, into registers nobody uses.
-      auto body = [&](auto P_) {
-        constexpr int P = decltype(P_)::value;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this step's fragments (and a dropped tile) are where they belong
-        __builtin_amdgcn_s_barrier();  // B_{g+1}: stage g + 1 landed; everybody holds the fragments of stage g
-        open_stage();
-#pragma unroll
-        for (int i = 0; i < 4; ++i) a1[1 - P][i] = *reinterpret_cast<const f16x8*>(Ab + i * 2048);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) b1[1 - P][j] = *reinterpret_cast<const f16x8*>(Bb + j * 2048);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma3(a1[P], b1[P], 0);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) b2[j] = *reinterpret_cast<const f16x8*>(Bb2 + j * 2048);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma3(a1[P], b1[P], 1);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) a2[i] = *reinterpret_cast<const f16x8*>(Ab2 + i * 2048);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma3(a1[P], b1[P], 2);
-        __builtin_amdgcn_sched_barrier(0);
-      };
-      for (int it = 0; it < ntiles; ++it) {  // (KT is even: a tile starts on set 0)
-        for (int kp = 0; kp < KT; kp += 2) {
-          body(std::integral_constant<int, 0>{});
-          body(std::integral_constant<int, 1>{});
-        }
-        tile_end();
-      }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();  // T: the last tile is in the hold area
-    return;
-  }
-
-  if (wave < 6) {
-    // ---------------------------------------------------------------------------------------------------- producers
-    const int d = wave - 4;
-    const int wstride = a.taps * c.Cin;
-    const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, x_bytes), rw = make_rsrc(a.w, w_bytes);
-    const int lrow = lane >> 3;
-    const unsigned cq[2] = {dma_chunk16(lane, 0), dma_chunk16(lane, 1)};
-    RowPos rp[8];  // this wave's eight 8-row pieces of A (rows 64 d .. 64 d + 63) and of B
-    int tap_i = 0, c0_i = 0;
-    unsigned bofs[8], aofs[8];
-    int it_i = 0, i_left = 0, st_issue = 0, issued = 0;
-    auto set_tap = [&](int tp) {
-      const int rr = tp / c.kw, ss = tp - rr * c.kw;
-#pragma unroll
-      for (int k = 0; k < 8; ++k) aofs[k] = row_tap_ofs(rp[k], rr, ss, c, cq[k & 1]);
-    };
-    auto open_item = [&]() {
-      const int tile = swz + it_i * nblk;
-      ++it_i;
-      i_left = KT;
-      const int m0 = (tile / a.tilesN) * BM, n0 = (tile % a.tilesN) * BN;
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        rp[k] = row_pos(m0 + (d * 8 + k) * 8 + lrow, a.M, c);
-        const int n = n0 + (d * 8 + k) * 8 + lrow;
-        bofs[k] = n < c.Cout ? (unsigned)n * wstride * 4u + cq[k & 1] : OOB;
-      }
-      tap_i = 0;
-      c0_i = 0;
-      set_tap(0);
-    };
-    auto issue_step = [&]() {
-      if (i_left == 0) {
-        if (it_i >= ntiles) return;
-        open_item();
-      }
-#if defined(__HIP_DEVICE_COMPILE__)
-      const int sa = c0_i * 4, sb = (tap_i * c.Cin + c0_i) * 4;
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        unsigned char* dst = lds + st_issue + (d * 8 + k) * 1024;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)dst, 16, aofs[k], sa, 0, 0);
-      }
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        unsigned char* dst = lds + st_issue + A_BYTES + (d * 8 + k) * 1024;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)dst, 16, bofs[k], sb, 0, 0);
-      }
-#endif
-      st_issue = next_stage(st_issue);
-      ++issued;
-      --i_left;
-      c0_i += BK;
-      if (c0_i == c.Cin) {
-        c0_i = 0;
-        ++tap_i;
-        if (i_left > 0) set_tap(tap_i);
-      }
-    };
-    issue_step();
-    issue_step();
-    for (int g = 0; g < G; ++g) {
-      // the DMAs of step g have landed; those of step g + 1 (if issued: the 16 youngest) may still fly
-      if (issued > g + 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPW) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();  // B_g: publishes stage g; the consumers are done with stage g - 1
-      issue_step();                  // step g + 2 -> the stage of step g - 1
-    }
-    __builtin_amdgcn_s_barrier();  // B_G
-    __builtin_amdgcn_s_barrier();  // T
-    return;
-  }
-
-  // -------------------------------------------------------------------------------------------------------- epilogue
-  {
-    const int e = wave - 6;
-    const float* hold = reinterpret_cast<const float*>(lds + RING);
-    const Scale2 sx = scale_of(xamax), sw = scale_of(wamax);
-    const float ua = sx.inv, ub = sw.inv;  // always applied one after the other: their product may leave the normal range
-    const bool limb = a.yl != nullptr;
-    const bool affine = a.scale != nullptr || a.shift != nullptr || a.res != nullptr || c.relu;
-    const bool plain = (c.out_os == 1 && c.Hf == c.Ho && c.Wf == c.Wo);
-    const int SR = a.stats_rows;
-    float so = 1.f, ri = 0.f;
-    if (limb) {
-      const float bound = limb_out_bound(a);
-      so = scale_from(bound).s;
-      if (wave == 6 && lane == 0) a.ybound[(blockIdx.x & (ONDA_AMAX_SLOTS - 1)) * AMAX_STRIDE] = bound;
-      ri = a.resl != nullptr ? scale_of(a.res_amax).inv : 0.f;
-    }
-    const int cpi = (NCH + KT - 2) / (KT - 1);  // chunks per barrier interval: a tile is gone within KT - 1 intervals
-    float st[4][4];
-    float mx = 0.f;
-    int chunk = NCH;  // next chunk of the tile being written out (NCH: none pending)
-    int m0 = 0, n0 = 0, tile_m = 0;
-    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-    auto open_tile = [&](int seq) {
-      const int tile = swz + seq * nblk;
-      tile_m = tile / a.tilesN;
-      m0 = tile_m * BM;
-      n0 = (tile % a.tilesN) * BN;
-      chunk = 0;
-      mx = 0.f;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        st[j][0] = st[j][1] = 0.f;
-        st[j][2] = 3.0e38f;
-        st[j][3] = -3.0e38f;
-      }
-      const int n = n0 + 64 * e + 4 * (lane & 15);
-      sc = f32x4{1.f, 1.f, 1.f, 1.f};
-      sh = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (n < c.Cout && a.scale) sc = *reinterpret_cast<const f32x4*>(a.scale + n);
-      if (n < c.Cout && a.shift) sh = *reinterpret_cast<const f32x4*>(a.shift + n);
-      sc = (sc * ua) * ub;
-    };
-    auto close_tile = [&]() {  // column statistics over the tile's 128 rows: this wave holds all of them, no cross-wave step
-      if (a.stats != nullptr) {
-        f32x4 o[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          rows_reduce4(st[j][0], st[j][1], st[j][2], st[j][3]);
-          o[0][j] = (st[j][0] * ua) * ub;
-          o[1][j] = (((st[j][1] * ua) * ub) * ua) * ub;
-          o[2][j] = (st[j][2] * ua) * ub;
-          o[3][j] = (st[j][3] * ua) * ub;
-        }
-        const int n = n0 + 64 * e + 4 * lane;
-        if (lane < 16 && n < c.Cout) {
-          float* dst = a.stats + (size_t)tile_m * SR * c.Cout + n;
-          *reinterpret_cast<f32x4*>(dst) = o[0];
-          *reinterpret_cast<f32x4*>(dst + c.Cout) = o[1];
-          if (SR == 4) {
-            *reinterpret_cast<f32x4*>(dst + 2 * c.Cout) = o[2];
-            *reinterpret_cast<f32x4*>(dst + 3 * c.Cout) = o[3];
-          }
-        }
-      }
-      if (a.amax != nullptr) {
-        const float m = wave_max(mx);
-        if (lane == 0 && m > 0.f)
-          atomicMax(reinterpret_cast<unsigned*>(a.amax) + ((blockIdx.x * 2 + e) & (ONDA_AMAX_SLOTS - 1)) * AMAX_STRIDE, __float_as_uint(m));
-      }
-    };
-    auto work = [&](int n_chunks) {
-      for (int k = 0; k < n_chunks && chunk < NCH; ++k, ++chunk) {
-        if (limb) l2p_chunk<true, true>(a, hold, e, lane, chunk, m0, n0, sc, sh, so, ri, plain, st, mx);
-        else if (affine) l2p_chunk<false, true>(a, hold, e, lane, chunk, m0, n0, sc, sh, so, ri, plain, st, mx);
-        else l2p_chunk<false, false>(a, hold, e, lane, chunk, m0, n0, sc, sh, so, ri, plain, st, mx);
-        if (chunk == NCH - 1) close_tile();
-      }
-    };
-    int it = 0, kt = 0;  // where the consumers stand at barrier B_g: K-step kt of their tile number it
-    for (int g = 0; g < G; ++g) {
-      __builtin_amdgcn_s_barrier();  // B_g
-      // tile it - 1 lies in the hold area: dropped behind B_first(it) (PIPE) / before it (not PIPE), replaced behind
-      // B_first(it + 1) / B_last(it)
-      if (it > 0) {
-        const bool may = PIPE ? kt >= 1 : kt <= KT - 2;
-        if (may) {
-          if (chunk == NCH && kt == (PIPE ? 1 : 0)) open_tile(it - 1);
-          work(cpi);
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the chunk reads are done before the next barrier lets a drop in
-        }
-      }
-      if (++kt == KT) {
-        kt = 0;
-        ++it;
-      }
-    }
-    __builtin_amdgcn_s_barrier();  // B_G
-    __builtin_amdgcn_s_barrier();  // T: the last tile
-    open_tile(ntiles - 1);
-    work(NCH);
   }
 }
 
@@ -1725,7 +1324,15 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_wgrad_l2_kernel(const 
   const int dh = rr * c.dil - c.pad, dw = ss * c.dil - c.pad;
   unsigned long long* stp = a.stamps != nullptr && t == 0 && blockIdx.x < 4096 ? a.stamps + (size_t)blockIdx.x * 8 : nullptr;
   if (stp) stp[0] = __builtin_amdgcn_s_memtime();
-  const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, x_bytes), rdy = make_rsrc(a.dy, dy_bytes);
+  // Both operands as buffers that start where this workgroup's pixel range starts (dy: its first pixel; x: the first image that
+  // pixel lies in): the 32-bit offsets span one pixel range (<= 65 536 pixels and the images they touch), the tensors may be
+  // larger than 2 GiB (4 + 4 images of 1024 x 2048: 2.17 GB of 2048-channel limb rows)
+  constexpr unsigned PAST = 0x7FFFF000u;  // an offset at or behind the end of any window, that OOB + PAST does not wrap
+  const int b_first = mbeg / (c.Ho * c.Wo);
+  const long long x_at = (long long)b_first * c.Hi * c.Wi * c.ldx * 4, dy_at = (long long)mbeg * a.lddy * 4;
+  const long long x_left = a.x_total - x_at, dy_left = a.dy_total - dy_at;
+  const __amdgpu_buffer_rsrc_t rx = make_rsrc(reinterpret_cast<const char*>(a.x) + x_at, (unsigned)(x_left < PAST ? (x_left > 0 ? x_left : 0) : PAST));
+  const __amdgpu_buffer_rsrc_t rdy = make_rsrc(reinterpret_cast<const char*>(a.dy) + dy_at, (unsigned)(dy_left < PAST ? (dy_left > 0 ? dy_left : 0) : PAST));
   const Scale2 sx = scale_of(xamax), sd = scale_of(dyamax);
   const float unscale_a = sx.inv, unscale_b = sd.inv;
 
@@ -1769,12 +1376,12 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_wgrad_l2_kernel(const 
 #pragma unroll
       for (int sI = 0; sI < SA; ++sI) {
         const int n = n0 + sI * 128 + ch * 8;
-        ch_dy[d][h][sI] = n < c.Cout ? (unsigned)(limb_at(0, n, 0) + limb * LIMB2_OFS) * 2u : dy_bytes;  // past the buffer whatever pixel offset is added
+        ch_dy[d][h][sI] = n < c.Cout ? (unsigned)(limb_at(0, n, 0) + limb * LIMB2_OFS) * 2u : PAST;  // past the buffer whatever pixel offset is added
       }
 #pragma unroll
       for (int sI = 0; sI < SB; ++sI) {
         const int cc = c0 + sI * 128 + ch * 8;
-        ch_x[d][h][sI] = cc < c.Cin ? (unsigned)(limb_at(0, cc, 0) + limb * LIMB2_OFS) * 2u : x_bytes;
+        ch_x[d][h][sI] = cc < c.Cin ? (unsigned)(limb_at(0, cc, 0) + limb * LIMB2_OFS) * 2u : PAST;
       }
     }
   // this lane's FIRST pixel of each group (its second one is the next pixel): (image, output row, output column), advanced
@@ -1787,7 +1394,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_wgrad_l2_kernel(const 
     p_wo[d] = m % c.Wo;
     const int tq = m / c.Wo;
     p_ho[d] = tq % c.Ho;
-    p_b[d] = tq / c.Ho;
+    p_b[d] = tq / c.Ho - b_first;  // (relative to the window of x)
   }
   int k_decoded = 0;  // the K-step p_* stand at
   // A step's DMAs in two parts -- first limb planes, second limb planes -- so that the staggered kernel can issue one
@@ -1841,7 +1448,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_wgrad_l2_kernel(const 
       for (int h = 0; h < 2; ++h) {  // this lane's two pixels: m and m + 1
         unsigned pdy = OOB, px = OOB;
         if (m < mend) {
-          pdy = (unsigned)m * (unsigned)a.lddy * 4u;  // a limb row: 4 bytes per channel
+          pdy = (unsigned)(m - mbeg) * (unsigned)a.lddy * 4u;  // a limb row: 4 bytes per channel
           const int hi = ho * c.stride + dh, wi = wo * c.stride + dw;
           if ((unsigned)hi < (unsigned)c.Hi && (unsigned)wi < (unsigned)c.Wi) px = (unsigned)(((b * c.Hi + hi) * c.Wi + wi) * c.ldx) * 4u;
         }
@@ -2083,14 +1690,8 @@ int onda_conv_l2_variant(int64_t M, int Cout) {
  * problems with at most 32 K-steps per tile (bench.py names its per-kernel figures after this) */
 int onda_conv_l2_kernel_id(int64_t M, int Cout, int taps, int Cin) {
   const int variant = onda_conv_l2_variant(M, Cout);
-  static const int xt = getenv("ONDA_L2_XT") ? atoi(getenv("ONDA_L2_XT")) : 1;
-  static const int l2p = getenv("ONDA_L2P") ? atoi(getenv("ONDA_L2P")) : 0;  // 0: off (default: measured slower), 1: on, 2: on without the fragment pre-fetch
-  const int KT = taps * (Cin / 32);
-  const bool short_k = KT <= 32 || xt == 2;
-  // 4 = conv_l2p_kernel: the producer / consumer form (128 x 128 tiles, the epilogue under the next tile's K loop) takes the
-  // continuous-stream kernel's problems when a tile has at least two K-steps to spread the previous tile's epilogue over
-  if (variant == 0 && xt && KT <= 32 && KT >= 2 && KT % 2 == 0 && l2p) return 4;
-  return variant == 0 && xt && short_k ? 3 : variant;
+  const bool short_k = taps * (Cin / 32) <= 32;
+  return variant == 0 && short_k ? 3 : variant;
 }
 
 }  // extern "C"
@@ -2101,29 +1702,14 @@ namespace {
 struct L2Schedule {
   int variant, BM, BN, tilesM, tilesN, G, rem, sub;
   bool balanced;
-  bool p128 = false;  // conv_l2p_kernel (128 x 128 tiles, whole tiles only)
   int rem_rows() const { return tilesM - (tilesM * tilesN - rem) / tilesN; }  // tile rows that hold remainder tiles
   int stats_rows_total() const { return tilesM + (balanced ? rem_rows() * (sub - 1) : 0); }
 };
-bool l2_small_ring2() {
-  static const int on = getenv("ONDA_L2_RING2") ? atoi(getenv("ONDA_L2_RING2")) : 1;
-  return on != 0;
-}
+bool l2_small_ring2() { return true; }  // (the four-wave tiles on a three-stage ring, one workgroup per CU, lost: DESIGN.md section 3)
 
 L2Schedule l2_schedule(long long M, int Cout, int taps, int Cin, bool have_ws, long long stat_split = 0, bool plain = false) {
   L2Schedule q;
   q.variant = onda_conv_l2_variant(M, Cout);
-  if (onda_conv_l2_kernel_id(M, Cout, taps, Cin) == 4) {
-    q.p128 = true;
-    q.BM = q.BN = 128;
-    q.tilesM = (int)((M + 127) / 128);
-    q.tilesN = (Cout + 127) / 128;
-    q.G = conv_resident_workgroups() / 2;  // all of a CU's LDS: one workgroup per CU
-    q.rem = 0;
-    q.sub = 1;
-    q.balanced = false;
-    return q;
-  }
   q.BM = q.variant == 1 ? 128 : 256;
   q.BN = q.variant == 2 ? 64 : 128;
   q.tilesM = (int)((M + q.BM - 1) / q.BM);
@@ -2226,7 +1812,6 @@ static int l2_fwd_impl(const void* xl, int64_t xplane, const float* xamax, const
     ONDA_REQUIRE(lo->out && lo->out_bound && lo->kb && lo->xtrue && !stats && !residual);
     ONDA_REQUIRE(c->out_os == 1 && c->Hf == c->Ho && c->Wf == c->Wo && c->ldy % 32 == 0 && c->ldy >= c->Cout);
     ONDA_REQUIRE(!lo->res || (lo->res_amax && c->ldr % 32 == 0 && c->ldr >= c->Cout));
-    ONDA_REQUIRE((long long)c->B * c->Ho * c->Wo * c->ldy * 4 < 0x7FFFF000ll);
     if (!ONDA_ALIGNED16(lo->out) || (lo->res && !ONDA_ALIGNED16(lo->res))) return ONDA_EALIGN;
   }
   ONDA_REQUIRE(c->Cin > 0 && c->Cin % 32 == 0 && c->Cout > 0 && c->Cout % 4 == 0 && c->ldx % 32 == 0 && c->ldx >= c->Cin);
@@ -2253,10 +1838,8 @@ static int l2_fwd_impl(const void* xl, int64_t xplane, const float* xamax, const
     k.res_amax = lo->res_amax;
     k.res_true = lo->res_true ? lo->res_true : lo->res_amax;
   }
-  static const int noskip = getenv("ONDA_L2_NOSKIP") ? atoi(getenv("ONDA_L2_NOSKIP")) : 0;
-  k.skip_dead_taps = !noskip;
-  static const int late_issue = getenv("ONDA_L2X_LATE") ? atoi(getenv("ONDA_L2X_LATE")) : 1;
-  k.late_issue = late_issue;
+  k.skip_dead_taps = 1;
+  k.late_issue = 1;
   static const int stamp_on = getenv("ONDA_L2X_STAMP") ? atoi(getenv("ONDA_L2X_STAMP")) : 0;
   if (stamp_on)  // the last 64 KiB of the workspace (beyond anything the schedules use: checked below)
     k.stamps = reinterpret_cast<unsigned long long*>(ws + onda_conv_ws_floats()) - 1024 * 32;
@@ -2264,7 +1847,11 @@ static int l2_fwd_impl(const void* xl, int64_t xplane, const float* xamax, const
   const long long M = (long long)c->B * c->Ho * c->Wo;
   ONDA_REQUIRE(M > 0 && M < (1ll << 31));
   const long long x_total = (long long)c->B * c->Hi * c->Wi * c->ldx * 4;  // limb rows: 4 bytes per element
-  ONDA_REQUIRE(x_total < 0x7FFFF000ll);  // 32-bit byte offsets
+  {  // 32-bit byte offsets inside a tile's WINDOW (x_window: the images its <= 256 rows touch), not inside the tensor
+    const long long img = (long long)c->Hi * c->Wi * c->ldx * 4, per_tile = 256 / ((long long)c->Ho * c->Wo) + 2;
+    ONDA_REQUIRE((per_tile < c->B ? per_tile : c->B) * img < 0x7FFFF000ll);
+  }
+  k.x_total = x_total;
   k.M = (int)M;
   k.taps = c->kh * c->kw;
   k.kcper = c->Cin / 32;
@@ -2274,7 +1861,7 @@ static int l2_fwd_impl(const void* xl, int64_t xplane, const float* xamax, const
   k.tilesN = q.tilesN;
   const size_t limb_elems = (size_t)c->Cout * k.taps * c->Cin;  // weight planes are [Cout][taps*Cin]
   ONDA_REQUIRE(limb_elems * 4 < (1ull << 31));
-  const unsigned x_bytes = (unsigned)x_total, w_bytes = (unsigned)(limb_elems * 4);
+  const unsigned x_bytes = 0, w_bytes = (unsigned)(limb_elems * 4);  // (x: ConvK.x_total, windows per tile)
   const unsigned xpl = 0, wpl = 0;  // (unused by the kernels since the limbs share a row)
   const int tiles = k.tilesM * k.tilesN;
   k.tiles_dp = tiles - q.rem;
@@ -2291,24 +1878,14 @@ static int l2_fwd_impl(const void* xl, int64_t xplane, const float* xamax, const
                          x_bytes, w_bytes, xamax, wamax);                                                                   \
     }                                                                                                                        \
   } while (0)
-  static const int xt = getenv("ONDA_L2_XT") ? atoi(getenv("ONDA_L2_XT")) : 1;  // 0: one cold start per tile (conv_l2_kernel)
   // the output as a buffer: last byte any tile can store (dense rows of ldy floats; scattered stride-2 gradients included)
   const long long y_rows = (long long)c->B * (c->out_os == 1 && c->Hf == c->Ho && c->Wf == c->Wo ? (long long)c->Ho * c->Wo : (long long)c->Hf * c->Wf);
   const long long y_total = ((y_rows - 1) * c->ldy + c->Cout) * 4;
   // short K loops (1 x 1 convolutions up to 1024 input channels) gain 6-17 % from the continuous stream; long ones lose
   // ~4 % against the slot-staggered kernel, whose per-tile start / end they amortise anyway (measured per shape, one process)
-  const bool short_k = k.taps * k.kcper <= 32 || xt == 2;
-  if (q.p128) {
-    static const int l2p = getenv("ONDA_L2P") ? atoi(getenv("ONDA_L2P")) : 1;
-    k.tiles_dp = tiles;
-    const int grid = tiles < q.G ? tiles : q.G;
-    if (l2p == 2)
-      hipLaunchKernelGGL((conv_l2p_kernel<false>), dim3(grid), dim3(512), 0, st, k, xpl, wpl, x_bytes, w_bytes, xamax, wamax);
-    else
-      hipLaunchKernelGGL((conv_l2p_kernel<true>), dim3(grid), dim3(512), 0, st, k, xpl, wpl, x_bytes, w_bytes, xamax, wamax);
-    return ONDA_LAUNCH_RESULT();
-  }
-  if (xt && short_k && q.variant == 0 && y_total < 0x7FFFF000ll) {
+  const bool short_k = k.taps * k.kcper <= 32;
+  const bool dense_out = c->out_os == 1 && c->Hf == c->Ho && c->Wf == c->Wo;  // (buffer stores relative to the tile: any size)
+  if (short_k && q.variant == 0 && (dense_out || y_total < 0x7FFFF000ll)) {
     if (!q.balanced) k.tiles_dp = tiles;  // persistent either way: whole tiles only
     const int grid = tiles < q.G ? tiles : q.G;
     hipLaunchKernelGGL((conv_l2x_kernel<4, 2, 3, 2>), dim3(q.balanced ? q.G : grid), dim3(512), 0, st, k, xpl, wpl, x_bytes, w_bytes,
@@ -2374,7 +1951,6 @@ void onda_debug_stamps(void* p) { g_debug_stamps = static_cast<unsigned long lon
 
 int onda_conv_wgrad_l2_variant(int Cout, int Cin) {
   (void)Cin;
-  if (const char* e = getenv("ONDA_WGRAD_L2_VARIANT")) return atoi(e);
   return Cout >= 256 ? 0 : 1;
 }
 
@@ -2389,7 +1965,6 @@ int onda_conv2d_wgrad_l2(const void* xl, int64_t xplane, const float* xamax, con
   ONDA_REQUIRE(M > 0 && M < (1ll << 31));
   const long long x_total = (long long)c->B * c->Hi * c->Wi * c->ldx * 4;
   const long long dy_total = M * lddy * 4;
-  ONDA_REQUIRE(x_total < 0x7FFF0000ll && dy_total < 0x7FFF0000ll);
   WgradK k;
   k.x = static_cast<const float*>(xl); k.dy = static_cast<const float*>(dyl); k.slabs = slabs; k.c = *c;
   k.M = (int)M;
@@ -2398,6 +1973,12 @@ int onda_conv2d_wgrad_l2(const void* xl, int64_t xplane, const float* xamax, con
   k.stamps = g_debug_stamps;
   k.mchunk = (int)(((M + splitk - 1) / splitk + 31) / 32 * 32);
   ONDA_REQUIRE(k.mchunk / 32 <= 2048);  // the kernel lists a workgroup's live K-steps in LDS (MAX_KT); raise splitk beyond that
+  {  // 32-bit offsets inside a workgroup's windows (its pixel range of dy; the images of x that range touches)
+    const long long img = (long long)c->Hi * c->Wi * c->ldx * 4, per_wg = k.mchunk / ((long long)c->Ho * c->Wo) + 2;
+    ONDA_REQUIRE((long long)k.mchunk * lddy * 4 < 0x7FFFF000ll && (per_wg < c->B ? per_wg : c->B) * img < 0x7FFFF000ll);
+  }
+  k.x_total = x_total;
+  k.dy_total = dy_total;
   k.taps = c->kh * c->kw;
   const int variant = onda_conv_wgrad_l2_variant(c->Cout, c->Cin);
   const int TN = variant == 0 ? 256 : 128;
@@ -2406,11 +1987,9 @@ int onda_conv2d_wgrad_l2(const void* xl, int64_t xplane, const float* xamax, con
   const unsigned grid = (unsigned)(k.tilesN * k.tilesC * k.taps * splitk);
   const unsigned xpl = 0, dypl = 0;
   if (variant == 0)
-    hipLaunchKernelGGL((conv_wgrad_l2_kernel<4, 2, 3, 2>), dim3(grid), dim3(512), 0, ONDA_STREAM(s), k, xpl, dypl, (unsigned)x_total,
-                       (unsigned)dy_total, xamax, dyamax);
+    hipLaunchKernelGGL((conv_wgrad_l2_kernel<4, 2, 3, 2>), dim3(grid), dim3(512), 0, ONDA_STREAM(s), k, xpl, dypl, 0u, 0u, xamax, dyamax);
   else
-    hipLaunchKernelGGL((conv_wgrad_l2_kernel<2, 2, 2, 2>), dim3(grid), dim3(256), 0, ONDA_STREAM(s), k, xpl, dypl, (unsigned)x_total,
-                       (unsigned)dy_total, xamax, dyamax);
+    hipLaunchKernelGGL((conv_wgrad_l2_kernel<2, 2, 2, 2>), dim3(grid), dim3(256), 0, ONDA_STREAM(s), k, xpl, dypl, 0u, 0u, xamax, dyamax);
   return ONDA_LAUNCH_RESULT();
 }
 

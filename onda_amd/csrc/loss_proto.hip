@@ -690,10 +690,7 @@ int onda_proto_sigma(const float* proto, const float* sqmean, const float* count
 // workspace of onda_proto_assign in units of 3 floats: partial sums of the MFMA pass (PA_GRID workgroups) and of the direct
 // pass over the close decisions (PA_LIST_GRID), the list itself (N ints) and its length
 constexpr int PA_GRID = 256, PA_LIST_GRID = 256;
-static bool proto_direct_only() {
-  static const int on = getenv("ONDA_PROTO_DIRECT") ? atoi(getenv("ONDA_PROTO_DIRECT")) : 0;
-  return on != 0;
-}
+static bool proto_direct_only() { return false; }  // (true: every pixel in the direct form -- the round-1 path the MFMA contraction replaced)
 int onda_proto_assign_blocks(int64_t N) {
   int64_t nb = (N + 3) / 4;
   if (nb > 2048) nb = 2048;

@@ -40,20 +40,34 @@ import os
 
 # the student's source-replay pass and its target pass as ONE pass over both batches (ops.row_groups); 0 = one after the
 # other, as the reference orders them.  PAIR_MAX_ROWS: feature-grid pixels of both batches together up to which the paired
-# pass is used -- the kernels address an operand with 32-bit byte offsets, and the widest activation (layer4's 2048 channels,
-# two f16 limb planes) passes 2 GiB at 262 143 rows: 4 + 4 images of 512x1024 (67 080 rows, 22 GB peak with both autograd
-# graphs alive) pair, 4 + 4 images of 1024x2048 (265 224 rows) run one pass after the other
+# pass is used -- a sanity bound only since round 5: the kernels address an operand with 32-bit byte offsets RELATIVE to the
+# images a tile (a weight-gradient pixel range) touches, so the widest activation (layer4's 2048 channels: 2.17 GB of limb
+# rows for 4 + 4 images of 1024x2048, 265 224 rows) may pass 2 GiB.  4 + 4 images of 512x1024 (67 080 rows): 22 GB peak
+# with both autograd graphs alive; of 1024x2048: ~90 GB
 PAIR_STUDENT = os.environ.get("ONDA_PAIR_STUDENT", "1") != "0"
-PAIR_MAX_ROWS = int(os.environ.get("ONDA_PAIR_MAX_ROWS", str(0x7FFFF000 // (2048 * 4))))
+PAIR_MAX_ROWS = 1 << 21
 # the no-grad passes of a step (teacher; static -> switch -> dynamic) on two side streams, beside the student's forward
 # pass on the main stream: three independent chains of launches, so one chain's latency-bound kernels (statistics
 # finalisation, stream-K fix-ups, 264-tiles-on-256-CUs tails) are covered by another chain's convolutions.  0 = one stream
 SIDE_STREAMS = os.environ.get("ONDA_SIDE_STREAMS", "1") != "0"
-# ... and their convolutions without the stream-K remainder (ops.plain_schedule), on the idea that the other streams fill a
-# short last round: measured WORSE (104.5 against 102.6 ms per step, A/B on one box) -- the balanced schedule keeps every
-# workgroup of a launch on the same K position (one weight slice shared in L2), a second round beside another stream's
-# kernel does not.  Off; the switch stays for measurements.
-SIDE_PLAIN = os.environ.get("ONDA_SIDE_PLAIN", "0") != "0"
+
+
+def _flat_int_buffers(module):
+    """Rebind the integer buffers of `module` (BatchNorm's 0-dim `num_batches_tracked`) as views of one flat tensor, values
+    kept; returns the flat tensor (None: no such buffers).  state_dict / load_state_dict / deepcopy see ordinary buffers."""
+    slots = [(m, name, b) for m in module.modules() for name, b in m._buffers.items()
+             if b is not None and not b.is_floating_point() and b.dim() == 0]
+    if not slots:
+        return None
+    owner = getattr(module, "_onda_int_flat", None)
+    if owner is not None and owner.numel() == len(slots) and all(b.data_ptr() == owner.data_ptr() + i * owner.element_size()
+                                                               for i, (_, _, b) in enumerate(slots)):
+        return owner
+    flat = torch.stack([b.detach().to(slots[0][2].dtype) for _, _, b in slots])
+    for i, (m, name, _) in enumerate(slots):
+        m._buffers[name] = flat[i]
+    module.__dict__["_onda_int_flat"] = flat
+    return flat
 
 
 def regular_loss(regularizer, activation):
@@ -452,7 +466,7 @@ class online_proDA(da_model):
             # main stream (busy with the student meanwhile) must not get its memory back before stream 1 has read it
             teacher_mask.record_stream(s1)
         t = {"image": image, "student_mask": student_mask}
-        with torch.no_grad(), ops.plain_schedule(SIDE_PLAIN):
+        with torch.no_grad():
             with torch.cuda.stream(s1):
                 t["pred"], prior_ema, t["conf_ema"], t["cls"] = self._forward_prior(self.ema_model, image, True, teacher_mask)
             with torch.cuda.stream(s2):
@@ -595,18 +609,18 @@ class online_proDA(da_model):
             # the walk over both module trees (~1 ms) and the table are kept between steps: this runs when the device has
             # nothing queued (right behind the optimizer launch), so its host time is idle device time
             pairs = [(k, q, keep, 1.0 - keep) for q, k in zip(self.model.parameters(), self.ema_model.parameters())]
-            ints_q, ints_k = [], []
             for bq, bk in zip(self.model.buffers(), self.ema_model.buffers()):
                 if bq.dtype == torch.float32:
                     pairs.append((bk, bq, 0.0, 1.0))
-                else:
-                    ints_q.append(bq)
-                    ints_k.append(bk)
-            plan = self.__dict__["_ema_plan"] = {"of": (self.model, self.ema_model, keep), "pairs": pairs, "ints_q": ints_q,
-                                                 "ints_k": ints_k, "cache": {}}
+            # the integer buffers (53 `num_batches_tracked` counters) of each model become views of ONE tensor, so that the
+            # teacher's copy of them is one device copy per step instead of 53 (each a 4 us launch at the end of the step,
+            # where nothing else is queued)
+            plan = self.__dict__["_ema_plan"] = {"of": (self.model, self.ema_model, keep), "pairs": pairs,
+                                                 "ints_q": _flat_int_buffers(self.model), "ints_k": _flat_int_buffers(self.ema_model),
+                                                 "cache": {}}
         ops.ema_multi(plan["pairs"], plan["cache"])
-        if plan["ints_k"]:
-            torch._foreach_copy_(plan["ints_k"], plan["ints_q"])
+        if plan["ints_k"] is not None and plan["ints_q"] is not None:
+            plan["ints_k"].copy_(plan["ints_q"])
 
     # -------------------------------------------------------------------------------------------------------- step
     def _source_replay(self, batches_source, scale=1.0, masks=None):

@@ -63,7 +63,6 @@ class HipBatchNorm2d(nn.BatchNorm2d):
         return new
 
 
-EVAL_LIMBS = os.environ.get("ONDA_EVAL_LIMBS", "1") != "0"  # measurement knob: 0 = fp32 eval outputs + split passes
 
 
 def conv_bn(conv, bn, x, relu, residual=None):
@@ -87,7 +86,7 @@ def conv_bn(conv, bn, x, relu, residual=None):
     with torch.no_grad():
         wp = conv._pack.get_fwd(conv.weight)
         limb_out = None
-        if EVAL_LIMBS and ops.limb_mode(conv.out_channels) and ops._use_l2(wp, x.shape[3]):
+        if ops.limb_mode(conv.out_channels) and ops._use_l2(wp, x.shape[3]):
             # the result feeds convolutions (and residual adds) only: written as limb planes by the conv epilogue itself,
             # scaled by an a-priori bound (ops.fold_bounds; cached per weight / statistics version)
             w = conv.weight
@@ -317,14 +316,6 @@ class ResNetMulti(nn.Module):
     def _stem(self, x):
         bn = self.bn1
         if bn.training:
-            first = ops.ROW_GROUPS
-            if 0 < first < x.shape[0] and ops.stem_patch_rows(x) > ops.STEM_MAX_ROWS:
-                # two row groups whose patch matrix together passes the kernels' 32-bit offsets (1024x2048, 4 + 4 images):
-                # the stem runs once per group -- the first with frozen running statistics, as the source pass has them --
-                # and the groups meet again behind the pool
-                with ops.row_groups(0):
-                    parts = [self._stem_train(x[:first], None), self._stem_train(x[first:], self._running(bn))]
-                return torch.cat(parts, 0)
             return self._stem_train(x, self._running(bn))
         return ops.MaxPoolFn.apply(ops.stem_eval(x, self.conv1.weight, self.conv1._pack, *bn.folded()))
 

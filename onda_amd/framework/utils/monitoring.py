@@ -15,7 +15,7 @@ import os
 import numpy as np
 import torch
 
-_SYNC_TRANSFERS = os.environ.get("ONDA_MONITOR_SYNC", "0") == "1"  # measurement knob: wait for every transfer at once
+_SYNC_TRANSFERS = False  # (tests: wait for every transfer at once)
 
 
 class _Series:

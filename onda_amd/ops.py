@@ -53,7 +53,7 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-_L2_KERNELS = ("conv_l2_kernel<4,2>", "conv_l2_kernel<2,2>", "conv_l2_kernel<4,1>", "conv_l2x_kernel<4,2>", "conv_l2p_kernel")
+_L2_KERNELS = ("conv_l2_kernel<4,2>", "conv_l2_kernel<2,2>", "conv_l2_kernel<4,1>", "conv_l2x_kernel<4,2>")
 
 
 def _l2_name(M, cout, taps, cin):
@@ -152,28 +152,7 @@ def predicates_supported():
 
 def _desc(B, Hi, Wi, Cin, Ho, Wo, Cout, k, stride, dil, pad, ldx, ldy, ldr=0, out_os=1, Hf=None, Wf=None, relu=0, split=0):
     return OndaConv(B, Hi, Wi, Cin, Ho, Wo, Cout, k, k, stride, dil, pad, ldx, ldy, ldr, out_os,
-                    Ho if Hf is None else Hf, Wo if Wf is None else Wf, int(relu), _p(PREDICATE), int(split), int(PLAIN_SCHEDULE))
-
-
-# ``with ops.plain_schedule():`` -- convolutions launched inside run one tile per workgroup without the stream-K remainder:
-# for passes that share the GPU with other streams' launches (the no-grad passes of an adaptation step, on side streams),
-# whose short last round of tiles is filled by those.
-PLAIN_SCHEDULE = False
-
-
-class plain_schedule:
-    def __init__(self, on=True):
-        self.on = bool(on)
-
-    def __enter__(self):
-        global PLAIN_SCHEDULE
-        self.old, PLAIN_SCHEDULE = PLAIN_SCHEDULE, self.on
-        return self
-
-    def __exit__(self, *exc):
-        global PLAIN_SCHEDULE
-        PLAIN_SCHEDULE = self.old
-        return False
+                    Ho if Hf is None else Hf, Wo if Wf is None else Wf, int(relu), _p(PREDICATE), int(split), 0)
 
 
 # Row groups: inside ``with ops.row_groups(n):`` the first n images of every batch that passes a train-mode BatchNorm are
@@ -365,7 +344,7 @@ def limb_mode(channels):
     return CONV_MODE == "f16x2" and channels % 32 == 0 and LIMB_ONLY
 
 
-LIMB_ONLY = os.environ.get("ONDA_LIMB_ONLY", "1") != "0"
+LIMB_ONLY = True  # (tests flip it to compare with fp32 outputs + split passes)
 
 
 def materialize(x):
@@ -522,7 +501,7 @@ def conv_forward(x, wp, k, stride, dil, pad, cout, out=None, scale=None, shift=N
         if split and not l2:
             raise RuntimeError("onda_amd: row groups (ops.row_groups) need the pre-split conv path")
         tile_rows = ctypes.c_int(0)
-        tiles = (query("onda_conv_l2_tiles_m_split", B * Ho * Wo, cout, k * k, Cin, split, int(PLAIN_SCHEDULE), byref(tile_rows)) if l2
+        tiles = (query("onda_conv_l2_tiles_m_split", B * Ho * Wo, cout, k * k, Cin, split, 0, byref(tile_rows)) if l2
                  else query("onda_conv_tiles_m", B * Ho * Wo))
         stats = torch.empty(tiles, stats_rows, cout, device=x.device, dtype=torch.float32)
         if l2:  # GEMM rows one partial row covers: depends on the kernel the problem runs on (the BatchNorm row groups need it)
@@ -855,14 +834,6 @@ def stem_patches(x_nchw, Ho, Wo, l2):
     return col
 
 
-STEM_MAX_ROWS = 0x7FFFF000 // (STEM_K * 4)  # rows of a patch matrix the kernels' 32-bit byte offsets reach (two f16 planes)
-
-
-def stem_patch_rows(x_nchw):
-    B, _, H, W = x_nchw.shape
-    return B * conv_out_size(H, 7, 2, 1, 3) * conv_out_size(W, 7, 2, 1, 3)
-
-
 def stem_prefetch(x_nchw):
     """Build (and cache on the tensor) the stem's patch matrix of an image batch now, on the current stream: several passes
     that read the same batch from different streams then all find it."""
@@ -1000,7 +971,6 @@ class BNTrainFn(torch.autograd.Function):
         return dx, None, None, None, dres, None, None, None
 
 
-RELU_BITMASK = os.environ.get("ONDA_RELU_BITMASK", "1") == "1"  # measurement knob: 0 = the backward reads out's first limb
 
 
 class BNTrainLimbFn(torch.autograd.Function):
@@ -1035,7 +1005,7 @@ class BNTrainLimbFn(torch.autograd.Function):
                 torch.autograd.graph.increment_version(t)
         planes = torch.empty(2, M, C, device=dev, dtype=torch.float16)
         # [out > 0] as one bit per element for the backward passes (they would read 2 bytes of `planes` per element instead)
-        mask = torch.empty(M * C // 8, device=dev, dtype=torch.uint8) if relu and RELU_BITMASK and any(ctx.needs_input_grad) else None
+        mask = torch.empty(M * C // 8, device=dev, dtype=torch.uint8) if relu and any(ctx.needs_input_grad) else None
         call("onda_bn_apply_l2", _p(y), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(res.planes) if res is not None else None,
              res.plane if res is not None else 0, _p(res.amax) if res is not None else None, _p(planes), M * C, _p(out_amax),
              M, C, int(relu), _p(mask), split, _stream())
@@ -1176,7 +1146,6 @@ class GNConcatFn(torch.autograd.Function):
         return (None, None, *dys, *dgs, *dbs)
 
 
-SE_LIMBS = os.environ.get("ONDA_SE_LIMBS", "1") != "0"  # measurement knob: 0 = the gated concat as fp32 + max pass + split pass
 
 
 class SEScaleFn(torch.autograd.Function):
@@ -1191,7 +1160,7 @@ class SEScaleFn(torch.autograd.Function):
         gate = torch.empty(B, C, device=x.device, dtype=torch.float32)
         call("onda_se_fc_fwd", _p(pooled), _p(w1), _p(b1), _p(w2), _p(b2), _p(hidden), _p(gate), B, C, R, _stream())
         slot = known_amax(x)
-        if SE_LIMBS and slot is not None and limb_mode(C) and x.is_contiguous():
+        if slot is not None and limb_mode(C) and x.is_contiguous():
             # the result feeds the bottleneck conv only: written as that conv's operand (limb planes scaled by max|x|, which
             # the sigmoid gate cannot raise) -- no fp32 copy, no max pass, no split pass over the 1280-channel buffer
             planes = torch.empty(2, B * H * W, C, device=x.device, dtype=torch.float16)
@@ -1394,7 +1363,6 @@ def gate_scalar(flag, v):
 
 # ------------------------------------------------------------------------------- multi-tensor
 _TABLE_STAGES = {}
-_TABLE_SYNC = os.environ.get("ONDA_TABLE_SYNC", "0") == "1"  # measurement knob: the old pageable (stream-draining) copy
 
 
 def _table(entries, struct, device):
@@ -1406,7 +1374,7 @@ def _table(entries, struct, device):
     raw = bytearray(bytes(arr))
     n = len(raw)
     host = torch.frombuffer(raw, dtype=torch.uint8)
-    if torch.device(device).type != "cuda" or _TABLE_SYNC:
+    if torch.device(device).type != "cuda":
         return host.to(device)
     ring = _TABLE_STAGES.setdefault(str(device), [])
     slot = None

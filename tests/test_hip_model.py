@@ -370,8 +370,9 @@ def test_bench_step_golden(golden, tmp_path, conv_mode):
 def test_full_resolution_step_golden(golden, tmp_path, conv_mode, batch, name):
     """One adaptation step at BASELINE config 5's resolution, 1024x2048 (feature grid 129x257): at batch 2 (fixture G13) and at
     batch 4 -- config 5's own batch, the one bench.py's config-5 line runs; the reference's CPU run of the batch-4 step takes
-    30 GB and eight minutes in the build container (make_golden.py::g13b).  At this size the student's two passes run one
-    after the other (PAIR_MAX_ROWS: the 2048-channel activations of 4 + 4 such images pass the kernels' 32-bit byte offsets)."""
+    30 GB and eight minutes in the build container (make_golden.py::g13b).  Since round 5 the student's two passes pair at
+    this size as well (4 + 4 images: layer4's 2048-channel limb rows are 2.17 GB -- the kernels address an operand through
+    per-tile windows, csrc/conv_l2.hip x_window)."""
     if conv_mode != "f16x2":
         pytest.skip("full-size step: default conv mode only (the small-size step runs in both)")
     _full_size_step_against(golden, tmp_path, name, 2048, 1024, batch, 40.0, seeds=(1300, 2300))
@@ -1100,8 +1101,8 @@ def test_train_loop_golden(golden, tmp_path):
     print("g14 worst relative deviations:", {k: round(v, 6) for k, v in sorted(worst.items(), key=lambda kv: -kv[1])[:8]})
 
 
-@pytest.mark.parametrize("b_src,b_trg,split_stem", [(2, 2, False), (2, 3, False), (3, 2, True)])
-def test_paired_student_pass_matches_the_two_passes(tmp_path, b_src, b_trg, split_stem):
+@pytest.mark.parametrize("b_src,b_trg", [(2, 2), (2, 3), (3, 2)])
+def test_paired_student_pass_matches_the_two_passes(tmp_path, b_src, b_trg):
     """The student's source-replay and target passes as ONE pass over both batches (row groups) against the same step with
     the two passes one after the other (ONDA_PAIR_STUDENT=0: the reference's order): same kernels, same batch statistics per
     group -- logs, prototypes, running statistics and the weight update agree to summation-order noise at step 0 (and the
@@ -1119,9 +1120,6 @@ def test_paired_student_pass_matches_the_two_passes(tmp_path, b_src, b_trg, spli
 
     def run(paired):
         old, pmod.PAIR_STUDENT = pmod.PAIR_STUDENT, paired
-        # (split_stem: the two groups' patch matrix counted as past the kernels' 32-bit offsets, as 4 + 4 images of 1024x2048
-        #  are: the stem then runs once per group and the groups meet behind the pool)
-        old_rows, ops.STEM_MAX_ROWS = ops.STEM_MAX_ROWS, (1 if split_stem else ops.STEM_MAX_ROWS)
         try:
             cfg, spec = hybrid_switch_cfg(256, 128, DEV, str(tmp_path), batch_size=2)
             model = get_model(cfg, 19)
@@ -1150,7 +1148,6 @@ def test_paired_student_pass_matches_the_two_passes(tmp_path, b_src, b_trg, spli
                 deeplabv2.drop_mask_fn = deeplabv2._default_drop_mask
         finally:
             pmod.PAIR_STUDENT = old
-            ops.STEM_MAX_ROWS = old_rows
 
     sa, la, pa = run(True)
     sb, lb, pb = run(False)
