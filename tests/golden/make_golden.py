@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Generate the golden vectors (G1-G14) by IMPORTING the reference on CPU.
+"""Generate the golden vectors (G1-G15) by IMPORTING the reference on CPU.
 
 Run in the build container only (the reference does not exist on the GPU box):
 
@@ -538,6 +538,67 @@ def g11():
 G14 = dict(head_scale=7.0, monitor=4, perc_fill=0.0009, np_seed=3, steps=3, val_frames=10, lr=2e-7)
 
 
+# ------------------------------------------------------------------------------------- G15
+G15 = {"warm_steps": 3, "warm_lr_div": 50.0, "threads": (8, 3)}
+
+
+def g15():
+    """ONE step at the yml's own learning rate from a WARM state -- three steps at a rate 50x lower (the rate G14 pins a whole
+    trajectory at) -- captured TWICE, with 8 and with 3 CPU threads: the distance between the two captures is the reference's
+    own noise floor for that step (torch's CPU convolutions sum in another order), and the HIP step is held to a small
+    multiple of it (tests/test_hip_model.py::test_step_at_the_yml_learning_rate_from_a_warm_state).  G7 pins a cold start
+    (step 0: 2 %, step 1: 60 %, both at the yml's rate on random weights); this brackets the step the trajectory tests
+    leave open -- the yml's rate on a state that several optimizer steps have already moved."""
+    import warnings
+    runs = {}
+    for threads in G15["threads"]:
+        torch.set_num_threads(threads)
+        with tempfile.TemporaryDirectory() as tmp:
+            cfg, spec = make_cfg(tmp)
+            lr = float(spec.LEARNING_RATE)
+            model = ref_model(1, 40.0)
+            da = hybrid_proDA(model, cfg, spec)
+            n = G15["warm_steps"] + 1
+            src = [synth_batch(2, 64, 128, seed=500 + i) for i in range(n)]
+            trg = [synth_batch(2, 64, 128, seed=600 + i) for i in range(n)]
+            torch.manual_seed(123)
+            da.update_dynamic()
+            switch_batch_statistics(da.model, False)
+            da.calculate_prototypes(src[:2])
+            switch_batch_statistics(da.model, True)
+            da.optimizer.zero_grad()
+            logs, states = [], []
+            for s_ in range(n):
+                da.cfg_spec.LEARNING_RATE = lr / G15["warm_lr_div"] if s_ < G15["warm_steps"] else lr
+                da.adjust_learning_rate(s_, 8)
+                if s_ == n - 1:
+                    states.append({k: v.detach().double().clone() for k, v in da.model.state_dict().items()})
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    log = da.step([src[s_]], trg[s_])
+                da.update_ema()
+                logs.append({k: v for k, v in tolog(log).items() if np.isscalar(v)})
+            states.append({k: v.detach().double().clone() for k, v in da.model.state_dict().items()})
+            runs[threads] = (logs, states, int(da.model_select.current))
+    torch.set_num_threads(8)
+    (logs_a, st_a, br_a), (logs_b, st_b, br_b) = runs[G15["threads"][0]], runs[G15["threads"][1]]
+    names = [k for k, v in st_a[0].items() if v.is_floating_point() and v.dim() > 0]
+    num = den = 0.0
+    upd_a, upd_b, pre = [], [], []
+    for k in names:
+        ua, ub = st_a[1][k] - st_a[0][k], st_b[1][k] - st_b[0][k]
+        num += float(((ua - ub) ** 2).sum())
+        den += float((ua ** 2).sum())
+        upd_a.append(digest(ua, 64))
+        upd_b.append(digest(ub, 64))
+        pre.append(digest(st_a[0][k], 64))
+    floor = (num / den) ** 0.5
+    print("g15: the reference against itself (8 vs 3 threads), last step's update, relative L2:", floor, "branches", br_a, br_b)
+    save("g15_warm_step", names=np.array(names), update_8=np.stack(upd_a), update_3=np.stack(upd_b), pre_8=np.stack(pre),
+         noise_floor=np.array(floor), logs_8=np.array(json.dumps(logs_a)), logs_3=np.array(json.dumps(logs_b)),
+         branch=np.array(br_a), cfg=np.array(json.dumps(G15)))
+
+
 def g14_config(cfg, spec):
     """The settings G14 adds to make_cfg's (shared with the tests that replay it: tests/test_oracle_golden.py,
     tests/test_hip_model.py): a 4-sample monitor window, so that the trend `dev_avg` -- zero until the window is full
@@ -648,6 +709,6 @@ def g14():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15"]
     for w in which:
         globals()[w]()

@@ -184,6 +184,47 @@ def test_g7_full_step(golden, tag, head_scale):
                 assert np.abs(mine[2:] - row[2:]).max() <= 1e-3 * max(np.abs(row[2:]).max(), 1e-6) + 1e-6, (s, who + k)
 
 
+def test_g15_yml_rate_step_from_a_warm_state(golden):
+    """G15: three steps at a rate 50x below the yml's, then one step at the yml's rate; the reference captured it with 8 and
+    with 3 threads.  The oracle's last update has to lie within 2x the reference's own 8-vs-3 distance of both captures."""
+    g = golden("g15_warm_step")
+    setup = json.loads(str(g["cfg"]))
+    n = setup["warm_steps"] + 1
+    sd = oracle_sd(1, 40.0)
+    src = [synth_batch(2, 64, 128, seed=500 + i) for i in range(n)]
+    trg = [synth_batch(2, 64, 128, seed=600 + i) for i in range(n)]
+    torch.manual_seed(123)
+    ad = OracleAdapter(sd, (torch.zeros(19, 256), torch.zeros(19, 256), torch.zeros(19)))
+    ad.refresh_dynamic()
+    ad.proto = ad.initial_prototypes(src[:2])
+    lr = ad.cfg["LEARNING_RATE"]
+    ref_logs = json.loads(str(g["logs_8"]))
+    for s in range(n):
+        ad.cfg["LEARNING_RATE"] = lr / setup["warm_lr_div"] if s < setup["warm_steps"] else lr
+        if s == n - 1:
+            before = {k: v.detach().double().clone() for k, v in ad.student.items()}
+        masks = tuple(model.draw_drop_mask(2) for _ in range(3))
+        log = ad.step(src[s], trg[s], masks)
+        ad.update_ema()
+        for k, v in ref_logs[s].items():
+            if k not in log:
+                continue
+            mine = log[k]
+            mine = mine.item() if isinstance(mine, torch.Tensor) else float(mine)
+            assert mine == pytest.approx(v, rel=5e-3 * 1.5 ** s, abs=2e-5) or ("pixel_num" in k and abs(mine - v) <= 2) or \
+                (("agreement" in k or "percentage" in k) and abs(mine - v) <= 2.01 / 306), (s, k, mine, v)  # (a pixel or two of 306 at a tie)
+    assert int(g["branch"]) == ad.switch.current
+    floor = float(g["noise_floor"])
+    for tag in ("update_8", "update_3"):
+        num = den = 0.0
+        for i, k in enumerate(list(g["names"])):
+            mine = digest(ad.student[k].detach().double() - before[k], 64)[2:]
+            row = g[tag][i][2:]
+            num += ((mine - row) ** 2).sum()
+            den += (row ** 2).sum()
+        assert (num / den) ** 0.5 <= 2.0 * floor, (tag, (num / den) ** 0.5, floor)
+
+
 G8 = {"online_static": ("online", dict(SWITCH_PRIOR_THRESH=1, STATIC_LAMBDA=1, DYNAMIC_LAMBDA=0), 40.0),
       "online_dynamic": ("online", dict(SWITCH_PRIOR_THRESH=0, STATIC_LAMBDA=0, DYNAMIC_LAMBDA=1), 40.0),
       "hswitch": ("hswitch", dict(SWITCH_PRIOR_THRESH=0.86, SOFT_TRANS=True), 9.0),

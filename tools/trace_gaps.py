@@ -1,6 +1,6 @@
 """Idle time between kernels, from a rocprofv3 --kernel-trace CSV: where the device waits for the host.
 
-    rocprofv3 --kernel-trace -d gpurun_out/trace -o t -- python3 bench.py --steps 6 --warmup 3 --no-eager ...
+    rocprofv3 --kernel-trace --output-format csv -d gpurun_out/trace -o t -- python3 bench.py --steps 6 --warmup 3 --no-eager ...
     python tools/trace_gaps.py gpurun_out/trace/**/t_kernel_trace.csv
 
 Steps are delimited by `sgd_multi_kernel` (one launch per adaptation step); the first `skip` steps are dropped.
