@@ -21,18 +21,22 @@ def read(path, scale):
 
 def main():
     out, cmd = sys.argv[1], sys.argv[sys.argv.index("--") + 1:]
-    hw = None
+    cands = []  # every amdgpu hwmon that reports power: a node may show several boards while the job runs on one of them
     for d in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")):
-        if os.path.exists(os.path.join(d, "power1_average")) or os.path.exists(os.path.join(d, "power1_input")):
-            hw = d
-            break
+        for f in ("power1_average", "power1_input"):
+            if os.path.exists(os.path.join(d, f)):
+                cands.append((d, os.path.join(d, f)))
+                break
     child = subprocess.Popen(cmd)
-    rows, t0 = [], time.time()
-    if hw:
-        pw = os.path.join(hw, "power1_average") if os.path.exists(os.path.join(hw, "power1_average")) else os.path.join(hw, "power1_input")
-        while child.poll() is None:
-            rows.append((time.time() - t0, read(pw, 1e6), read(os.path.join(hw, "power1_cap"), 1e6), read(os.path.join(hw, "freq1_input"), 1e6)))
-            time.sleep(0.02)
+    series, t0 = {d: [] for d, _ in cands}, time.time()
+    while cands and child.poll() is None:
+        now = time.time() - t0
+        for d, pw in cands:
+            series[d].append((now, read(pw, 1e6), read(os.path.join(d, "power1_cap"), 1e6), read(os.path.join(d, "freq1_input"), 1e6)))
+        time.sleep(0.02)
+    # the board the job ran on = the one that drew the most
+    hw = max(series, key=lambda d: max((r[1] for r in series[d]), default=0.0)) if series else None
+    rows = series[hw] if hw else []
     rc = child.wait()
     with open(out, "w") as f:
         f.write("# hwmon: %s\nseconds,power_w,cap_w,sclk_mhz\n" % hw)
