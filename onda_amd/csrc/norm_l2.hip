@@ -72,6 +72,33 @@ __device__ __forceinline__ void join8(const u32x4 l1, const u32x4 l2, f32x4& v0,
 
 #define LD4(p) (*reinterpret_cast<const f32x4*>(p))
 
+// Store the two limbs of this thread's 8 channels (l1 at `o`, l2 32 f16 further) as WHOLE cache lines.  Four consecutive
+// lanes own one 32-channel block = one 128-byte line [4 x l1 | 4 x l2]; stored as they stand, each of a lane's two stores
+// covers half of its line (the limb planes of rounds 2-4 wrote whole lines; the limb rows cost bn_bwd_apply 7 % this way).
+// So two neighbouring quads trade: the low quad's lanes store their own l1 and the HIGH quad's l1, the high quad's lanes the
+// LOW quad's l2 and their own -- store 1 = the low block's whole line, store 2 = the high block's.  `whole`: every lane of
+// the wave is in here with a valid item (wave-uniform); otherwise the plain two stores.
+__device__ __forceinline__ void store_limb_lines(_Float16* o, u32x4 l1, u32x4 l2, bool whole) {
+  if (!whole) {
+    *reinterpret_cast<u32x4*>(o) = l1;
+    *reinterpret_cast<u32x4*>(o + LIMB2_OFS) = l2;
+    return;
+  }
+  const bool hi = (threadIdx.x & 4) != 0;
+  const u32x4 send = hi ? l1 : l2;
+  u32x4 recv;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) recv[j] = (unsigned)__shfl_xor((int)send[j], 4, 64);
+  const unsigned long long mine = reinterpret_cast<unsigned long long>(o);
+  const unsigned long long partner = ((unsigned long long)(unsigned)__shfl_xor((int)(mine >> 32), 4, 64) << 32) |
+                                     (unsigned)__shfl_xor((int)(unsigned)mine, 4, 64);
+  _Float16* po = reinterpret_cast<_Float16*>(partner);
+  _Float16* a1 = hi ? po + LIMB2_OFS : o;   // store 1: the low quad's line
+  _Float16* a2 = hi ? o + LIMB2_OFS : po;   // store 2: the high quad's line
+  *reinterpret_cast<u32x4*>(a1) = hi ? recv : l1;
+  *reinterpret_cast<u32x4*>(a2) = hi ? l2 : recv;
+}
+
 // The big tensors of these passes are touched once per launch (8-20 bytes per element streamed through): with
 // ONDA_NT_BN their loads and stores carry the non-temporal hint, so that they do not cycle through the L2.
 // (A measurement switch: see DESIGN.md for what it measured.)
@@ -268,7 +295,7 @@ __global__ __launch_bounds__(256) void bn_apply_l2_kernel(const float* __restric
   // item e = 8 channels `col` of row e / c8; in limb rows: first limbs at limb_at(row, col, C), second limbs 32 f16 further
   const size_t lcol = limb_at(0, col, C);
   auto lofs = [&](size_t e) { return (size_t)((unsigned)e / (unsigned)c8) * 2 * (size_t)C + lcol; };  // (items < 2^32: 32-bit division)
-  auto one = [&](size_t e, f32x4 x0, f32x4 x1, u32x4 r1, u32x4 r2) {
+  auto one = [&](size_t e, f32x4 x0, f32x4 x1, u32x4 r1, u32x4 r2, bool whole) {
     const bool second = group1_at > 0 && e >= group1_at;
     f32x4 v0 = (x0 - (second ? nu0 : mu0)) * (second ? tc0 : sc0) + be0, v1 = (x1 - (second ? nu1 : mu1)) * (second ? tc1 : sc1) + be1;
     if (res) {
@@ -292,9 +319,7 @@ __global__ __launch_bounds__(256) void bn_apply_l2_kernel(const float* __restric
     }
     u32x4 l1, l2;
     split8(v0 * so, v1 * so, l1, l2);
-    _Float16* o = out + lofs(e);
-    st_stream(reinterpret_cast<u32x4*>(o), l1);
-    st_stream(reinterpret_cast<u32x4*>(o + LIMB2_OFS), l2);
+    store_limb_lines(out + lofs(e), l1, l2, whole);
   };
   size_t e = e0;
   // two independent items per iteration: all loads of both are issued before the first is used
@@ -308,8 +333,9 @@ __global__ __launch_bounds__(256) void bn_apply_l2_kernel(const float* __restric
       rb1 = ld_stream(reinterpret_cast<const u32x4*>(res + lofs(f)));
       rb2 = ld_stream(reinterpret_cast<const u32x4*>(res + lofs(f) + LIMB2_OFS));
     }
-    one(e, a0, a1, ra1, ra2);
-    one(f, b0, b1, rb1, rb2);
+    const bool whole = __ballot(1) == ~0ull;  // (the loop condition holds for every lane of this wave)
+    one(e, a0, a1, ra1, ra2, whole);
+    one(f, b0, b1, rb1, rb2, whole);
   }
   if (e < total8) {
     u32x4 r1 = {}, r2 = {};
@@ -317,7 +343,7 @@ __global__ __launch_bounds__(256) void bn_apply_l2_kernel(const float* __restric
       r1 = *reinterpret_cast<const u32x4*>(res + lofs(e));
       r2 = *reinterpret_cast<const u32x4*>(res + lofs(e) + LIMB2_OFS);
     }
-    one(e, LD4(x + e * 8), LD4(x + e * 8 + 4), r1, r2);
+    one(e, LD4(x + e * 8), LD4(x + e * 8 + 4), r1, r2, __ballot(1) == ~0ull);
   }
 }
 
@@ -487,9 +513,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_l2_kernel(const float* __res
     }
     u32x4 l1, l2;
     split8(v[0] * sd, v[1] * sd, l1, l2);
-    _Float16* o = dx + (size_t)((unsigned)e / (unsigned)c8) * 2 * (size_t)C + limb_at(0, col, C);
-    st_stream(reinterpret_cast<u32x4*>(o), l1);
-    st_stream(reinterpret_cast<u32x4*>(o + LIMB2_OFS), l2);
+    store_limb_lines(dx + (size_t)((unsigned)e / (unsigned)c8) * 2 * (size_t)C + limb_at(0, col, C), l1, l2, __ballot(1) == ~0ull);
   }
 }
 
