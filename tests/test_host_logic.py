@@ -400,3 +400,36 @@ def test_watch_ranks_kills_only_its_own_children():
     assert codes[1] == 5 and codes[0] not in (0, None)
     ok = [subprocess.Popen([sys.executable, "-c", "pass"]) for _ in range(2)]
     assert bench.watch_ranks(ok, poll_s=0.05) == [0, 0]
+
+
+def test_live_k_step_fractions_of_the_dilated_convolutions():
+    """bench.py's `pipe.executed_tflops` rests on onda_conv_l2_live_fraction / onda_conv_wgrad_l2_live_fraction (host
+    arithmetic that repeats the kernels' dead-tap tests): checked here against a direct count -- a filter tap of a tile is dead
+    when every output row the tile touches maps to an input row outside the image -- on the ASPP branches' shapes."""
+    from ctypes import byref
+    from onda_amd._lib import OndaConv, query
+
+    def desc(B, H, W, cin, cout, k, dil):
+        return OndaConv(B, H, W, cin, H, W, cout, k, k, 1, dil, dil * (k - 1) // 2, cin, cout, 0, 1, H, W, 0, None, 0, 0)
+
+    def direct(B, H, W, cout, dil, bm=256, resident=256):
+        M = B * H * W
+        tiles_m, tiles_n = -(-M // bm), -(-cout // 128)
+        tiles = tiles_m * tiles_n
+        rem = tiles % resident
+        dp = tiles - rem  # (the long K loops of these shapes always take the balanced schedule: the remainder runs every tap)
+        live_steps = rem * 9
+        for t in range(dp):
+            tm = t // tiles_n
+            r0, r1 = tm * bm // W, (min(M, tm * bm + bm) - 1) // W
+            live = sum(any(0 <= (r % H) + (tp // 3 - 1) * dil < H for r in range(r0, r1 + 1)) for tp in range(9))
+            live_steps += max(live, 1)
+        return live_steps / (tiles * 9)
+
+    assert query("onda_conv_l2_live_fraction", byref(desc(4, 65, 129, 512, 512, 1, 1)), 0) == 1.0
+    for dil in (6, 12, 18, 24):
+        got = query("onda_conv_l2_live_fraction", byref(desc(4, 65, 129, 2048, 256, 3, dil)), 0)
+        assert abs(got - direct(4, 65, 129, 256, dil)) < 1e-12, (dil, got)
+        assert 0.75 < got < 1.0
+        w = query("onda_conv_wgrad_l2_live_fraction", byref(desc(4, 65, 129, 2048, 256, 3, dil)), 7)
+        assert 0.7 < w < got  # (the weight gradient skips per 32-pixel step: finer than per 256-row tile)
