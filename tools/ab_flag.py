@@ -1,0 +1,10 @@
+"""A/B of a module-level flag on ONE box: run bench.py with `module.FLAG = value` set before main().
+    python tools/ab_flag.py onda_amd.ops LAZY_RES_MASK 0 -- --steps 20 --warmup 5 --no-eager ...   (value: a Python literal)"""
+import ast, importlib, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+mod, flag, val = sys.argv[1:4]
+setattr(importlib.import_module(mod), flag, ast.literal_eval(val))
+sys.argv = [os.path.join(ROOT, "bench.py")] + sys.argv[sys.argv.index("--") + 1:]
+import bench  # noqa: E402
+bench.main()
