@@ -265,6 +265,10 @@ int onda_gn_bwd(const float* dout, int lddo, const float* out, int ldo, const fl
 /* ---- MaxPool 3x3 s2 p1 ceil_mode (deeplabv2.py:289-291), NHWC; idx = winning window slot -- */
 int onda_maxpool_fwd(const float* x, float* y, uint8_t* idx, int B, int Hi, int Wi, int C, int Ho, int Wo,
                      onda_stream_t s);
+/* the same with the result written as limb rows yl[B*Ho*Wo][C/32][2][32] f16 (the operand format of the convolutions that
+ * read the pooled stem output; scale from xamax = max|x|, which a maximum over windows cannot pass): no fp32 copy, no split pass */
+int onda_maxpool_fwd_limbs(const float* x, const float* xamax, void* yl, uint8_t* idx, int B, int Hi, int Wi, int C, int Ho, int Wo,
+                           onda_stream_t s);
 int onda_maxpool_bwd(const float* dy, const uint8_t* idx, float* dx, int B, int Hi, int Wi, int C, int Ho, int Wo,
                      onda_stream_t s);
 

@@ -90,6 +90,7 @@ SIGNATURES = {
     "onda_gn_fwd": (I, [P, I, P, P, P, P, I, P, P, P, I, L, I, I, F, I, P, P]),
     "onda_gn_bwd": (I, [P, I, P, I, P, I, P, P, P, P, P, P, P, P, I, L, I, I, I, P]),
     "onda_maxpool_fwd": (I, [P, P, P, I, I, I, I, I, I, P]),
+    "onda_maxpool_fwd_limbs": (I, [P, P, P, P, I, I, I, I, I, I, P]),
     "onda_maxpool_bwd": (I, [P, P, P, I, I, I, I, I, I, P]),
     "onda_colsum_ws": (L, [I, L, I]),
     "onda_colsum": (I, [P, I, P, I, P, F, P, I, L, I, P]),

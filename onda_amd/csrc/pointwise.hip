@@ -7,10 +7,27 @@ namespace {
 #define LD4(p) (*reinterpret_cast<const f32x4*>(p))
 
 // ---- MaxPool 3x3 / s2 / p1 / ceil_mode, NHWC -------------------------------------------
+// yl != nullptr: the result goes out as LIMB ROWS (the operand format of the convolutions that read it, conv_l2.hip; scale from
+// `amax` = max|x|: a maximum over windows of x cannot pass it) instead of fp32 -- no fp32 copy, no split pass behind the pool
+typedef _Float16 mp_f16x2 __attribute__((ext_vector_type(2)));
+typedef float mp_f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned mp_u32x2 __attribute__((ext_vector_type(2)));
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                           uint8_t* __restrict__ idx, int B, int Hi, int Wi, int C,
-                                                          int Ho, int Wo) {
+                                                          int Ho, int Wo, _Float16* __restrict__ yl,
+                                                          const float* __restrict__ amax) {
   const int c4 = C / 4;
+  float so = 1.f;
+  if (yl != nullptr) {  // 2^e with max|x| * 2^e in [2^14, 2^15) (conv_h2.hip)
+    const float m = amax_read(amax);
+    int ex = 0;
+    if (m > 0.f && m < 3.0e38f) {
+      frexpf(m, &ex);
+      ex = 15 - ex;
+      ex = ex > 100 ? 100 : (ex < -100 ? -100 : ex);
+    }
+    so = ldexpf(1.f, ex);
+  }
   const size_t total = (size_t)B * Ho * Wo * c4;
   for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
     const int col = (int)(e % c4) * 4;
@@ -39,7 +56,22 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restric
         first = false;
       }
     }
-    *reinterpret_cast<f32x4*>(y + e * 4) = best;
+    if (yl != nullptr) {
+      const f32x4 w = best * so;
+      mp_u32x2 l1, l2;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const mp_f16x2 p = __builtin_convertvector(mp_f32x2{w[2 * h], w[2 * h + 1]}, mp_f16x2);
+        const mp_f32x2 f = __builtin_convertvector(p, mp_f32x2);
+        l1[h] = __builtin_bit_cast(unsigned, p);
+        l2[h] = __builtin_bit_cast(unsigned, __builtin_convertvector(mp_f32x2{(w[2 * h] - f[0]) * ONDA_LIMB2_SCALE, (w[2 * h + 1] - f[1]) * ONDA_LIMB2_SCALE}, mp_f16x2));
+      }
+      _Float16* o = yl + limb_at(e / c4, col, C);
+      *reinterpret_cast<mp_u32x2*>(o) = l1;
+      *reinterpret_cast<mp_u32x2*>(o + LIMB2_OFS) = l2;
+    } else {
+      *reinterpret_cast<f32x4*>(y + e * 4) = best;
+    }
     *reinterpret_cast<uint32_t*>(idx + e * 4) =
         (uint32_t)slot[0] | ((uint32_t)slot[1] << 8) | ((uint32_t)slot[2] << 16) | ((uint32_t)slot[3] << 24);
   }
@@ -470,7 +502,17 @@ int onda_maxpool_fwd(const float* x, float* y, uint8_t* idx, int B, int Hi, int 
   ONDA_REQUIRE(x && y && idx && C % 4 == 0);
   const size_t total = (size_t)B * Ho * Wo * (C / 4);
   hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(ew_grid(total)), dim3(256), 0, ONDA_STREAM(s), x, y, idx, B, Hi, Wi, C, Ho,
-                     Wo);
+                     Wo, static_cast<_Float16*>(nullptr), static_cast<const float*>(nullptr));
+  return ONDA_LAUNCH_RESULT();
+}
+
+int onda_maxpool_fwd_limbs(const float* x, const float* xamax, void* yl, uint8_t* idx, int B, int Hi, int Wi, int C, int Ho, int Wo,
+                           onda_stream_t s) {
+  ONDA_REQUIRE(x && xamax && yl && idx && C % 32 == 0);
+  if (!ONDA_ALIGNED16(yl)) return ONDA_EALIGN;
+  const size_t total = (size_t)B * Ho * Wo * (C / 4);
+  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(ew_grid(total)), dim3(256), 0, ONDA_STREAM(s), x, static_cast<float*>(nullptr), idx, B,
+                     Hi, Wi, C, Ho, Wo, static_cast<_Float16*>(yl), xamax);
   return ONDA_LAUNCH_RESULT();
 }
 

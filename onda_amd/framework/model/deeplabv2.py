@@ -317,7 +317,7 @@ class ResNetMulti(nn.Module):
         bn = self.bn1
         if bn.training:
             return self._stem_train(x, self._running(bn))
-        return ops.MaxPoolFn.apply(ops.stem_eval(x, self.conv1.weight, self.conv1._pack, *bn.folded()))
+        return ops.MaxPoolFn.apply(ops.stem_eval(x, self.conv1.weight, self.conv1._pack, *bn.folded()), True)
 
     @staticmethod
     def _running(bn):
@@ -327,7 +327,7 @@ class ResNetMulti(nn.Module):
         bn = self.bn1
         y, stats = ops.StemConvFn.apply(x, self.conv1.weight, self.conv1._pack, True)
         y = ops.BNTrainFn.apply(y, stats, bn.weight, bn.bias, None, True, running, bn.momentum)
-        return ops.MaxPoolFn.apply(y)
+        return ops.MaxPoolFn.apply(y, True)
 
     def forward(self, x):
         if x.dim() != 4 or x.shape[1] != 3:

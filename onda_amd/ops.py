@@ -1062,22 +1062,28 @@ def bn_eval_fold(gamma, beta, rm, rv):
 
 class MaxPoolFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, limbs=False):
         B, Hi, Wi, C = x.shape
         Ho, Wo = -(-(Hi - 1) // 2) + 1, -(-(Wi - 1) // 2) + 1  # k3 s2 p1 ceil_mode
         if (Ho - 1) * 2 - 1 >= Hi:
             Ho -= 1
         if (Wo - 1) * 2 - 1 >= Wi:
             Wo -= 1
-        y = torch.empty(B, Ho, Wo, C, device=x.device, dtype=torch.float32)
         idx = torch.empty(B, Ho, Wo, C, device=x.device, dtype=torch.uint8)
         x = x.contiguous()
-        call("onda_maxpool_fwd", _p(x), _p(y), _p(idx), B, Hi, Wi, C, Ho, Wo, _stream())
         slot = known_amax(x)
-        if slot is not None:  # a max over windows of x >= 0 (behind the stem's ReLU) cannot pass max|x|: no max pass over y
-            tag_amax(y, slot)
         ctx.save_for_backward(idx)
         ctx.in_shape = (B, Hi, Wi, C)
+        if limbs and slot is not None and limb_mode(C):
+            # the pooled stem output feeds convolutions only: written as their operand (limb rows scaled by max|x|, which a
+            # maximum over windows cannot pass) -- no fp32 copy, no split pass
+            planes = torch.empty(2, B * Ho * Wo, C, device=x.device, dtype=torch.float16)
+            call("onda_maxpool_fwd_limbs", _p(x), _p(slot), _p(planes), _p(idx), B, Hi, Wi, C, Ho, Wo, _stream())
+            return limb_only((B, Ho, Wo, C), x.device, Limbs(planes, slot, C, B * Ho * Wo * C))
+        y = torch.empty(B, Ho, Wo, C, device=x.device, dtype=torch.float32)
+        call("onda_maxpool_fwd", _p(x), _p(y), _p(idx), B, Hi, Wi, C, Ho, Wo, _stream())
+        if slot is not None:  # a max over windows of x >= 0 (behind the stem's ReLU) cannot pass max|x|: no max pass over y
+            tag_amax(y, slot)
         return y
 
     @staticmethod
@@ -1087,7 +1093,7 @@ class MaxPoolFn(torch.autograd.Function):
         dy = dy.contiguous()
         dx = torch.empty(B, Hi, Wi, C, device=dy.device, dtype=torch.float32)
         call("onda_maxpool_bwd", _p(dy), _p(idx), _p(dx), B, Hi, Wi, C, dy.shape[1], dy.shape[2], _stream())
-        return dx
+        return dx, None
 
 
 class GNConcatFn(torch.autograd.Function):

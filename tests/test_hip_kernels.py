@@ -518,6 +518,16 @@ def test_maxpool_ceil(H, W):
     assert torch.equal(nchw(y).cpu(), yr.detach())
     y.backward(nhwc(gy).to(DEV))
     assert torch.equal(nchw(xd.grad).cpu(), xr.grad)
+    # the same pool with its result written as limb rows (what the model uses behind the stem): values to the format's 22 bits,
+    # the same window choice (identical gradient)
+    if ops.limb_mode(64):
+        xl = nhwc(x).to(DEV).requires_grad_(True)
+        ops.activation_scale(xl)  # max|x| known, as behind BatchNorm + ReLU
+        yl = ops.MaxPoolFn.apply(xl, True)
+        assert ops.is_limb_only(yl)
+        close(nchw(ops.materialize(yl)), yr.detach(), 5e-7, "pool output as limb rows")
+        yl.backward(nhwc(gy).to(DEV))
+        assert torch.equal(nchw(xl.grad).cpu(), xr.grad)
 
 
 @pytest.mark.parametrize("known_scale", [False, True])
