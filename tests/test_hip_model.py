@@ -423,11 +423,8 @@ def _full_size_step_against(golden, tmp_path, name, width, height, batch, head_s
 
 
 def test_full_size_step_golden(golden, tmp_path, conv_mode):
-    """BASELINE config 3 on the STATIC side of the switch (head x40): 512x1024, batch 4 (fixture G10).
-    (ONDA_FULLSIZE_F32=1 runs it on the exact-fp32 kernels too: 4 s more; its measured deviations are in
-    profiles/r05_g10_exact_f32_mode.txt.)"""
-    if conv_mode != "f16x2" and os.environ.get("ONDA_FULLSIZE_F32") != "1":
-        pytest.skip("full-size step: default conv mode only (the small-size step runs in both)")
+    """BASELINE config 3 on the STATIC side of the switch (head x40): 512x1024, batch 4 (fixture G10) -- in BOTH conv modes
+    since round 5 (the exact-fp32 kernels take 4 s for it; measured deviations: profiles/r05_g10_exact_f32_mode.txt)."""
     _full_size_step_against(golden, tmp_path, "g10_step_full", 1024, 512, 4, 40.0)
 
 
