@@ -1091,3 +1091,27 @@ def test_predicated_convolutions_and_select():
         assert torch.equal(ops.select_prior(flag, b, 1.0, a, 2.0), 2.0 * a) and ops.gate_scalar(flag, a[0, 0]).item() == a[0, 0].item()
     finally:
         ops.CONV_MODE = old
+
+
+@pytest.mark.parametrize("K", [19, 22, 32])
+def test_upsample_ce_for_every_class_count_the_library_accepts(K):
+    """loss_calc(interp(logits), label) fused (onda_upsample_ce_fwd / _bwd) against torch: value and gradient, for the
+    19 classes of the network, and for 22 and 32 -- the backward's row pass needs more than the default 64 KB of dynamic LDS from
+    22 classes on (round-4 advisor: such a model trained forward and died in backward)."""
+    from onda_amd import ops
+    g = torch.Generator().manual_seed(K)
+    B, h, w, H, W = 2, 17, 33, 65, 129
+    logits = torch.randn(B, K, h, w, generator=g) * 2
+    labels = torch.randint(0, K, (B, H, W), generator=g)
+    labels[0, :5] = 255
+    lr = logits.clone().requires_grad_(True)
+    up = F.interpolate(lr, size=(H, W), mode="bilinear", align_corners=True)
+    ref = F.cross_entropy(up, labels, ignore_index=255)
+    ref.backward()
+    ld = torch.zeros(B, h, w, ops.HEAD_PAD, device=DEV)
+    ld[..., :K] = logits.permute(0, 2, 3, 1).to(DEV)
+    out = ld[..., :K].permute(0, 3, 1, 2).requires_grad_(True)  # pixel-major NCHW view, as the model returns its logits
+    loss = ops.upsample_ce(out, labels.to(DEV))
+    loss.backward()
+    assert abs(float(loss.detach()) - float(ref.detach())) <= 1e-5 * abs(float(ref.detach()))
+    close(out.grad, lr.grad, 2e-4, f"d loss / d logits, K = {K}")
