@@ -433,3 +433,32 @@ def test_live_k_step_fractions_of_the_dilated_convolutions():
         assert 0.75 < got < 1.0
         w = query("onda_conv_wgrad_l2_live_fraction", byref(desc(4, 65, 129, 2048, 256, 3, dil)), 7)
         assert 0.7 < w < got  # (the weight gradient skips per 32-pixel step: finer than per 256-row tile)
+
+
+def test_limb_row_format_round_trip_on_the_host():
+    """The operand format of the pre-split kernels as include/onda_hip.h documents it -- element (row r, channel c): first limb
+    at f16 index r * 2 * ld + (c / 32) * 64 + c % 32, second limb 32 further, both of x * 2^e with max|x| * 2^e in [2^14, 2^15),
+    the second one times 2^11 -- written out with numpy and decoded by ops.materialize (the decoder the GPU tests read the
+    kernels' output with): 22 significant bits back."""
+    import numpy as np
+    from onda_amd import ops
+    rng = np.random.default_rng(5)
+    B, H, W, C = 2, 3, 5, 96
+    x = (rng.standard_normal((B, H, W, C)) * np.exp(rng.standard_normal((B, H, W, C)) * 3)).astype(np.float32)
+    amax = np.abs(x).max()
+    e = 15 - int(np.frexp(amax)[1])
+    xs = x.astype(np.float64) * 2.0 ** e
+    l1 = xs.astype(np.float16)
+    l2 = ((xs - l1.astype(np.float64)) * 2048.0).astype(np.float16)
+    rows, ld = B * H * W, C
+    flat = np.zeros(rows * 2 * ld, dtype=np.float16)
+    r, c = np.meshgrid(np.arange(rows), np.arange(C), indexing="ij")
+    at = r * 2 * ld + (c // 32) * 64 + c % 32
+    flat[at.ravel()] = l1.reshape(rows, C).ravel()
+    flat[at.ravel() + 32] = l2.reshape(rows, C).ravel()
+    slot = torch.zeros(ops.AMAX_SLOTS)
+    slot[0] = float(amax)
+    t = ops.limb_only((B, H, W, C), "cpu", ops.Limbs(torch.from_numpy(flat), slot, ld, rows * ld))
+    back = ops.materialize(t).numpy()
+    assert np.abs(back - x).max() <= 2.0 ** -21 * amax  # (two 11-bit limbs below the maximum's exponent)
+    assert np.abs(back - x).max() > 0                    # ... and not a pass-through of fp32 values
