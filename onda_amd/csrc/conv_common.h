@@ -44,6 +44,10 @@ struct WgradK {
   int M, lddy, splitk, mchunk, tilesN, tilesC, taps;
   long long x_total = 0, dy_total = 0;  // bytes of the operands: a workgroup addresses them relative to its pixel range's start
   unsigned long long* stamps = nullptr;  // diagnostics (onda_debug_stamps, tools/wgrad_stamps.py): [8] s_memtime per workgroup
+  // [taps][pix_stride] input pixel ((b*Hi + hi)*Wi + wi, or -1 in the padding) of output pixel m under each tap: a table per
+  // convolution geometry, built once by the library (csrc/conv_l2.hip, wgrad_pixel_table)
+  const int* pix = nullptr;
+  long long pix_stride = 0;
 };
 
 constexpr int BK = 32;

@@ -20,6 +20,10 @@
 // function of the row (swz8) on the DMA's source side and in the fragment read: conflict-free ds_read_b128.
 #include "conv_common.h"
 
+#include <map>
+#include <mutex>
+#include <tuple>
+
 namespace {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -28,6 +32,7 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 // Order of a 4 x 4 grid of MFMAs: a snake -- row i runs left to right, row i + 1 right to left -- so that consecutive
 // instructions differ in ONE operand fragment only.  These loops run against the chip's power management:
@@ -1281,7 +1286,7 @@ __device__ __forceinline__ void lds_wait(f16x8& a, f16x8& b, f16x8& c_, f16x8& d
   asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c_), "+v"(d));
 }
 
-template <int WM, int WN, int STAGES, int OCC>
+template <int WM, int WN, int STAGES, int OCC, int MODE = 0>
 __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_wgrad_l2_kernel(const WgradK a, unsigned xplane, unsigned dyplane, unsigned x_bytes,
                                                                          unsigned dy_bytes, const float* __restrict__ xamax,
                                                                          const float* __restrict__ dyamax) {
@@ -1330,7 +1335,9 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_wgrad_l2_kernel(const 
   constexpr unsigned PAST = 0x7FFFF000u;  // an offset at or behind the end of any window, that OOB + PAST does not wrap
   const int b_first = mbeg / (c.Ho * c.Wo);
   const long long x_at = (long long)b_first * c.Hi * c.Wi * c.ldx * 4, dy_at = (long long)mbeg * a.lddy * 4;
-  const long long x_left = a.x_total - x_at, dy_left = a.dy_total - dy_at;
+  const long long x_left = a.x_total - x_at;
+  // (MODE 1: the dy window ends with the pixel range -- rows past it read as zeros, no per-pixel test)
+  const long long dy_left = MODE == 1 ? (long long)(mend - mbeg) * a.lddy * 4 : a.dy_total - dy_at;
   const __amdgpu_buffer_rsrc_t rx = make_rsrc(reinterpret_cast<const char*>(a.x) + x_at, (unsigned)(x_left < PAST ? (x_left > 0 ? x_left : 0) : PAST));
   const __amdgpu_buffer_rsrc_t rdy = make_rsrc(reinterpret_cast<const char*>(a.dy) + dy_at, (unsigned)(dy_left < PAST ? (dy_left > 0 ? dy_left : 0) : PAST));
   const Scale2 sx = scale_of(xamax), sd = scale_of(dyamax);
@@ -1537,8 +1544,10 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_wgrad_l2_kernel(const 
   };
   constexpr int AHEAD = STAGES >= 3 ? 2 : 1;  // (two-stage ring: two workgroups per CU cover each other's waits)
   static_assert(!STAGGER || STAGES >= 3, "the staggered halves need two steps in flight");
-  if (i_iss < nlive) issue_next();
-  if (AHEAD == 2 && i_iss < nlive) issue_next();
+  if constexpr (MODE == 0) {
+    if (i_iss < nlive) issue_next();
+    if (AHEAD == 2 && i_iss < nlive) issue_next();
+  }
   f16x8 af[4][2], bf[4], b1[4];
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
   unsigned base;
@@ -1584,7 +1593,129 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_wgrad_l2_kernel(const 
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) acc[i][ZZ(i, jj)] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][0], b1[ZZ(i, jj)], acc[i][ZZ(i, jj)], 0, 0, 0);
   };
-  if constexpr (!STAGGER) {
+  if constexpr (MODE >= 1) {
+    // MODE 1 / 2: the prepare slot holds the fragment reads only; a step's pixel offsets and all of its DMAs are issued from
+    // the compute slot, behind the first 16 MFMAs.  The late half runs one step further ahead than the early one (its
+    // compute slot is the slot in which the stage it refills has just been read for the last time -- by itself), so every
+    // DMA has at least two slots of flight.  The pixel offsets must cost next to nothing there (branchy index arithmetic
+    // among the MFMAs lost, see above): MODE 1 is the 1 x 1 stride-1 convolution (x pixel = output pixel), MODE 2 reads
+    // the wave's four input pixels of a step from the geometry's table (a.pix) with ONE scalar load, issued a step early.
+    static_assert(STAGGER && GPW == 1 && STAGES == 3, "the eight-wave tile");
+    const unsigned lddy4 = (unsigned)a.lddy * 4u, ldx4 = (unsigned)c.ldx * 4u;
+    unsigned dy_lane[2], x_lane[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const unsigned pix = (unsigned)(wave * 4 + 2 * lam + h);
+      dy_lane[h] = pix * lddy4;
+      x_lane[h] = (pix + (unsigned)(mbeg - b_first * c.Ho * c.Wo)) * ldx4;
+    }
+    const int base_px = b_first * c.Hi * c.Wi;  // first pixel of the x window
+    const i32x4* tab = MODE == 2 ? reinterpret_cast<const i32x4*>(a.pix + (size_t)tap * a.pix_stride + mbeg + wave * 4) : nullptr;
+    i32x4 t_next = {-1, -1, -1, -1};
+    // Every slot issues: behind the last live step the offsets get `kill` added (out of range: the DMA writes zeros into a
+    // stage nobody reads any more), so that the ring's waits are the same constant everywhere and the loop body is ONE basic
+    // block -- which is what lets the offsets and the DMA issue be interleaved with the MFMAs below.
+    auto offsets = [&](int kt, const i32x4& te, unsigned kill) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        pdy_s[0][h] = (unsigned)kt * 32u * lddy4 + dy_lane[h] + kill;
+        if constexpr (MODE == 1) {
+          px_s[0][h] = (unsigned)kt * 32u * ldx4 + x_lane[h] + kill;
+        } else {
+          const int lo = te[h], hi = te[2 + h];
+          const int e = lam ? hi : lo;
+          px_s[0][h] = (e >= 0 ? __umul24((unsigned)(e - base_px), ldx4) : PAST) + kill;  // (a window is < 2^24 pixels, a row < 2^24 bytes)
+        }
+      }
+    };
+    auto issue_dmas = [&]() {
+      stage_s = st_issue;
+      issue_part(0);
+      issue_part(1);
+      st_issue = st_issue + STAGE == STAGES * STAGE ? 0 : st_issue + STAGE;
+      ++i_iss;
+    };
+    // (a SCALAR load, in assembly: the compiler makes the table read a vector load, which would sit in the vmcnt queue that
+    //  the ring's waits count; scalar loads return through lgkmcnt, which every prepare slot drains anyway.  The value is
+    //  valid behind the next entry_wait only.)
+    const unsigned long long tab_u = reinterpret_cast<unsigned long long>(tab);
+    const unsigned tab_lo = __builtin_amdgcn_readfirstlane((unsigned)tab_u), tab_hi = __builtin_amdgcn_readfirstlane((unsigned)(tab_u >> 32));
+    auto entry = [&](int kt) -> i32x4 {
+      i32x4 r = {0, 0, 0, 0};
+      if constexpr (MODE == 2) {
+        const unsigned long long p = (((unsigned long long)tab_hi << 32) | tab_lo) + (unsigned long long)(unsigned)kt * 128ull;
+        asm volatile("s_load_dwordx4 %0, %1, 0x0" : "=s"(r) : "s"(p));
+      }
+      return r;
+    };
+    auto entry_wait = [&](i32x4& r) {
+      if constexpr (MODE == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(r));
+    };
+    const int n_pre = late ? 3 : 2;
+    if (nlive > 0) {  // (a workgroup whose pixel range is empty or all padding stores a slab of zeros)
+      for (int j = 0; j < n_pre; ++j) {
+        const int kt = live_at(j < nlive ? j : 0);
+        i32x4 te = entry(kt);
+        entry_wait(te);
+        offsets(kt, te, j < nlive ? 0u : PAST);
+        issue_dmas();
+      }
+      int kt_next = live_at(i_iss < nlive ? i_iss : 0);
+      t_next = entry(kt_next);
+      entry_wait(t_next);
+      if (late) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DPW) : "memory");
+        __builtin_amdgcn_s_barrier();
+      }
+      for (; i_cur < nlive; ++i_cur) {
+        if (!late) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPW) : "memory");
+        __builtin_amdgcn_s_barrier();
+        // the step this wave issues in its NEXT compute slot: its index from the live list now (an LDS read among the fragment
+        // reads), its table entry by a scalar load that has a whole slot to arrive
+        const unsigned short ktv = live_list[i_iss + 1 < nlive ? i_iss + 1 : 0];
+        prepare();
+        prepared();
+        const int kt_after = __builtin_amdgcn_readfirstlane((int)ktv);
+        i32x4 t_after = entry(kt_after);
+        if (late) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPW) : "memory");
+        __builtin_amdgcn_s_barrier();
+        offsets(kt_next, t_next, i_iss < nlive ? 0u : PAST);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) accx[i][ZZ(i, jj)] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][0], bf[ZZ(i, jj)], accx[i][ZZ(i, jj)], 0, 0, 0);
+        issue_dmas();
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) accx[i][ZZ(i, jj)] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][1], b1[ZZ(i, jj)], accx[i][ZZ(i, jj)], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) acc[i][ZZ(i, jj)] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][0], b1[ZZ(i, jj)], acc[i][ZZ(i, jj)], 0, 0, 0);
+        // the order the scheduler is asked for: the offsets' VALU two per MFMA under the first 16, then one DMA (its m0, its
+        // address add) per two MFMAs, then the rest of the MFMAs
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < DPW; ++q) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x006, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 48 - 16 - 2 * DPW, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        entry_wait(t_after);  // (issued a slot ago: nothing to wait for)
+        kt_next = kt_after;
+        t_next = t_after;
+      }
+      if (!late) __builtin_amdgcn_s_barrier();
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the zero-fill DMAs behind the last step: the slab store reuses the ring)
+    }
+  } else if constexpr (!STAGGER) {
     for (; i_cur < nlive; ++i_cur) {
       wait_landed(AHEAD == 2 && i_cur + 1 < nlive);
       __builtin_amdgcn_s_barrier();
@@ -1954,6 +2085,75 @@ int onda_conv_wgrad_l2_variant(int Cout, int Cin) {
   return Cout >= 256 ? 0 : 1;
 }
 
+}  // extern "C"
+
+namespace {
+// Input pixel of every (tap, output pixel) of a convolution geometry: what the weight-gradient kernel's compute slot reads
+// instead of working it out (conv_wgrad_l2_kernel, MODE 2).  [taps][stride] int32, -1 in the padding and behind the last
+// pixel.  One table per (device, geometry), built on first use on the caller's stream (the call waits for it, once), for at
+// least the batch asked for; a larger batch later builds a larger table and the old one stays allocated (launches on other
+// streams may still read it).  Independent of the batch otherwise: a prefix of a larger batch's table is the smaller one's.
+__global__ __launch_bounds__(256) void wgrad_pixel_table_kernel(int* __restrict__ t, long long stride, int B, int Hi, int Wi, int Ho,
+                                                               int Wo, int kw, int cstride, int dil, int pad) {
+  const long long M = (long long)B * Ho * Wo;
+  const int tap = blockIdx.y, rr = tap / kw, ss = tap - rr * kw;
+  for (long long m = (long long)blockIdx.x * 256 + threadIdx.x; m < stride; m += (long long)gridDim.x * 256) {
+    int v = -1;
+    if (m < M) {
+      const int wo = (int)(m % Wo);
+      const long long q = m / Wo;
+      const int ho = (int)(q % Ho), b = (int)(q / Ho);
+      const int hi = ho * cstride + rr * dil - pad, wi = wo * cstride + ss * dil - pad;
+      if ((unsigned)hi < (unsigned)Hi && (unsigned)wi < (unsigned)Wi) v = (b * Hi + hi) * Wi + wi;
+    }
+    t[(size_t)tap * stride + m] = v;
+  }
+}
+struct PixKey {
+  int dev, Hi, Wi, Ho, Wo, kh, kw, stride, dil, pad;
+  bool operator<(const PixKey& o) const {
+    return std::tie(dev, Hi, Wi, Ho, Wo, kh, kw, stride, dil, pad) < std::tie(o.dev, o.Hi, o.Wi, o.Ho, o.Wo, o.kh, o.kw, o.stride, o.dil, o.pad);
+  }
+};
+struct PixTable {
+  int* p;
+  int B;
+  long long stride;
+};
+std::map<PixKey, PixTable> g_pix;
+std::mutex g_pix_mu;
+
+bool wgrad_pixel_table(const OndaConv& c, hipStream_t st, const int** p, long long* stride) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return false;
+  const PixKey key{dev, c.Hi, c.Wi, c.Ho, c.Wo, c.kh, c.kw, c.stride, c.dil, c.pad};
+  std::lock_guard<std::mutex> lock(g_pix_mu);
+  auto it = g_pix.find(key);
+  if (it == g_pix.end() || it->second.B < c.B) {
+    const long long M = (long long)c.B * c.Ho * c.Wo;
+    if ((long long)c.B * c.Hi * c.Wi >= (1ll << 31)) return false;
+    PixTable t;
+    t.B = c.B;
+    t.stride = (M + 31) / 32 * 32 + 64;  // (a workgroup's last K-step may reach past M)
+    const int taps = c.kh * c.kw;
+    if (hipMalloc(reinterpret_cast<void**>(&t.p), (size_t)taps * t.stride * sizeof(int)) != hipSuccess) {
+      (void)hipGetLastError();
+      return false;
+    }
+    hipLaunchKernelGGL(wgrad_pixel_table_kernel, dim3(512, taps), dim3(256), 0, st, t.p, t.stride, c.B, c.Hi, c.Wi, c.Ho, c.Wo, c.kw,
+                       c.stride, c.dil, c.pad);
+    if (hipStreamSynchronize(st) != hipSuccess) return false;  // once per geometry: other streams may use the table from here on
+    g_pix[key] = t;
+    it = g_pix.find(key);
+  }
+  *p = it->second.p;
+  *stride = it->second.stride;
+  return true;
+}
+}  // namespace
+
+extern "C" {
+
 int onda_conv2d_wgrad_l2(const void* xl, int64_t xplane, const float* xamax, const void* dyl, int64_t dyplane, const float* dyamax,
                          float* slabs, int lddy, int splitk, const OndaConv* c, onda_stream_t s) {
   ONDA_REQUIRE(xl && dyl && xamax && dyamax && slabs && c && splitk >= 1);
@@ -1986,7 +2186,13 @@ int onda_conv2d_wgrad_l2(const void* xl, int64_t xplane, const float* xamax, con
   k.tilesC = (c->Cin + 127) / 128;
   const unsigned grid = (unsigned)(k.tilesN * k.tilesC * k.taps * splitk);
   const unsigned xpl = 0, dypl = 0;
-  if (variant == 0)
+  static const int mode = getenv("ONDA_WGRAD_MODE") ? atoi(getenv("ONDA_WGRAD_MODE")) : 1;
+  const bool linear = c->kh == 1 && c->kw == 1 && c->stride == 1 && c->pad == 0 && c->Hi == c->Ho && c->Wi == c->Wo;
+  if (variant == 0 && mode == 1 && linear)
+    hipLaunchKernelGGL((conv_wgrad_l2_kernel<4, 2, 3, 2, 1>), dim3(grid), dim3(512), 0, ONDA_STREAM(s), k, xpl, dypl, 0u, 0u, xamax, dyamax);
+  else if (variant == 0 && mode == 1 && wgrad_pixel_table(*c, ONDA_STREAM(s), &k.pix, &k.pix_stride))
+    hipLaunchKernelGGL((conv_wgrad_l2_kernel<4, 2, 3, 2, 2>), dim3(grid), dim3(512), 0, ONDA_STREAM(s), k, xpl, dypl, 0u, 0u, xamax, dyamax);
+  else if (variant == 0)
     hipLaunchKernelGGL((conv_wgrad_l2_kernel<4, 2, 3, 2>), dim3(grid), dim3(512), 0, ONDA_STREAM(s), k, xpl, dypl, 0u, 0u, xamax, dyamax);
   else
     hipLaunchKernelGGL((conv_wgrad_l2_kernel<2, 2, 2, 2>), dim3(grid), dim3(256), 0, ONDA_STREAM(s), k, xpl, dypl, 0u, 0u, xamax, dyamax);

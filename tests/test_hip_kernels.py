@@ -91,6 +91,27 @@ def test_conv_full_size_against_torch_cpu(case):
     close(wd.grad, wr.grad, 1e-4, "wgrad")
 
 
+def test_weight_gradient_pixel_table_across_batch_sizes():
+    """The 256-output-channel weight-gradient kernel reads its input pixels from a per-geometry table the library builds on
+    first use (csrc/conv_l2.hip, wgrad_pixel_table): the same geometry at batch 1, then 3 (a larger table replaces it), then
+    2 (a prefix of the larger one), dilated 3 x 3 and a stride-2 1 x 1, each against fp32 torch on the CPU."""
+    from onda_amd import ops
+    for (cin, cout, k, stride, dil, pad, H, W) in [(256, 256, 3, 1, 2, 2, 11, 19), (256, 512, 1, 2, 1, 0, 11, 19)]:
+        for B in (1, 3, 2):
+            g = torch.Generator().manual_seed(100 * B + k)
+            x = torch.randn(B, cin, H, W, generator=g)
+            w = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+            wr = w.clone().requires_grad_(True)
+            yr = F.conv2d(x, wr, None, stride, pad, dil)
+            gy = torch.randn(yr.shape, generator=g)
+            yr.backward(gy)
+            xd = nhwc(x).to(DEV).requires_grad_(True)
+            wd = w.to(DEV).requires_grad_(True)
+            y, _ = ops.Conv2dFn.apply(xd, wd, None, ops._PackCache(), stride, dil, pad, True, None)
+            y.backward(nhwc(gy).to(DEV))
+            close(wd.grad, wr.grad, 5e-5, f"wgrad k={k} stride={stride} B={B}")
+
+
 @pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "x".join(map(str, c[:6])))
 def test_conv_fwd_bwd(case, conv_mode):
     from onda_amd import ops
