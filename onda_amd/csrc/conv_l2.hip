@@ -532,7 +532,7 @@ __device__ __forceinline__ void l2_epilogue_limbs(const ConvK& a, const f32x4 (&
 }
 
 // ---- forward / data gradient ------------------------------------------------------------------------------------------
-template <int WM, int WN, int STAGES, int OCC, bool SK, int DBG = 0, bool CI = false>
+template <int WM, int WN, int STAGES, int OCC, bool SK, int DBG = 0>
 __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_l2_kernel(const ConvK a, unsigned xplane, unsigned wplane, unsigned x_bytes,
                                                                    unsigned w_bytes, const float* __restrict__ xamax,
                                                                    const float* __restrict__ wamax) {
@@ -672,15 +672,13 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_l2_kernel(const ConvK 
     set_tap(tap_i);
     int st_issue = 0, st_read = 0;  // byte offsets of the ring stages
     const int nsteps = dp && a.taps > 1 && a.skip_dead_taps ? __builtin_popcount(live & ((1u << a.taps) - 1u)) * a.kcper : k_end - k_begin;
-    if constexpr (!CI) {
+    issue(st_issue);
+    st_issue += STAGE;
+    if (AHEAD == 2 && nsteps > 1) {
       issue(st_issue);
       st_issue += STAGE;
-      if (AHEAD == 2 && nsteps > 1) {
-        issue(st_issue);
-        st_issue += STAGE;
-      }
-      if (st_issue == STAGES * STAGE) st_issue = 0;
     }
+    if (st_issue == STAGES * STAGE) st_issue = 0;
     stamp(tk_setup);
     auto wait_landed = [&](bool more_in_flight) {  // this wave's DMAs of a step have landed; those of the step after may still fly
       if (DBG == 1) return;
@@ -746,86 +744,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_l2_kernel(const ConvK 
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) acc[i][ZZ(i, jj)] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][0], b1[ZZ(i, jj)], acc[i][ZZ(i, jj)], 0, 0, 0);
     };
-    if constexpr (CI) {
-      // Compute-slot issue (the weight-gradient kernel's MODE 1 / 2 below, where it was measured first): the prepare slot
-      // holds the fragment reads only; a step's six DMAs are issued from the COMPUTE slot, one per two MFMAs behind the
-      // first 16.  The late half runs one step further ahead than the early one (in its compute slot the stage it refills
-      // has just been read for the last time, by itself), so every DMA has two slots of flight or more.  Every slot issues:
-      // behind the tile's last step the offsets are out of range (zeros into a stage nobody reads any more), so the ring's
-      // waits are one constant and the loop body one basic block.  The K position advances (a tap switch now and then:
-      // four row offsets with their bounds tests) at the end of the slot, behind the MFMAs.
-      static_assert(STAGGER && STAGES == 3 && DBG == 0, "the eight-wave tile");
-      auto issue_dmas = [&](bool real) {
-#if defined(__HIP_DEVICE_COMPILE__)
-        const int sa = c0_i * 4;
-        const int sb = (tap_i * c.Cin + c0_i) * 4;
-#pragma unroll
-        for (int d = 0; d < APW; ++d) {
-          unsigned char* dst = lds + st_issue + (wave * APW + d) * 1024;
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)dst, 16, real ? aofs[d] : OOB, sa, 0, 0);
-        }
-#pragma unroll
-        for (int d = 0; d < BPW; ++d) {
-          unsigned char* dst = lds + st_issue + A_BYTES + (wave * BPW + d) * 1024;
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)dst, 16, real ? bofs[d] : OOB, sb, 0, 0);
-        }
-#else
-        (void)real;
-#endif
-        st_issue = st_issue + STAGE == STAGES * STAGE ? 0 : st_issue + STAGE;
-      };
-      auto advance = [&]() {
-        c0_i += BK;
-        if (c0_i == c.Cin) {
-          c0_i = 0;
-          tap_i = next_live_tap(tap_i + 1);
-          if (tap_i < a.taps) set_tap(tap_i);
-        }
-      };
-      const int n_pre = late ? 3 : 2;
-      for (int j = 0; j < n_pre; ++j) {
-        issue_dmas(j < nsteps);
-        advance();
-      }
-      if (late) {
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DPW) : "memory");
-        __builtin_amdgcn_s_barrier();
-      }
-      for (int kt = 0; kt < nsteps; ++kt) {
-        if (!late) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPW) : "memory");
-        __builtin_amdgcn_s_barrier();
-        prepare();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the stage is read before anybody may refill it
-        if (late) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPW) : "memory");
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);  // (the MFMAs belong behind the barrier: the slots are what staggers the halves)
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int jj = 0; jj < 4; ++jj) accx[i][ZZ(i, jj)] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][0], bf[ZZ(i, jj)], accx[i][ZZ(i, jj)], 0, 0, 0);
-        issue_dmas(kt + n_pre < nsteps);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int jj = 0; jj < 4; ++jj) accx[i][ZZ(i, jj)] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][1], b1[ZZ(i, jj)], accx[i][ZZ(i, jj)], 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int jj = 0; jj < 4; ++jj) acc[i][ZZ(i, jj)] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][0], b1[ZZ(i, jj)], acc[i][ZZ(i, jj)], 0, 0, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
-#pragma unroll
-        for (int q = 0; q < DPW; ++q) {
-          __builtin_amdgcn_sched_group_barrier(0x006, 2, 0);
-          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-        }
-        __builtin_amdgcn_sched_group_barrier(0x008, 48 - 16 - 2 * DPW, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        advance();
-      }
-      if (!late) __builtin_amdgcn_s_barrier();
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the zero-fill DMAs behind the last step: the epilogue reuses the ring)
-    } else if constexpr (!STAGGER) {
+    if constexpr (!STAGGER) {
       // (a two-stage ring -- half the LDS, two workgroups per CU hide each other's waits -- has one step in flight)
       for (int kt = 0; kt < nsteps; ++kt) {
         wait_landed(AHEAD == 2 && kt + 1 < nsteps);
@@ -1367,7 +1286,7 @@ __device__ __forceinline__ void lds_wait(f16x8& a, f16x8& b, f16x8& c_, f16x8& d
   asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c_), "+v"(d));
 }
 
-template <int WM, int WN, int STAGES, int OCC, int MODE = 0, bool SPLIT = false>
+template <int WM, int WN, int STAGES, int OCC, int MODE = 0>
 __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_wgrad_l2_kernel(const WgradK a, unsigned xplane, unsigned dyplane, unsigned x_bytes,
                                                                          unsigned dy_bytes, const float* __restrict__ xamax,
                                                                          const float* __restrict__ dyamax) {
@@ -1675,12 +1594,17 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_wgrad_l2_kernel(const 
       for (int jj = 0; jj < 4; ++jj) acc[i][ZZ(i, jj)] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][0], b1[ZZ(i, jj)], acc[i][ZZ(i, jj)], 0, 0, 0);
   };
   if constexpr (MODE >= 1) {
-    // MODE 1 / 2: the prepare slot holds the fragment reads only; a step's pixel offsets and all of its DMAs are issued from
-    // the compute slot, behind the first 16 MFMAs.  The late half runs one step further ahead than the early one (its
-    // compute slot is the slot in which the stage it refills has just been read for the last time -- by itself), so every
-    // DMA has at least two slots of flight.  The pixel offsets must cost next to nothing there (branchy index arithmetic
-    // among the MFMAs lost, see above): MODE 1 is the 1 x 1 stride-1 convolution (x pixel = output pixel), MODE 2 reads
-    // the wave's four input pixels of a step from the geometry's table (a.pix) with ONE scalar load, issued a step early.
+    // MODE 1 / 2 (round 5; MODE 0 above is the loop of rounds 2-4, kept for the four-wave tile and as the fallback).  The stamps
+    // said the PREPARE slot was the long one (620 cycles of pixel arithmetic + DMA issue, 640 of fragment reads, against 768
+    // of MFMA in the compute slot), so the pixel arithmetic is gone and the DMA issue is shared between the slots:
+    //   * a step's pixel offsets cost a dozen VALU instructions, two per MFMA under the compute slot's first 16 MFMAs:
+    //     MODE 1 is the 1 x 1 stride-1 convolution (x pixel = output pixel); MODE 2 reads the wave's four input pixels of a
+    //     step from the geometry's table (a.pix) with ONE scalar load, issued a slot early (branchy index arithmetic among
+    //     the MFMAs had lost, see above);
+    //   * its first three DMAs follow there, one per two MFMAs, its other three at the start of the NEXT prepare slot;
+    //   * the late half runs one step further ahead than the early one (in its compute slot the stage it refills has just
+    //     been read for the last time -- by itself), so every DMA has two slots of flight or more.
+    // Measured (tools/ab_conv_shapes.sh, one box): 313-376 -> 390-500 TFLOP/s per shape.
     static_assert(STAGGER && GPW == 1 && STAGES == 3, "the eight-wave tile");
     const unsigned lddy4 = (unsigned)a.lddy * 4u, ldx4 = (unsigned)c.ldx * 4u;
     unsigned dy_lane[2], x_lane[2];
@@ -1718,7 +1642,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_wgrad_l2_kernel(const 
       st_issue = st_issue + STAGE == STAGES * STAGE ? 0 : st_issue + STAGE;
       ++i_iss;
     };
-    auto issue_dmas = [&]() {
+    auto issue_dmas = [&]() {  // (the prologue's whole steps)
       issue_first();
       issue_second();
     };
@@ -1755,11 +1679,12 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_wgrad_l2_kernel(const 
         __builtin_amdgcn_s_barrier();
       }
       for (; i_cur < nlive; ++i_cur) {
-        // SPLIT: the second three DMAs of a step go out at the start of the NEXT prepare slot (a DMA instruction holds its
-        // wave's issue port for ~60 cycles wherever it stands: three beside the reads, three beside the MFMAs)
-        if (!late) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SPLIT ? DPW / 2 : DPW) : "memory");
+        // the second three DMAs of a step go out at the start of the NEXT prepare slot (a DMA instruction holds its wave's
+        // issue port for ~60 cycles wherever it stands: three beside the reads, three beside the MFMAs -- all six in the
+        // compute slot: 4-12 % slower).  Early half: behind step i_cur only the first three of the next step are in flight.
+        if (!late) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPW / 2) : "memory");
         __builtin_amdgcn_s_barrier();
-        if (SPLIT && i_cur > 0) issue_second();
+        if (i_cur > 0) issue_second();
         // the step this wave issues in its NEXT compute slot: its index from the live list now (an LDS read among the fragment
         // reads), its table entry by a scalar load that has a whole slot to arrive
         const unsigned short ktv = live_list[i_iss + 1 < nlive ? i_iss + 1 : 0];
@@ -1774,7 +1699,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_wgrad_l2_kernel(const 
         for (int i = 0; i < 4; ++i)
 #pragma unroll
           for (int jj = 0; jj < 4; ++jj) accx[i][ZZ(i, jj)] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][0], bf[ZZ(i, jj)], accx[i][ZZ(i, jj)], 0, 0, 0);
-        if constexpr (SPLIT) issue_first(); else issue_dmas();
+        issue_first();
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -1785,7 +1710,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_wgrad_l2_kernel(const 
           for (int jj = 0; jj < 4; ++jj) acc[i][ZZ(i, jj)] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][0], b1[ZZ(i, jj)], acc[i][ZZ(i, jj)], 0, 0, 0);
         // the order the scheduler is asked for: the offsets' VALU two per MFMA under the first 16, then one DMA (its m0, its
         // address add) per two MFMAs, then the rest of the MFMAs
-        constexpr int NI = SPLIT ? DPW / 2 : DPW;
+        constexpr int NI = DPW / 2;
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -2143,16 +2068,6 @@ static int l2_fwd_impl(const void* xl, int64_t xplane, const float* xamax, const
 #undef L2_DBG_LAUNCH
   }
 #endif
-  static const int ci = getenv("ONDA_L2_CI") ? atoi(getenv("ONDA_L2_CI")) : 0;
-  if (q.variant == 0 && ci) {
-    if (q.balanced) {
-      hipLaunchKernelGGL((conv_l2_kernel<4, 2, 3, 2, true, 0, true>), dim3(q.G), dim3(512), 0, st, k, xpl, wpl, x_bytes, w_bytes, xamax, wamax);
-      hipLaunchKernelGGL((conv_l2_fixup_kernel<256, 128>), dim3(q.rem_rows() * q.tilesN, q.sub), dim3(256), 0, st, k, q.G, q.tilesM);
-    } else {
-      hipLaunchKernelGGL((conv_l2_kernel<4, 2, 3, 2, false, 0, true>), dim3(tiles), dim3(512), 0, st, k, xpl, wpl, x_bytes, w_bytes, xamax, wamax);
-    }
-    return ONDA_LAUNCH_RESULT();
-  }
   if (q.variant == 0) L2_LAUNCH(4, 2, 3, 2);
   else if (q.variant == 1 && l2_small_ring2()) L2_LAUNCH(2, 2, 2, 2);
   else if (q.variant == 1) L2_LAUNCH(2, 2, 3, 1);
@@ -2289,13 +2204,8 @@ int onda_conv2d_wgrad_l2(const void* xl, int64_t xplane, const float* xamax, con
   const unsigned xpl = 0, dypl = 0;
   static const int mode = getenv("ONDA_WGRAD_MODE") ? atoi(getenv("ONDA_WGRAD_MODE")) : 1;
   const bool linear = c->kh == 1 && c->kw == 1 && c->stride == 1 && c->pad == 0 && c->Hi == c->Ho && c->Wi == c->Wo;
-  static const int split = getenv("ONDA_WGRAD_SPLIT") ? atoi(getenv("ONDA_WGRAD_SPLIT")) : 1;
-  if (variant == 0 && mode == 1 && linear && split)
-    hipLaunchKernelGGL((conv_wgrad_l2_kernel<4, 2, 3, 2, 1, true>), dim3(grid), dim3(512), 0, ONDA_STREAM(s), k, xpl, dypl, 0u, 0u, xamax, dyamax);
-  else if (variant == 0 && mode == 1 && linear)
+  if (variant == 0 && mode == 1 && linear)
     hipLaunchKernelGGL((conv_wgrad_l2_kernel<4, 2, 3, 2, 1>), dim3(grid), dim3(512), 0, ONDA_STREAM(s), k, xpl, dypl, 0u, 0u, xamax, dyamax);
-  else if (variant == 0 && mode == 1 && split && wgrad_pixel_table(*c, ONDA_STREAM(s), &k.pix, &k.pix_stride))
-    hipLaunchKernelGGL((conv_wgrad_l2_kernel<4, 2, 3, 2, 2, true>), dim3(grid), dim3(512), 0, ONDA_STREAM(s), k, xpl, dypl, 0u, 0u, xamax, dyamax);
   else if (variant == 0 && mode == 1 && wgrad_pixel_table(*c, ONDA_STREAM(s), &k.pix, &k.pix_stride))
     hipLaunchKernelGGL((conv_wgrad_l2_kernel<4, 2, 3, 2, 2>), dim3(grid), dim3(512), 0, ONDA_STREAM(s), k, xpl, dypl, 0u, 0u, xamax, dyamax);
   else if (variant == 0)
