@@ -199,8 +199,14 @@ int onda_bn_bwd_l2(const float* dout, const void* out, int64_t out_plane, const 
                    int64_t M, int C, int relu, const uint8_t* relu_mask, int64_t split, onda_stream_t s);
 
 /* onda_conv2d_wgrad slabs with both operands pre-split: [pixel][channel] limb planes in, LDS-DMA + transposed LDS reads
- * (ds_read_b64_tr_b16), tiles of 256 x 128 or 128 x 128 (output x input channels) per tap and pixel range */
+ * (ds_read_b64_tr_b16), tiles of 256 x 128 or 128 x 128 (output x input channels) per tap and pixel range.
+ * The 256 x 128 kernel reads the input pixel of every (tap, output pixel) from a table per convolution GEOMETRY (input and
+ * output size, kernel, stride, dilation, padding; 4 bytes per tap and output pixel) that the library owns.  The one exception
+ * to "never allocates, never synchronises": the first call for a geometry (or for a larger batch of it) hipMallocs and fills
+ * the table on `s` and waits for `s` once.  onda_conv2d_wgrad_l2_prepare does exactly that ahead of time (before a stream
+ * capture, say) and nothing else; 1 x 1 stride-1 convolutions and the 128 x 128 tile need no table. */
 int onda_conv_wgrad_l2_variant(int Cout, int Cin);
+int onda_conv2d_wgrad_l2_prepare(const OndaConv* c, onda_stream_t s);
 int onda_conv2d_wgrad_l2(const void* xl, int64_t xplane, const float* xamax, const void* dyl, int64_t dyplane, const float* dyamax,
                          float* slabs, int lddy, int splitk, const OndaConv* c, onda_stream_t s);
 

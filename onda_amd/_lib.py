@@ -69,6 +69,7 @@ SIGNATURES = {
     "onda_conv_l2_live_fraction": (ctypes.c_double, [POINTER(OndaConv), I]),
     "onda_conv_wgrad_l2_live_fraction": (ctypes.c_double, [POINTER(OndaConv), I]),
     "onda_conv_wgrad_l2_variant": (I, [I, I]),
+    "onda_conv2d_wgrad_l2_prepare": (I, [POINTER(OndaConv), P]),
     "onda_conv2d_wgrad_l2": (I, [P, L, P, P, L, P, P, I, I, POINTER(OndaConv), P]),
     "onda_conv2d_fwd_l2": (I, [P, L, P, P, P, P, P, P, P, P, I, P, P, POINTER(OndaConv), P]),
     "onda_bn_finalize_l2": (I, [P, I, I, L, F, P, P, P, P, P, F, P, P, P, I, P, P, L, I, I, P, I, P]),

@@ -2170,6 +2170,18 @@ bool wgrad_pixel_table(const OndaConv& c, hipStream_t st, const int** p, long lo
 
 extern "C" {
 
+static bool wgrad_l2_linear(const OndaConv* c) {  // x pixel = output pixel: no table
+  return c->kh == 1 && c->kw == 1 && c->stride == 1 && c->pad == 0 && c->Hi == c->Ho && c->Wi == c->Wo;
+}
+
+int onda_conv2d_wgrad_l2_prepare(const OndaConv* c, onda_stream_t s) {
+  ONDA_REQUIRE(c && c->B > 0 && c->Ho > 0 && c->Wo > 0);
+  if (onda_conv_wgrad_l2_variant(c->Cout, c->Cin) != 0 || wgrad_l2_linear(c)) return 0;
+  const int* p;
+  long long stride;
+  return wgrad_pixel_table(*c, ONDA_STREAM(s), &p, &stride) ? 0 : (int)hipErrorOutOfMemory;
+}
+
 int onda_conv2d_wgrad_l2(const void* xl, int64_t xplane, const float* xamax, const void* dyl, int64_t dyplane, const float* dyamax,
                          float* slabs, int lddy, int splitk, const OndaConv* c, onda_stream_t s) {
   ONDA_REQUIRE(xl && dyl && xamax && dyamax && slabs && c && splitk >= 1);
@@ -2203,7 +2215,7 @@ int onda_conv2d_wgrad_l2(const void* xl, int64_t xplane, const float* xamax, con
   const unsigned grid = (unsigned)(k.tilesN * k.tilesC * k.taps * splitk);
   const unsigned xpl = 0, dypl = 0;
   static const int mode = getenv("ONDA_WGRAD_MODE") ? atoi(getenv("ONDA_WGRAD_MODE")) : 1;
-  const bool linear = c->kh == 1 && c->kw == 1 && c->stride == 1 && c->pad == 0 && c->Hi == c->Ho && c->Wi == c->Wo;
+  const bool linear = wgrad_l2_linear(c);
   if (variant == 0 && mode == 1 && linear)
     hipLaunchKernelGGL((conv_wgrad_l2_kernel<4, 2, 3, 2, 1>), dim3(grid), dim3(512), 0, ONDA_STREAM(s), k, xpl, dypl, 0u, 0u, xamax, dyamax);
   else if (variant == 0 && mode == 1 && wgrad_pixel_table(*c, ONDA_STREAM(s), &k.pix, &k.pix_stride))

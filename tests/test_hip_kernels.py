@@ -96,7 +96,13 @@ def test_weight_gradient_pixel_table_across_batch_sizes():
     first use (csrc/conv_l2.hip, wgrad_pixel_table): the same geometry at batch 1, then 3 (a larger table replaces it), then
     2 (a prefix of the larger one), dilated 3 x 3 and a stride-2 1 x 1, each against fp32 torch on the CPU."""
     from onda_amd import ops
+    from onda_amd._lib import call
+    import ctypes
     for (cin, cout, k, stride, dil, pad, H, W) in [(256, 256, 3, 1, 2, 2, 11, 19), (256, 512, 1, 2, 1, 0, 11, 19)]:
+        Ho, Wo = (H + 2 * pad - dil * (k - 1) - 1) // stride + 1, (W + 2 * pad - dil * (k - 1) - 1) // stride + 1
+        # the table can be asked for ahead of time (the one call of the library that allocates); here for the smallest batch
+        d = ops._desc(1, H, W, cin, Ho, Wo, cout, k, stride, dil, pad, cin, cout)
+        call("onda_conv2d_wgrad_l2_prepare", ctypes.byref(d), ops._stream())
         for B in (1, 3, 2):
             g = torch.Generator().manual_seed(100 * B + k)
             x = torch.randn(B, cin, H, W, generator=g)
