@@ -30,6 +30,6 @@ for (B, H, W, Cin, Cout, k, dil) in [(4, 65, 129, 512, 512, 3, 4), (4, 65, 129, 
     print(f"Cin={Cin} Cout={Cout} k={k} d={dil}:")
     for half, label in ((0, "early half"), (1, "late half ")):
         rows = st[:, half]
-        rows = rows[rows[:, 0] > 0]
+        rows = rows[(rows > 0).all(1) & ((rows[:, 1:] - rows[:, :-1]) >= 0).all(1)]  # (workgroups whose first whole tile was stamped in full)
         d = (rows[:, 1:] - rows[:, :-1]).mean(0)
         print(f"  {label} ({rows.shape[0]} workgroups): " + " | ".join(f"{n} {v:.0f}" for n, v in zip(names, d.tolist())) + f" | total {float((rows[:, 7] - rows[:, 0]).mean()):.0f} ticks")
