@@ -1275,10 +1275,11 @@ __global__ __launch_bounds__(256) void conv_l2_fixup_kernel(const ConvK a, int G
 // ring.  In assembly nothing is waited for automatically: lds_wait() below is the s_waitcnt lgkmcnt(0) for them, tied to
 // the destination registers so that no MFMA that uses them can be scheduled above it.
 typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+template <int OFS = 0>  // (byte offset in the instruction's immediate field: the second limbs lie 256 bytes behind the first)
 __device__ __forceinline__ f16x8 tr_read8(unsigned a0, unsigned a1) {
   u32x2_t lo, hi;
-  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(a0));
-  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(hi) : "v"(a1));
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(a0), "n"(OFS));
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(a1), "n"(OFS));
   const u32x4 r = {lo[0], lo[1], hi[0], hi[1]};
   return __builtin_bit_cast(f16x8, r);
 }
@@ -1492,6 +1493,9 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_wgrad_l2_kernel(const 
         const int cha = (wm & 1) * 8 + 2 * i + (pp >> 1), chb = (wn & 1) * 8 + 2 * i + (pp >> 1);
         fa[i][h] = (unsigned)((wm >> 1) * SUB + 512 * row + 16 * (cha ^ swz) + 8 * (pp & 1));  // (+ 256: the second limbs)
         fb[i][h] = (unsigned)(A_BYTES + (wn >> 1) * SUB + 512 * row + 16 * (chb ^ swz) + 8 * (pp & 1));
+        // (opaque: left alone the compiler recomputes all sixteen from the lane id in every K-step -- 65 VALU instructions
+        //  in the prepare slot -- rather than keep them in registers)
+        asm volatile("" : "+v"(fa[i][h]), "+v"(fb[i][h]));
       }
     }
   }
@@ -1554,15 +1558,19 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_wgrad_l2_kernel(const 
   auto prepare = [&]() {  // "P": issue the transposed reads of the a1, a2, b2 fragments of the stage at st_read
     base = lds0 + st_read;
     st_read = st_read + STAGE == STAGES * STAGE ? 0 : st_read + STAGE;
+    // (one address add per register pair -- the stage -- and the limb in the immediate: every VALU instruction of the prepare
+    //  slot is paid by the OTHER wave of the SIMD, whose MFMAs it delays: 32 of them measured -16 % on the forward kernel)
 #pragma unroll
-    for (int l = 0; l < 2; ++l)
+    for (int i = 0; i < 4; ++i) {
+      const unsigned a0 = base + fa[i][0], a1 = base + fa[i][1];
+      af[i][0] = tr_read8<0>(a0, a1);
+      af[i][1] = tr_read8<256>(a0, a1);
+    }
 #pragma unroll
-      for (int i = 0; i < 4; ++i) af[i][l] = tr_read8(base + l * 256 + fa[i][0], base + l * 256 + fa[i][1]);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) bf[j] = tr_read8(base + 256 + fb[j][0], base + 256 + fb[j][1]);
-    if constexpr (STAGGER) {  // staggered halves: the compute slot reads nothing from LDS (see conv_l2_kernel)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) b1[j] = tr_read8(base + fb[j][0], base + fb[j][1]);
+    for (int j = 0; j < 4; ++j) {
+      const unsigned a0 = base + fb[j][0], a1 = base + fb[j][1];
+      bf[j] = tr_read8<256>(a0, a1);
+      if constexpr (STAGGER) b1[j] = tr_read8<0>(a0, a1);  // staggered halves: the compute slot reads nothing from LDS (see conv_l2_kernel)
     }
   };
   auto prepared = [&]() {  // ... and wait for them (before the barrier that lets the stage be refilled / before the MFMAs)
