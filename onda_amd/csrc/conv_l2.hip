@@ -1719,8 +1719,9 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_wgrad_l2_kernel(const 
         // the order the scheduler is asked for: the offsets' VALU two per MFMA under the first 16, then one DMA (its m0, its
         // address add) per two MFMAs, then the rest of the MFMAs
         constexpr int NI = DPW / 2;
+        __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);  // (an MFMA-only head: VALU in a compute segment's first ~250 cycles does not overlap)
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
+        for (int q = 0; q < 14; ++q) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
           __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
         }
@@ -1730,7 +1731,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_wgrad_l2_kernel(const 
           __builtin_amdgcn_sched_group_barrier(0x006, 2, 0);
           __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
         }
-        __builtin_amdgcn_sched_group_barrier(0x008, 48 - 16 - 2 * NI, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 48 - 16 - 14 - 2 * NI, 0);
         __builtin_amdgcn_sched_barrier(0);
         entry_wait(t_after);  // (issued a slot ago: nothing to wait for)
         kt_next = kt_after;
