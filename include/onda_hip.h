@@ -153,9 +153,11 @@ void onda_debug_stamps(void* buffer);
  * over the image).  Replaces the stem's F.conv2d input side (deeplabv2.py:283) in "f16x2" pre-split mode. */
 int onda_stem_im2col_l2(const float* x_nchw, const float* xamax, void* dst, int64_t plane, int B, int H, int W, int Ho, int Wo,
                         int Kp, onda_stream_t s);
-int onda_conv_l2_variant(int64_t M, int Cout);  /* tile shape used for an (M, Cout) problem: 0 256x128, 1 128x128, 2 256x64 */
+int onda_conv_l2_variant(int64_t M, int Cout);  /* base tile shape of an (M, Cout) problem: 0 256x128, 1 128x128, 2 256x64 */
 /* device kernel launched for a problem: 0 / 1 / 2 = conv_l2_kernel<4,2> / <2,2> / <4,1>, 3 = conv_l2x_kernel<4,2> (256x128 tiles,
- * at most 32 K-steps per tile: the continuous K-step stream); bench.py names its per-kernel figures after this */
+ * at most 32 K-steps per tile: the continuous K-step stream); bench.py names its per-kernel figures after this.  Short K loops
+ * (1x1 convolutions) of a 256x128 problem run as 128x128 tiles on two workgroups per CU where that measured faster (few K-steps,
+ * or many column tiles: csrc/conv_l2.hip, l2_variant_k) */
 int onda_conv_l2_kernel_id(int64_t M, int Cout, int taps, int Cin);
 int onda_conv_l2_tiles_m(int64_t M, int Cout, int taps, int Cin);  /* rows of the `stats` partials the conv writes for this problem */
 /* the same for a launch with a row-group boundary (OndaConv.stat_split) and / or OndaConv.plain_schedule; *tile_rows (optional)

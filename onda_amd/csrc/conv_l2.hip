@@ -1841,11 +1841,25 @@ int onda_conv_l2_variant(int64_t M, int Cout) {
   return t256 >= 200 ? 0 : 1;
 }
 
+// ... and for an (M, Cout, K) problem: short K loops whose epilogue outweighs them run faster as 128 x 128 tiles on TWO
+// four-wave workgroups per CU (one's epilogue beside the other's K loop) than in the 256 x 128 stream kernel -- when there
+// are many column tiles to share the activation rows in L2, or so few K-steps that the tile is all epilogue.  Measured per
+// shape (tools/ab_conv_shapes.sh with ONDA_L2_VARIANT=1, profiles/r05_short_k_tiles_ab.txt): -4...-23 % where the rule
+// says yes at 4 images, +2...+15 % for 256 output channels with 16-32 K-steps, where it says no; at 8 images the data
+// gradients gain the same and the train-mode forwards are +-3 %; the step: 92.81 -> 92.35 ms (three alternating runs).
+static int l2_variant_k(long long M, int Cout, int taps, int Cin) {
+  const int v = onda_conv_l2_variant(M, Cout);
+  static const int on = getenv("ONDA_L2_SHORTK128") ? atoi(getenv("ONDA_L2_SHORTK128")) : 1;
+  if (v != 0 || !on || getenv("ONDA_L2_VARIANT")) return v;
+  const int kts = taps * (Cin / 32);
+  return kts <= 8 || (kts <= 16 && Cout >= 512) || (kts <= 32 && Cout >= 2048) ? 1 : 0;
+}
+
 /* which device kernel onda_conv2d_fwd_l2 launches for a problem: the tile variant (0: 256 x 128, 1: 128 x 128, 2: 256 x 64
  * = conv_l2_kernel<4,2> / <2,2> / <4,1>), or 3: conv_l2x_kernel<4,2>, the continuous K-step stream taken by 256 x 128
  * problems with at most 32 K-steps per tile (bench.py names its per-kernel figures after this) */
 int onda_conv_l2_kernel_id(int64_t M, int Cout, int taps, int Cin) {
-  const int variant = onda_conv_l2_variant(M, Cout);
+  const int variant = l2_variant_k(M, Cout, taps, Cin);
   const bool short_k = taps * (Cin / 32) <= 32;
   return variant == 0 && short_k ? 3 : variant;
 }
@@ -1865,7 +1879,7 @@ bool l2_small_ring2() { return true; }  // (the four-wave tiles on a three-stage
 
 L2Schedule l2_schedule(long long M, int Cout, int taps, int Cin, bool have_ws, long long stat_split = 0, bool plain = false) {
   L2Schedule q;
-  q.variant = onda_conv_l2_variant(M, Cout);
+  q.variant = l2_variant_k(M, Cout, taps, Cin);
   q.BM = q.variant == 1 ? 128 : 256;
   q.BN = q.variant == 2 ? 64 : 128;
   q.tilesM = (int)((M + q.BM - 1) / q.BM);
