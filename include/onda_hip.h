@@ -53,6 +53,8 @@ typedef struct OndaConv {
   int32_t plain_schedule; /* != 0: one tile per workgroup, no stream-K remainder (a launch that shares the GPU with launches of
                            * other streams: its short last round is filled by them, the remainder's partial tiles and fix-up
                            * launch are not worth their traffic) */
+  const int32_t* pix_table; /* onda_conv2d_wgrad_l2 only: NULL, or the caller's table of this geometry's input pixels      */
+  int64_t pix_stride;       /* (onda_conv2d_wgrad_l2_table) and its int32 entries per tap                                  */
 } OndaConv;
 
 /* Number of float partials conv_fwd writes when `stats` != NULL: tiles_m * 2 * Cout, where
@@ -115,7 +117,8 @@ int onda_pack_weights_h2_multi(const OndaPackEntry* table, int n, int64_t total_
  * tensor whose max|x| is known.  The conv kernel then moves both operands HBM/L2 -> LDS by LDS-DMA only (no VALU,
  * no LDS stores in the K loop), 256 x 128 tiles on a 3-stage ring filled two K-steps ahead.
  * Replaces the same F.conv2d call sites as onda_conv2d_fwd (deeplabv2.py:53-68, :243-257); c->ldx counts f16
- * elements (channels) of a row. */
+ * elements (channels) of a row.  onda_split_h2: ldo (and the Kp of onda_stem_im2col_l2) must be a multiple of 32 --
+ * whole 32-channel blocks per row; anything else is ONDA_EINVAL. */
 int onda_split_h2(const float* x, int64_t rows, int C, int ldx, void* dst, int ldo, int64_t plane, const float* amax,
                   onda_stream_t s);
 /* onda_conv2d_fwd_l2 whose OUTPUT is limb planes as well: eval-mode conv + folded BatchNorm (scale, shift) [+ residual
@@ -203,12 +206,15 @@ int onda_bn_bwd_l2(const float* dout, const void* out, int64_t out_plane, const 
 /* onda_conv2d_wgrad slabs with both operands pre-split: [pixel][channel] limb planes in, LDS-DMA + transposed LDS reads
  * (ds_read_b64_tr_b16), tiles of 256 x 128 or 128 x 128 (output x input channels) per tap and pixel range.
  * The 256 x 128 kernel reads the input pixel of every (tap, output pixel) from a table per convolution GEOMETRY (input and
- * output size, kernel, stride, dilation, padding; 4 bytes per tap and output pixel) that the library owns.  The one exception
- * to "never allocates, never synchronises": the first call for a geometry (or for a larger batch of it) hipMallocs and fills
- * the table on `s` and waits for `s` once.  onda_conv2d_wgrad_l2_prepare does exactly that ahead of time (before a stream
- * capture, say) and nothing else; 1 x 1 stride-1 convolutions and the 128 x 128 tile need no table. */
+ * output size, kernel, stride, dilation, padding; 4 bytes per tap and output pixel) that the CALLER owns, like every other
+ * buffer: onda_conv2d_wgrad_l2_table_stride(c) = int32 entries per tap at c->B images (0: this problem needs no table --
+ * 1 x 1 stride-1 convolutions, the 128 x 128 tile), the table holds kh*kw times that; onda_conv2d_wgrad_l2_table(c, table, s)
+ * fills it with one launch on `s`; c->pix_table / c->pix_stride hand it to onda_conv2d_wgrad_l2.  A table built for a larger
+ * batch of the same geometry serves a smaller one.  Without a table (pix_table NULL) the kernel works the pixels out in its
+ * K loop (the loop of rounds 2-4: same results, 15-25 % slower).  No call of this library allocates or synchronises. */
 int onda_conv_wgrad_l2_variant(int Cout, int Cin);
-int onda_conv2d_wgrad_l2_prepare(const OndaConv* c, onda_stream_t s);
+int64_t onda_conv2d_wgrad_l2_table_stride(const OndaConv* c);
+int onda_conv2d_wgrad_l2_table(const OndaConv* c, int32_t* table, onda_stream_t s);
 int onda_conv2d_wgrad_l2(const void* xl, int64_t xplane, const float* xamax, const void* dyl, int64_t dyplane, const float* dyamax,
                          float* slabs, int lddy, int splitk, const OndaConv* c, onda_stream_t s);
 

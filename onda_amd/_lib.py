@@ -16,7 +16,8 @@ I, L, F = c_int, c_int64, c_float
 
 class OndaConv(Structure):
     _fields_ = [(n, c_int) for n in ("B Hi Wi Cin Ho Wo Cout kh kw stride dil pad ldx ldy ldr out_os Hf Wf relu").split()] + \
-               [("run_if", c_void_p), ("stat_split", c_int64), ("plain_schedule", c_int)]
+               [("run_if", c_void_p), ("stat_split", c_int64), ("plain_schedule", c_int), ("pix_table", c_void_p),
+                ("pix_stride", c_int64)]
 
 
 class OndaSwitchCfg(Structure):
@@ -69,7 +70,8 @@ SIGNATURES = {
     "onda_conv_l2_live_fraction": (ctypes.c_double, [POINTER(OndaConv), I]),
     "onda_conv_wgrad_l2_live_fraction": (ctypes.c_double, [POINTER(OndaConv), I]),
     "onda_conv_wgrad_l2_variant": (I, [I, I]),
-    "onda_conv2d_wgrad_l2_prepare": (I, [POINTER(OndaConv), P]),
+    "onda_conv2d_wgrad_l2_table_stride": (L, [POINTER(OndaConv)]),
+    "onda_conv2d_wgrad_l2_table": (I, [POINTER(OndaConv), P, P]),
     "onda_conv2d_wgrad_l2": (I, [P, L, P, P, L, P, P, I, I, POINTER(OndaConv), P]),
     "onda_conv2d_fwd_l2": (I, [P, L, P, P, P, P, P, P, P, P, I, P, P, POINTER(OndaConv), P]),
     "onda_bn_finalize_l2": (I, [P, I, I, L, F, P, P, P, P, P, F, P, P, P, I, P, P, L, I, I, P, I, P]),

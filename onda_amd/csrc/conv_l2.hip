@@ -20,10 +20,6 @@
 // function of the row (swz8) on the DMA's source side and in the fragment read: conflict-free ds_read_b128.
 #include "conv_common.h"
 
-#include <map>
-#include <mutex>
-#include <tuple>
-
 namespace {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -1812,8 +1808,10 @@ extern "C" {
 
 int onda_split_h2(const float* x, int64_t rows, int C, int ldx, void* dst, int ldo, int64_t plane, const float* amax,
                   onda_stream_t s) {
-  ONDA_REQUIRE(x && dst && amax && rows > 0 && C > 0 && C % 8 == 0 && ldx >= C && ldx % 4 == 0 && ldo >= C && ldo % 8 == 0 &&
-               plane % 8 == 0);
+  // limb rows (common.h limb_at): a row is ldo / 32 blocks of [32 x l1][32 x l2] -- a stride that is not a multiple of 32 would
+  // put the channels past the last whole block into the next row (`plane` is ignored since round 5: the limbs share a row)
+  (void)plane;
+  ONDA_REQUIRE(x && dst && amax && rows > 0 && C > 0 && C % 8 == 0 && ldx >= C && ldx % 4 == 0 && ldo >= C && ldo % 32 == 0);
   if (!ONDA_ALIGNED16(x) || !ONDA_ALIGNED16(dst)) return ONDA_EALIGN;
   const long long n = rows * (C / 8);
   const int blocks = (int)(n / 256 / 4 + 1 > 2048 ? 2048 : n / 256 / 4 + 1);
@@ -1824,7 +1822,8 @@ int onda_split_h2(const float* x, int64_t rows, int C, int ldx, void* dst, int l
 
 int onda_stem_im2col_l2(const float* x_nchw, const float* xamax, void* dst, int64_t plane, int B, int H, int W, int Ho, int Wo,
                         int Kp, onda_stream_t s) {
-  ONDA_REQUIRE(x_nchw && xamax && dst && Kp % 8 == 0 && Kp >= 147 && plane % 8 == 0 && B > 0 && Ho > 0 && Wo > 0);
+  (void)plane;
+  ONDA_REQUIRE(x_nchw && xamax && dst && Kp % 32 == 0 && Kp >= 147 && B > 0 && Ho > 0 && Wo > 0);  // limb rows: whole 32-channel blocks
   if (!ONDA_ALIGNED16(dst)) return ONDA_EALIGN;
   const long long n = (long long)B * Ho * Wo * (Kp / 8);
   const int blocks = (int)(n / 256 / 2 + 1 > 4096 ? 4096 : n / 256 / 2 + 1);
@@ -2016,6 +2015,9 @@ static int l2_fwd_impl(const void* xl, int64_t xplane, const float* xamax, const
   k.c = *c;
   const long long M = (long long)c->B * c->Ho * c->Wo;
   ONDA_REQUIRE(M > 0 && M < (1ll << 31));
+  // RowPos packs a tile row's input coordinates of tap (0, 0) into 16 bits each (-32768 = no such row)
+  ONDA_REQUIRE((long long)c->Ho * c->stride + (long long)c->dil * (c->kh - 1) < 32768 &&
+               (long long)c->Wo * c->stride + (long long)c->dil * (c->kw - 1) < 32768 && c->pad < 32768);
   const long long x_total = (long long)c->B * c->Hi * c->Wi * c->ldx * 4;  // limb rows: 4 bytes per element
   {  // 32-bit byte offsets inside a tile's WINDOW (x_window: the images its <= 256 rows touch), not inside the tensor
     const long long img = (long long)c->Hi * c->Wi * c->ldx * 4, per_tile = 256 / ((long long)c->Ho * c->Wo) + 2;
@@ -2129,9 +2131,9 @@ int onda_conv_wgrad_l2_variant(int Cout, int Cin) {
 namespace {
 // Input pixel of every (tap, output pixel) of a convolution geometry: what the weight-gradient kernel's compute slot reads
 // instead of working it out (conv_wgrad_l2_kernel, MODE 2).  [taps][stride] int32, -1 in the padding and behind the last
-// pixel.  One table per (device, geometry), built on first use on the caller's stream (the call waits for it, once), for at
-// least the batch asked for; a larger batch later builds a larger table and the old one stays allocated (launches on other
-// streams may still read it).  Independent of the batch otherwise: a prefix of a larger batch's table is the smaller one's.
+// pixel.  The CALLER owns the table (OndaConv.pix_table / pix_stride; onda_conv2d_wgrad_l2_table_stride sizes it,
+// onda_conv2d_wgrad_l2_table fills it with one launch): the library neither allocates nor synchronises.  A table built for a
+// larger batch of the same geometry serves a smaller one (same stride argument: the rows of a tap are `stride` apart).
 __global__ __launch_bounds__(256) void wgrad_pixel_table_kernel(int* __restrict__ t, long long stride, int B, int Hi, int Wi, int Ho,
                                                                int Wo, int kw, int cstride, int dil, int pad) {
   const long long M = (long long)B * Ho * Wo;
@@ -2148,47 +2150,6 @@ __global__ __launch_bounds__(256) void wgrad_pixel_table_kernel(int* __restrict_
     t[(size_t)tap * stride + m] = v;
   }
 }
-struct PixKey {
-  int dev, Hi, Wi, Ho, Wo, kh, kw, stride, dil, pad;
-  bool operator<(const PixKey& o) const {
-    return std::tie(dev, Hi, Wi, Ho, Wo, kh, kw, stride, dil, pad) < std::tie(o.dev, o.Hi, o.Wi, o.Ho, o.Wo, o.kh, o.kw, o.stride, o.dil, o.pad);
-  }
-};
-struct PixTable {
-  int* p;
-  int B;
-  long long stride;
-};
-std::map<PixKey, PixTable> g_pix;
-std::mutex g_pix_mu;
-
-bool wgrad_pixel_table(const OndaConv& c, hipStream_t st, const int** p, long long* stride) {
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return false;
-  const PixKey key{dev, c.Hi, c.Wi, c.Ho, c.Wo, c.kh, c.kw, c.stride, c.dil, c.pad};
-  std::lock_guard<std::mutex> lock(g_pix_mu);
-  auto it = g_pix.find(key);
-  if (it == g_pix.end() || it->second.B < c.B) {
-    const long long M = (long long)c.B * c.Ho * c.Wo;
-    if ((long long)c.B * c.Hi * c.Wi >= (1ll << 31)) return false;
-    PixTable t;
-    t.B = c.B;
-    t.stride = (M + 31) / 32 * 32 + 64;  // (a workgroup's last K-step may reach past M)
-    const int taps = c.kh * c.kw;
-    if (hipMalloc(reinterpret_cast<void**>(&t.p), (size_t)taps * t.stride * sizeof(int)) != hipSuccess) {
-      (void)hipGetLastError();
-      return false;
-    }
-    hipLaunchKernelGGL(wgrad_pixel_table_kernel, dim3(512, taps), dim3(256), 0, st, t.p, t.stride, c.B, c.Hi, c.Wi, c.Ho, c.Wo, c.kw,
-                       c.stride, c.dil, c.pad);
-    if (hipStreamSynchronize(st) != hipSuccess) return false;  // once per geometry: other streams may use the table from here on
-    g_pix[key] = t;
-    it = g_pix.find(key);
-  }
-  *p = it->second.p;
-  *stride = it->second.stride;
-  return true;
-}
 }  // namespace
 
 extern "C" {
@@ -2197,18 +2158,31 @@ static bool wgrad_l2_linear(const OndaConv* c) {  // x pixel = output pixel: no 
   return c->kh == 1 && c->kw == 1 && c->stride == 1 && c->pad == 0 && c->Hi == c->Ho && c->Wi == c->Wo;
 }
 
-int onda_conv2d_wgrad_l2_prepare(const OndaConv* c, onda_stream_t s) {
-  ONDA_REQUIRE(c && c->B > 0 && c->Ho > 0 && c->Wo > 0);
+/* int32 entries between two taps' rows of the pixel table of this geometry AT THIS BATCH (the table is taps * stride
+ * entries), or 0 when the problem runs without one (1 x 1 stride-1 convolutions, the 128 x 128 tile) */
+int64_t onda_conv2d_wgrad_l2_table_stride(const OndaConv* c) {
+  if (!c || c->B <= 0 || c->Ho <= 0 || c->Wo <= 0) return 0;
   if (onda_conv_wgrad_l2_variant(c->Cout, c->Cin) != 0 || wgrad_l2_linear(c)) return 0;
-  const int* p;
-  long long stride;
-  return wgrad_pixel_table(*c, ONDA_STREAM(s), &p, &stride) ? 0 : (int)hipErrorOutOfMemory;
+  if ((long long)c->B * c->Hi * c->Wi >= (1ll << 31)) return 0;
+  const long long M = (long long)c->B * c->Ho * c->Wo;
+  return (M + 31) / 32 * 32 + 64;  // (a workgroup's last K-step may reach past M)
+}
+
+int onda_conv2d_wgrad_l2_table(const OndaConv* c, int32_t* table, onda_stream_t s) {
+  ONDA_REQUIRE(c && table);
+  const long long stride = onda_conv2d_wgrad_l2_table_stride(c);
+  ONDA_REQUIRE(stride > 0);
+  hipLaunchKernelGGL(wgrad_pixel_table_kernel, dim3(512, c->kh * c->kw), dim3(256), 0, ONDA_STREAM(s), table, stride, c->B, c->Hi, c->Wi,
+                     c->Ho, c->Wo, c->kw, c->stride, c->dil, c->pad);
+  return ONDA_LAUNCH_RESULT();
 }
 
 int onda_conv2d_wgrad_l2(const void* xl, int64_t xplane, const float* xamax, const void* dyl, int64_t dyplane, const float* dyamax,
                          float* slabs, int lddy, int splitk, const OndaConv* c, onda_stream_t s) {
   ONDA_REQUIRE(xl && dyl && xamax && dyamax && slabs && c && splitk >= 1);
   ONDA_REQUIRE(c->Cin % 8 == 0 && c->Cout % 8 == 0 && c->ldx % 32 == 0 && lddy % 32 == 0);
+  // a caller's pixel table: at least this batch's rows per tap (a larger batch's table of the same geometry is fine)
+  ONDA_REQUIRE(c->pix_table == nullptr || c->pix_stride >= ((long long)c->B * c->Ho * c->Wo + 31) / 32 * 32 + 64);
   (void)xplane;
   (void)dyplane;  // (limb rows: kept in the signature)
   if (!ONDA_ALIGNED16(xl) || !ONDA_ALIGNED16(dyl) || !ONDA_ALIGNED16(slabs)) return ONDA_EALIGN;
@@ -2241,7 +2215,7 @@ int onda_conv2d_wgrad_l2(const void* xl, int64_t xplane, const float* xamax, con
   const bool linear = wgrad_l2_linear(c);
   if (variant == 0 && mode == 1 && linear)
     hipLaunchKernelGGL((conv_wgrad_l2_kernel<4, 2, 3, 2, 1>), dim3(grid), dim3(512), 0, ONDA_STREAM(s), k, xpl, dypl, 0u, 0u, xamax, dyamax);
-  else if (variant == 0 && mode == 1 && wgrad_pixel_table(*c, ONDA_STREAM(s), &k.pix, &k.pix_stride))
+  else if (variant == 0 && mode == 1 && c->pix_table != nullptr && (k.pix = c->pix_table, k.pix_stride = c->pix_stride, true))
     hipLaunchKernelGGL((conv_wgrad_l2_kernel<4, 2, 3, 2, 2>), dim3(grid), dim3(512), 0, ONDA_STREAM(s), k, xpl, dypl, 0u, 0u, xamax, dyamax);
   else if (variant == 0)
     hipLaunchKernelGGL((conv_wgrad_l2_kernel<4, 2, 3, 2>), dim3(grid), dim3(512), 0, ONDA_STREAM(s), k, xpl, dypl, 0u, 0u, xamax, dyamax);

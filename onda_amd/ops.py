@@ -339,6 +339,18 @@ def limbs_of(x):
     return activation_limbs(x)
 
 
+def _stat_tile_rows(stats):
+    """GEMM rows one row of a conv's statistic partials covers (256 or 128: l2_schedule's tile height, recorded by
+    conv_forward).  Two row groups split their partials by it; there is no way to re-derive it from (M, C) alone -- short K
+    loops run 128-row tiles (l2_variant_k) -- so a partial table that lost the attribute (detached, cloned, re-wrapped) is an
+    error, not a guess (round-5 advisor)."""
+    rows = getattr(stats, "_onda_tile_rows", None)
+    if not rows:
+        raise RuntimeError("onda_amd: BatchNorm with two row groups needs the statistic partials as conv_forward returned "
+                           "them (the tensor lost its tile height: it was copied or re-wrapped on the way)")
+    return rows
+
+
 def limb_mode(channels):
     """Do the BatchNorm kernels write their output as limb planes only (no fp32 copy)?"""
     return CONV_MODE == "f16x2" and channels % 32 == 0 and LIMB_ONLY
@@ -464,7 +476,7 @@ def conv_forward(x, wp, k, stride, dil, pad, cout, out=None, scale=None, shift=N
     ldx = 0 if is_limb_only(x) else nhwc_ld(x)
     Ho, Wo = conv_out_size(Hi, k, stride, dil, pad), conv_out_size(Wi, k, stride, dil, pad)
     if limb_out is not None:
-        if out is not None or want_stats or not _use_l2(wp, Cin) or cout % 8 != 0:
+        if out is not None or want_stats or not _use_l2(wp, Cin) or cout % 32 != 0:
             raise RuntimeError("onda_amd: limb-plane conv output needs the pre-split path, a dense result and no statistics")
         dev, M = x.device, B * Ho * Wo
         xl = limbs_of(x)
@@ -606,6 +618,36 @@ def _best_splitk(M, cout, cin, taps, tiles, G, rate):
     return best
 
 
+# Pixel tables of the pre-split weight gradient (include/onda_hip.h, onda_conv2d_wgrad_l2_table): input pixel of every
+# (filter tap, output pixel) of a convolution GEOMETRY, owned here like every other buffer the library works on -- one int32
+# tensor per (device, geometry) from torch's allocator, built with one launch at the first backward pass of that geometry
+# (eight geometries, 17 MB, in this network), kept for the life of the process; a larger batch builds a larger table and the
+# smaller one is dropped when its last launch has been queued (same-stream order; other streams wait for the build's event).
+_PIX_TABLES = {}
+
+
+def _wgrad_pixel_table(d, device):
+    """Fill d.pix_table / d.pix_stride for a weight-gradient descriptor (no-op for problems that run without a table)."""
+    stride = query("onda_conv2d_wgrad_l2_table_stride", byref(d))
+    if stride == 0:
+        return
+    key = (str(device), d.Hi, d.Wi, d.Ho, d.Wo, d.kh, d.kw, d.stride, d.dil, d.pad)
+    hit = _PIX_TABLES.get(key)
+    cur = torch.cuda.current_stream(device)
+    if hit is None or hit[1] < d.B:
+        table = torch.empty(d.kh * d.kw * stride, device=device, dtype=torch.int32)
+        call("onda_conv2d_wgrad_l2_table", byref(d), _p(table), cur.cuda_stream)
+        done = torch.cuda.Event()
+        done.record(cur)
+        if hit is not None:
+            hit[0].record_stream(cur)  # (launches already queued on this stream still read the smaller table)
+        hit = _PIX_TABLES[key] = (table, d.B, stride, done, {cur.cuda_stream})
+    elif cur.cuda_stream not in hit[4]:
+        cur.wait_event(hit[3])
+        hit[4].add(cur.cuda_stream)
+    d.pix_table, d.pix_stride = hit[0].data_ptr(), hit[2]
+
+
 def conv_wgrad(x, dy, k, stride, dil, pad, cout_real, cin_real, flat_k=0, into=None, xscale=None, xlimbs=None):
     """Weight gradient in OIHW.  x NHWC input of the conv, dy NHWC output gradient.  With `into`
     (an existing contiguous gradient tensor) the result is ADDED to it and None is returned.
@@ -624,6 +666,7 @@ def conv_wgrad(x, dy, k, stride, dil, pad, cout_real, cin_real, flat_k=0, into=N
         xl = xlimbs if xlimbs is not None else limbs_of(x)
         dyl = limbs_of(dy)
         d.ldx = xl.ld
+        _wgrad_pixel_table(d, x.device)
         _launch("conv_wgrad_l2_kernel<%d>" % query("onda_conv_wgrad_l2_variant", Co, Cin), 2.0 * M * Co * taps * Cin,
                 "onda_conv2d_wgrad_l2", _p(xl.planes), xl.plane, _p(xl.amax), _p(dyl.planes), dyl.plane, _p(dyl.amax), _p(slabs),
                 dyl.ld, sk, byref(d), _stream(), tag=("wgrad", M, Co, Cin, k, stride, dil, sk),
@@ -918,7 +961,7 @@ class BNTrainFn(torch.autograd.Function):
             if G > 1:
                 # the conv's partial rows cover 256 (128) GEMM rows each: a group takes its own rows when the boundary falls
                 # between two of them (every power-of-two image size), one reduction pass over its rows of y otherwise
-                bm = getattr(stats, "_onda_tile_rows", None) or (128 if query("onda_conv_l2_variant", B * H * W, C) == 1 else 256)
+                bm = _stat_tile_rows(stats)
                 if groups[1][0] % bm == 0 and stats.shape[1] == 2:
                     ts = groups[1][0] // bm
                     part = stats[:ts] if g == 0 else stats[ts:]
@@ -996,7 +1039,7 @@ class BNTrainLimbFn(torch.autograd.Function):
         if res is not None and (res.ld != C or tuple(residual.shape) != (B, H, W, C)):
             raise RuntimeError("onda_amd: residual of a BatchNorm must be a dense [B,H,W,C] activation")
         out_amax = amax_slot(dev)
-        tile_rows = (getattr(stats, "_onda_tile_rows", None) or (128 if query("onda_conv_l2_variant", M, C) == 1 else 256)) if split else 0
+        tile_rows = _stat_tile_rows(stats) if split else 0
         call("onda_bn_finalize_l2", _p(stats), stats.shape[0], C, M, BN_EPS, _p(mean), _p(invstd), _p(rm), _p(rv), _p(nbt),
              float(momentum), _p(gamma), _p(beta), _p(res.amax) if res is not None else None, int(relu), _p(xhat_amax),
              _p(out_amax), split, tile_rows, 1, _p(y) if split else None, nhwc_ld(y) if split else 0, _stream())

@@ -138,10 +138,11 @@ def g3():
         reg = regular_loss("MRKLD", logits)
         res[f"{case}_logits"], res[f"{case}_target"] = logits, target
         res[f"{case}_ce"], res[f"{case}_rce"], res[f"{case}_mrkld"] = ce, r, reg
-        if case != "all_ignored":
-            total = 0.1 * ce + 1.0 * r + 0.1 * reg
-            res[f"{case}_grad"] = torch.autograd.grad(total, logits)[0]
-            res[f"{case}_grad_ce"] = torch.autograd.grad(loss_calc(logits, target, "cpu"), logits)[0]
+        # (all_ignored: ce is NaN = the mean over an empty selection, but its GRADIENT is exact zeros -- autograd scatters
+        #  an empty gradient back through predict[mask] -- so the total's gradient is finite: RCE + MRKLD only)
+        total = 0.1 * ce + 1.0 * r + 0.1 * reg
+        res[f"{case}_grad"] = torch.autograd.grad(total, logits)[0]
+        res[f"{case}_grad_ce"] = torch.autograd.grad(loss_calc(logits, target, "cpu"), logits)[0]
     save("g3_losses", **res)
 
 

@@ -92,30 +92,46 @@ def test_conv_full_size_against_torch_cpu(case):
 
 
 def test_weight_gradient_pixel_table_across_batch_sizes():
-    """The 256-output-channel weight-gradient kernel reads its input pixels from a per-geometry table the library builds on
-    first use (csrc/conv_l2.hip, wgrad_pixel_table): the same geometry at batch 1, then 3 (a larger table replaces it), then
-    2 (a prefix of the larger one), dilated 3 x 3 and a stride-2 1 x 1, each against fp32 torch on the CPU."""
+    """The 256-output-channel weight-gradient kernel reads its input pixels from a per-geometry table that the CALLER owns
+    (onda_conv2d_wgrad_l2_table; ops._wgrad_pixel_table keeps one per geometry): the same geometry at batch 1, then 3 (a
+    larger table replaces it), then 2 (served by the larger one), dilated 3 x 3 and a stride-2 1 x 1, each against fp32
+    torch on the CPU -- and once with no table at all (the kernel then works the pixels out in its K loop: same result)."""
     from onda_amd import ops
-    from onda_amd._lib import call
+    from onda_amd._lib import query
     import ctypes
     for (cin, cout, k, stride, dil, pad, H, W) in [(256, 256, 3, 1, 2, 2, 11, 19), (256, 512, 1, 2, 1, 0, 11, 19)]:
         Ho, Wo = (H + 2 * pad - dil * (k - 1) - 1) // stride + 1, (W + 2 * pad - dil * (k - 1) - 1) // stride + 1
-        # the table can be asked for ahead of time (the one call of the library that allocates); here for the smallest batch
-        d = ops._desc(1, H, W, cin, Ho, Wo, cout, k, stride, dil, pad, cin, cout)
-        call("onda_conv2d_wgrad_l2_prepare", ctypes.byref(d), ops._stream())
-        for B in (1, 3, 2):
-            g = torch.Generator().manual_seed(100 * B + k)
-            x = torch.randn(B, cin, H, W, generator=g)
-            w = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
-            wr = w.clone().requires_grad_(True)
-            yr = F.conv2d(x, wr, None, stride, pad, dil)
-            gy = torch.randn(yr.shape, generator=g)
-            yr.backward(gy)
-            xd = nhwc(x).to(DEV).requires_grad_(True)
-            wd = w.to(DEV).requires_grad_(True)
-            y, _ = ops.Conv2dFn.apply(xd, wd, None, ops._PackCache(), stride, dil, pad, True, None)
-            y.backward(nhwc(gy).to(DEV))
-            close(wd.grad, wr.grad, 5e-5, f"wgrad k={k} stride={stride} B={B}")
+        d = ops._desc(3, H, W, cin, Ho, Wo, cout, k, stride, dil, pad, cin, cout)
+        assert query("onda_conv2d_wgrad_l2_table_stride", ctypes.byref(d)) == (3 * Ho * Wo + 31) // 32 * 32 + 64
+        d1 = ops._desc(3, H, W, cin, H, W, cout, 1, 1, 1, 0, cin, cout)
+        assert query("onda_conv2d_wgrad_l2_table_stride", ctypes.byref(d1)) == 0  # 1 x 1 stride 1: x pixel = output pixel
+        for B in (1, 3, 2, 0):
+            no_table = B == 0
+            B = B or 2
+            real = ops._wgrad_pixel_table
+            if no_table:
+                ops._wgrad_pixel_table = lambda d, device: None
+            try:
+                _wgrad_case(ops, cin, cout, k, stride, dil, pad, H, W, B)
+            finally:
+                ops._wgrad_pixel_table = real
+        key = [kk for kk in ops._PIX_TABLES if kk[1:] == (H, W, Ho, Wo, k, k, stride, dil, pad)]
+        assert len(key) == 1 and ops._PIX_TABLES[key[0]][1] == 3  # one table per geometry, the largest batch's
+
+
+def _wgrad_case(ops, cin, cout, k, stride, dil, pad, H, W, B):
+    g = torch.Generator().manual_seed(100 * B + k)
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    wr = w.clone().requires_grad_(True)
+    yr = F.conv2d(x, wr, None, stride, pad, dil)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    xd = nhwc(x).to(DEV).requires_grad_(True)
+    wd = w.to(DEV).requires_grad_(True)
+    y, _ = ops.Conv2dFn.apply(xd, wd, None, ops._PackCache(), stride, dil, pad, True, None)
+    y.backward(nhwc(gy).to(DEV))
+    close(wd.grad, wr.grad, 5e-5, f"wgrad k={k} stride={stride} B={B}")
 
 
 @pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "x".join(map(str, c[:6])))
@@ -624,11 +640,19 @@ def test_losses_golden(golden, case):
     np.testing.assert_allclose(rce.item(), g[f"{case}_rce"], rtol=2e-6)
     np.testing.assert_allclose(reg.item(), g[f"{case}_mrkld"], rtol=2e-6)
     if case == "all_ignored":
+        # the reference's value is NaN and its GRADIENT is finite: autograd scatters an empty gradient back through
+        # predict[mask] (loss.py:36-44), so CE contributes exact zeros and the total's gradient is RCE + MRKLD (G3 holds both)
         assert torch.isnan(ce).item() and torch.isnan(total).item()
-        return
-    np.testing.assert_allclose(ce.item(), g[f"{case}_ce"], rtol=2e-6)
+        assert not g["all_ignored_grad_ce"].any()
+    else:
+        np.testing.assert_allclose(ce.item(), g[f"{case}_ce"], rtol=2e-6)
     total.backward()
+    assert torch.isfinite(out.grad).all()
     close(out.grad, torch.from_numpy(g[f"{case}_grad"]), 2e-5, "loss grad")
+    if case == "all_ignored":  # CE alone: exact zeros, as the reference
+        out1 = _head_out(logits).detach().requires_grad_(True)
+        ops.seg_losses(out1, target.to(DEV), 1.0, 0.0, 0.0)[0].backward()
+        assert not out1.grad.any()
 
 
 def test_losses_full_size_property():
@@ -850,6 +874,29 @@ def test_bad_arguments_raise():
     x = torch.zeros(1, 4, 4, 48, device=DEV)  # Cin not a multiple of 32
     with pytest.raises(RuntimeError, match="ONDA_EINVAL"):
         ops.conv_forward(x, torch.zeros(32, 48, device=DEV), 1, 1, 1, 0, 32)
+
+
+def test_limb_row_strides_must_be_whole_32_channel_blocks():
+    """Limb rows hold [32 x l1][32 x l2] per block of 32 channels (common.h limb_at): a row stride of 40 would put channels
+    32..39 into the next row (and past the buffer on the last one).  The two public producers of limb rows refuse it
+    (round-5 advisor: they still validated the two-plane contract, % 8)."""
+    from onda_amd import ops
+    from onda_amd._lib import call
+    rows = 64
+    x = torch.randn(rows, 40, device=DEV)
+    amax = ops.amax_slot(torch.device(DEV))
+    dst = torch.empty(2 * rows * 64, device=DEV, dtype=torch.float16)
+    with pytest.raises(RuntimeError, match="ONDA_EINVAL"):
+        call("onda_split_h2", ops._p(x), rows, 40, 40, ops._p(dst), 40, 0, ops._p(amax), ops._stream())
+    with pytest.raises(RuntimeError, match="ONDA_EINVAL"):  # C = 32 of a 40-wide row: still a 40-channel stride
+        call("onda_split_h2", ops._p(x), rows, 32, 40, ops._p(dst), 40, 0, ops._p(amax), ops._stream())
+    call("onda_split_h2", ops._p(x), rows, 32, 40, ops._p(dst), 64, 0, ops._p(amax), ops._stream())  # 64: fine
+    img = torch.randn(1, 3, 16, 16, device=DEV)
+    col = torch.empty(2 * 64 * 160, device=DEV, dtype=torch.float16)
+    with pytest.raises(RuntimeError, match="ONDA_EINVAL"):
+        call("onda_stem_im2col_l2", ops._p(img), ops._p(amax), ops._p(col), 0, 1, 16, 16, 8, 8, 152, ops._stream())
+    call("onda_stem_im2col_l2", ops._p(img), ops._p(amax), ops._p(col), 0, 1, 16, 16, 8, 8, 160, ops._stream())
+    torch.cuda.synchronize()
 
 
 # ------------------------------------------------------------------------------------------- f16x2 specifics
@@ -1118,6 +1165,32 @@ def test_predicated_convolutions_and_select():
         assert torch.equal(ops.select_prior(flag, b, 1.0, a, 2.0), 2.0 * a) and ops.gate_scalar(flag, a[0, 0]).item() == a[0, 0].item()
     finally:
         ops.CONV_MODE = old
+
+
+def test_upsample_ce_all_ignored_batch_matches_the_reference_gradient():
+    """config 2's loss head on a batch whose labels are all 255: the reference's loss_calc(interp(logits), label) is NaN and
+    its gradient exact ZEROS (func.py:88-96 -> loss.py:36-44: the gradient of an empty selection scattered back), so the SGD
+    step that follows moves on weight decay and momentum only.  The fused head does the same -- value NaN, gradient zeros, not
+    NaN -- checked against torch's autograd on the reference's formulation."""
+    from onda_amd import ops
+    g = torch.Generator().manual_seed(5)
+    B, K, h, w, H, W = 2, 19, 9, 17, 33, 65
+    logits = torch.randn(B, K, h, w, generator=g) * 2
+    labels = torch.full((B, H, W), 255, dtype=torch.long)
+    lr = logits.clone().requires_grad_(True)
+    up = F.interpolate(lr, size=(H, W), mode="bilinear", align_corners=True)
+    mask = labels != 255  # the reference's own selection (loss.py:34-42)
+    sel = up.permute(0, 2, 3, 1)[mask.view(B, H, W, 1).repeat(1, 1, 1, K)].view(-1, K)
+    ref = F.cross_entropy(sel, labels[mask])
+    ref.backward()
+    assert torch.isnan(ref) and not lr.grad.any()
+    ld = torch.zeros(B, h, w, ops.HEAD_PAD, device=DEV)
+    ld[..., :K] = logits.permute(0, 2, 3, 1).to(DEV)
+    out = ld[..., :K].permute(0, 3, 1, 2).requires_grad_(True)
+    loss = ops.upsample_ce(out, labels.to(DEV))
+    loss.backward()
+    assert torch.isnan(loss).item()
+    assert not out.grad.any()
 
 
 @pytest.mark.parametrize("K", [19, 22, 32])

@@ -27,7 +27,8 @@ def test_library_exports_every_declared_symbol():
         assert n in _lib.SIGNATURES, f"{n} has no ctypes prototype"
     assert set(_lib.SIGNATURES) == set(names)
     assert b"gfx950" in lib.onda_version()
-    assert ctypes.sizeof(_lib.OndaConv) == 19 * 4 + 4 + 8 + 8 + 8 and ctypes.sizeof(_lib.OndaSgdEntry) == 48  # 19 ints, pad, run_if, stat_split, plain_schedule + pad
+    # 19 ints, pad, run_if, stat_split, plain_schedule + pad, pix_table, pix_stride
+    assert ctypes.sizeof(_lib.OndaConv) == 19 * 4 + 4 + 8 + 8 + 8 + 8 + 8 and ctypes.sizeof(_lib.OndaSgdEntry) == 48
     assert ctypes.sizeof(_lib.OndaSwitchCfg) == 16 + 6 * 8
     assert lib.onda_conv_tiles_m(33540) == 263
 

@@ -30,7 +30,7 @@ for f in lines:
     open(os.path.join(P, os.path.basename(f)), "w").write(json.dumps(j) + "\n")
     print(os.path.basename(f), j["ms_per_step"], j["value"], (j.get("roofline") or {}).get("frac"))
 for n in ("bench_kernel_stats.csv", "bench_kernel_stats_one_stream.csv", "sq_counters.txt", "conv_shapes.txt", "hbm_traffic_top.txt",
-          "step_kernel_table.txt", "power_during_bench.csv"):
+          "step_kernel_table.txt", "power_summary.txt"):
     if os.path.exists(os.path.join(G, f"{tag}_{n}")):
         shutil.copy(os.path.join(G, f"{tag}_{n}"), os.path.join(P, f"{tag}_{n}"))
 print("library_src", src)

@@ -6,7 +6,10 @@
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 tag=${1:-r05_x}; G=gpurun_out; mkdir -p $G
 common="--no-cpu-baseline --no-eager --no-other-configs"
-python3 tools/power_log.py $G/${tag}_power_during_bench.csv -- python3 bench.py --steps 20 --warmup 5 > $G/${tag}_bench_line.json 2> $G/${tag}_bench_line.err
+# the headline line: bench.py alone, nothing wrapped around it (round-5 advisor); board power is logged in a run of its own below
+python3 bench.py --steps 20 --warmup 5 > $G/${tag}_bench_line.json 2> $G/${tag}_bench_line.err
+python3 tools/power_log.py $G/${tag}_power_during_bench.csv -- python3 bench.py --steps 40 --warmup 5 $common --no-exact-f32 --no-roofline > /dev/null 2> $G/${tag}_power_summary.txt
+rm -f $G/${tag}_power_during_bench.csv   # (20 ms samples, thousands of lines: the one-line summary on stderr is what is kept)
 python3 bench.py --steps 10 --warmup 3 --branch static $common --no-exact-f32 > $G/${tag}_bench_line_static_branch.json 2>/dev/null
 python3 bench.py --steps 10 --warmup 3 --config 1 $common > $G/${tag}_bench_line_config1.json 2>/dev/null
 python3 bench.py --steps 10 --warmup 3 --config 1 --eval-batch 1 $common > $G/${tag}_bench_line_config1_one_frame_at_a_time.json 2>/dev/null
