@@ -198,10 +198,21 @@ int onda_bn_finalize_l2(const float* partials, int tiles, int C, int64_t count, 
 int onda_bn_apply_l2(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
                      const void* res, int64_t res_plane, const float* res_amax, void* out, int64_t out_plane,
                      const float* out_amax, int64_t M, int C, int relu, uint8_t* relu_mask, int64_t split, onda_stream_t s);
+/* finalize + apply in ONE launch (round 6): BatchNorm's statistics are a grid-wide dependency between a pass of a few
+ * workgroups and one of thousands; as two launches the small one costs more in launch latency than in work.  Here the first
+ * (C / 16) * groups workgroups of the apply launch finalize, publish (release fence + atomic count) and every workgroup waits
+ * for the count (workgroups are dispatched in ascending order: the ones waited for never wait themselves; the wait is bounded).
+ * Same arguments and results as the two calls (x dense [M][C]); out_amax = ONDA_AMAX_FLOATS ZEROED floats as before, whose
+ * floats 1..3 carry the hand-over's counter (zero before the call, not reusable after it).  onda_bn_bwd_l2's fuse_sums != 0
+ * does the same for the backward pass's small reduction (two launches instead of three; counter in dx_amax). */
+int onda_bn_train_l2(const float* x, const float* partials, int tiles, float eps, float* mean, float* invstd, float* running_mean,
+                     float* running_var, int64_t* nbt, float momentum, const float* gamma, const float* beta, const void* res,
+                     const float* res_amax, int relu, float* xhat_amax, void* out, float* out_amax, int64_t M, int C,
+                     uint8_t* relu_mask, int64_t split, int tile_rows, int run_group, onda_stream_t s);
 int64_t onda_bn_bwd_l2_ws(int64_t M, int C);
 int onda_bn_bwd_l2(const float* dout, const void* out, int64_t out_plane, const float* x, const float* mean, const float* invstd,
                    const float* gamma, const float* xhat_amax, void* dx, int64_t dx_plane, float* dx_amax, float* dres, float* ws,
-                   int64_t M, int C, int relu, const uint8_t* relu_mask, int64_t split, onda_stream_t s);
+                   int64_t M, int C, int relu, const uint8_t* relu_mask, int64_t split, int fuse_sums, onda_stream_t s);
 
 /* onda_conv2d_wgrad slabs with both operands pre-split: [pixel][channel] limb planes in, LDS-DMA + transposed LDS reads
  * (ds_read_b64_tr_b16), tiles of 256 x 128 or 128 x 128 (output x input channels) per tap and pixel range.

@@ -77,7 +77,8 @@ SIGNATURES = {
     "onda_bn_finalize_l2": (I, [P, I, I, L, F, P, P, P, P, P, F, P, P, P, I, P, P, L, I, I, P, I, P]),
     "onda_bn_apply_l2": (I, [P, P, P, P, P, P, L, P, P, L, P, L, I, I, P, L, P]),
     "onda_bn_bwd_l2_ws": (L, [L, I]),
-    "onda_bn_bwd_l2": (I, [P, P, L, P, P, P, P, P, P, L, P, P, P, L, I, I, P, L, P]),
+    "onda_bn_train_l2": (I, [P, P, I, F, P, P, P, P, P, F, P, P, P, P, I, P, P, P, L, I, P, L, I, I, P]),
+    "onda_bn_bwd_l2": (I, [P, P, L, P, P, P, P, P, P, L, P, P, P, L, I, I, P, L, I, P]),
     "onda_conv2d_wgrad": (I, [P, P, P, I, I, POINTER(OndaConv), P]),
     "onda_wgrad_reduce": (I, [P, P, I, I, I, I, I, I, I, I, P]),
     "onda_pack_weight_fwd": (I, [P, P, I, I, I, I, I, P]),

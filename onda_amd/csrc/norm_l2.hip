@@ -115,6 +115,39 @@ __device__ __forceinline__ void st_stream(T* p, T v) {  // (bit 1: stores)
 }
 #define LD4S(p) ld_stream(reinterpret_cast<const f32x4*>(p))
 
+// ---- a dependent pass without a launch boundary ---------------------------------------------------------------------------
+// BatchNorm's statistics are a grid-wide dependency between two passes over the tensor: finalize (a few workgroups, a few
+// microseconds of latency-bound table reduction) -> apply (thousands of workgroups).  As two launches the small one costs
+// more in launch latency than in work (9 us per BatchNorm, 156 of them per adaptation step: round-3..5 reviews).  Fused: the
+// FIRST `nfin` workgroups of the big launch do the small pass, publish it (release fence + one atomic increment each) and
+// every workgroup waits for the count before it touches the results.  Workgroups are dispatched in ascending order (per XCD:
+// ids k, k + 8, ...), so the ones everybody waits for are resident before any waiter and depend on nobody: no deadlock,
+// whatever else shares the GPU.  The wait is bounded all the same (a GPU that hangs is worse than a wrong number the
+// parity tests catch): after ~1 s it gives up and raises word 2 of the sync line.
+// The counter needs a zeroed word that nobody else uses: floats 1..3 of the OUTPUT's amax buffer (ONDA_AMAX_FLOATS zeroed
+// floats, written by exactly one producer, never reused; only every AMAX_STRIDE-th float of it carries a maximum).
+__device__ __forceinline__ void grid_publish(float* amax_buf) {
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_fetch_add(reinterpret_cast<int*>(amax_buf) + 1, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void grid_wait(float* amax_buf, int target) {
+  if (threadIdx.x == 0) {
+    int* flag = reinterpret_cast<int*>(amax_buf) + 1;
+    int spins = 0;
+    while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      if (++spins > (1 << 21)) {  // ~1 s of s_sleep: never seen; do not hang the box
+        reinterpret_cast<int*>(amax_buf)[2] = 1;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(8);
+    }
+  }
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  asm volatile("" ::: "memory");
+}
+
 // Column reduction of small partial tables [rows][NV][C] (conv tile statistics, the backward reduction's chunks), 16
 // channels per 256-thread workgroup: thread t reads the 16-byte channel quad (t & 3) of the rows t >> 2, t >> 2 + 64, ...
 // (64-byte segments instead of the 4-byte, row-strided reads of a wave per channel: 16 times fewer cache-line requests
@@ -204,15 +237,36 @@ __device__ __forceinline__ void reduce_rows16(const float* __restrict__ partials
 // workgroup): group 0 adds them, group 1 subtracts them.  Extrema only have to BOUND a group's: group 1 keeps the whole
 // row's.  (The host guarantees that the straddling tile is not a stream-K remainder tile: csrc/conv_l2.hip, l2_schedule.)
 // run_group: the group whose statistics move the running buffers (-1: none).
-__global__ __launch_bounds__(256) void bn_finalize_l2_kernel(const float* __restrict__ partials, int tiles, int C, double count, float eps,
-                                                             float* mean, float* invstd, float* rmean, float* rvar, int64_t* nbt,
-                                                             float momentum, const float* __restrict__ gamma,
-                                                             const float* __restrict__ beta, const float* __restrict__ res_amax,
-                                                             int relu, float* __restrict__ xhat_amax, float* __restrict__ out_amax,
-                                                             long long split, int bm, int run_group, const float* __restrict__ y,
-                                                             int ldy) {
-  const int g = blockIdx.y;
-  if (blockIdx.x == 0 && g == 0 && threadIdx.x == 0 && nbt) *nbt += 1;
+struct BnFinalizeArgs {
+  const float* partials;
+  int tiles, C;
+  double count;
+  float eps;
+  float *mean, *invstd, *rmean, *rvar;
+  int64_t* nbt;
+  float momentum;
+  const float *gamma, *beta, *res_amax;
+  int relu;
+  float *xhat_amax, *out_amax;
+  long long split;
+  int bm, run_group;
+  const float* y;
+  int ldy;
+};
+// one workgroup (256 threads) = 16 channels `bx` of row group `g`
+__device__ __forceinline__ void bn_finalize_block(const BnFinalizeArgs& a, const int bx, const int g) {
+  const float* __restrict__ partials = a.partials;
+  const int tiles = a.tiles, C = a.C, relu = a.relu, bm = a.bm, run_group = a.run_group, ldy = a.ldy;
+  double count = a.count;
+  const float eps = a.eps, momentum = a.momentum;
+  float *mean = a.mean, *invstd = a.invstd, *rmean = a.rmean, *rvar = a.rvar, *xhat_amax = a.xhat_amax, *out_amax = a.out_amax;
+  int64_t* nbt = a.nbt;
+  const float* __restrict__ gamma = a.gamma;
+  const float* __restrict__ beta = a.beta;
+  const float* __restrict__ res_amax = a.res_amax;
+  const float* __restrict__ y = a.y;
+  const long long split = a.split;
+  if (bx == 0 && g == 0 && threadIdx.x == 0 && nbt) *nbt += 1;
   int row0 = 0, nrows = tiles;
   if (split > 0) {
     const int ts = (int)(split / bm);
@@ -221,8 +275,8 @@ __global__ __launch_bounds__(256) void bn_finalize_l2_kernel(const float* __rest
   }
   double sum[2];
   float ext[2];
-  reduce_rows16<4, 2, true>(partials + (size_t)row0 * 4 * C, nrows, C, blockIdx.x * 16, sum, ext);
-  const int ch = blockIdx.x * 16 + threadIdx.x;
+  reduce_rows16<4, 2, true>(partials + (size_t)row0 * 4 * C, nrows, C, bx * 16, sum, ext);
+  const int ch = bx * 16 + threadIdx.x;
   float bound = 0.f;
   if (threadIdx.x < 16 && ch < C) {
     if (split > 0 && split % bm != 0) {  // the group-0 rows of the straddling tile
@@ -265,19 +319,39 @@ __global__ __launch_bounds__(256) void bn_finalize_l2_kernel(const float* __rest
   if (res_amax != nullptr) bound += amax_read(res_amax);
   bound *= 1.0000005f;  // the apply pass rounds differently; the scale leaves a factor 2 of headroom anyway
   __shared__ float red[4];
-  amax_update_block(out_amax, bound, red);
+  // one atomic per workgroup, slot by (bx, g) (amax_update_block takes blockIdx.x, which is something else in the fused launch)
+  float m = wave_max(bound);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    if (m > 0.f)
+      atomicMax(reinterpret_cast<unsigned*>(out_amax) + ((bx + 7 * g) & (ONDA_AMAX_SLOTS - 1)) * AMAX_STRIDE, __float_as_uint(m));
+  }
 }
+__global__ __launch_bounds__(256) void bn_finalize_l2_kernel(const BnFinalizeArgs a) { bn_finalize_block(a, blockIdx.x, blockIdx.y); }
 
 // out limbs = [relu]( (x - mean)*invstd*gamma + beta [+ residual limbs] ), 8 channels per thread.
 // group1_at > 0: two row groups -- 8-channel items [0, group1_at) normalise with the statistics at mean / invstd, the others with
 // those at mean + C / invstd + C (gamma / beta are shared).
-__global__ __launch_bounds__(256) void bn_apply_l2_kernel(const float* __restrict__ x, const float* __restrict__ mean,
-                                                          const float* __restrict__ invstd, const float* __restrict__ gamma,
-                                                          const float* __restrict__ beta, const _Float16* __restrict__ res,
-                                                          size_t res_plane, const float* __restrict__ res_amax,
-                                                          _Float16* __restrict__ out, size_t out_plane,
-                                                          const float* __restrict__ out_amax, size_t total8, int C, int relu,
-                                                          unsigned char* __restrict__ mask, size_t group1_at) {
+// FUSED: the first `nfin` workgroups run bn_finalize_block first and everybody waits for them (grid_publish / grid_wait above):
+// finalize + apply in ONE launch; mean / invstd / out_amax are then written by this very launch (no __restrict__ on them).
+template <bool FUSED>
+__global__ __launch_bounds__(256) void bn_apply_l2_kernel(const float* __restrict__ x, const float* mean, const float* invstd,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          const _Float16* __restrict__ res, size_t res_plane,
+                                                          const float* __restrict__ res_amax, _Float16* __restrict__ out,
+                                                          size_t out_plane, const float* out_amax, size_t total8, int C, int relu,
+                                                          unsigned char* __restrict__ mask, size_t group1_at, const BnFinalizeArgs fin,
+                                                          int nfin) {
+  if constexpr (FUSED) {
+    const int nb = (C + 15) / 16;
+    if ((int)blockIdx.x < nfin) {
+      bn_finalize_block(fin, blockIdx.x % nb, blockIdx.x / nb);
+      grid_publish(fin.out_amax);
+    }
+    grid_wait(fin.out_amax, nfin);
+  }
   const int c8 = C / 8;
   const float so = scale_of(out_amax).s;
   const float ri = res ? scale_of(res_amax).inv : 0.f;
@@ -448,39 +522,62 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_l2_kernel(const float* __re
 // pass 2: chunk partials [chunks][3][C] -> sums[2][C] and the bound of max|dx| into dx_amax; 16 channels per workgroup.
 // Row groups: blockIdx.y = group; its chunk rows are [0, chunks0) / [chunks0, chunks), its results go to sums + g*2*C, its
 // statistics sit at invstd + g*C / xhat_amax + g*C.
-__global__ __launch_bounds__(256) void bn_bwd_sums_l2_kernel(const float* __restrict__ partials, int chunks, int C, double inv_m0,
-                                                             double inv_m1, const float* __restrict__ gamma,
-                                                             const float* __restrict__ invstd, const float* __restrict__ xhat_amax,
-                                                             float* __restrict__ sums, float* __restrict__ dx_amax, int chunks0) {
-  const int g = blockIdx.y;
-  const int row0 = g == 0 ? 0 : chunks0, nrows = gridDim.y == 1 ? chunks : (g == 0 ? chunks0 : chunks - chunks0);
-  const double inv_m = g == 0 ? inv_m0 : inv_m1;
+struct BnBwdSumsArgs {
+  const float* partials;
+  int chunks, C;
+  double inv_m0, inv_m1;
+  const float *gamma, *invstd, *xhat_amax;
+  float *sums, *dx_amax;
+  int chunks0, groups;
+};
+__device__ __forceinline__ void bn_bwd_sums_block(const BnBwdSumsArgs& a, const int bx, const int g) {
+  const int C = a.C;
+  const int row0 = g == 0 ? 0 : a.chunks0, nrows = a.groups == 1 ? a.chunks : (g == 0 ? a.chunks0 : a.chunks - a.chunks0);
+  const double inv_m = g == 0 ? a.inv_m0 : a.inv_m1;
   double sum[2];
   float ext[1];
-  reduce_rows16<3, 2, false>(partials + (size_t)row0 * 3 * C, nrows, C, blockIdx.x * 16, sum, ext);
-  const int ch = blockIdx.x * 16 + threadIdx.x;
+  reduce_rows16<3, 2, false>(a.partials + (size_t)row0 * 3 * C, nrows, C, bx * 16, sum, ext);
+  const int ch = bx * 16 + threadIdx.x;
   float bound = 0.f;
   if (threadIdx.x < 16 && ch < C) {
-    sums[g * 2 * C + ch] = (float)sum[0];
-    sums[g * 2 * C + C + ch] = (float)sum[1];
-    bound = fabsf(gamma[ch] * invstd[g * C + ch]) *
-            (ext[0] + (float)(fabs(sum[0]) * inv_m) + xhat_amax[g * C + ch] * (float)(fabs(sum[1]) * inv_m));
+    a.sums[g * 2 * C + ch] = (float)sum[0];
+    a.sums[g * 2 * C + C + ch] = (float)sum[1];
+    bound = fabsf(a.gamma[ch] * a.invstd[g * C + ch]) *
+            (ext[0] + (float)(fabs(sum[0]) * inv_m) + a.xhat_amax[g * C + ch] * (float)(fabs(sum[1]) * inv_m));
   }
   bound *= 1.000001f;
   __shared__ float red[4];
-  amax_update_block(dx_amax, bound, red);
+  float m = wave_max(bound);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    if (m > 0.f)
+      atomicMax(reinterpret_cast<unsigned*>(a.dx_amax) + ((bx + 7 * g) & (ONDA_AMAX_SLOTS - 1)) * AMAX_STRIDE, __float_as_uint(m));
+  }
 }
+__global__ __launch_bounds__(256) void bn_bwd_sums_l2_kernel(const BnBwdSumsArgs a) { bn_bwd_sums_block(a, blockIdx.x, blockIdx.y); }
 
 // pass 3: dx limbs.  group1_at > 0: the 8-channel items from there on belong to row group 1 (statistics at + C, sums at + 2C,
 // 1 / M of that group)
+// FUSED: the first `nfin` workgroups reduce the chunk partials first (bn_bwd_sums_block) and everybody waits for them
+template <bool FUSED>
 __global__ __launch_bounds__(256) void bn_bwd_apply_l2_kernel(const float* __restrict__ dout, const _Float16* __restrict__ out,
                                                               size_t out_plane, const float* __restrict__ x,
                                                               const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                              const float* __restrict__ gamma, const float* __restrict__ sums,
-                                                              _Float16* __restrict__ dx, size_t dx_plane,
-                                                              const float* __restrict__ dx_amax, size_t total8, int C, float inv_m,
-                                                              int relu, const unsigned char* __restrict__ mask, size_t group1_at,
-                                                              float inv_m1) {
+                                                              const float* __restrict__ gamma, const float* sums,
+                                                              _Float16* __restrict__ dx, size_t dx_plane, const float* dx_amax,
+                                                              size_t total8, int C, float inv_m, int relu,
+                                                              const unsigned char* __restrict__ mask, size_t group1_at, float inv_m1,
+                                                              const BnBwdSumsArgs fin, int nfin) {
+  if constexpr (FUSED) {
+    const int nb = (C + 15) / 16;
+    if ((int)blockIdx.x < nfin) {
+      bn_bwd_sums_block(fin, blockIdx.x % nb, blockIdx.x / nb);
+      grid_publish(fin.dx_amax);
+    }
+    grid_wait(fin.dx_amax, nfin);
+  }
   const int c8 = C / 8;
   const float sd = scale_of(dx_amax).s;
   const size_t e0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -551,6 +648,14 @@ static inline unsigned ew_grid(size_t total) {
 
 extern "C" {
 
+static BnFinalizeArgs finalize_args(const float* partials, int tiles, int C, int64_t count, float eps, float* mean, float* invstd,
+                                    float* running_mean, float* running_var, int64_t* nbt, float momentum, const float* gamma,
+                                    const float* beta, const float* res_amax, int relu, float* xhat_amax, float* out_amax,
+                                    int64_t split, int tile_rows, int run_group, const float* y, int ldy) {
+  return BnFinalizeArgs{partials, tiles, C, (double)count, eps, mean, invstd, running_mean, running_var, nbt, momentum, gamma, beta,
+                        res_amax, relu, xhat_amax, out_amax, (long long)split, tile_rows > 0 ? tile_rows : 1, run_group, y, ldy};
+}
+
 int onda_bn_finalize_l2(const float* partials, int tiles, int C, int64_t count, float eps, float* mean, float* invstd,
                         float* running_mean, float* running_var, int64_t* nbt, float momentum, const float* gamma,
                         const float* beta, const float* res_amax, int relu, float* xhat_amax, float* out_amax, int64_t split,
@@ -558,9 +663,9 @@ int onda_bn_finalize_l2(const float* partials, int tiles, int C, int64_t count, 
   ONDA_REQUIRE(partials && mean && invstd && gamma && beta && xhat_amax && out_amax && tiles >= 1 && C >= 4 && C % 4 == 0 && count >= 1);
   ONDA_REQUIRE(split >= 0 && split < count && (split == 0 || (tile_rows > 0 && y && ldy >= C && split / tile_rows < tiles)));
   if (!ONDA_ALIGNED16(partials)) return ONDA_EALIGN;
-  hipLaunchKernelGGL(bn_finalize_l2_kernel, dim3((C + 15) / 16, split > 0 ? 2 : 1), dim3(256), 0, ONDA_STREAM(s), partials, tiles, C,
-                     (double)count, eps, mean, invstd, running_mean, running_var, nbt, momentum, gamma, beta, res_amax, relu, xhat_amax,
-                     out_amax, (long long)split, tile_rows > 0 ? tile_rows : 1, run_group, y, ldy);
+  hipLaunchKernelGGL(bn_finalize_l2_kernel, dim3((C + 15) / 16, split > 0 ? 2 : 1), dim3(256), 0, ONDA_STREAM(s),
+                     finalize_args(partials, tiles, C, count, eps, mean, invstd, running_mean, running_var, nbt, momentum, gamma, beta,
+                                   res_amax, relu, xhat_amax, out_amax, split, tile_rows, run_group, y, ldy));
   return ONDA_LAUNCH_RESULT();
 }
 
@@ -583,9 +688,32 @@ int onda_bn_apply_l2(const float* x, const float* mean, const float* invstd, con
   ONDA_REQUIRE(split >= 0 && split < M);
   if (!ONDA_ALIGNED16(x) || !ONDA_ALIGNED16(out) || (res && !ONDA_ALIGNED16(res))) return ONDA_EALIGN;
   const size_t total8 = (size_t)M * C / 8;
-  hipLaunchKernelGGL(bn_apply_l2_kernel, dim3(ew_grid(total8)), dim3(256), 0, ONDA_STREAM(s), x, mean, invstd, gamma, beta,
+  hipLaunchKernelGGL(bn_apply_l2_kernel<false>, dim3(ew_grid(total8)), dim3(256), 0, ONDA_STREAM(s), x, mean, invstd, gamma, beta,
                      static_cast<const _Float16*>(res), (size_t)res_plane, res_amax, static_cast<_Float16*>(out), (size_t)out_plane,
-                     out_amax, total8, C, relu, relu_mask, (size_t)split * C / 8);
+                     out_amax, total8, C, relu, relu_mask, (size_t)split * C / 8, BnFinalizeArgs{}, 0);
+  return ONDA_LAUNCH_RESULT();
+}
+
+/* onda_bn_finalize_l2 + onda_bn_apply_l2 in ONE launch (grid_publish / grid_wait above): the first (C / 16) * groups
+ * workgroups finalize, every workgroup waits for them.  out_amax: zeroed ONDA_AMAX_FLOATS floats as for the two calls; its
+ * floats 1..3 serve as the hand-over's counter (zero before the call, not reusable after it). */
+int onda_bn_train_l2(const float* x, const float* partials, int tiles, float eps, float* mean, float* invstd, float* running_mean,
+                     float* running_var, int64_t* nbt, float momentum, const float* gamma, const float* beta, const void* res,
+                     const float* res_amax, int relu, float* xhat_amax, void* out, float* out_amax, int64_t M, int C,
+                     uint8_t* relu_mask, int64_t split, int tile_rows, int run_group, onda_stream_t s) {
+  ONDA_REQUIRE(x && partials && mean && invstd && gamma && beta && xhat_amax && out && out_amax && tiles >= 1 && M >= 1);
+  ONDA_REQUIRE(C % 32 == 0 && (!res || res_amax) && (256 % (C / 8) == 0 || (C / 8) % 256 == 0));
+  ONDA_REQUIRE(split >= 0 && split < M && (split == 0 || (tile_rows > 0 && split / tile_rows < tiles)));
+  if (!ONDA_ALIGNED16(x) || !ONDA_ALIGNED16(out) || (res && !ONDA_ALIGNED16(res)) || !ONDA_ALIGNED16(partials)) return ONDA_EALIGN;
+  const size_t total8 = (size_t)M * C / 8;
+  const int nfin = (C + 15) / 16 * (split > 0 ? 2 : 1);
+  const unsigned grid = ew_grid(total8) > (unsigned)nfin ? ew_grid(total8) : (unsigned)nfin;
+  hipLaunchKernelGGL(bn_apply_l2_kernel<true>, dim3(grid), dim3(256), 0, ONDA_STREAM(s), x, mean, invstd, gamma, beta,
+                     static_cast<const _Float16*>(res), (size_t)0, res_amax, static_cast<_Float16*>(out), (size_t)0, out_amax, total8, C,
+                     relu, relu_mask, (size_t)split * C / 8,
+                     finalize_args(partials, tiles, C, M, eps, mean, invstd, running_mean, running_var, nbt, momentum, gamma, beta, res_amax,
+                                   relu, xhat_amax, out_amax, split, tile_rows, run_group, x, C),
+                     nfin);
   return ONDA_LAUNCH_RESULT();
 }
 
@@ -604,9 +732,11 @@ int64_t onda_bn_bwd_l2_ws(int64_t M, int C) {
   return (int64_t)(p.chunks + 1) * 3 * C + 4 * C;  // (+1 chunk row: two row groups round up separately; sums[2][2][C])
 }
 
+/* fuse_sums != 0: the chunk partials are reduced by the first workgroups of the apply launch (two launches instead of three);
+ * dx_amax's floats 1..3 then serve as the hand-over's counter (see onda_bn_train_l2) */
 int onda_bn_bwd_l2(const float* dout, const void* out, int64_t out_plane, const float* x, const float* mean, const float* invstd,
                    const float* gamma, const float* xhat_amax, void* dx, int64_t dx_plane, float* dx_amax, float* dres, float* ws,
-                   int64_t M, int C, int relu, const uint8_t* relu_mask, int64_t split, onda_stream_t s) {
+                   int64_t M, int C, int relu, const uint8_t* relu_mask, int64_t split, int fuse_sums, onda_stream_t s) {
   ONDA_REQUIRE(dout && x && mean && invstd && gamma && xhat_amax && dx && dx_amax && ws && C % 32 == 0 && (!relu || out || relu_mask));
   ONDA_REQUIRE(256 % (C / 8) == 0 || (C / 8) % 256 == 0);
   ONDA_REQUIRE(split >= 0 && split < M);
@@ -619,12 +749,21 @@ int onda_bn_bwd_l2(const float* dout, const void* out, int64_t out_plane, const 
   hipLaunchKernelGGL(bn_bwd_reduce_l2_kernel, dim3(p.gridx, chunks), dim3(256), 0, st, dout, static_cast<const _Float16*>(out),
                      (size_t)out_plane, x, mean, invstd, dres, M, C, relu, p.cx, p.rows_per_chunk, ws, relu_mask, split, chunks0);
   const double inv_m0 = 1.0 / (double)(split > 0 ? split : M), inv_m1 = 1.0 / (double)(M - split);
-  hipLaunchKernelGGL(bn_bwd_sums_l2_kernel, dim3((C + 15) / 16, split > 0 ? 2 : 1), dim3(256), 0, st, ws, chunks, C, inv_m0, inv_m1,
-                     gamma, invstd, xhat_amax, sums, dx_amax, chunks0);
+  const int groups = split > 0 ? 2 : 1;
+  const BnBwdSumsArgs fin{ws, chunks, C, inv_m0, inv_m1, gamma, invstd, xhat_amax, sums, dx_amax, chunks0, groups};
   const size_t total8 = (size_t)M * C / 8;
-  hipLaunchKernelGGL(bn_bwd_apply_l2_kernel, dim3(ew_grid(total8)), dim3(256), 0, st, dout, static_cast<const _Float16*>(out),
+  if (fuse_sums) {
+    const int nfin = (C + 15) / 16 * groups;
+    const unsigned grid = ew_grid(total8) > (unsigned)nfin ? ew_grid(total8) : (unsigned)nfin;
+    hipLaunchKernelGGL(bn_bwd_apply_l2_kernel<true>, dim3(grid), dim3(256), 0, st, dout, static_cast<const _Float16*>(out),
+                       (size_t)out_plane, x, mean, invstd, gamma, sums, static_cast<_Float16*>(dx), (size_t)dx_plane, dx_amax, total8, C,
+                       (float)inv_m0, relu, relu_mask, (size_t)split * C / 8, (float)inv_m1, fin, nfin);
+    return ONDA_LAUNCH_RESULT();
+  }
+  hipLaunchKernelGGL(bn_bwd_sums_l2_kernel, dim3((C + 15) / 16, groups), dim3(256), 0, st, fin);
+  hipLaunchKernelGGL(bn_bwd_apply_l2_kernel<false>, dim3(ew_grid(total8)), dim3(256), 0, st, dout, static_cast<const _Float16*>(out),
                      (size_t)out_plane, x, mean, invstd, gamma, sums, static_cast<_Float16*>(dx), (size_t)dx_plane, dx_amax, total8,
-                     C, (float)inv_m0, relu, relu_mask, (size_t)split * C / 8, (float)inv_m1);
+                     C, (float)inv_m0, relu, relu_mask, (size_t)split * C / 8, (float)inv_m1, BnBwdSumsArgs{}, 0);
   return ONDA_LAUNCH_RESULT();
 }
 

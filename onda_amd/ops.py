@@ -1016,6 +1016,12 @@ class BNTrainFn(torch.autograd.Function):
 
 
 
+# BatchNorm's small statistics passes inside the big launches that need them (csrc/norm_l2.hip: bn_finalize_l2 in the apply
+# launch, bn_bwd_sums_l2 in the backward apply launch): 156 launches per adaptation step fewer.  0: the separate launches of
+# rounds 2-5 (same numbers; tools/ab_flag.py onda_amd.ops FUSE_BN_FINALIZE 0 -- ...).
+FUSE_BN_FINALIZE = os.environ.get("ONDA_FUSE_BN", "1") != "0"
+
+
 class BNTrainLimbFn(torch.autograd.Function):
     """BNTrainFn whose output exists as limb planes only ("f16x2" / "dma"): the output of a train-mode BatchNorm
     (+residual, +ReLU) is consumed by convolutions, a later residual add and its own backward mask -- all of which
@@ -1040,18 +1046,25 @@ class BNTrainLimbFn(torch.autograd.Function):
             raise RuntimeError("onda_amd: residual of a BatchNorm must be a dense [B,H,W,C] activation")
         out_amax = amax_slot(dev)
         tile_rows = _stat_tile_rows(stats) if split else 0
-        call("onda_bn_finalize_l2", _p(stats), stats.shape[0], C, M, BN_EPS, _p(mean), _p(invstd), _p(rm), _p(rv), _p(nbt),
-             float(momentum), _p(gamma), _p(beta), _p(res.amax) if res is not None else None, int(relu), _p(xhat_amax),
-             _p(out_amax), split, tile_rows, 1, _p(y) if split else None, nhwc_ld(y) if split else 0, _stream())
-        if running is not None:
-            for t in running:
-                torch.autograd.graph.increment_version(t)
         planes = torch.empty(2, M, C, device=dev, dtype=torch.float16)
         # [out > 0] as one bit per element for the backward passes (they would read 2 bytes of `planes` per element instead)
         mask = torch.empty(M * C // 8, device=dev, dtype=torch.uint8) if relu and any(ctx.needs_input_grad) else None
-        call("onda_bn_apply_l2", _p(y), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(res.planes) if res is not None else None,
-             res.plane if res is not None else 0, _p(res.amax) if res is not None else None, _p(planes), M * C, _p(out_amax),
-             M, C, int(relu), _p(mask), split, _stream())
+        if FUSE_BN_FINALIZE and nhwc_ld(y) == C:
+            # statistics and apply pass in one launch (csrc/norm_l2.hip, grid_publish / grid_wait)
+            call("onda_bn_train_l2", _p(y), _p(stats), stats.shape[0], BN_EPS, _p(mean), _p(invstd), _p(rm), _p(rv), _p(nbt),
+                 float(momentum), _p(gamma), _p(beta), _p(res.planes) if res is not None else None,
+                 _p(res.amax) if res is not None else None, int(relu), _p(xhat_amax), _p(planes), _p(out_amax), M, C, _p(mask),
+                 split, tile_rows, 1, _stream())
+        else:
+            call("onda_bn_finalize_l2", _p(stats), stats.shape[0], C, M, BN_EPS, _p(mean), _p(invstd), _p(rm), _p(rv), _p(nbt),
+                 float(momentum), _p(gamma), _p(beta), _p(res.amax) if res is not None else None, int(relu), _p(xhat_amax),
+                 _p(out_amax), split, tile_rows, 1, _p(y) if split else None, nhwc_ld(y) if split else 0, _stream())
+            call("onda_bn_apply_l2", _p(y), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(res.planes) if res is not None else None,
+                 res.plane if res is not None else 0, _p(res.amax) if res is not None else None, _p(planes), M * C, _p(out_amax),
+                 M, C, int(relu), _p(mask), split, _stream())
+        if running is not None:
+            for t in running:
+                torch.autograd.graph.increment_version(t)
         lb = Limbs(planes, out_amax, C, M * C)
         ctx.split = split
         ctx.save_for_backward(y, mean, invstd, gamma, xhat_amax)
@@ -1080,7 +1093,8 @@ class BNTrainLimbFn(torch.autograd.Function):
         ol = ctx.out_limbs
         call("onda_bn_bwd_l2", _p(dout), _p(ol.planes) if ol is not None else None, ol.plane if ol is not None else 0, _p(y),
              _p(mean), _p(invstd), _p(gamma), _p(xhat_amax), _p(planes), M * C, _p(dx_amax),
-             _p(dres) if (need_res and ctx.relu) else None, _p(ws), M, C, int(ctx.relu), _p(ctx.relu_mask), ctx.split, _stream())
+             _p(dres) if (need_res and ctx.relu) else None, _p(ws), M, C, int(ctx.relu), _p(ctx.relu_mask), ctx.split,
+             int(FUSE_BN_FINALIZE), _stream())
         dx = limb_only((B, H, W, C), dev, Limbs(planes, dx_amax, C, M * C))
         if need_res:
             dres = _sink_give(ctx.res_sink, dres, ctx.relu)
