@@ -1081,6 +1081,226 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_l2x_kernel(const ConvK
   }
 }
 
+// ---- activation-stationary 1 x 1 convolution: the activation rows of a workgroup live in REGISTERS, only weight rows stream ----
+// The short-K 1 x 1 convolutions (Cin <= 256: conv3 / downsample of layer1-3, the data gradients of their conv1) have as
+// few as 2-8 K-steps per tile: in the tile kernels above every column tile re-delivers its 256 (128) activation rows into
+// LDS -- 8-16 times per row tile, two thirds of the bytes a K-step waits for -- and pays a cold start and an epilogue per
+// 8 K-steps (round-5 measurement: weights only 18 us, activations only 43 us, whole kernel 86 us for 256 -> 1024).
+// Here a workgroup (4 waves, one per SIMD, 128 rows) loads its rows' WHOLE K extent once, straight from memory into the
+// MFMA fragment layout (a lane's 16 bytes of a fragment are contiguous in a limb row: no LDS, no transposition) --
+// the 512-register budget of one wave per SIMD is what makes that possible -- and then sweeps the column tiles of Cout
+// against them: per K-step only 16 KB of weight rows (hot in every L2) arrive by LDS-DMA, through a ring of NST stages that
+// runs NST - 1 steps ahead ACROSS column tiles and row panels.  Delivered bytes per MFMA: 2/3 of the 256 x 128 tile's,
+// fragment reads per MFMA: half.  With 256 input channels both limbs of the rows would take 256 registers per lane, which
+// the compiler cannot hold beside 128 accumulators (it spilled the fragments as it loaded them): A2L keeps the SECOND limbs
+// (used by one of the three products) in LDS instead -- 64 KB per panel, filled once per panel by LDS-DMA, 64-byte rows with
+// the 16-byte chunk XOR-ed by (row >> 2) & 3 (conflict-free ds_read_b128) -- and the first limbs in registers.
+// Work items (row panel, column tile) in row-major order are dealt to the workgroups in equal contiguous runs: a workgroup
+// changes its panel (reloads its rows) two or three times per launch.
+// Epilogue: l2_epilogue / l2_epilogue_limbs as they stand (COUNTED: 16 or 32 buffer stores per wave, no vmcnt(0)), on LDS
+// scratch of their own.  Same products in the same order per accumulator as the tile kernels: bit-identical results.
+template <int KB, int NST, bool A2L>
+__global__ __launch_bounds__(256, 1) void conv_l2a_kernel(const ConvK a, unsigned w_bytes, unsigned y_bytes, const float* __restrict__ xamax,
+                                                          const float* __restrict__ wamax) {
+  if (a.c.run_if != nullptr && *a.c.run_if == 0) return;  // predicated launch (onda_switch_step decided on the device)
+  constexpr int WM = 2, WN = 2, NW = 4, BM = 128, BN = 128;
+  constexpr int STAGE = BN * 128;          // 128 weight rows x (32 channels x 2 limbs)
+  constexpr int BPW = (BN / 8) / NW;       // 8-row pieces (one LDS-DMA instruction) per wave and K-step
+  constexpr int EST = 16;                  // buffer stores per wave and epilogue (twice that for limb output)
+  constexpr int AHEAD = NST - 1;           // K-steps in flight beyond the one being read
+  static_assert(AHEAD <= KB, "at most one epilogue's stores are younger than a DMA step that is waited for");
+  static_assert((AHEAD - 1) * BPW + 2 * EST <= 63, "vmcnt holds 6 bits");
+  constexpr int SCRATCH = NW * (16 * 68 * 4) + WM * BN * 4 * 4 + 64;  // l2_epilogue: transposition buffers, statistics, amax
+  constexpr int A2_BYTES = A2L ? KB * (BM / 16) * 1024 : 0;           // second limbs: [kb][16-row block][16 rows x 64 B]
+  constexpr int NA = A2L ? 1 : 2;                                     // limbs of the rows held in registers
+  __shared__ __attribute__((aligned(16))) unsigned char lds[NST * STAGE + SCRATCH + A2_BYTES];
+  unsigned char* const a2lds = lds + NST * STAGE + SCRATCH;
+
+  const OndaConv& c = a.c;
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int nblk = gridDim.x, bid = blockIdx.x;
+  const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
+  const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  const long long items = (long long)a.tilesM * a.tilesN;
+  const int it_begin = (int)(swz * items / nblk), it_end = (int)((swz + 1) * items / nblk);
+  if (it_begin >= it_end) return;
+  const int wstride = c.Cin;  // (taps == 1)
+  const __amdgpu_buffer_rsrc_t rw = make_rsrc(a.w, w_bytes);
+  const Scale2 sx = scale_of(xamax), sw = scale_of(wamax);
+  const float unscale_a = sx.inv, unscale_b = sw.inv;
+  const int lrow = lane >> 3;
+  const unsigned cq[2] = {dma_chunk16(lane, 0), dma_chunk16(lane, 1)};
+  const int fr0 = frag_ofs(lane, 0), fr1 = frag_ofs(lane, 1);
+  const int fa2 = (lane & 15) * 64 + (((lane >> 4) ^ (((lane & 15) >> 2) & 3)) << 4);  // this lane's 16 bytes of a 1 KB A2 unit
+  const bool limb_out = a.yl != nullptr;
+
+  // ---- issue side: the weight stream, one step = (item, kb); behind the last item the offsets are out of range (the DMA
+  // writes zeros into a stage nobody reads): every step issues, so the number of DMAs in flight is a constant
+  int i_item = it_begin, i_kb = 0, st_issue = 0;
+  unsigned bofs[BPW];
+  auto open_issue_item = [&]() {
+    const int n0 = (i_item % a.tilesN) * BN;
+#pragma unroll
+    for (int d = 0; d < BPW; ++d) {
+      const int n = n0 + (wave * BPW + d) * 8 + lrow;
+      bofs[d] = i_item < it_end && n < c.Cout ? (unsigned)n * wstride * 4u + cq[d & 1] : OOB;
+    }
+  };
+  auto issue_step = [&]() {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+    for (int d = 0; d < BPW; ++d) {
+      unsigned char* dst = lds + st_issue + (wave * BPW + d) * 1024;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)dst, 16, bofs[d], i_kb * 128, 0, 0);
+    }
+#endif
+    st_issue = st_issue + STAGE == NST * STAGE ? 0 : st_issue + STAGE;
+    if (++i_kb == KB) {
+      i_kb = 0;
+      ++i_item;
+      open_issue_item();
+    }
+  };
+  int stores_young = 0;
+  auto wait_step = [&]() {  // this wave's DMAs of the oldest step in flight have landed; AHEAD - 1 younger steps may still fly
+    constexpr int D = (AHEAD - 1) * BPW;
+    if (stores_young && limb_out) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D + 2 * EST) : "memory");
+    else if (stores_young) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D + EST) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D) : "memory");
+    if (stores_young) --stores_young;
+  };
+
+  open_issue_item();
+#pragma unroll
+  for (int sI = 0; sI < AHEAD; ++sI) issue_step();
+
+  // ---- the row panel's activations: fragment (kb, i, limb) of this lane = 16 bytes of row m0 + wm*64 + i*16 + (lane & 15):
+  // bytes [limb*64 + (lane >> 4)*16, +16) of the row's 128-byte block kb
+  f16x8 af[KB][4][NA];
+  int cur_p = -1, st_read = 0;
+  // input pixel of GEMM row m: the pixel itself, or (stride 2) the one it samples
+  auto pixel_of = [&](int m) -> long long {
+    if (c.stride == 1) return m;
+    const int mm = m < a.M ? m : a.M - 1;
+    const int wo = mm % c.Wo, tq = mm / c.Wo;
+    const int ho = tq % c.Ho, b = tq / c.Ho;
+    return ((long long)b * c.Hi + (long long)ho * c.stride) * c.Wi + (long long)wo * c.stride;
+  };
+  for (int item = it_begin; item < it_end; ++item) {
+    const int p = item / a.tilesN, tile_n = item - p * a.tilesN;
+    const int m0 = p * BM, n0 = tile_n * BN;
+    if (p != cur_p) {
+      cur_p = p;
+      // (the weight ring keeps its contents and its order; only the rows change)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      stores_young = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+      if constexpr (A2L) {
+        __builtin_amdgcn_s_barrier();  // everybody has read its last second-limb fragments of the old panel
+        // second limbs -> LDS: unit (kb, rb) = 16 rows x 64 B; lane L lands at byte 16 L = row L >> 2, position L & 3, and
+        // fetches chunk (L & 3) ^ ((row >> 2) & 3) of its row's second-limb half.  The buffer starts at the panel's first pixel.
+        const long long pix0 = pixel_of(m0);
+        const long long left = a.x_total - pix0 * c.ldx * 4;
+        const __amdgpu_buffer_rsrc_t rxa = make_rsrc(reinterpret_cast<const char*>(a.x) + pix0 * c.ldx * 4,
+                                                     (unsigned)(left < 0x7FFFF000ll ? left : 0x7FFFF000ll));
+        const int ur = lane >> 2;
+        const unsigned uch = (unsigned)((((lane & 3) ^ ((ur >> 2) & 3)) << 4) + 64);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {  // this wave's two 16-row blocks
+          const int rb = wave * 2 + u;
+          const int m = m0 + rb * 16 + ur;
+          const unsigned rofs = m < a.M ? (unsigned)((pixel_of(m) - pix0) * c.ldx * 4) + uch : OOB;
+#pragma unroll
+          for (int kb = 0; kb < KB; ++kb) {
+            unsigned char* dst = a2lds + ((kb * (BM / 16) + rb) << 10);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rxa, (__attribute__((address_space(3))) void*)dst, 16, rofs, kb * 128, 0, 0);
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wm * 64 + i * 16 + (lane & 15);
+        const char* rowp = reinterpret_cast<const char*>(a.x) + pixel_of(m) * c.ldx * 4 + (lane >> 4) * 16;
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+          for (int l = 0; l < NA; ++l) {
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (m < a.M) v = *reinterpret_cast<const u32x4*>(rowp + kb * 128 + l * 64);
+            af[kb][i][l] = __builtin_bit_cast(f16x8, v);
+          }
+      }
+      if constexpr (A2L) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // everybody's second-limb pieces have landed
+      }
+#endif
+    }
+    f32x4 acc[4][4], accx[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[i][j][e] = accx[i][j][e] = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+      wait_step();
+      __builtin_amdgcn_s_barrier();  // everybody's DMAs of this step have landed; the stage read one step ago is free
+      issue_step();                  // AHEAD steps ahead in the stream, whatever column tile / row panel that is
+      const unsigned char* Bb = lds + st_read + wn * 64 * 128 + fr0;
+      const unsigned char* Bb2 = lds + st_read + wn * 64 * 128 + fr1;
+      st_read = st_read + STAGE == NST * STAGE ? 0 : st_read + STAGE;
+      f16x8 bf[4], a2[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bf[j] = *reinterpret_cast<const f16x8*>(Bb2 + j * 2048);
+      if constexpr (A2L) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a2[i] = *reinterpret_cast<const f16x8*>(a2lds + ((kb * (BM / 16) + wm * 4 + i) << 10) + fa2);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a2[i] = af[kb][i][NA - 1];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) accx[i][ZZ(i, jj)] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[kb][i][0], bf[ZZ(i, jj)], accx[i][ZZ(i, jj)], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bf[j] = *reinterpret_cast<const f16x8*>(Bb + j * 2048);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) accx[i][ZZ(i, jj)] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2[i], bf[ZZ(i, jj)], accx[i][ZZ(i, jj)], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) acc[i][ZZ(i, jj)] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[kb][i][0], bf[ZZ(i, jj)], acc[i][ZZ(i, jj)], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);  // (nothing of the next K-step above this point)
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = acc[i][j] + accx[i][j] * LIMB2_UNSCALE;
+    float ua = unscale_a, ub = unscale_b;
+    if (const float u = ua * ub; !(u >= 0x1p-100f && u <= 0x1p100f)) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (acc[i][j] * ua) * ub;
+      ua = ub = 1.f;
+    }
+    unsigned char* scratch = lds + NST * STAGE;
+    if (limb_out)
+      l2_epilogue_limbs<WM, WN, true>(a, acc, scratch, m0, n0, wm, wn, lane, ua, ub);
+    else if (a.scale != nullptr || a.shift != nullptr || a.res != nullptr || c.relu)
+      l2_epilogue<WM, WN, true, true>(a, acc, scratch, p, m0, n0, wm, wn, lane, ua, ub, y_bytes);
+    else
+      l2_epilogue<WM, WN, true, false>(a, acc, scratch, p, m0, n0, wm, wn, lane, ua, ub, y_bytes);
+    stores_young = AHEAD;
+  }
+}
+
 // ---- stream-K remainder: partial tiles -> output, in ONE wide launch ---------------------------------------------------
 // A remainder tile was cut into pieces by the workgroups of conv_l2_kernel<.., SK = true> (raw accumulators in `ws`).
 // One workgroup per 8 rows of a remainder tile sums that tile's pieces in ascending-workgroup order (fixed order:
@@ -1854,10 +2074,21 @@ static int l2_variant_k(long long M, int Cout, int taps, int Cin) {
   return kts <= 8 || (kts <= 16 && Cout >= 512) || (kts <= 32 && Cout >= 2048) ? 1 : 0;
 }
 
+// ... and 1 x 1 convolutions with 64 / 128 / 256 input channels and at least 128 output channels run ACTIVATION-STATIONARY
+// (conv_l2a_kernel: a workgroup's 128 rows in registers, the weight rows streamed): the same 128-row statistic tiles as
+// variant 1, no stream-K remainder.  ONDA_L2_STATIONARY=0: the tile kernels of round 5 (tools only).
+static bool l2_stationary(long long M, int Cout, int taps, int Cin) {
+  static const int on = getenv("ONDA_L2_STATIONARY") ? atoi(getenv("ONDA_L2_STATIONARY")) : 1;
+  if (!on || getenv("ONDA_L2_VARIANT")) return false;
+  return taps == 1 && (Cin == 64 || Cin == 128 || Cin == 256) && l2_variant_k(M, Cout, taps, Cin) == 1;
+}
+
 /* which device kernel onda_conv2d_fwd_l2 launches for a problem: the tile variant (0: 256 x 128, 1: 128 x 128, 2: 256 x 64
- * = conv_l2_kernel<4,2> / <2,2> / <4,1>), or 3: conv_l2x_kernel<4,2>, the continuous K-step stream taken by 256 x 128
- * problems with at most 32 K-steps per tile (bench.py names its per-kernel figures after this) */
+ * = conv_l2_kernel<4,2> / <2,2> / <4,1>), 3: conv_l2x_kernel<4,2>, the continuous K-step stream taken by 256 x 128
+ * problems with at most 32 K-steps per tile, or 4: conv_l2a_kernel, the activation-stationary 1 x 1 kernel (bench.py names
+ * its per-kernel figures after this) */
 int onda_conv_l2_kernel_id(int64_t M, int Cout, int taps, int Cin) {
+  if (l2_stationary(M, Cout, taps, Cin)) return 4;
   const int variant = l2_variant_k(M, Cout, taps, Cin);
   const bool short_k = taps * (Cin / 32) <= 32;
   return variant == 0 && short_k ? 3 : variant;
@@ -1870,7 +2101,7 @@ namespace {
 // resident workgroups) is cut into equal K ranges over all workgroups when that pays (hybrid stream-K).
 struct L2Schedule {
   int variant, BM, BN, tilesM, tilesN, G, rem, sub;
-  bool balanced;
+  bool balanced, stationary;
   int rem_rows() const { return tilesM - (tilesM * tilesN - rem) / tilesN; }  // tile rows that hold remainder tiles
   int stats_rows_total() const { return tilesM + (balanced ? rem_rows() * (sub - 1) : 0); }
 };
@@ -1894,6 +2125,8 @@ L2Schedule l2_schedule(long long M, int Cout, int taps, int Cin, bool have_ws, l
   q.balanced = have_ws && q.rem != 0 && KT >= 4 && t_tile_us * (1.0 - (double)q.rem / q.G) > fix_us &&
                (size_t)q.G * 2 * q.BM * q.BN <= (size_t)onda_conv_ws_floats() && q.G <= 1024;
   if (plain) q.balanced = false;  // OndaConv.plain_schedule
+  q.stationary = l2_stationary(M, Cout, taps, Cin);
+  if (q.stationary) q.balanced = false;  // contiguous runs of (row panel, column tile) items: balanced to one item by construction
   if (const int force = conv_sched_override()) {  // ONDA_CONV_SCHED: 1 tile-per-workgroup, 2 hybrid
     if (force == 1 || !have_ws) q.balanced = false;
     else if (force == 2) q.balanced = q.rem != 0;
@@ -2053,6 +2286,21 @@ static int l2_fwd_impl(const void* xl, int64_t xplane, const float* xamax, const
   // the output as a buffer: last byte any tile can store (dense rows of ldy floats; scattered stride-2 gradients included)
   const long long y_rows = (long long)c->B * (c->out_os == 1 && c->Hf == c->Ho && c->Wf == c->Wo ? (long long)c->Ho * c->Wo : (long long)c->Hf * c->Wf);
   const long long y_total = ((y_rows - 1) * c->ldy + c->Cout) * 4;
+  if (q.stationary) {  // 1 x 1, Cin 64 / 128 / 256: the rows in registers, the weights streamed (conv_l2a_kernel)
+    ONDA_REQUIRE(c->pad == 0 && (c->stride == 1 || (c->Hi >= (c->Ho - 1) * c->stride + 1 && c->Wi >= (c->Wo - 1) * c->stride + 1)));
+    ONDA_REQUIRE(c->out_os == 1 || y_total < 0x7FFFF000ll);
+    const long long items = (long long)k.tilesM * k.tilesN;
+    const int cus = conv_resident_workgroups() / 2;
+    const int slots = cus;  // one workgroup per CU (the rows' fragments take the register file of one wave per SIMD)
+    const int grid = (int)(items < slots ? items : slots);
+    if (c->Cin == 256)
+      hipLaunchKernelGGL((conv_l2a_kernel<8, 4, true>), dim3(grid), dim3(256), 0, st, k, w_bytes, (unsigned)y_total, xamax, wamax);
+    else if (c->Cin == 128)
+      hipLaunchKernelGGL((conv_l2a_kernel<4, 5, false>), dim3(grid), dim3(256), 0, st, k, w_bytes, (unsigned)y_total, xamax, wamax);
+    else
+      hipLaunchKernelGGL((conv_l2a_kernel<2, 3, false>), dim3(grid), dim3(256), 0, st, k, w_bytes, (unsigned)y_total, xamax, wamax);
+    return ONDA_LAUNCH_RESULT();
+  }
   // short K loops (1 x 1 convolutions up to 1024 input channels) gain 6-17 % from the continuous stream; long ones lose
   // ~4 % against the slot-staggered kernel, whose per-tile start / end they amortise anyway (measured per shape, one process)
   const bool short_k = k.taps * k.kcper <= 32;

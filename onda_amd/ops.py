@@ -53,7 +53,7 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-_L2_KERNELS = ("conv_l2_kernel<4,2>", "conv_l2_kernel<2,2>", "conv_l2_kernel<4,1>", "conv_l2x_kernel<4,2>")
+_L2_KERNELS = ("conv_l2_kernel<4,2>", "conv_l2_kernel<2,2>", "conv_l2_kernel<4,1>", "conv_l2x_kernel<4,2>", "conv_l2a_kernel")
 
 
 def _l2_name(M, cout, taps, cin):
@@ -1017,9 +1017,13 @@ class BNTrainFn(torch.autograd.Function):
 
 
 # BatchNorm's small statistics passes inside the big launches that need them (csrc/norm_l2.hip: bn_finalize_l2 in the apply
-# launch, bn_bwd_sums_l2 in the backward apply launch): 156 launches per adaptation step fewer.  0: the separate launches of
-# rounds 2-5 (same numbers; tools/ab_flag.py onda_amd.ops FUSE_BN_FINALIZE 0 -- ...).
-FUSE_BN_FINALIZE = os.environ.get("ONDA_FUSE_BN", "1") != "0"
+# launch, bn_bwd_sums_l2 in the backward apply launch): 156 launches per adaptation step fewer -- and 27 ms per step SLOWER
+# (A/B on one box, twice: 94.1 / 94.1 ms with the separate launches, 121.5 / 121.7 ms fused; gpurun_out/r06_a_*):
+# the ~2 000 resident workgroups that wait for the first 64 poll ONE line at device scope, across the 8 XCDs' fabric, and the
+# finalizing workgroups' own table reads and atomics queue behind the polls (175 us per fused launch against 9 us for the
+# launch it removes).  Built, correct (the whole GPU suite passes with it on), OFF by default; ONDA_FUSE_BN=1 /
+# tools/ab_flag.py onda_amd.ops FUSE_BN_FINALIZE True -- ... to measure it again.
+FUSE_BN_FINALIZE = os.environ.get("ONDA_FUSE_BN", "0") == "1"
 
 
 class BNTrainLimbFn(torch.autograd.Function):

@@ -134,6 +134,75 @@ def _wgrad_case(ops, cin, cout, k, stride, dil, pad, H, W, B):
     close(wd.grad, wr.grad, 5e-5, f"wgrad k={k} stride={stride} B={B}")
 
 
+STATIONARY_CASES = [
+    # cin, cout, stride, B, H, W       (1 x 1 convolutions the activation-stationary kernel takes: Cin 64 / 128 / 256, Cout >= 128)
+    (256, 1024, 1, 2, 33, 65),   # 4290 rows: 34 panels of 128 (the last one 66 rows), 8 column tiles, 8 K-steps (second limbs in LDS)
+    (256, 320, 1, 1, 19, 23),    # Cout not a multiple of 128
+    (256, 512, 2, 2, 17, 33),    # stride 2 (layer2's downsample): GEMM row m reads pixel (2 ho, 2 wo)
+    (128, 512, 1, 2, 33, 65),    # 4 K-steps, both limbs in registers
+    (128, 128, 1, 1, 9, 17),     # ONE column tile: an item per panel
+    (64, 256, 1, 2, 65, 129),    # 2 K-steps
+    (64, 192, 1, 3, 7, 11),
+]
+
+
+@pytest.mark.parametrize("case", STATIONARY_CASES, ids=lambda c: "x".join(map(str, c)))
+@pytest.mark.parametrize("epilogue", ["stats", "affine_res_relu", "limbs"])
+def test_activation_stationary_conv_is_the_tile_kernel_bit_for_bit(case, epilogue):
+    """conv_l2a_kernel (round 6: a workgroup's rows in registers, weight rows streamed; deeplabv2.py:22-24,44,351-357) against
+    the 128 x 128 tile kernel it replaces (ONDA_L2_VARIANT=1 forces it): the same products in the same order per accumulator,
+    so outputs, BatchNorm statistic partials and limb-row outputs must be IDENTICAL -- in all three epilogues (train-mode
+    statistics; folded BatchNorm + residual + ReLU; eval-mode limb rows) -- and close to an fp64 reference."""
+    import os
+    from onda_amd import ops
+    from onda_amd._lib import query
+    cin, cout, stride, B, H, W = case
+    old, ops.CONV_MODE = ops.CONV_MODE, "f16x2"
+    try:
+        Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+        M = B * Ho * Wo
+        assert query("onda_conv_l2_kernel_id", M, cout, 1, cin) == 4
+        g = torch.Generator().manual_seed(cin + cout + stride)
+        x = torch.randn(B, H, W, cin, generator=g).to(DEV)
+        w = (torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5).to(DEV)
+        wp = ops.pack_weight_fwd(w)
+        scale = (0.5 + torch.rand(cout, generator=g)).to(DEV)
+        shift = torch.randn(cout, generator=g).to(DEV)
+        res = torch.randn(B, Ho, Wo, cout, generator=g).to(DEV)
+
+        def run():
+            if epilogue == "stats":
+                y, st, _ = ops.conv_forward(x, wp, 1, stride, 1, 0, cout, want_stats=4)
+                return y, st
+            if epilogue == "affine_res_relu":
+                y, _, _ = ops.conv_forward(x, wp, 1, stride, 1, 0, cout, scale=scale, shift=shift, residual=res, relu=True)
+                return y, ops.known_amax(y)
+            if cout % 32:
+                pytest.skip("limb rows need whole 32-channel blocks")
+            y, _, _ = ops.conv_forward(x, wp, 1, stride, 1, 0, cout, scale=scale, shift=shift, relu=True,
+                                       limb_out=ops.fold_bounds(w, scale, shift))
+            lb = ops.limbs_of(y)
+            return lb.planes, lb.true_amax
+
+        got = run()
+        os.environ["ONDA_L2_VARIANT"] = "1"
+        os.environ["ONDA_CONV_SCHED"] = "1"  # (no stream-K remainder: the same statistic rows)
+        try:
+            assert query("onda_conv_l2_kernel_id", M, cout, 1, cin) == 1
+            want = run()
+        finally:
+            del os.environ["ONDA_L2_VARIANT"], os.environ["ONDA_CONV_SCHED"]
+        torch.cuda.synchronize()
+        assert torch.equal(got[0], want[0]), (got[0].float() - want[0].float()).abs().max().item()
+        assert torch.equal(got[1].max() if epilogue != "stats" else got[1], want[1].max() if epilogue != "stats" else want[1])
+        if epilogue == "stats":
+            ref = torch.einsum("bhwc,oc->bhwo", x[:, ::stride, ::stride].double().cpu(), w[:, :, 0, 0].double().cpu())
+            close(got[0], ref.float(), 2e-6, "stationary conv vs fp64")
+            np.testing.assert_allclose(got[1][:, 0].sum(0).cpu().numpy(), ref.reshape(-1, cout).sum(0).numpy(), rtol=1e-4, atol=1e-2)
+    finally:
+        ops.CONV_MODE = old
+
+
 @pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "x".join(map(str, c[:6])))
 def test_conv_fwd_bwd(case, conv_mode):
     from onda_amd import ops
