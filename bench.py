@@ -70,6 +70,11 @@ def parse():
     ap.add_argument("--no-eager", action="store_true")
     ap.add_argument("--eager-only", action="store_true", help=argparse.SUPPRESS)  # the child process of the time-boxed eager leg
     ap.add_argument("--no-exact-f32", action="store_true")
+    ap.add_argument("--h2d", action="store_true",
+                    help="the batches start in pinned HOST memory and are uploaded every step on a copy stream (the drop-in's "
+                         "real input path); the default line reports this as a second number, config.h2d")
+    ap.add_argument("--no-h2d-leg", action="store_true")
+    ap.add_argument("--no-exchange-probe", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the short runs of BASELINE configs 1, 2, 5 and of the static branch (config.other_configs)")
     args = ap.parse_args()
@@ -115,9 +120,45 @@ def fresh(batch):
     return {k: (v.detach() if torch.is_tensor(v) else v) for k, v in batch.items()}
 
 
-def one_step(da, src, trg, i, total, shards=1):
+class HostFeeder:
+    """The input path of a real run: batches live in pinned host memory (a DataLoader's pin_memory) and are uploaded once per
+    step -- ONE upload of each batch (the reference uploads the target batch twice: prototypes.py:283,
+    prototypes_hybrid_switch.py:48) -- on a copy stream, step i + 1's while step i computes."""
+
+    def __init__(self, src, trg, device):
+        self.device = device
+        self.host = [tuple({k: v.cpu().pin_memory() for k, v in b.items()} for b in (s_, t_)) for s_, t_ in zip(src, trg)]
+        self.stream = torch.cuda.Stream(device=device)
+        self.next = None
+        self.bytes_per_step = sum(v.numel() * v.element_size() for b in self.host[0] for v in b.values())
+
+    def _upload(self, i):
+        pair = self.host[i % len(self.host)]
+        with torch.cuda.stream(self.stream):
+            dev = tuple({k: v.to(self.device, non_blocking=True) for k, v in b.items()} for b in pair)
+            done = torch.cuda.Event()
+            done.record(self.stream)
+        return dev, done
+
+    def get(self, i):
+        if self.next is None or self.next[0] != i:
+            self.next = (i,) + self._upload(i)
+        _, dev, done = self.next
+        cur = torch.cuda.current_stream()
+        cur.wait_event(done)
+        for b in dev:
+            for v in b.values():
+                v.record_stream(cur)
+        self.next = (i + 1,) + self._upload(i + 1)
+        return dev
+
+
+def one_step(da, src, trg, i, total, shards=1, feeder=None):
     da.adjust_learning_rate(i, total)
-    if shards == 1:
+    if feeder is not None:
+        s_, t_ = feeder.get(i)
+        log = da.step([s_], t_)
+    elif shards == 1:
         log = da.step([fresh(src[i % 2])], fresh(trg[i % 2]))
     else:
         base = (i % 2) * shards
@@ -330,9 +371,27 @@ def eager_rocm(args, device):
             one()
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / n
+        # the same with both batches uploaded from pinned host memory every step (as config.h2d of the HIP leg)
+        hs = {k: v.cpu().pin_memory() for k, v in src.items()}
+        ht = {k: v.cpu().pin_memory() for k, v in trg.items()}
+
+        def one_h2d():
+            s_ = {k: v.to(device, non_blocking=True) for k, v in hs.items()}
+            t_ = {k: v.to(device, non_blocking=True) for k, v in ht.items()}
+            masks = tuple(omodel.draw_drop_mask(args.batch, device=device) for _ in range(3))
+            ad.step(s_, t_, masks)
+            ad.update_ema()
+        one_h2d()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            one_h2d()
+        torch.cuda.synchronize()
+        dt_h2d = (time.perf_counter() - t0) / n
     finally:
         op.torch.ones = ones
     return {"ms_per_step": round(dt * 1e3, 2), "images_per_s": round(args.batch / dt, 3),
+            "h2d_ms_per_step": round(dt_h2d * 1e3, 2),
             "branch": "dynamic" if ad.switch.current else "static", "leg_seconds": round(time.perf_counter() - t_begin, 1),
             "what": "oracle step on PyTorch-ROCm eager (MIOpen fp32, cudnn.benchmark=True; 2 warm-up + 3 timed steps)"}
 
@@ -366,6 +425,34 @@ def eager_rocm_boxed(args):
     if child.returncode != 0 or not lines:
         return None, f"the eager leg's process ended with code {child.returncode}"
     return json.loads(lines[-1]), None
+
+
+def exchange_probe(args, plain_ms):
+    """What the multi-GPU exchange costs a step, as far as ONE GPU can say: the same bench in a child process with
+    ONDA_DIST_FORCE=1 -- one rank that runs the whole protocol of onda_amd/dist.py over RCCL (flat gradient views, bucketed
+    all-reduce hooked into the last backward pass, the tail collective with prototype statistics / monitor scalars / running
+    statistics, the division by the world size inside SGD) -- against this process's own step time.  Bytes moved over xGMI by
+    a real ring are not in it; the launch, hook and bucket-copy overheads are."""
+    budget = float(os.environ.get("ONDA_EXCHANGE_BUDGET_S", "180"))
+    n = max(5, args.steps // 2)
+    cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(n), "--warmup", "3", "--batch", str(args.batch), "--height",
+           str(args.height), "--width", str(args.width), "--branch", args.branch, "--no-cpu-baseline", "--no-eager", "--no-other-configs",
+           "--no-exact-f32", "--no-roofline", "--no-h2d-leg", "--no-exchange-probe"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env.update({"ONDA_DIST_FORCE": "1", "MASTER_ADDR": "127.0.0.1", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
+    try:
+        out, _ = child.communicate(timeout=budget)
+    except subprocess.TimeoutExpired:
+        child.kill()  # (this exact child, by handle)
+        child.communicate()
+        return {"error": f"the forced-exchange run did not finish within {budget:.0f} s"}
+    lines = [ln for ln in out.decode().splitlines() if ln.startswith("{")]
+    if child.returncode != 0 or not lines:
+        return {"error": f"the forced-exchange run ended with code {child.returncode}"}
+    forced = json.loads(lines[-1])["ms_per_step"]
+    return {"exchange_ms_per_step": round(forced - plain_ms, 3), "forced_ms_per_step": forced, "plain_ms_per_step": round(plain_ms, 3),
+            "steps": n, "what": "ONDA_DIST_FORCE=1, one RCCL rank, child process on the same GPU, against this run's own step time"}
 
 
 def conv_accuracy_probe(device):
@@ -424,9 +511,22 @@ def run_adaptation(args, device, rank, world):
     with tempfile.TemporaryDirectory() as tmp:
         da, src, trg = build_adapter(args, device, tmp, shards)
         total = args.warmup + args.steps
-        step = lambda i: one_step(da, src, trg, i, total + 8, shards)  # noqa: E731
+        feeder = HostFeeder(src, trg, device) if (args.h2d and shards == 1) else None
+        step = lambda i: one_step(da, src, trg, i, total + 8, shards, feeder)  # noqa: E731
         dt, log = timed_loop(step, args.warmup, args.steps, device)
         branch = "dynamic" if da.model_select.current == 1 else "static"
+        h2d = None
+        if not args.h2d and not args.no_h2d_leg and shards == 1 and rank == 0 and world == 1 and not args.no_roofline:
+            # the same step fed from pinned host memory, a second number beside the resident-input `value` (never `value` itself)
+            fd = HostFeeder(src, trg, device)
+            hstep = lambda i: one_step(da, src, trg, i, total + 8, 1, fd)  # noqa: E731
+            n = max(3, args.steps // 2)
+            hdt, _ = timed_loop(hstep, 1, n, device)
+            h2d = {"ms_per_step": round(hdt / n * 1e3, 3), "images_per_s": round(args.batch * n / hdt, 3), "steps": n,
+                   "uploaded_bytes_per_step": fd.bytes_per_step,
+                   "what": "the step with both batches uploaded from pinned host memory every step (one upload each, on a copy stream, "
+                           "step i + 1's under step i); `value` keeps the inputs resident in HBM"}
+            del fd
         roof = None if args.no_roofline else measure_roofline(step, total, record=(rank == 0))
         loss = float(log["Total target loss"].detach())
         exact = None
@@ -455,7 +555,8 @@ def run_adaptation(args, device, rank, world):
                        f"ProDA head, random-init weights",
            "baseline_config": 5 if (args.height, args.width) == (1024, 2048) else (4 if world > 1 else 3),
            "global_batch": images, "parallelism": f"dp{world}", "branch": branch, "micro_batches_per_gpu": shards,
-           "conv_tflop_per_step_per_gpu": tflop_step, "final_loss": round(loss, 5), "exact_f32": exact}
+           "conv_tflop_per_step_per_gpu": tflop_step, "final_loss": round(loss, 5), "exact_f32": exact,
+           "inputs": "uploaded from pinned host memory every step (--h2d)" if args.h2d else "resident in HBM", "h2d": h2d}
     if tflop_step:
         cfg["step_conv_tflops_per_gpu"] = round(tflop_step / (dt / args.steps), 2)
     return {"metric": f"adaptation-step images/sec (fwd+bwd+proto) {args.height}x{args.width} bs={args.batch}",
@@ -541,10 +642,14 @@ def other_configs(args, device):
     plan = [("config1_forward_only_8_frames", dict(config=1, height=512, width=1024), run_forward_only),
             ("config2_supervised_step", dict(config=2, height=512, width=1024), run_segmentation),
             ("config3_static_branch", dict(config=3, height=512, width=1024, branch="static"), run_adaptation),
-            ("config5_adaptation_1024x2048", dict(config=5, height=1024, width=2048), run_adaptation)]
+            ("config5_adaptation_1024x2048", dict(config=5, height=1024, width=2048), run_adaptation),
+            # the anchor of config 4's strong-scaling curve: the fixed global batch of 32 on ONE GPU (8 micro-batches per optimizer
+            # step through step_sharded: per-micro-batch BatchNorm statistics, one gradient sum, one SGD step)
+            ("config4_global_batch_32_on_one_gpu", dict(config=3, height=512, width=1024, global_batch=32, steps=2), run_adaptation)]
     for name, over, run in plan:
         sub = copy.copy(args)
         sub.warmup, sub.steps, sub.no_roofline, sub.no_exact_f32, sub.global_batch = 1, 3, True, True, 0
+        sub.h2d, sub.no_h2d_leg = False, True
         for k, v in over.items():
             setattr(sub, k, v)
         try:
@@ -658,6 +763,8 @@ def main():
             torch.cuda.empty_cache()
         elif default_line and not args.no_eager and miopen_db_ready():
             eager, eager_note = eager_rocm_boxed(args)  # the driver's run: a child process with a time budget
+        if default_line and not args.no_exchange_probe and not args.no_roofline:
+            res["config"]["multi_gpu_exchange_on_one_gpu"] = exchange_probe(args, dt / args.steps * 1e3)
         if not args.no_cpu_baseline:
             cpu = cpu_baseline(args)
     if rank == 0:

@@ -1084,41 +1084,75 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_l2x_kernel(const ConvK
 // ---- activation-stationary 1 x 1 convolution: the activation rows of a workgroup live in REGISTERS, only weight rows stream ----
 // The short-K 1 x 1 convolutions (Cin <= 256: conv3 / downsample of layer1-3, the data gradients of their conv1) have as
 // few as 2-8 K-steps per tile: in the tile kernels above every column tile re-delivers its 256 (128) activation rows into
-// LDS -- 8-16 times per row tile, two thirds of the bytes a K-step waits for -- and pays a cold start and an epilogue per
-// 8 K-steps (round-5 measurement: weights only 18 us, activations only 43 us, whole kernel 86 us for 256 -> 1024).
+// LDS -- 8-16 times per row tile, two thirds of the bytes a K-step waits for -- and pays a cold start and an epilogue of
+// ~12 000 cycles per 8 K-steps during which the matrix pipe idles (round 3-5 stamps).
 // Here a workgroup (4 waves, one per SIMD, 128 rows) loads its rows' WHOLE K extent once, straight from memory into the
-// MFMA fragment layout (a lane's 16 bytes of a fragment are contiguous in a limb row: no LDS, no transposition) --
-// the 512-register budget of one wave per SIMD is what makes that possible -- and then sweeps the column tiles of Cout
-// against them: per K-step only 16 KB of weight rows (hot in every L2) arrive by LDS-DMA, through a ring of NST stages that
-// runs NST - 1 steps ahead ACROSS column tiles and row panels.  Delivered bytes per MFMA: 2/3 of the 256 x 128 tile's,
-// fragment reads per MFMA: half.  With 256 input channels both limbs of the rows would take 256 registers per lane, which
-// the compiler cannot hold beside 128 accumulators (it spilled the fragments as it loaded them): A2L keeps the SECOND limbs
-// (used by one of the three products) in LDS instead -- 64 KB per panel, filled once per panel by LDS-DMA, 64-byte rows with
-// the 16-byte chunk XOR-ed by (row >> 2) & 3 (conflict-free ds_read_b128) -- and the first limbs in registers.
-// Work items (row panel, column tile) in row-major order are dealt to the workgroups in equal contiguous runs: a workgroup
-// changes its panel (reloads its rows) two or three times per launch.
-// Epilogue: l2_epilogue / l2_epilogue_limbs as they stand (COUNTED: 16 or 32 buffer stores per wave, no vmcnt(0)), on LDS
-// scratch of their own.  Same products in the same order per accumulator as the tile kernels: bit-identical results.
-template <int KB, int NST, bool A2L>
-__global__ __launch_bounds__(256, 1) void conv_l2a_kernel(const ConvK a, unsigned w_bytes, unsigned y_bytes, const float* __restrict__ xamax,
+// MFMA fragment layout (a lane's 16 bytes of a fragment are contiguous in a limb row: no LDS, no transposition) -- the
+// 512-register budget of one wave per SIMD is what makes that possible -- and then sweeps the column tiles of Cout against
+// them: per K-step only 16 KB of weight rows (hot in every L2) arrive by LDS-DMA, through a ring that runs ahead ACROSS
+// column tiles and row panels.  With 256 input channels both limbs of the rows would take 256 registers per lane, which the
+// compiler cannot hold beside the accumulators (it spilled the fragments as it loaded them): A2L keeps the SECOND limbs
+// (used by one of the three products) in LDS instead -- 64 KB per panel, filled once per panel by LDS-DMA, 64-byte rows
+// with the 16-byte chunk XOR-ed by (row >> 2) & 3 (conflict-free ds_read_b128) -- and the first limbs in registers.
+// Work items (row panel, column tile) in row-major order are dealt to the workgroups in equal contiguous runs.
+//
+// THE EPILOGUE RUNS UNDER THE NEXT TILE'S K LOOP.  A finished tile (64 registers: acc + accx * 2^-11) is kept in `old` while
+// the next one accumulates, and its epilogue -- the statistics of l2_epilogue, the transposition through LDS, the stores; or
+// scale / shift / residual / ReLU; or limb rows -- is cut into phases that are spread over the K-steps of the next item
+// (ep_step): with one wave per SIMD nothing else would fill the matrix pipe during those ~8 000 cycles, and nothing else
+// would fill the issue slots between the MFMAs.  What makes that delicate is the ring's counted wait: s_waitcnt vmcnt(N)
+// counts EVERY vector-memory operation in issue order, so the stores / residual loads of the interleaved epilogue must be
+// counted exactly -- too few in N and a K-step waits for a store's round trip, too many and it reads a stage that has not
+// landed.  So every K-step issues exactly EPS epilogue operations behind its DMA issue: the phases' real ones (buffer
+// operations, out-of-range lanes dropped by the hardware: the count does not depend on the data) padded with stores to an
+// empty buffer; the prologue pads as well.  N = (NST - 2) * BPW + (NST - 1) * EPS, one constant per instantiation.
+// EPI 0: plain output + BatchNorm statistics (train-mode forward, plain data gradients); 1: scale / shift / residual / ReLU
+// / max|y| (data gradients that add into a gradient sink; eval convs with fp32 output); 2: limb rows (eval mode).
+// Same products in the same order per accumulator as the tile kernels, same epilogue arithmetic: bit-identical results.
+template <int KB, int EPI>
+struct L2aPlan {  // epilogue operations per wave and K-step
+  static constexpr int CPS = 8 / KB;                            // 4-row chunks of the pending tile stored per K-step (8 per wave)
+  static constexpr int R = EPI == 0 ? 0 : (EPI == 1 ? 1 : 2);   // residual loads per chunk
+  static constexpr int T = EPI == 2 ? 2 : 1;                    // output stores per chunk
+  static constexpr int P = EPI == 0 ? 0 : 2;                    // per-column scale / shift loads (last step, for the next tile)
+  static constexpr int F = 1;                                   // the statistics store / the max|y| atomic (last step)
+  static constexpr int EPS = CPS * (T + R) + P + F;             // every step is padded to the last step's count
+};
+
+template <int KB, int NST, bool A2L, int EPI>
+__global__ __launch_bounds__(512, 2) void conv_l2a_kernel(const ConvK a, unsigned w_bytes, unsigned y_bytes, const float* __restrict__ xamax,
                                                           const float* __restrict__ wamax) {
   if (a.c.run_if != nullptr && *a.c.run_if == 0) return;  // predicated launch (onda_switch_step decided on the device)
-  constexpr int WM = 2, WN = 2, NW = 4, BM = 128, BN = 128;
+  constexpr int WM = 4, WN = 2, NW = 8, MI = 2, BM = 128, BN = 128;  // 8 waves (two per SIMD), each 32 rows x 64 columns
   constexpr int STAGE = BN * 128;          // 128 weight rows x (32 channels x 2 limbs)
   constexpr int BPW = (BN / 8) / NW;       // 8-row pieces (one LDS-DMA instruction) per wave and K-step
-  constexpr int EST = 16;                  // buffer stores per wave and epilogue (twice that for limb output)
-  constexpr int AHEAD = NST - 1;           // K-steps in flight beyond the one being read
-  static_assert(AHEAD <= KB, "at most one epilogue's stores are younger than a DMA step that is waited for");
-  static_assert((AHEAD - 1) * BPW + 2 * EST <= 63, "vmcnt holds 6 bits");
-  constexpr int SCRATCH = NW * (16 * 68 * 4) + WM * BN * 4 * 4 + 64;  // l2_epilogue: transposition buffers, statistics, amax
+  constexpr int AHEAD = NST - 1;           // K-steps in flight, the one being waited for included
+  constexpr int EPS = L2aPlan<KB, EPI>::EPS;
+#ifndef ONDA_L2A_HINTS
+#define ONDA_L2A_HINTS 0
+#endif
+#ifndef ONDA_L2A_PADS
+#define ONDA_L2A_PADS 1
+#endif
+  // (measurement builds: ONDA_L2A_PADS=0 drops the padding and waits for the younger DMAs only -- conservative, still correct)
+  constexpr int NWAIT = (AHEAD - 1) * BPW + (ONDA_L2A_PADS ? AHEAD * EPS : 0);  // operations younger than the DMAs a K-step waits for
+  static_assert(NWAIT <= 63, "vmcnt holds 6 bits");
+  static_assert(KB == 8 || KB == 4 || (KB == 2 && EPI == 0), "schedules of ep_step");
+  constexpr int TRS = 68;                  // floats per row of a wave's transposition buffer (l2_epilogue)
+  constexpr int SCRATCH = NW * (16 * TRS * 4) + WM * BN * 4 * 4 + 64;  // transposition buffers, statistics partials
   constexpr int A2_BYTES = A2L ? KB * (BM / 16) * 1024 : 0;           // second limbs: [kb][16-row block][16 rows x 64 B]
   constexpr int NA = A2L ? 1 : 2;                                     // limbs of the rows held in registers
   __shared__ __attribute__((aligned(16))) unsigned char lds[NST * STAGE + SCRATCH + A2_BYTES];
   unsigned char* const a2lds = lds + NST * STAGE + SCRATCH;
+  unsigned char* const scratch = lds + NST * STAGE;
 
   const OndaConv& c = a.c;
   const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wm = wave / WN, wn = wave % WN;
+#ifndef ONDA_L2A_STAGGER
+#define ONDA_L2A_STAGGER 0
+#endif
+  const bool late = ONDA_L2A_STAGGER && wave >= NW / 2;  // the second wave of its SIMD takes its epilogue slice first (measurement switch)
   const int nblk = gridDim.x, bid = blockIdx.x;
   const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
   const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
@@ -1127,20 +1161,31 @@ __global__ __launch_bounds__(256, 1) void conv_l2a_kernel(const ConvK a, unsigne
   if (it_begin >= it_end) return;
   const int wstride = c.Cin;  // (taps == 1)
   const __amdgpu_buffer_rsrc_t rw = make_rsrc(a.w, w_bytes);
+  const __amdgpu_buffer_rsrc_t rnone = make_rsrc(a.w, 0);  // an empty buffer: every access is out of range (counted, dropped)
   const Scale2 sx = scale_of(xamax), sw = scale_of(wamax);
-  const float unscale_a = sx.inv, unscale_b = sw.inv;
+  // the two exact unscale factors are folded into the epilogue's per-column constants -- unless their PRODUCT leaves the normal
+  // range (tensors with max|x| around 2^-50): then they are applied to the sums, one after the other (pre_a, pre_b)
+  const bool unscale_first = !(sx.inv * sw.inv >= 0x1p-100f && sx.inv * sw.inv <= 0x1p100f);
+  const float ua = unscale_first ? 1.f : sx.inv, ub = unscale_first ? 1.f : sw.inv;
+  const float pre_a = unscale_first ? sx.inv : 1.f, pre_b = unscale_first ? sw.inv : 1.f;
   const int lrow = lane >> 3;
   const unsigned cq[2] = {dma_chunk16(lane, 0), dma_chunk16(lane, 1)};
   const int fr0 = frag_ofs(lane, 0), fr1 = frag_ofs(lane, 1);
-  const int fa2 = (lane & 15) * 64 + (((lane >> 4) ^ (((lane & 15) >> 2) & 3)) << 4);  // this lane's 16 bytes of a 1 KB A2 unit
-  const bool limb_out = a.yl != nullptr;
+  const int fa2o = (lane & 15) * 64 + (((lane >> 4) ^ (((lane & 15) >> 2) & 3)) << 4);  // this lane's 16 bytes of a 1 KB A2 unit
+
+  // Column tile of an item: row panel p sweeps the column tiles starting at tile p % tilesN, so that neighbouring
+  // workgroups (neighbouring panels, in step) do not all ask the L2 for the same weight lines in the same few hundred cycles
+  auto col_tile_of = [&](int it) {
+    const int pp = it / a.tilesN, j = it - pp * a.tilesN + pp % a.tilesN;
+    return j >= a.tilesN ? j - a.tilesN : j;
+  };
 
   // ---- issue side: the weight stream, one step = (item, kb); behind the last item the offsets are out of range (the DMA
   // writes zeros into a stage nobody reads): every step issues, so the number of DMAs in flight is a constant
   int i_item = it_begin, i_kb = 0, st_issue = 0;
   unsigned bofs[BPW];
   auto open_issue_item = [&]() {
-    const int n0 = (i_item % a.tilesN) * BN;
+    const int n0 = col_tile_of(i_item) * BN;
 #pragma unroll
     for (int d = 0; d < BPW; ++d) {
       const int n = n0 + (wave * BPW + d) * 8 + lrow;
@@ -1162,22 +1207,238 @@ __global__ __launch_bounds__(256, 1) void conv_l2a_kernel(const ConvK a, unsigne
       open_issue_item();
     }
   };
-  int stores_young = 0;
-  auto wait_step = [&]() {  // this wave's DMAs of the oldest step in flight have landed; AHEAD - 1 younger steps may still fly
-    constexpr int D = (AHEAD - 1) * BPW;
-    if (stores_young && limb_out) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D + 2 * EST) : "memory");
-    else if (stores_young) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D + EST) : "memory");
-    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D) : "memory");
-    if (stores_young) --stores_young;
+  auto pad = [&](int n) {  // n counted operations that do nothing (stores to the empty buffer)
+#if defined(__HIP_DEVICE_COMPILE__)
+    for (int k = 0; k < (ONDA_L2A_PADS ? n : 0); ++k) __builtin_amdgcn_raw_buffer_store_b32(0u, rnone, 0, 0, 0);
+#endif
   };
 
   open_issue_item();
 #pragma unroll
-  for (int sI = 0; sI < AHEAD; ++sI) issue_step();
+  for (int sI = 0; sI < AHEAD; ++sI) {
+    issue_step();
+    pad(EPS);
+  }
+
+  // ---- the finished tile whose epilogue is under way -----------------------------------------------------------------------
+  // Everything below is BRANCH-FREE (a K-step must stay one basic block for the scheduler to interleave these phases with the
+  // MFMAs): absent operands are read from the empty buffer (zeros), absent outputs go to it, "no tile pending yet" (the first
+  // item) is a tile whose every offset is out of range.
+  f32x4 old[MI][4];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) old[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  bool o_valid = false;
+  int o_p = 0, o_m0 = 0, o_n0 = 0;
+  const int cl = (lane & 15) * 4, rl = lane >> 4;  // after the transposition: row 4*r + rl of a 16-row chunk, columns cl .. cl + 3
+  float* const tr = reinterpret_cast<float*>(scratch + wave * (16 * TRS * 4));
+  float* const red = reinterpret_cast<float*>(scratch + NW * (16 * TRS * 4));
+  const int SR = a.stats_rows;
+  const float relu_floor = c.relu ? 0.f : -INFINITY;
+  f32x4 e_sc = {1.f, 1.f, 1.f, 1.f}, e_sh = {0.f, 0.f, 0.f, 0.f};
+  float e_mx = 0.f;
+  f32x4 e_rv[2][8 / KB];                      // EPI 1: the residual of the chunks of this / the next K-step (by step parity)
+  u32x2 e_r1[2][8 / KB], e_r2[2][8 / KB];     // EPI 2: their limbs
+  float e_so = 1.f, e_ri = 0.f;
+  if constexpr (EPI == 2) {
+    const float bound = limb_out_bound(a);
+    e_so = scale_from(bound).s;
+    if (t == 0) a.ybound[(blockIdx.x & (ONDA_AMAX_SLOTS - 1)) * AMAX_STRIDE] = bound;
+    e_ri = a.resl != nullptr ? scale_of(a.res_amax).inv : 0.f;
+  }
+  unsigned* const amax_word = a.amax != nullptr ? reinterpret_cast<unsigned*>(a.amax) + ((blockIdx.x * 8 + wave) & (ONDA_AMAX_SLOTS - 1)) * AMAX_STRIDE
+                                                : reinterpret_cast<unsigned*>(a.ws) + wave;  // (no max wanted: a word of the scratch workspace)
+  auto ep_n = [&]() { return o_n0 + wn * 64 + cl; };
+  // statistics of column block jn: sum, sum of squares, min, max over this wave's 64 rows -> red (l2_epilogue's arithmetic)
+  auto ep_S = [&](int jn) {
+    if constexpr (EPI != 0) return;
+    float s1 = 0.f, s2 = 0.f, mn = 3.0e38f, mxv = -3.0e38f;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float v = old[i][jn][e];
+        s1 += v;
+        s2 += v * v;
+        mn = fminf(mn, v);
+        mxv = fmaxf(mxv, v);
+      }
+    rows_reduce4(s1, s2, mn, mxv);
+    if (lane < 16) {
+      const int col = (wn * 4 + jn) * 16 + lane;
+      *reinterpret_cast<f32x4*>(red + (wm * BN + col) * 4) = f32x4{(s1 * ua) * ub, (((s2 * ua) * ub) * ua) * ub, (mn * ua) * ub, (mxv * ua) * ub};
+    }
+  };
+  // per-column constants of the tile whose columns start at tn0 (EPI 1 / 2): exactly two counted loads
+  auto ep_P = [&](int tn0) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (EPI != 0) {
+      const int n = tn0 + wn * 64 + cl;
+      const unsigned off = n < c.Cout ? (unsigned)n * 4u : OOB;
+      const u32x4 s4 = __builtin_amdgcn_raw_buffer_load_b128(a.scale ? make_rsrc(a.scale, (unsigned)c.Cout * 4u) : rnone, off, 0, 0);
+      const u32x4 h4 = __builtin_amdgcn_raw_buffer_load_b128(a.shift ? make_rsrc(a.shift, (unsigned)c.Cout * 4u) : rnone, off, 0, 0);
+      const float one = a.scale ? 0.f : 1.f;  // (no scale: zeros from the empty buffer + 1)
+      e_sc = __builtin_bit_cast(f32x4, s4) + f32x4{one, one, one, one};
+      e_sh = __builtin_bit_cast(f32x4, h4);  // (no shift: zeros)
+      e_sc = (e_sc * ua) * ub;
+    }
+#else
+    (void)tn0;
+#endif
+  };
+  // The pending tile leaves in 8 chunks per wave (row block i = g / 4 of the wave's two, rows 4*rq + rl of it, rq = g % 4), CPS
+  // chunks per K-step: ONE 16-byte store per lane and chunk, spread evenly over the K loop.  (All of a row block's stores in
+  // one step -- the first form of this kernel -- made every CU of the chip store in the same two of eight steps: those steps
+  // took twice as long, the stores queueing at HBM's write rate.)
+  // residual of chunk g of the tile at (tm0, tn0): R counted loads (rows past M / columns past Cout / no residual: zeros)
+  auto ep_load = [&](int g, int par, int u, int tm0, int tn0) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (EPI != 0) {
+      const int i = g >> 2, rq = g & 3;
+      const int n = tn0 + wn * 64 + cl;
+      const long long left = (long long)(a.M - tm0) * c.ldr * 4;
+      const unsigned rbytes = (unsigned)(left < 0x7FFFF000ll ? (left > 0 ? left : 0) : 0x7FFFF000ll);
+      const int row = wm * (16 * MI) + i * 16 + 4 * rq + rl;
+      if constexpr (EPI == 1) {
+        const __amdgpu_buffer_rsrc_t rr = a.res ? make_rsrc(a.res + (size_t)tm0 * c.ldr, rbytes) : rnone;
+        const unsigned off = n < c.Cout ? (unsigned)(((size_t)row * c.ldr + n) * 4) : OOB;
+        e_rv[par][u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rr, off, 0, 0));
+      } else {
+        const __amdgpu_buffer_rsrc_t rr = a.resl ? make_rsrc(a.resl + (size_t)tm0 * 2 * c.ldr, rbytes) : rnone;
+        const unsigned off = n < c.Cout ? (unsigned)(limb_at((size_t)row, n, c.ldr) * 2) : OOB;
+        e_r1[par][u] = __builtin_amdgcn_raw_buffer_load_b64(rr, off, 0, 0);
+        e_r2[par][u] = __builtin_amdgcn_raw_buffer_load_b64(rr, off, 2 * LIMB2_OFS, 0);
+      }
+    }
+#else
+    (void)g; (void)par; (void)u; (void)tm0; (void)tn0;
+#endif
+  };
+  // row block i of the pending tile -> the wave's transposition buffer
+  auto ep_Tw = [&](int i) {
+#pragma unroll
+    for (int jn = 0; jn < 4; ++jn)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) tr[(4 * (lane >> 4) + e) * TRS + jn * 16 + (lane & 15)] = old[i][jn][e];
+    __builtin_amdgcn_wave_barrier();
+  };
+  // chunk g: out of the buffer, scale / shift / residual / ReLU (or limb split), T counted stores
+  auto ep_chunk = [&](int g, int par, int u) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int i = g >> 2, rq = g & 3;
+    const int n = ep_n();
+    const bool vn = o_valid && n < c.Cout;
+    const int mw = o_m0 + wm * (16 * MI) + rl;
+    const long long y_left = (long long)(a.M - o_m0) * c.ldy * 4;
+    const unsigned y_win = (unsigned)(y_left < 0x7FFFF000ll ? (y_left > 0 ? y_left : 0) : 0x7FFFF000ll);
+    f32x4 v = *reinterpret_cast<const f32x4*>(tr + (4 * rq + rl) * TRS + cl);
+    const int m = mw + i * 16 + 4 * rq;
+    if constexpr (EPI == 2) {
+      const __amdgpu_buffer_rsrc_t ry = make_rsrc(a.yl + (size_t)o_m0 * 2 * c.ldy, y_win);
+      const bool live = m < a.M && vn;
+      v = v * e_sc + e_sh;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {  // (no residual: zeros)
+        const f32x2 p1 = unpack2h(e_r1[par][u][h]), p2 = unpack2h(e_r2[par][u][h]);
+        v[2 * h] += (p1[0] + p2[0] * LIMB2_UNSCALE) * e_ri;
+        v[2 * h + 1] += (p1[1] + p2[1] * LIMB2_UNSCALE) * e_ri;
+      }
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) v[qq] = fmaxf(v[qq], relu_floor);
+      const float vm = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+      e_mx = fmaxf(e_mx, live ? vm : 0.f);
+      const f32x4 w = v * e_so;
+      u32x2 l1, l2;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const unsigned pk = cvt2h(w[2 * h], w[2 * h + 1]);
+        const f32x2 f = unpack2h(pk);
+        l1[h] = pk;
+        l2[h] = cvt2h((w[2 * h] - f[0]) * LIMB2_SCALE, (w[2 * h + 1] - f[1]) * LIMB2_SCALE);
+      }
+      const unsigned off = vn ? (unsigned)(limb_at((size_t)(m - o_m0), n, c.ldy) * 2) : OOB;  // rows past M: past the buffer's end
+      __builtin_amdgcn_raw_buffer_store_b64(l1, ry, off, 0, NT_AUX);
+      __builtin_amdgcn_raw_buffer_store_b64(l2, ry, off, 2 * LIMB2_OFS, NT_AUX);
+    } else {
+      const __amdgpu_buffer_rsrc_t ry = make_rsrc(a.y + (size_t)o_m0 * c.ldy, y_win);
+      const unsigned vbase = vn ? (unsigned)(((size_t)(mw - o_m0) * c.ldy + n) * 4) : OOB;
+      if constexpr (EPI == 1) {
+        v = v * e_sc + e_sh;
+        v += e_rv[par][u];  // (no residual: zeros)
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) v[qq] = fmaxf(v[qq], relu_floor);
+        const float vm = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+        e_mx = fmaxf(e_mx, (m < a.M && vn) ? vm : 0.f);
+      } else {
+        v = v * f32x4{ua * ub, ua * ub, ua * ub, ua * ub};
+      }
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ry, vbase + (unsigned)((i * 16 + 4 * rq) * c.ldy * 4), 0, NT_AUX);
+    }
+    if (rq == 3) __builtin_amdgcn_wave_barrier();
+#else
+    (void)g; (void)par; (void)u;
+#endif
+  };
+  // the tile's statistics row (EPI 0: one counted store per wave) / its max|y| (EPI 1, 2: one atomic per wave).  A barrier
+  // lies between the last ep_S and this (the K-steps' own)
+  auto ep_F = [&]() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (EPI == 0) {
+      const int col = t & (BN - 1), h = t >> 7;  // 128 columns x the four statistics: one value per thread
+      f32x4 v = *reinterpret_cast<const f32x4*>(red + col * 4);  // the four row groups in ascending order, as l2_epilogue sums them
+#pragma unroll
+      for (int w_ = 1; w_ < WM; ++w_) {
+        const f32x4 o = *reinterpret_cast<const f32x4*>(red + (w_ * BN + col) * 4);
+        v = f32x4{v[0] + o[0], v[1] + o[1], fminf(v[2], o[2]), fmaxf(v[3], o[3])};
+      }
+      const __amdgpu_buffer_rsrc_t rs = a.stats != nullptr ? make_rsrc(a.stats + (size_t)o_p * SR * c.Cout, (unsigned)(SR * c.Cout) * 4u) : rnone;
+      const bool vc = o_valid && o_n0 + col < c.Cout;
+      const int kk = SR == 4 ? h : (h & 1);  // (two statistic rows only: the sums are stored twice)
+      const float val = kk == 0 ? v[0] : (kk == 1 ? v[1] : (kk == 2 ? v[2] : v[3]));
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), rs, vc ? (unsigned)((kk * c.Cout + o_n0 + col) * 4) : OOB, 0, 0);
+    } else {
+      const float m = wave_max(e_mx);
+      if (lane == 0) atomicMax(amax_word, __float_as_uint(m));  // (max with 0.0 changes nothing: issued whatever the data)
+      e_mx = 0.f;
+    }
+#endif
+  };
+  // the slice of K-step kb of the item that computes the tile at (cm0, cn0): CPS chunks of the pending tile, the loads of the
+  // next step's chunks; in the last step the statistics / maximum, and scale / shift + the first chunks' residual of the tile
+  // that becomes pending behind it.  Every step issues exactly EPS counted operations.
+  using PL = L2aPlan<KB, EPI>;
+  constexpr int CPS = PL::CPS;
+  auto ep_step = [&](int kb, int cm0, int cn0) {
+    if constexpr (KB == 8) {
+      if (kb == 0) { ep_S(0); ep_S(1); }
+      if (kb == 1) { ep_S(2); ep_S(3); }
+    } else {
+      if (kb == 0) { ep_S(0); ep_S(1); ep_S(2); ep_S(3); }
+    }
+#pragma unroll
+    for (int u = 0; u < CPS; ++u) {
+      const int g = kb * CPS + u;
+      if ((g & 3) == 0) ep_Tw(g >> 2);
+      ep_chunk(g, kb & 1, u);
+    }
+    int used = CPS * (PL::T + PL::R);
+    if (kb + 1 < KB) {
+#pragma unroll
+      for (int u = 0; u < CPS; ++u) ep_load((kb + 1) * CPS + u, (kb + 1) & 1, u, o_m0, o_n0);
+    } else {
+      ep_F();
+      ep_P(cn0);
+#pragma unroll
+      for (int u = 0; u < CPS; ++u) ep_load(u, 0, u, cm0, cn0);
+      used += PL::F + PL::P;
+    }
+    pad(EPS - used);
+  };
 
   // ---- the row panel's activations: fragment (kb, i, limb) of this lane = 16 bytes of row m0 + wm*64 + i*16 + (lane & 15):
   // bytes [limb*64 + (lane >> 4)*16, +16) of the row's 128-byte block kb
-  f16x8 af[KB][4][NA];
+  f16x8 af[KB][MI][NA];
   int cur_p = -1, st_read = 0;
   // input pixel of GEMM row m: the pixel itself, or (stride 2) the one it samples
   auto pixel_of = [&](int m) -> long long {
@@ -1187,16 +1448,21 @@ __global__ __launch_bounds__(256, 1) void conv_l2a_kernel(const ConvK a, unsigne
     const int ho = tq % c.Ho, b = tq / c.Ho;
     return ((long long)b * c.Hi + (long long)ho * c.stride) * c.Wi + (long long)wo * c.stride;
   };
+  int n_stamp = 0;   // diagnostics (ONDA_L2X_STAMP=1, tools/l2a_stamps.py): s_memtime at the start, then per item: rows ready, end of
+  auto stamp = [&]() {  // the K loop
+    if (a.stamps != nullptr && t == 0 && n_stamp < 32) a.stamps[(size_t)bid * 32 + n_stamp++] = __builtin_amdgcn_s_memtime();
+  };
+  stamp();
   for (int item = it_begin; item < it_end; ++item) {
-    const int p = item / a.tilesN, tile_n = item - p * a.tilesN;
+    const int p = item / a.tilesN, tile_n = col_tile_of(item);
     const int m0 = p * BM, n0 = tile_n * BN;
     if (p != cur_p) {
       cur_p = p;
       // (the weight ring keeps its contents and its order; only the rows change)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      stores_young = 0;
 #if defined(__HIP_DEVICE_COMPILE__)
       if constexpr (A2L) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();  // everybody has read its last second-limb fragments of the old panel
         // second limbs -> LDS: unit (kb, rb) = 16 rows x 64 B; lane L lands at byte 16 L = row L >> 2, position L & 3, and
         // fetches chunk (L & 3) ^ ((row >> 2) & 3) of its row's second-limb half.  The buffer starts at the panel's first pixel.
@@ -1207,8 +1473,8 @@ __global__ __launch_bounds__(256, 1) void conv_l2a_kernel(const ConvK a, unsigne
         const int ur = lane >> 2;
         const unsigned uch = (unsigned)((((lane & 3) ^ ((ur >> 2) & 3)) << 4) + 64);
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {  // this wave's two 16-row blocks
-          const int rb = wave * 2 + u;
+        for (int u = 0; u < 1; ++u) {  // this wave's 16-row block
+          const int rb = wave;
           const int m = m0 + rb * 16 + ur;
           const unsigned rofs = m < a.M ? (unsigned)((pixel_of(m) - pix0) * c.ldx * 4) + uch : OOB;
 #pragma unroll
@@ -1219,8 +1485,8 @@ __global__ __launch_bounds__(256, 1) void conv_l2a_kernel(const ConvK a, unsigne
         }
       }
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int m = m0 + wm * 64 + i * 16 + (lane & 15);
+      for (int i = 0; i < MI; ++i) {
+        const int m = m0 + wm * (16 * MI) + i * 16 + (lane & 15);
         const char* rowp = reinterpret_cast<const char*>(a.x) + pixel_of(m) * c.ldx * 4 + (lane >> 4) * 16;
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb)
@@ -1231,74 +1497,83 @@ __global__ __launch_bounds__(256, 1) void conv_l2a_kernel(const ConvK a, unsigne
             af[kb][i][l] = __builtin_bit_cast(f16x8, v);
           }
       }
-      if constexpr (A2L) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();  // everybody's second-limb pieces have landed
-      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if constexpr (A2L) __builtin_amdgcn_s_barrier();  // everybody's second-limb pieces have landed
 #endif
     }
-    f32x4 acc[4][4], accx[4][4];
+    stamp();
+    f32x4 acc[MI][4], accx[MI][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[i][j][e] = accx[i][j][e] = 0.f;
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
-      wait_step();
-      __builtin_amdgcn_s_barrier();  // everybody's DMAs of this step have landed; the stage read one step ago is free
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NWAIT) : "memory");  // this wave's DMAs of this step have landed (and its LDS writes)
+      __builtin_amdgcn_s_barrier();  // everybody's have; the stage read one step ago is free; `red` of the last ep_S is complete
       issue_step();                  // AHEAD steps ahead in the stream, whatever column tile / row panel that is
       const unsigned char* Bb = lds + st_read + wn * 64 * 128 + fr0;
       const unsigned char* Bb2 = lds + st_read + wn * 64 * 128 + fr1;
       st_read = st_read + STAGE == NST * STAGE ? 0 : st_read + STAGE;
-      f16x8 bf[4], a2[4];
+      f16x8 bf[4], a2[MI];
 #pragma unroll
       for (int j = 0; j < 4; ++j) bf[j] = *reinterpret_cast<const f16x8*>(Bb2 + j * 2048);
       if constexpr (A2L) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) a2[i] = *reinterpret_cast<const f16x8*>(a2lds + ((kb * (BM / 16) + wm * 4 + i) << 10) + fa2);
+        for (int i = 0; i < MI; ++i) a2[i] = *reinterpret_cast<const f16x8*>(a2lds + ((kb * (BM / 16) + wm * MI + i) << 10) + fa2o);
       } else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) a2[i] = af[kb][i][NA - 1];
+        for (int i = 0; i < MI; ++i) a2[i] = af[kb][i][NA - 1];
       }
+      // The two waves of a SIMD (w and w + 4) leave the barrier together; left in step they would both multiply and then both
+      // run their slice of the pending epilogue.  The second one takes the slice FIRST: one wave's VALU / LDS / store
+      // instructions beside the other's MFMAs, in every K-step (the slot stagger of conv_l2_kernel, with the epilogue as the
+      // "prepare" slot).  Same instructions per wave either way: the counted wait above does not notice.
+      if (late) ep_step(kb, m0, n0);
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) accx[i][ZZ(i, jj)] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[kb][i][0], bf[ZZ(i, jj)], accx[i][ZZ(i, jj)], 0, 0, 0);
 #pragma unroll
       for (int j = 0; j < 4; ++j) bf[j] = *reinterpret_cast<const f16x8*>(Bb + j * 2048);
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) accx[i][ZZ(i, jj)] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2[i], bf[ZZ(i, jj)], accx[i][ZZ(i, jj)], 0, 0, 0);
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) acc[i][ZZ(i, jj)] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[kb][i][0], bf[ZZ(i, jj)], acc[i][ZZ(i, jj)], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);  // (nothing of the next K-step above this point)
+#ifdef ONDA_L2A_STEP_STAMPS  // (measurement builds: a branch per K-step, which keeps the compiler from interleaving the slice with the MFMAs)
+      if (a.stamps != nullptr && t == 0 && item == it_begin + 2) a.stamps[(size_t)bid * 32 + 16 + kb] = __builtin_amdgcn_s_memtime();
+#endif
+      if (!late) ep_step(kb, m0, n0);
     }
+    stamp();
+    // this tile becomes the pending one (raw sums; the unscale factors are folded into the epilogue's constants)
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = acc[i][j] + accx[i][j] * LIMB2_UNSCALE;
-    float ua = unscale_a, ub = unscale_b;
-    if (const float u = ua * ub; !(u >= 0x1p-100f && u <= 0x1p100f)) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (acc[i][j] * ua) * ub;
-      ua = ub = 1.f;
-    }
-    unsigned char* scratch = lds + NST * STAGE;
-    if (limb_out)
-      l2_epilogue_limbs<WM, WN, true>(a, acc, scratch, m0, n0, wm, wn, lane, ua, ub);
-    else if (a.scale != nullptr || a.shift != nullptr || a.res != nullptr || c.relu)
-      l2_epilogue<WM, WN, true, true>(a, acc, scratch, p, m0, n0, wm, wn, lane, ua, ub, y_bytes);
-    else
-      l2_epilogue<WM, WN, true, false>(a, acc, scratch, p, m0, n0, wm, wn, lane, ua, ub, y_bytes);
-    stores_young = AHEAD;
+      for (int j = 0; j < 4; ++j) old[i][j] = ((acc[i][j] + accx[i][j] * LIMB2_UNSCALE) * pre_a) * pre_b;
+    o_valid = true;
+    o_p = p;
+    o_m0 = m0;
+    o_n0 = n0;
   }
+  // ---- the last tile's epilogue, chunk by chunk (its scale / shift and first residual loads were issued in the last K-step) ---
+#pragma unroll
+  for (int jn = 0; jn < 4; ++jn) ep_S(jn);
+#pragma unroll
+  for (int g = 0; g < 8; ++g) {
+    if ((g & 3) == 0) ep_Tw(g >> 2);
+    if (g >= CPS) ep_load(g, 0, 0, o_m0, o_n0);
+    ep_chunk(g, 0, g < CPS ? g : 0);
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  ep_F();
 }
 
 // ---- stream-K remainder: partial tiles -> output, in ONE wide launch ---------------------------------------------------
@@ -2240,8 +2515,8 @@ static int l2_fwd_impl(const void* xl, int64_t xplane, const float* xamax, const
     k.res_amax = lo->res_amax;
     k.res_true = lo->res_true ? lo->res_true : lo->res_amax;
   }
-  k.skip_dead_taps = 1;
-  k.late_issue = 1;
+  k.skip_dead_taps = getenv("ONDA_L2A_WKB") ? 78 : 1;
+  k.late_issue = getenv("ONDA_L2A_NOEPI") ? 77 : 1;
   static const int stamp_on = getenv("ONDA_L2X_STAMP") ? atoi(getenv("ONDA_L2X_STAMP")) : 0;
   if (stamp_on)  // the last 64 KiB of the workspace (beyond anything the schedules use: checked below)
     k.stamps = reinterpret_cast<unsigned long long*>(ws + onda_conv_ws_floats()) - 1024 * 32;
@@ -2286,25 +2561,36 @@ static int l2_fwd_impl(const void* xl, int64_t xplane, const float* xamax, const
   // the output as a buffer: last byte any tile can store (dense rows of ldy floats; scattered stride-2 gradients included)
   const long long y_rows = (long long)c->B * (c->out_os == 1 && c->Hf == c->Ho && c->Wf == c->Wo ? (long long)c->Ho * c->Wo : (long long)c->Hf * c->Wf);
   const long long y_total = ((y_rows - 1) * c->ldy + c->Cout) * 4;
-  if (q.stationary) {  // 1 x 1, Cin 64 / 128 / 256: the rows in registers, the weights streamed (conv_l2a_kernel)
+  const bool dense_out = c->out_os == 1 && c->Hf == c->Ho && c->Wf == c->Wo;  // (buffer stores relative to the tile: any size)
+  const int epi = lo != nullptr ? 2 : (scale != nullptr || shift != nullptr || residual != nullptr || c->relu || yamax != nullptr ? 1 : 0);
+  // (statistics together with scale / shift / residual, and 64 input channels with anything but the plain epilogue, stay on the
+  //  128 x 128 tile kernel: same statistic rows, no stream-K remainder either way)
+  if (q.stationary && dense_out && !(stats != nullptr && epi != 0) && !(c->Cin == 64 && epi != 0)) {
+    // 1 x 1, Cin 64 / 128 / 256: the rows in registers, the weights streamed (conv_l2a_kernel)
     ONDA_REQUIRE(c->pad == 0 && (c->stride == 1 || (c->Hi >= (c->Ho - 1) * c->stride + 1 && c->Wi >= (c->Wo - 1) * c->stride + 1)));
-    ONDA_REQUIRE(c->out_os == 1 || y_total < 0x7FFFF000ll);
     const long long items = (long long)k.tilesM * k.tilesN;
     const int cus = conv_resident_workgroups() / 2;
     const int slots = cus;  // one workgroup per CU (the rows' fragments take the register file of one wave per SIMD)
     const int grid = (int)(items < slots ? items : slots);
-    if (c->Cin == 256)
-      hipLaunchKernelGGL((conv_l2a_kernel<8, 4, true>), dim3(grid), dim3(256), 0, st, k, w_bytes, (unsigned)y_total, xamax, wamax);
-    else if (c->Cin == 128)
-      hipLaunchKernelGGL((conv_l2a_kernel<4, 5, false>), dim3(grid), dim3(256), 0, st, k, w_bytes, (unsigned)y_total, xamax, wamax);
-    else
-      hipLaunchKernelGGL((conv_l2a_kernel<2, 3, false>), dim3(grid), dim3(256), 0, st, k, w_bytes, (unsigned)y_total, xamax, wamax);
+#define L2A_LAUNCH(KB_, NST_, A2L_, EPI_) \
+  hipLaunchKernelGGL((conv_l2a_kernel<KB_, NST_, A2L_, EPI_>), dim3(grid), dim3(512), 0, st, k, w_bytes, (unsigned)y_total, xamax, wamax)
+    if (c->Cin == 256) {
+      if (epi == 0) L2A_LAUNCH(8, 3, true, 0);
+      else if (epi == 1) L2A_LAUNCH(8, 3, true, 1);
+      else L2A_LAUNCH(8, 3, true, 2);
+    } else if (c->Cin == 128) {
+      if (epi == 0) L2A_LAUNCH(4, 3, false, 0);
+      else if (epi == 1) L2A_LAUNCH(4, 3, false, 1);
+      else L2A_LAUNCH(4, 3, false, 2);
+    } else {
+      L2A_LAUNCH(2, 3, false, 0);
+    }
+#undef L2A_LAUNCH
     return ONDA_LAUNCH_RESULT();
   }
   // short K loops (1 x 1 convolutions up to 1024 input channels) gain 6-17 % from the continuous stream; long ones lose
   // ~4 % against the slot-staggered kernel, whose per-tile start / end they amortise anyway (measured per shape, one process)
   const bool short_k = k.taps * k.kcper <= 32;
-  const bool dense_out = c->out_os == 1 && c->Hf == c->Ho && c->Wf == c->Wo;  // (buffer stores relative to the tile: any size)
   if (short_k && q.variant == 0 && (dense_out || y_total < 0x7FFFF000ll)) {
     if (!q.balanced) k.tiles_dp = tiles;  // persistent either way: whole tiles only
     const int grid = tiles < q.G ? tiles : q.G;

@@ -151,7 +151,7 @@ STATIONARY_CASES = [
 def test_activation_stationary_conv_is_the_tile_kernel_bit_for_bit(case, epilogue):
     """conv_l2a_kernel (round 6: a workgroup's rows in registers, weight rows streamed; deeplabv2.py:22-24,44,351-357) against
     the 128 x 128 tile kernel it replaces (ONDA_L2_VARIANT=1 forces it): the same products in the same order per accumulator,
-    so outputs, BatchNorm statistic partials and limb-row outputs must be IDENTICAL -- in all three epilogues (train-mode
+    so outputs and limb-row outputs must be IDENTICAL (the statistic partials: equal up to the association of the row sums) -- in all three epilogues (train-mode
     statistics; folded BatchNorm + residual + ReLU; eval-mode limb rows) -- and close to an fp64 reference."""
     import os
     from onda_amd import ops
@@ -194,7 +194,11 @@ def test_activation_stationary_conv_is_the_tile_kernel_bit_for_bit(case, epilogu
             del os.environ["ONDA_L2_VARIANT"], os.environ["ONDA_CONV_SCHED"]
         torch.cuda.synchronize()
         assert torch.equal(got[0], want[0]), (got[0].float() - want[0].float()).abs().max().item()
-        assert torch.equal(got[1].max() if epilogue != "stats" else got[1], want[1].max() if epilogue != "stats" else want[1])
+        if epilogue != "stats":
+            assert torch.equal(got[1].max(), want[1].max())  # max|y| as the kernel left it
+        else:  # the statistic partials: the same sums over a tile's 128 rows, associated by four waves of 32 rows instead of two of 64
+            assert torch.equal(got[1][:, 2:], want[1][:, 2:])  # (minima and maxima do not depend on the order)
+            np.testing.assert_allclose(got[1][:, :2].cpu().numpy(), want[1][:, :2].cpu().numpy(), rtol=2e-5, atol=1e-4)
         if epilogue == "stats":
             ref = torch.einsum("bhwc,oc->bhwo", x[:, ::stride, ::stride].double().cpu(), w[:, :, 0, 0].double().cpu())
             close(got[0], ref.float(), 2e-6, "stationary conv vs fp64")
