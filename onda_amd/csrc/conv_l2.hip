@@ -1106,17 +1106,18 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_l2x_kernel(const ConvK
 // landed.  So every K-step issues exactly EPS epilogue operations behind its DMA issue: the phases' real ones (buffer
 // operations, out-of-range lanes dropped by the hardware: the count does not depend on the data) padded with stores to an
 // empty buffer; the prologue pads as well.  N = (NST - 2) * BPW + (NST - 1) * EPS, one constant per instantiation.
-// EPI 0: plain output + BatchNorm statistics (train-mode forward, plain data gradients); 1: scale / shift / residual / ReLU
-// / max|y| (data gradients that add into a gradient sink; eval convs with fp32 output); 2: limb rows (eval mode).
+// EPI 0: plain output + BatchNorm statistics (train-mode forward, plain data gradients); EPI 1: the result is ADDED to what
+// y holds (a data gradient that joins a gradient sink, ops.GradSink: residual == y) by no-return buffer_atomic_add_f32 -- one
+// thread per element, one addition: the same sum as the tile kernels' "load residual, add, store", without a load in the
+// interleaved epilogue (a first form that fetched the residual one K-step ahead spilled and ran 2.2-2.4x SLOWER than the tile
+// kernel: gpurun_out/r06_b_conv_shapes_stationary*.txt).  Scale / shift / ReLU / max|y| / limb-row outputs stay on the tile kernels.
 // Same products in the same order per accumulator as the tile kernels, same epilogue arithmetic: bit-identical results.
 template <int KB, int EPI>
 struct L2aPlan {  // epilogue operations per wave and K-step
-  static constexpr int CPS = 8 / KB;                            // 4-row chunks of the pending tile stored per K-step (8 per wave)
-  static constexpr int R = EPI == 0 ? 0 : (EPI == 1 ? 1 : 2);   // residual loads per chunk
-  static constexpr int T = EPI == 2 ? 2 : 1;                    // output stores per chunk
-  static constexpr int P = EPI == 0 ? 0 : 2;                    // per-column scale / shift loads (last step, for the next tile)
-  static constexpr int F = 1;                                   // the statistics store / the max|y| atomic (last step)
-  static constexpr int EPS = CPS * (T + R) + P + F;             // every step is padded to the last step's count
+  static constexpr int CPS = 8 / KB;               // 4-row chunks of the pending tile stored per K-step (8 per wave)
+  static constexpr int T = EPI == 1 ? 4 : 1;       // output operations per chunk: one 16-byte store, or four 4-byte atomic adds
+  static constexpr int F = 1;                      // the statistics store (last step)
+  static constexpr int EPS = CPS * T + F;          // every step is padded to the last step's count
 };
 
 template <int KB, int NST, bool A2L, int EPI>
@@ -1137,7 +1138,7 @@ __global__ __launch_bounds__(512, 2) void conv_l2a_kernel(const ConvK a, unsigne
   // (measurement builds: ONDA_L2A_PADS=0 drops the padding and waits for the younger DMAs only -- conservative, still correct)
   constexpr int NWAIT = (AHEAD - 1) * BPW + (ONDA_L2A_PADS ? AHEAD * EPS : 0);  // operations younger than the DMAs a K-step waits for
   static_assert(NWAIT <= 63, "vmcnt holds 6 bits");
-  static_assert(KB == 8 || KB == 4 || (KB == 2 && EPI == 0), "schedules of ep_step");
+  static_assert((KB == 8 || KB == 4 || KB == 2) && (EPI == 0 || EPI == 1), "schedules of ep_step");
   constexpr int TRS = 68;                  // floats per row of a wave's transposition buffer (l2_epilogue)
   constexpr int SCRATCH = NW * (16 * TRS * 4) + WM * BN * 4 * 4 + 64;  // transposition buffers, statistics partials
   constexpr int A2_BYTES = A2L ? KB * (BM / 16) * 1024 : 0;           // second limbs: [kb][16-row block][16 rows x 64 B]
@@ -1235,24 +1236,9 @@ __global__ __launch_bounds__(512, 2) void conv_l2a_kernel(const ConvK a, unsigne
   float* const tr = reinterpret_cast<float*>(scratch + wave * (16 * TRS * 4));
   float* const red = reinterpret_cast<float*>(scratch + NW * (16 * TRS * 4));
   const int SR = a.stats_rows;
-  const float relu_floor = c.relu ? 0.f : -INFINITY;
-  f32x4 e_sc = {1.f, 1.f, 1.f, 1.f}, e_sh = {0.f, 0.f, 0.f, 0.f};
-  float e_mx = 0.f;
-  f32x4 e_rv[2][8 / KB];                      // EPI 1: the residual of the chunks of this / the next K-step (by step parity)
-  u32x2 e_r1[2][8 / KB], e_r2[2][8 / KB];     // EPI 2: their limbs
-  float e_so = 1.f, e_ri = 0.f;
-  if constexpr (EPI == 2) {
-    const float bound = limb_out_bound(a);
-    e_so = scale_from(bound).s;
-    if (t == 0) a.ybound[(blockIdx.x & (ONDA_AMAX_SLOTS - 1)) * AMAX_STRIDE] = bound;
-    e_ri = a.resl != nullptr ? scale_of(a.res_amax).inv : 0.f;
-  }
-  unsigned* const amax_word = a.amax != nullptr ? reinterpret_cast<unsigned*>(a.amax) + ((blockIdx.x * 8 + wave) & (ONDA_AMAX_SLOTS - 1)) * AMAX_STRIDE
-                                                : reinterpret_cast<unsigned*>(a.ws) + wave;  // (no max wanted: a word of the scratch workspace)
   auto ep_n = [&]() { return o_n0 + wn * 64 + cl; };
   // statistics of column block jn: sum, sum of squares, min, max over this wave's 64 rows -> red (l2_epilogue's arithmetic)
   auto ep_S = [&](int jn) {
-    if constexpr (EPI != 0) return;
     float s1 = 0.f, s2 = 0.f, mn = 3.0e38f, mxv = -3.0e38f;
 #pragma unroll
     for (int i = 0; i < MI; ++i)
@@ -1270,51 +1256,10 @@ __global__ __launch_bounds__(512, 2) void conv_l2a_kernel(const ConvK a, unsigne
       *reinterpret_cast<f32x4*>(red + (wm * BN + col) * 4) = f32x4{(s1 * ua) * ub, (((s2 * ua) * ub) * ua) * ub, (mn * ua) * ub, (mxv * ua) * ub};
     }
   };
-  // per-column constants of the tile whose columns start at tn0 (EPI 1 / 2): exactly two counted loads
-  auto ep_P = [&](int tn0) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    if constexpr (EPI != 0) {
-      const int n = tn0 + wn * 64 + cl;
-      const unsigned off = n < c.Cout ? (unsigned)n * 4u : OOB;
-      const u32x4 s4 = __builtin_amdgcn_raw_buffer_load_b128(a.scale ? make_rsrc(a.scale, (unsigned)c.Cout * 4u) : rnone, off, 0, 0);
-      const u32x4 h4 = __builtin_amdgcn_raw_buffer_load_b128(a.shift ? make_rsrc(a.shift, (unsigned)c.Cout * 4u) : rnone, off, 0, 0);
-      const float one = a.scale ? 0.f : 1.f;  // (no scale: zeros from the empty buffer + 1)
-      e_sc = __builtin_bit_cast(f32x4, s4) + f32x4{one, one, one, one};
-      e_sh = __builtin_bit_cast(f32x4, h4);  // (no shift: zeros)
-      e_sc = (e_sc * ua) * ub;
-    }
-#else
-    (void)tn0;
-#endif
-  };
   // The pending tile leaves in 8 chunks per wave (row block i = g / 4 of the wave's two, rows 4*rq + rl of it, rq = g % 4), CPS
-  // chunks per K-step: ONE 16-byte store per lane and chunk, spread evenly over the K loop.  (All of a row block's stores in
-  // one step -- the first form of this kernel -- made every CU of the chip store in the same two of eight steps: those steps
-  // took twice as long, the stores queueing at HBM's write rate.)
-  // residual of chunk g of the tile at (tm0, tn0): R counted loads (rows past M / columns past Cout / no residual: zeros)
-  auto ep_load = [&](int g, int par, int u, int tm0, int tn0) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    if constexpr (EPI != 0) {
-      const int i = g >> 2, rq = g & 3;
-      const int n = tn0 + wn * 64 + cl;
-      const long long left = (long long)(a.M - tm0) * c.ldr * 4;
-      const unsigned rbytes = (unsigned)(left < 0x7FFFF000ll ? (left > 0 ? left : 0) : 0x7FFFF000ll);
-      const int row = wm * (16 * MI) + i * 16 + 4 * rq + rl;
-      if constexpr (EPI == 1) {
-        const __amdgpu_buffer_rsrc_t rr = a.res ? make_rsrc(a.res + (size_t)tm0 * c.ldr, rbytes) : rnone;
-        const unsigned off = n < c.Cout ? (unsigned)(((size_t)row * c.ldr + n) * 4) : OOB;
-        e_rv[par][u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rr, off, 0, 0));
-      } else {
-        const __amdgpu_buffer_rsrc_t rr = a.resl ? make_rsrc(a.resl + (size_t)tm0 * 2 * c.ldr, rbytes) : rnone;
-        const unsigned off = n < c.Cout ? (unsigned)(limb_at((size_t)row, n, c.ldr) * 2) : OOB;
-        e_r1[par][u] = __builtin_amdgcn_raw_buffer_load_b64(rr, off, 0, 0);
-        e_r2[par][u] = __builtin_amdgcn_raw_buffer_load_b64(rr, off, 2 * LIMB2_OFS, 0);
-      }
-    }
-#else
-    (void)g; (void)par; (void)u; (void)tm0; (void)tn0;
-#endif
-  };
+  // chunks per K-step, spread evenly over the K loop.  (All of a row block's stores in one step -- the first form of this
+  // kernel -- made every CU of the chip store in the same two of eight steps: those steps took twice as long, the stores
+  // queueing at HBM's write rate.)
   // row block i of the pending tile -> the wave's transposition buffer
   auto ep_Tw = [&](int i) {
 #pragma unroll
@@ -1323,8 +1268,8 @@ __global__ __launch_bounds__(512, 2) void conv_l2a_kernel(const ConvK a, unsigne
       for (int e = 0; e < 4; ++e) tr[(4 * (lane >> 4) + e) * TRS + jn * 16 + (lane & 15)] = old[i][jn][e];
     __builtin_amdgcn_wave_barrier();
   };
-  // chunk g: out of the buffer, scale / shift / residual / ReLU (or limb split), T counted stores
-  auto ep_chunk = [&](int g, int par, int u) {
+  // chunk g: out of the buffer, unscaled, T counted operations (rows past M / columns past Cout: out of range, dropped)
+  auto ep_chunk = [&](int g) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const int i = g >> 2, rq = g & 3;
     const int n = ep_n();
@@ -1332,108 +1277,63 @@ __global__ __launch_bounds__(512, 2) void conv_l2a_kernel(const ConvK a, unsigne
     const int mw = o_m0 + wm * (16 * MI) + rl;
     const long long y_left = (long long)(a.M - o_m0) * c.ldy * 4;
     const unsigned y_win = (unsigned)(y_left < 0x7FFFF000ll ? (y_left > 0 ? y_left : 0) : 0x7FFFF000ll);
+    const __amdgpu_buffer_rsrc_t ry = make_rsrc(a.y + (size_t)o_m0 * c.ldy, y_win);
+    const unsigned off = vn ? (unsigned)(((size_t)(mw - o_m0 + i * 16 + 4 * rq) * c.ldy + n) * 4) : OOB;
     f32x4 v = *reinterpret_cast<const f32x4*>(tr + (4 * rq + rl) * TRS + cl);
-    const int m = mw + i * 16 + 4 * rq;
-    if constexpr (EPI == 2) {
-      const __amdgpu_buffer_rsrc_t ry = make_rsrc(a.yl + (size_t)o_m0 * 2 * c.ldy, y_win);
-      const bool live = m < a.M && vn;
-      v = v * e_sc + e_sh;
+    v = v * f32x4{ua * ub, ua * ub, ua * ub, ua * ub};
+    if constexpr (EPI == 1) {
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {  // (no residual: zeros)
-        const f32x2 p1 = unpack2h(e_r1[par][u][h]), p2 = unpack2h(e_r2[par][u][h]);
-        v[2 * h] += (p1[0] + p2[0] * LIMB2_UNSCALE) * e_ri;
-        v[2 * h + 1] += (p1[1] + p2[1] * LIMB2_UNSCALE) * e_ri;
-      }
-#pragma unroll
-      for (int qq = 0; qq < 4; ++qq) v[qq] = fmaxf(v[qq], relu_floor);
-      const float vm = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
-      e_mx = fmaxf(e_mx, live ? vm : 0.f);
-      const f32x4 w = v * e_so;
-      u32x2 l1, l2;
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const unsigned pk = cvt2h(w[2 * h], w[2 * h + 1]);
-        const f32x2 f = unpack2h(pk);
-        l1[h] = pk;
-        l2[h] = cvt2h((w[2 * h] - f[0]) * LIMB2_SCALE, (w[2 * h + 1] - f[1]) * LIMB2_SCALE);
-      }
-      const unsigned off = vn ? (unsigned)(limb_at((size_t)(m - o_m0), n, c.ldy) * 2) : OOB;  // rows past M: past the buffer's end
-      __builtin_amdgcn_raw_buffer_store_b64(l1, ry, off, 0, NT_AUX);
-      __builtin_amdgcn_raw_buffer_store_b64(l2, ry, off, 2 * LIMB2_OFS, NT_AUX);
+      for (int e = 0; e < 4; ++e) __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(v[e], ry, off, 4 * e, 0);
     } else {
-      const __amdgpu_buffer_rsrc_t ry = make_rsrc(a.y + (size_t)o_m0 * c.ldy, y_win);
-      const unsigned vbase = vn ? (unsigned)(((size_t)(mw - o_m0) * c.ldy + n) * 4) : OOB;
-      if constexpr (EPI == 1) {
-        v = v * e_sc + e_sh;
-        v += e_rv[par][u];  // (no residual: zeros)
-#pragma unroll
-        for (int qq = 0; qq < 4; ++qq) v[qq] = fmaxf(v[qq], relu_floor);
-        const float vm = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
-        e_mx = fmaxf(e_mx, (m < a.M && vn) ? vm : 0.f);
-      } else {
-        v = v * f32x4{ua * ub, ua * ub, ua * ub, ua * ub};
-      }
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ry, vbase + (unsigned)((i * 16 + 4 * rq) * c.ldy * 4), 0, NT_AUX);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ry, off, 0, NT_AUX);
     }
     if (rq == 3) __builtin_amdgcn_wave_barrier();
 #else
-    (void)g; (void)par; (void)u;
+    (void)g;
 #endif
   };
-  // the tile's statistics row (EPI 0: one counted store per wave) / its max|y| (EPI 1, 2: one atomic per wave).  A barrier
-  // lies between the last ep_S and this (the K-steps' own)
+  // the tile's statistics row: one counted store per wave (no statistics wanted: to the empty buffer).  A barrier lies
+  // between the last ep_S and this (the K-steps' own)
   auto ep_F = [&]() {
 #if defined(__HIP_DEVICE_COMPILE__)
-    if constexpr (EPI == 0) {
-      const int col = t & (BN - 1), h = t >> 7;  // 128 columns x the four statistics: one value per thread
-      f32x4 v = *reinterpret_cast<const f32x4*>(red + col * 4);  // the four row groups in ascending order, as l2_epilogue sums them
+    const int col = t & (BN - 1), h = t >> 7;  // 128 columns x the four statistics: one value per thread
+    f32x4 v = *reinterpret_cast<const f32x4*>(red + col * 4);  // the four row groups in ascending order
 #pragma unroll
-      for (int w_ = 1; w_ < WM; ++w_) {
-        const f32x4 o = *reinterpret_cast<const f32x4*>(red + (w_ * BN + col) * 4);
-        v = f32x4{v[0] + o[0], v[1] + o[1], fminf(v[2], o[2]), fmaxf(v[3], o[3])};
-      }
-      const __amdgpu_buffer_rsrc_t rs = a.stats != nullptr ? make_rsrc(a.stats + (size_t)o_p * SR * c.Cout, (unsigned)(SR * c.Cout) * 4u) : rnone;
-      const bool vc = o_valid && o_n0 + col < c.Cout;
-      const int kk = SR == 4 ? h : (h & 1);  // (two statistic rows only: the sums are stored twice)
-      const float val = kk == 0 ? v[0] : (kk == 1 ? v[1] : (kk == 2 ? v[2] : v[3]));
-      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), rs, vc ? (unsigned)((kk * c.Cout + o_n0 + col) * 4) : OOB, 0, 0);
-    } else {
-      const float m = wave_max(e_mx);
-      if (lane == 0) atomicMax(amax_word, __float_as_uint(m));  // (max with 0.0 changes nothing: issued whatever the data)
-      e_mx = 0.f;
+    for (int w_ = 1; w_ < WM; ++w_) {
+      const f32x4 o = *reinterpret_cast<const f32x4*>(red + (w_ * BN + col) * 4);
+      v = f32x4{v[0] + o[0], v[1] + o[1], fminf(v[2], o[2]), fmaxf(v[3], o[3])};
     }
+    const __amdgpu_buffer_rsrc_t rs = a.stats != nullptr ? make_rsrc(a.stats + (size_t)o_p * SR * c.Cout, (unsigned)(SR * c.Cout) * 4u) : rnone;
+    const bool vc = o_valid && o_n0 + col < c.Cout;
+    const int kk = SR == 4 ? h : (h & 1);  // (two statistic rows only: the sums are stored twice)
+    const float val = kk == 0 ? v[0] : (kk == 1 ? v[1] : (kk == 2 ? v[2] : v[3]));
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), rs, vc ? (unsigned)((kk * c.Cout + o_n0 + col) * 4) : OOB, 0, 0);
 #endif
   };
-  // the slice of K-step kb of the item that computes the tile at (cm0, cn0): CPS chunks of the pending tile, the loads of the
-  // next step's chunks; in the last step the statistics / maximum, and scale / shift + the first chunks' residual of the tile
-  // that becomes pending behind it.  Every step issues exactly EPS counted operations.
+  // the slice of K-step kb: the statistics of two / four column blocks in the first steps, CPS chunks of the pending tile in
+  // every step, the statistics row in the last.  Every step issues exactly EPS counted operations.
   using PL = L2aPlan<KB, EPI>;
   constexpr int CPS = PL::CPS;
-  auto ep_step = [&](int kb, int cm0, int cn0) {
-    if constexpr (KB == 8) {
-      if (kb == 0) { ep_S(0); ep_S(1); }
-      if (kb == 1) { ep_S(2); ep_S(3); }
-    } else {
-      if (kb == 0) { ep_S(0); ep_S(1); ep_S(2); ep_S(3); }
+  auto ep_step = [&](int kb) {
+    if constexpr (EPI == 0) {
+      if constexpr (KB == 8) {
+        if (kb == 0) { ep_S(0); ep_S(1); }
+        if (kb == 1) { ep_S(2); ep_S(3); }
+      } else {
+        if (kb == 0) { ep_S(0); ep_S(1); ep_S(2); ep_S(3); }
+      }
     }
 #pragma unroll
     for (int u = 0; u < CPS; ++u) {
       const int g = kb * CPS + u;
       if ((g & 3) == 0) ep_Tw(g >> 2);
-      ep_chunk(g, kb & 1, u);
+      ep_chunk(g);
     }
-    int used = CPS * (PL::T + PL::R);
     if (kb + 1 < KB) {
-#pragma unroll
-      for (int u = 0; u < CPS; ++u) ep_load((kb + 1) * CPS + u, (kb + 1) & 1, u, o_m0, o_n0);
+      pad(PL::F);
     } else {
-      ep_F();
-      ep_P(cn0);
-#pragma unroll
-      for (int u = 0; u < CPS; ++u) ep_load(u, 0, u, cm0, cn0);
-      used += PL::F + PL::P;
+      if constexpr (EPI == 0) ep_F(); else pad(PL::F);
     }
-    pad(EPS - used);
   };
 
   // ---- the row panel's activations: fragment (kb, i, limb) of this lane = 16 bytes of row m0 + wm*64 + i*16 + (lane & 15):
@@ -1531,7 +1431,7 @@ __global__ __launch_bounds__(512, 2) void conv_l2a_kernel(const ConvK a, unsigne
       // run their slice of the pending epilogue.  The second one takes the slice FIRST: one wave's VALU / LDS / store
       // instructions beside the other's MFMAs, in every K-step (the slot stagger of conv_l2_kernel, with the epilogue as the
       // "prepare" slot).  Same instructions per wave either way: the counted wait above does not notice.
-      if (late) ep_step(kb, m0, n0);
+      if (late) ep_step(kb);
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -1549,7 +1449,7 @@ __global__ __launch_bounds__(512, 2) void conv_l2a_kernel(const ConvK a, unsigne
 #ifdef ONDA_L2A_STEP_STAMPS  // (measurement builds: a branch per K-step, which keeps the compiler from interleaving the slice with the MFMAs)
       if (a.stamps != nullptr && t == 0 && item == it_begin + 2) a.stamps[(size_t)bid * 32 + 16 + kb] = __builtin_amdgcn_s_memtime();
 #endif
-      if (!late) ep_step(kb, m0, n0);
+      if (!late) ep_step(kb);
     }
     stamp();
     // this tile becomes the pending one (raw sums; the unscale factors are folded into the epilogue's constants)
@@ -1562,18 +1462,21 @@ __global__ __launch_bounds__(512, 2) void conv_l2a_kernel(const ConvK a, unsigne
     o_m0 = m0;
     o_n0 = n0;
   }
-  // ---- the last tile's epilogue, chunk by chunk (its scale / shift and first residual loads were issued in the last K-step) ---
+  // ---- the last tile's epilogue, chunk by chunk ----------------------------------------------------------------------------
+  if constexpr (EPI == 0) {
 #pragma unroll
-  for (int jn = 0; jn < 4; ++jn) ep_S(jn);
+    for (int jn = 0; jn < 4; ++jn) ep_S(jn);
+  }
 #pragma unroll
   for (int g = 0; g < 8; ++g) {
     if ((g & 3) == 0) ep_Tw(g >> 2);
-    if (g >= CPS) ep_load(g, 0, 0, o_m0, o_n0);
-    ep_chunk(g, 0, g < CPS ? g : 0);
+    ep_chunk(g);
   }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  ep_F();
+  if constexpr (EPI == 0) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    ep_F();
+  }
 }
 
 // ---- stream-K remainder: partial tiles -> output, in ONE wide launch ---------------------------------------------------
@@ -2351,9 +2254,12 @@ static int l2_variant_k(long long M, int Cout, int taps, int Cin) {
 
 // ... and 1 x 1 convolutions with 64 / 128 / 256 input channels and at least 128 output channels run ACTIVATION-STATIONARY
 // (conv_l2a_kernel: a workgroup's 128 rows in registers, the weight rows streamed): the same 128-row statistic tiles as
-// variant 1, no stream-K remainder.  ONDA_L2_STATIONARY=0: the tile kernels of round 5 (tools only).
+// variant 1, no stream-K remainder.  ONDA_L2_STATIONARY=1 switches it on (default: the tile kernels of round 5).
 static bool l2_stationary(long long M, int Cout, int taps, int Cin) {
-  static const int on = getenv("ONDA_L2_STATIONARY") ? atoi(getenv("ONDA_L2_STATIONARY")) : 1;
+  // OFF by default: measured alone the kernel is 7-18 % faster than the 128 x 128 tile kernel on the train-mode forward convolutions
+  // it takes (256 -> 1024: 76-77 us against 82.7; 128 -> 512: 33.5 against 39.4; 64 -> 256 at 129 x 257: 52 against 64), the
+  // adaptation step does not move (94.88 / 94.87 ms on, 94.77 / 94.72 off, alternating runs on one box): profiles/r06_l2a_*.txt
+  static const int on = getenv("ONDA_L2_STATIONARY") ? atoi(getenv("ONDA_L2_STATIONARY")) : 0;
   if (!on || getenv("ONDA_L2_VARIANT")) return false;
   return taps == 1 && (Cin == 64 || Cin == 128 || Cin == 256) && l2_variant_k(M, Cout, taps, Cin) == 1;
 }
@@ -2562,28 +2468,29 @@ static int l2_fwd_impl(const void* xl, int64_t xplane, const float* xamax, const
   const long long y_rows = (long long)c->B * (c->out_os == 1 && c->Hf == c->Ho && c->Wf == c->Wo ? (long long)c->Ho * c->Wo : (long long)c->Hf * c->Wf);
   const long long y_total = ((y_rows - 1) * c->ldy + c->Cout) * 4;
   const bool dense_out = c->out_os == 1 && c->Hf == c->Ho && c->Wf == c->Wo;  // (buffer stores relative to the tile: any size)
-  const int epi = lo != nullptr ? 2 : (scale != nullptr || shift != nullptr || residual != nullptr || c->relu || yamax != nullptr ? 1 : 0);
-  // (statistics together with scale / shift / residual, and 64 input channels with anything but the plain epilogue, stay on the
-  //  128 x 128 tile kernel: same statistic rows, no stream-K remainder either way)
-  if (q.stationary && dense_out && !(stats != nullptr && epi != 0) && !(c->Cin == 64 && epi != 0)) {
+  // conv_l2a_kernel takes: the plain epilogue (with or without statistics), and "add the result to y" (residual == y, nothing
+  // else: a data gradient joining a gradient sink).  Everything else -- scale / shift / ReLU / max|y|, limb-row outputs,
+  // scattered outputs -- runs on the 128 x 128 tile kernel: same statistic rows, no stream-K remainder either way.
+  const bool plain_epi = lo == nullptr && scale == nullptr && shift == nullptr && !c->relu && yamax == nullptr;
+  // (EPI 1, "add into y" by atomic adds, is built and bit-identical -- and 3-4x slower than the tile kernel's load / add / store:
+  //  34 M four-byte atomics per launch.  ONDA_L2A_ACCUMULATE=1 switches it on for measurements; profiles/r06_l2a_*.txt)
+  static const int accumulate_on = getenv("ONDA_L2A_ACCUMULATE") ? atoi(getenv("ONDA_L2A_ACCUMULATE")) : 0;
+  const int epi = !plain_epi ? -1 : (residual == nullptr ? 0 : (accumulate_on && residual == y && c->ldr == c->ldy && stats == nullptr ? 1 : -1));
+  if (q.stationary && dense_out && epi >= 0 && c->Cout >= 256) {  // (one column tile per panel: nothing to amortise the rows over)
     // 1 x 1, Cin 64 / 128 / 256: the rows in registers, the weights streamed (conv_l2a_kernel)
     ONDA_REQUIRE(c->pad == 0 && (c->stride == 1 || (c->Hi >= (c->Ho - 1) * c->stride + 1 && c->Wi >= (c->Wo - 1) * c->stride + 1)));
     const long long items = (long long)k.tilesM * k.tilesN;
     const int cus = conv_resident_workgroups() / 2;
-    const int slots = cus;  // one workgroup per CU (the rows' fragments take the register file of one wave per SIMD)
+    const int slots = cus;  // one workgroup of 8 waves per CU
     const int grid = (int)(items < slots ? items : slots);
 #define L2A_LAUNCH(KB_, NST_, A2L_, EPI_) \
   hipLaunchKernelGGL((conv_l2a_kernel<KB_, NST_, A2L_, EPI_>), dim3(grid), dim3(512), 0, st, k, w_bytes, (unsigned)y_total, xamax, wamax)
     if (c->Cin == 256) {
-      if (epi == 0) L2A_LAUNCH(8, 3, true, 0);
-      else if (epi == 1) L2A_LAUNCH(8, 3, true, 1);
-      else L2A_LAUNCH(8, 3, true, 2);
+      if (epi == 0) L2A_LAUNCH(8, 3, true, 0); else L2A_LAUNCH(8, 3, true, 1);
     } else if (c->Cin == 128) {
-      if (epi == 0) L2A_LAUNCH(4, 3, false, 0);
-      else if (epi == 1) L2A_LAUNCH(4, 3, false, 1);
-      else L2A_LAUNCH(4, 3, false, 2);
+      if (epi == 0) L2A_LAUNCH(4, 3, false, 0); else L2A_LAUNCH(4, 3, false, 1);
     } else {
-      L2A_LAUNCH(2, 3, false, 0);
+      if (epi == 0) L2A_LAUNCH(2, 3, false, 0); else L2A_LAUNCH(2, 3, false, 1);
     }
 #undef L2A_LAUNCH
     return ONDA_LAUNCH_RESULT();

@@ -147,7 +147,7 @@ STATIONARY_CASES = [
 
 
 @pytest.mark.parametrize("case", STATIONARY_CASES, ids=lambda c: "x".join(map(str, c)))
-@pytest.mark.parametrize("epilogue", ["stats", "affine_res_relu", "limbs"])
+@pytest.mark.parametrize("epilogue", ["stats", "accumulate", "affine_res_relu", "limbs"])
 def test_activation_stationary_conv_is_the_tile_kernel_bit_for_bit(case, epilogue):
     """conv_l2a_kernel (round 6: a workgroup's rows in registers, weight rows streamed; deeplabv2.py:22-24,44,351-357) against
     the 128 x 128 tile kernel it replaces (ONDA_L2_VARIANT=1 forces it): the same products in the same order per accumulator,
@@ -161,7 +161,8 @@ def test_activation_stationary_conv_is_the_tile_kernel_bit_for_bit(case, epilogu
     try:
         Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
         M = B * Ho * Wo
-        assert query("onda_conv_l2_kernel_id", M, cout, 1, cin) == 4
+        if query("onda_conv_l2_kernel_id", M, cout, 1, cin) != 4:
+            pytest.skip("the activation-stationary kernel is off (default since its step-level A/B: ONDA_L2_STATIONARY=1 runs this test)")
         g = torch.Generator().manual_seed(cin + cout + stride)
         x = torch.randn(B, H, W, cin, generator=g).to(DEV)
         w = (torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5).to(DEV)
@@ -174,6 +175,10 @@ def test_activation_stationary_conv_is_the_tile_kernel_bit_for_bit(case, epilogu
             if epilogue == "stats":
                 y, st, _ = ops.conv_forward(x, wp, 1, stride, 1, 0, cout, want_stats=4)
                 return y, st
+            if epilogue == "accumulate":  # a data gradient that joins a gradient sink: residual == output (ops.GradSink)
+                buf = res.clone()
+                y, _, _ = ops.conv_forward(x, wp, 1, stride, 1, 0, cout, out=buf, residual=buf)
+                return y, y.abs().max()
             if epilogue == "affine_res_relu":
                 y, _, _ = ops.conv_forward(x, wp, 1, stride, 1, 0, cout, scale=scale, shift=shift, residual=res, relu=True)
                 return y, ops.known_amax(y)
