@@ -1106,16 +1106,15 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_l2x_kernel(const ConvK
 // landed.  So every K-step issues exactly EPS epilogue operations behind its DMA issue: the phases' real ones (buffer
 // operations, out-of-range lanes dropped by the hardware: the count does not depend on the data) padded with stores to an
 // empty buffer; the prologue pads as well.  N = (NST - 2) * BPW + (NST - 1) * EPS, one constant per instantiation.
-// EPI 0: plain output + BatchNorm statistics (train-mode forward, plain data gradients); EPI 1: the result is ADDED to what
-// y holds (a data gradient that joins a gradient sink, ops.GradSink: residual == y) by no-return buffer_atomic_add_f32 -- one
-// thread per element, one addition: the same sum as the tile kernels' "load residual, add, store", without a load in the
-// interleaved epilogue (a first form that fetched the residual one K-step ahead spilled and ran 2.2-2.4x SLOWER than the tile
-// kernel: gpurun_out/r06_b_conv_shapes_stationary*.txt).  Scale / shift / ReLU / max|y| / limb-row outputs stay on the tile kernels.
+// One epilogue (EPI 0): plain output + BatchNorm statistics (train-mode forward, plain data gradients).  Everything with a load
+// in it stays on the tile kernels: a form that fetched the residual one K-step ahead (counted buffer loads) spilled under the
+// 256-register cap and ran 2.2-2.4x slower than the tile kernel, "add into y" by no-return buffer_atomic_add_f32 (no load at all)
+// 3-4x slower (34 M four-byte atomics per launch): profiles/r06_l2a_activation_stationary_kernel.txt, `git log` for the code.
 // Same products in the same order per accumulator as the tile kernels, same epilogue arithmetic: bit-identical results.
 template <int KB, int EPI>
 struct L2aPlan {  // epilogue operations per wave and K-step
   static constexpr int CPS = 8 / KB;               // 4-row chunks of the pending tile stored per K-step (8 per wave)
-  static constexpr int T = EPI == 1 ? 4 : 1;       // output operations per chunk: one 16-byte store, or four 4-byte atomic adds
+  static constexpr int T = 1;                      // output operations per chunk: one 16-byte store
   static constexpr int F = 1;                      // the statistics store (last step)
   static constexpr int EPS = CPS * T + F;          // every step is padded to the last step's count
 };
@@ -1138,7 +1137,7 @@ __global__ __launch_bounds__(512, 2) void conv_l2a_kernel(const ConvK a, unsigne
   // (measurement builds: ONDA_L2A_PADS=0 drops the padding and waits for the younger DMAs only -- conservative, still correct)
   constexpr int NWAIT = (AHEAD - 1) * BPW + (ONDA_L2A_PADS ? AHEAD * EPS : 0);  // operations younger than the DMAs a K-step waits for
   static_assert(NWAIT <= 63, "vmcnt holds 6 bits");
-  static_assert((KB == 8 || KB == 4 || KB == 2) && (EPI == 0 || EPI == 1), "schedules of ep_step");
+  static_assert((KB == 8 || KB == 4 || KB == 2) && EPI == 0, "schedules of ep_step");
   constexpr int TRS = 68;                  // floats per row of a wave's transposition buffer (l2_epilogue)
   constexpr int SCRATCH = NW * (16 * TRS * 4) + WM * BN * 4 * 4 + 64;  // transposition buffers, statistics partials
   constexpr int A2_BYTES = A2L ? KB * (BM / 16) * 1024 : 0;           // second limbs: [kb][16-row block][16 rows x 64 B]
@@ -1281,12 +1280,7 @@ __global__ __launch_bounds__(512, 2) void conv_l2a_kernel(const ConvK a, unsigne
     const unsigned off = vn ? (unsigned)(((size_t)(mw - o_m0 + i * 16 + 4 * rq) * c.ldy + n) * 4) : OOB;
     f32x4 v = *reinterpret_cast<const f32x4*>(tr + (4 * rq + rl) * TRS + cl);
     v = v * f32x4{ua * ub, ua * ub, ua * ub, ua * ub};
-    if constexpr (EPI == 1) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(v[e], ry, off, 4 * e, 0);
-    } else {
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ry, off, 0, NT_AUX);
-    }
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ry, off, 0, NT_AUX);
     if (rq == 3) __builtin_amdgcn_wave_barrier();
 #else
     (void)g;
@@ -2268,10 +2262,14 @@ static bool l2_stationary(long long M, int Cout, int taps, int Cin) {
  * = conv_l2_kernel<4,2> / <2,2> / <4,1>), 3: conv_l2x_kernel<4,2>, the continuous K-step stream taken by 256 x 128
  * problems with at most 32 K-steps per tile, or 4: conv_l2a_kernel, the activation-stationary 1 x 1 kernel (bench.py names
  * its per-kernel figures after this) */
+// K-steps per tile up to which a 256 x 128 problem runs as the continuous K-step stream (conv_l2x_kernel).  (Round 6 re-measured
+// the threshold: 72-step tiles -- 256 -> 256 3 x 3 -- 130 us on the stream kernel against 120.5, 144-step tiles 391 against 363.)
+static constexpr int l2x_max_ksteps() { return 32; }
+
 int onda_conv_l2_kernel_id(int64_t M, int Cout, int taps, int Cin) {
   if (l2_stationary(M, Cout, taps, Cin)) return 4;
   const int variant = l2_variant_k(M, Cout, taps, Cin);
-  const bool short_k = taps * (Cin / 32) <= 32;
+  const bool short_k = taps * (Cin / 32) <= l2x_max_ksteps();
   return variant == 0 && short_k ? 3 : variant;
 }
 
@@ -2422,7 +2420,7 @@ static int l2_fwd_impl(const void* xl, int64_t xplane, const float* xamax, const
     k.res_true = lo->res_true ? lo->res_true : lo->res_amax;
   }
   k.skip_dead_taps = getenv("ONDA_L2A_WKB") ? 78 : 1;
-  k.late_issue = getenv("ONDA_L2A_NOEPI") ? 77 : 1;
+  k.late_issue = 1;
   static const int stamp_on = getenv("ONDA_L2X_STAMP") ? atoi(getenv("ONDA_L2X_STAMP")) : 0;
   if (stamp_on)  // the last 64 KiB of the workspace (beyond anything the schedules use: checked below)
     k.stamps = reinterpret_cast<unsigned long long*>(ws + onda_conv_ws_floats()) - 1024 * 32;
@@ -2468,14 +2466,10 @@ static int l2_fwd_impl(const void* xl, int64_t xplane, const float* xamax, const
   const long long y_rows = (long long)c->B * (c->out_os == 1 && c->Hf == c->Ho && c->Wf == c->Wo ? (long long)c->Ho * c->Wo : (long long)c->Hf * c->Wf);
   const long long y_total = ((y_rows - 1) * c->ldy + c->Cout) * 4;
   const bool dense_out = c->out_os == 1 && c->Hf == c->Ho && c->Wf == c->Wo;  // (buffer stores relative to the tile: any size)
-  // conv_l2a_kernel takes: the plain epilogue (with or without statistics), and "add the result to y" (residual == y, nothing
-  // else: a data gradient joining a gradient sink).  Everything else -- scale / shift / ReLU / max|y|, limb-row outputs,
-  // scattered outputs -- runs on the 128 x 128 tile kernel: same statistic rows, no stream-K remainder either way.
+  // conv_l2a_kernel takes the plain epilogue (with or without statistics).  Everything else -- scale / shift / residual / ReLU /
+  // max|y|, limb-row outputs, scattered outputs -- runs on the 128 x 128 tile kernel: same statistic rows, no stream-K remainder.
   const bool plain_epi = lo == nullptr && scale == nullptr && shift == nullptr && !c->relu && yamax == nullptr;
-  // (EPI 1, "add into y" by atomic adds, is built and bit-identical -- and 3-4x slower than the tile kernel's load / add / store:
-  //  34 M four-byte atomics per launch.  ONDA_L2A_ACCUMULATE=1 switches it on for measurements; profiles/r06_l2a_*.txt)
-  static const int accumulate_on = getenv("ONDA_L2A_ACCUMULATE") ? atoi(getenv("ONDA_L2A_ACCUMULATE")) : 0;
-  const int epi = !plain_epi ? -1 : (residual == nullptr ? 0 : (accumulate_on && residual == y && c->ldr == c->ldy && stats == nullptr ? 1 : -1));
+  const int epi = plain_epi && residual == nullptr ? 0 : -1;
   if (q.stationary && dense_out && epi >= 0 && c->Cout >= 256) {  // (one column tile per panel: nothing to amortise the rows over)
     // 1 x 1, Cin 64 / 128 / 256: the rows in registers, the weights streamed (conv_l2a_kernel)
     ONDA_REQUIRE(c->pad == 0 && (c->stride == 1 || (c->Hi >= (c->Ho - 1) * c->stride + 1 && c->Wi >= (c->Wo - 1) * c->stride + 1)));
@@ -2485,19 +2479,15 @@ static int l2_fwd_impl(const void* xl, int64_t xplane, const float* xamax, const
     const int grid = (int)(items < slots ? items : slots);
 #define L2A_LAUNCH(KB_, NST_, A2L_, EPI_) \
   hipLaunchKernelGGL((conv_l2a_kernel<KB_, NST_, A2L_, EPI_>), dim3(grid), dim3(512), 0, st, k, w_bytes, (unsigned)y_total, xamax, wamax)
-    if (c->Cin == 256) {
-      if (epi == 0) L2A_LAUNCH(8, 3, true, 0); else L2A_LAUNCH(8, 3, true, 1);
-    } else if (c->Cin == 128) {
-      if (epi == 0) L2A_LAUNCH(4, 3, false, 0); else L2A_LAUNCH(4, 3, false, 1);
-    } else {
-      if (epi == 0) L2A_LAUNCH(2, 3, false, 0); else L2A_LAUNCH(2, 3, false, 1);
-    }
+    if (c->Cin == 256) L2A_LAUNCH(8, 3, true, 0);
+    else if (c->Cin == 128) L2A_LAUNCH(4, 3, false, 0);
+    else L2A_LAUNCH(2, 3, false, 0);
 #undef L2A_LAUNCH
     return ONDA_LAUNCH_RESULT();
   }
   // short K loops (1 x 1 convolutions up to 1024 input channels) gain 6-17 % from the continuous stream; long ones lose
   // ~4 % against the slot-staggered kernel, whose per-tile start / end they amortise anyway (measured per shape, one process)
-  const bool short_k = k.taps * k.kcper <= 32;
+  const bool short_k = k.taps * k.kcper <= l2x_max_ksteps();
   if (short_k && q.variant == 0 && (dense_out || y_total < 0x7FFFF000ll)) {
     if (!q.balanced) k.tiles_dp = tiles;  // persistent either way: whole tiles only
     const int grid = tiles < q.G ? tiles : q.G;
@@ -2523,6 +2513,7 @@ static int l2_fwd_impl(const void* xl, int64_t xplane, const float* xamax, const
     }                                                                                                                          \
     return ONDA_LAUNCH_RESULT();                                                                                               \
   } while (0)
+    if (q.variant == 0 && dbg == 5) L2_DBG_LAUNCH(5);  // per-workgroup ticks of set-up / K loop / epilogue into the workspace (tools/l2_tile_stamps.py)
     if (q.variant == 0 && dbg == 1) L2_DBG_LAUNCH(1);
     if (q.variant == 0 && dbg == 2) L2_DBG_LAUNCH(2);
     if (q.variant == 0 && dbg == 7) L2_DBG_LAUNCH(7);
