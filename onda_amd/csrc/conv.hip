@@ -26,8 +26,12 @@ constexpr int LDS_ROW = 36;  // 32 floats + 4 pad: ds_read_b128 of 16 distinct r
 //             ranges (grid = resident workgroups), so every CU finishes together whatever the
 //             tile count; a range end inside a tile leaves a raw partial tile in `ws`, summed in
 //             fixed order by conv_fixup_kernel (deterministic, no atomics, no inter-block waits).
+// (256, 2): two workgroups per CU = two waves per SIMD, i.e. at most 256 registers.  Without the second bound the stream-K
+// instantiation -- the one most launches run -- grew to 296 registers: ONE wave per SIMD, nothing to cover a barrier, an LDS
+// round trip or the next step's global loads with, SQ_VALU_MFMA_BUSY 0.66 of the SIMD cycles on a board at 950 W and
+// 2.4 GHz (profiles/r06_d_f32_sq_counters.txt; round 6).
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool SK>
-__global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvK a) {
+__global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const ConvK a) {
   constexpr int TM = BM / (32 * WAVES_M), TN = BN / (32 * WAVES_N);
   constexpr int AL = BM / 32, BL = BN / 32;
   constexpr int STAGE = (BM + BN) * LDS_ROW;
@@ -364,7 +368,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK a) {
       const int m = mb + brow + RPB * u;
       bool ok = vb && m < mend;
       size_t pix = m;
-      if (!direct && ok) {
+      if (!direct && ok && a.pix != nullptr) {  // the caller's table of this geometry's input pixels (onda_conv2d_wgrad_l2_table):
+        const int pv = a.pix[(size_t)tap * a.pix_stride + m];  // no divisions in the K loop (4 rows x 4 of them per thread and K-step)
+        ok = pv >= 0;
+        pix = (size_t)(pv >= 0 ? pv : 0);
+      } else if (!direct && ok) {
         const int wo = m % c.Wo, tq = m / c.Wo;
         const int ho = tq % c.Ho, b = tq / c.Ho;
         const int hi = ho * c.stride + dh, wi = wo * c.stride + dw;
@@ -727,6 +735,9 @@ int onda_conv2d_wgrad(const float* x, const float* dy, float* slabs, int lddy, i
   k.splitk = splitk;
   k.mchunk = (int)(((M + splitk - 1) / splitk + 31) / 32 * 32);
   k.taps = c->kh * c->kw;
+  ONDA_REQUIRE(c->pix_table == nullptr || c->pix_stride >= M);
+  k.pix = c->pix_table;  // optional (OndaConv.pix_table): [taps][pix_stride] input pixel of every output pixel, -1 in the padding
+  k.pix_stride = c->pix_stride;
   if (c->Cout > 64 && c->Cin > 64) {
     k.tilesN = (c->Cout + 127) / 128;
     k.tilesC = (c->Cin + 127) / 128;

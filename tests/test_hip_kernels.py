@@ -93,7 +93,7 @@ def test_conv_full_size_against_torch_cpu(case):
 
 def test_weight_gradient_pixel_table_across_batch_sizes():
     """The 256-output-channel weight-gradient kernel reads its input pixels from a per-geometry table that the CALLER owns
-    (onda_conv2d_wgrad_l2_table; ops._wgrad_pixel_table keeps one per geometry): the same geometry at batch 1, then 3 (a
+    (onda_conv2d_wgrad_l2_table; ops.conv._wgrad_pixel_table keeps one per geometry): the same geometry at batch 1, then 3 (a
     larger table replaces it), then 2 (served by the larger one), dilated 3 x 3 and a stride-2 1 x 1, each against fp32
     torch on the CPU -- and once with no table at all (the kernel then works the pixels out in its K loop: same result)."""
     from onda_amd import ops
@@ -108,13 +108,13 @@ def test_weight_gradient_pixel_table_across_batch_sizes():
         for B in (1, 3, 2, 0):
             no_table = B == 0
             B = B or 2
-            real = ops._wgrad_pixel_table
+            real = ops.conv._wgrad_pixel_table
             if no_table:
-                ops._wgrad_pixel_table = lambda d, device: None
+                ops.conv._wgrad_pixel_table = lambda d, device: None
             try:
                 _wgrad_case(ops, cin, cout, k, stride, dil, pad, H, W, B)
             finally:
-                ops._wgrad_pixel_table = real
+                ops.conv._wgrad_pixel_table = real
         key = [kk for kk in ops._PIX_TABLES if kk[1:] == (H, W, Ho, Wo, k, k, stride, dil, pad)]
         assert len(key) == 1 and ops._PIX_TABLES[key[0]][1] == 3  # one table per geometry, the largest batch's
 

@@ -1,5 +1,5 @@
 """Split-K sweep of the pre-split weight-gradient path (kernel + slab reduction) per shape of the network: the time of every
-split count around the heuristic's choice (ops._wgrad_splitk), one process, interleaved repeats."""
+split count around the heuristic's choice (ops.conv._wgrad_splitk), one process, interleaved repeats."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -16,7 +16,7 @@ SHAPES = [  # (B,H,W,Cin,Cout,k,dil)
 ]
 N = 8
 ops.H2_PATH = "dma"
-heur = ops._wgrad_splitk
+heur = ops.conv._wgrad_splitk
 for (_b, H, W, Cin, Cout, k, dil) in SHAPES:
     B = BATCH
     x = torch.randn(B, H, W, Cin, device="cuda")
@@ -29,7 +29,7 @@ for (_b, H, W, Cin, Cout, k, dil) in SHAPES:
     res = {}
     for rep in range(3):
         for sk in cands:
-            ops._wgrad_splitk = lambda *a, _sk=sk, **kw: _sk
+            ops.conv._wgrad_splitk = lambda *a, _sk=sk, **kw: _sk
             try:
                 ops.conv_wgrad(x, dy, k, 1, dil, pad, Cout, Cin)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -45,4 +45,4 @@ for (_b, H, W, Cin, Cout, k, dil) in SHAPES:
     fl = 2.0 * M * Cout * Cin * k * k
     print(f"Cin={Cin:5d} Cout={Cout:5d} k={k} M={M:6d} | heuristic sk={sk0:3d} {res[sk0]:7.1f} us ({fl / res[sk0] / 1e6:5.0f} TF) | best sk={best:3d} {res[best]:7.1f} us"
           f" | " + " ".join(f"{s}:{res[s]:.0f}" for s in cands), flush=True)
-ops._wgrad_splitk = heur
+ops.conv._wgrad_splitk = heur
