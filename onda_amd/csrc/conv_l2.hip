@@ -2253,9 +2253,10 @@ static bool l2_stationary(long long M, int Cout, int taps, int Cin) {
   // OFF by default: measured alone the kernel is 7-18 % faster than the 128 x 128 tile kernel on the train-mode forward convolutions
   // it takes (256 -> 1024: 76-77 us against 82.7; 128 -> 512: 33.5 against 39.4; 64 -> 256 at 129 x 257: 52 against 64), the
   // adaptation step does not move (94.88 / 94.87 ms on, 94.77 / 94.72 off, alternating runs on one box): profiles/r06_l2a_*.txt
-  static const int on = getenv("ONDA_L2_STATIONARY") ? atoi(getenv("ONDA_L2_STATIONARY")) : 0;
-  if (!on || getenv("ONDA_L2_VARIANT")) return false;
-  return taps == 1 && (Cin == 64 || Cin == 128 || Cin == 256) && l2_variant_k(M, Cout, taps, Cin) == 1;
+  const char* e = getenv("ONDA_L2_STATIONARY");  // (read per call: the kernel's own test switches it on for its launches)
+  if (e == nullptr || atoi(e) == 0 || getenv("ONDA_L2_VARIANT")) return false;
+  // (at least two column tiles: with one, nothing amortises a panel's rows)
+  return taps == 1 && (Cin == 64 || Cin == 128 || Cin == 256) && Cout >= 256 && l2_variant_k(M, Cout, taps, Cin) == 1;
 }
 
 /* which device kernel onda_conv2d_fwd_l2 launches for a problem: the tile variant (0: 256 x 128, 1: 128 x 128, 2: 256 x 64
@@ -2470,7 +2471,7 @@ static int l2_fwd_impl(const void* xl, int64_t xplane, const float* xamax, const
   // max|y|, limb-row outputs, scattered outputs -- runs on the 128 x 128 tile kernel: same statistic rows, no stream-K remainder.
   const bool plain_epi = lo == nullptr && scale == nullptr && shift == nullptr && !c->relu && yamax == nullptr;
   const int epi = plain_epi && residual == nullptr ? 0 : -1;
-  if (q.stationary && dense_out && epi >= 0 && c->Cout >= 256) {  // (one column tile per panel: nothing to amortise the rows over)
+  if (q.stationary && dense_out && epi >= 0) {
     // 1 x 1, Cin 64 / 128 / 256: the rows in registers, the weights streamed (conv_l2a_kernel)
     ONDA_REQUIRE(c->pad == 0 && (c->stride == 1 || (c->Hi >= (c->Ho - 1) * c->stride + 1 && c->Wi >= (c->Wo - 1) * c->stride + 1)));
     const long long items = (long long)k.tilesM * k.tilesN;
