@@ -218,13 +218,13 @@ int onda_bn_bwd_l2(const float* dout, const void* out, int64_t out_plane, const 
  * (ds_read_b64_tr_b16), tiles of 256 x 128 or 128 x 128 (output x input channels) per tap and pixel range.
  * The 256 x 128 kernel reads the input pixel of every (tap, output pixel) from a table per convolution GEOMETRY (input and
  * output size, kernel, stride, dilation, padding; 4 bytes per tap and output pixel) that the CALLER owns, like every other
- * buffer: onda_conv2d_wgrad_l2_table_stride(c) = int32 entries per tap at c->B images (0: this geometry needs no table --
- * 1 x 1 stride-1 convolutions), the table holds kh*kw times that; onda_conv2d_wgrad_l2_table(c, table, s)
+ * buffer: onda_conv2d_wgrad_l2_table_stride(c) = int32 entries per tap at c->B images (0: this problem needs no table --
+ * 1 x 1 stride-1 convolutions, the 128 x 128 tile), the table holds kh*kw times that; onda_conv2d_wgrad_l2_table(c, table, s)
  * fills it with one launch on `s`; c->pix_table / c->pix_stride hand it to onda_conv2d_wgrad_l2.  A table built for a larger
  * batch of the same geometry serves a smaller one.  Without a table (pix_table NULL) the kernel works the pixels out in its
- * K loop (the loop of rounds 2-4: same results, 15-25 % slower).  The 128 x 128 tile of the f16x2 kernel ignores the table;
- * the exact-fp32 weight gradient (onda_conv2d_wgrad) reads it too when given (round 6: no divisions in its K loop either).
- * No call of this library allocates or synchronises. */
+ * K loop (the loop of rounds 2-4: same results, 15-25 % slower).  No call of this library allocates or synchronises.
+ * (Round 6 gave the exact-fp32 weight gradient the same table: 59.9 -> 61.6 ms per pass, and 66 with the entries fetched a
+ * K-step ahead -- its divisions were never what it waits for; not kept.) */
 int onda_conv_wgrad_l2_variant(int Cout, int Cin);
 int64_t onda_conv2d_wgrad_l2_table_stride(const OndaConv* c);
 int onda_conv2d_wgrad_l2_table(const OndaConv* c, int32_t* table, onda_stream_t s);

@@ -368,11 +368,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK a) {
       const int m = mb + brow + RPB * u;
       bool ok = vb && m < mend;
       size_t pix = m;
-      if (!direct && ok && a.pix != nullptr) {  // the caller's table of this geometry's input pixels (onda_conv2d_wgrad_l2_table):
-        const int pv = a.pix[(size_t)tap * a.pix_stride + m];  // no divisions in the K loop (4 rows x 4 of them per thread and K-step)
-        ok = pv >= 0;
-        pix = (size_t)(pv >= 0 ? pv : 0);
-      } else if (!direct && ok) {
+      if (!direct && ok) {
         const int wo = m % c.Wo, tq = m / c.Wo;
         const int ho = tq % c.Ho, b = tq / c.Ho;
         const int hi = ho * c.stride + dh, wi = wo * c.stride + dw;
@@ -735,9 +731,6 @@ int onda_conv2d_wgrad(const float* x, const float* dy, float* slabs, int lddy, i
   k.splitk = splitk;
   k.mchunk = (int)(((M + splitk - 1) / splitk + 31) / 32 * 32);
   k.taps = c->kh * c->kw;
-  ONDA_REQUIRE(c->pix_table == nullptr || c->pix_stride >= M);
-  k.pix = c->pix_table;  // optional (OndaConv.pix_table): [taps][pix_stride] input pixel of every output pixel, -1 in the padding
-  k.pix_stride = c->pix_stride;
   if (c->Cout > 64 && c->Cin > 64) {
     k.tilesN = (c->Cout + 127) / 128;
     k.tilesC = (c->Cin + 127) / 128;

@@ -2592,10 +2592,10 @@ static bool wgrad_l2_linear(const OndaConv* c) {  // x pixel = output pixel: no 
 }
 
 /* int32 entries between two taps' rows of the pixel table of this geometry AT THIS BATCH (the table is taps * stride
- * entries), or 0 when the problem runs without one (1 x 1 stride-1 convolutions: x pixel = output pixel) */
+ * entries), or 0 when the problem runs without one (1 x 1 stride-1 convolutions, the 128 x 128 tile) */
 int64_t onda_conv2d_wgrad_l2_table_stride(const OndaConv* c) {
   if (!c || c->B <= 0 || c->Ho <= 0 || c->Wo <= 0) return 0;
-  if (wgrad_l2_linear(c)) return 0;  // (a property of the geometry alone: the exact-fp32 weight gradient reads the same table)
+  if (onda_conv_wgrad_l2_variant(c->Cout, c->Cin) != 0 || wgrad_l2_linear(c)) return 0;
   if ((long long)c->B * c->Hi * c->Wi >= (1ll << 31)) return 0;
   const long long M = (long long)c->B * c->Ho * c->Wo;
   return (M + 31) / 32 * 32 + 64;  // (a workgroup's last K-step may reach past M)

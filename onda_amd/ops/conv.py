@@ -319,7 +319,6 @@ def conv_wgrad(x, dy, k, stride, dil, pad, cout_real, cin_real, flat_k=0, into=N
 
 
 def _wgrad_other(x, dy, slabs, sk, d, M, Co, taps, Cin, k, stride, dil):
-    _wgrad_pixel_table(d, x.device)
     _launch("conv_wgrad_kernel<%s>" % ("128,128" if (Co > 64 and Cin > 64) else "64,64"), 2.0 * M * Co * taps * Cin,
             "onda_conv2d_wgrad", _p(x), _p(dy), _p(slabs), nhwc_ld(dy), sk, byref(d), _stream(),
             tag=("wgrad", M, Co, Cin, k, stride, dil, sk))
