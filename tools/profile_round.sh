@@ -5,7 +5,7 @@
 #   tools/profile_round.sh r03_a      -> gpurun_out/r03_a_*
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 tag=${1:-r05_x}; G=gpurun_out; mkdir -p $G
-common="--no-cpu-baseline --no-eager --no-other-configs"
+common="--no-cpu-baseline --no-eager --no-other-configs --no-h2d-leg --no-exchange-probe"
 # the headline line: bench.py alone, nothing wrapped around it (round-5 advisor); board power is logged in a run of its own below
 python3 bench.py --steps 20 --warmup 5 > $G/${tag}_bench_line.json 2> $G/${tag}_bench_line.err
 python3 tools/power_log.py $G/${tag}_power_during_bench.csv -- python3 bench.py --steps 40 --warmup 5 $common --no-exact-f32 --no-roofline > /dev/null 2> $G/${tag}_power_summary.txt
@@ -29,7 +29,7 @@ ONDA_SIDE_STREAMS=0 rocprofv3 --kernel-trace --output-format csv -d $G/prof_$tag
 KERNELS=40 python3 tools/trace_gaps.py $(find $G/prof_$tag/tr -name "*kernel_trace.csv" | head -1) > $G/${tag}_step_kernel_table.txt 2>&1
 # HBM-side traffic ON THE BENCH STEP ITSELF (round-4 verdict: bytes and flops per launch of one `roofline` block must describe the
 # same launches), every pass on one stream as the roofline leg measures it; separate --pmc passes with --kernel-trace only
-pmc_cmd="bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-eager --no-other-configs --no-exact-f32 --no-roofline"
+pmc_cmd="bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-eager --no-other-configs --no-exact-f32 --no-roofline --no-h2d-leg --no-exchange-probe"
 ONDA_SIDE_STREAMS=0 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $G/prof_$tag/fetch -- python3 $pmc_cmd > /dev/null 2> $G/prof_$tag/fetch.err
 ONDA_SIDE_STREAMS=0 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $G/prof_$tag/write -- python3 $pmc_cmd > /dev/null 2> $G/prof_$tag/write.err
 python3 tools/pmc_summary.py $G/prof_$tag/fetch $G/prof_$tag/write $G/${tag}_hbm_traffic.json "ONDA_SIDE_STREAMS=0 python3 $pmc_cmd (the bench step: 5 steps + set-up passes)" > $G/${tag}_hbm_traffic_top.txt
