@@ -60,6 +60,9 @@ typedef struct OndaConv {
 /* Number of float partials conv_fwd writes when `stats` != NULL: tiles_m * 2 * Cout, where
  * tiles_m = onda_conv_tiles_m(M). */
 int onda_conv_tiles_m(int M);
+/* ... per problem: onda_conv2d_fwd runs (M, Cout) problems that fill the chip on 256 x 128 tiles (round 6) and writes one
+ * statistics row per tile row of the kernel it chose: size `stats` with onda_conv_tiles_mc(M, Cout) */
+int onda_conv_tiles_mc(int M, int Cout);
 
 /* y = epilogue(conv(x, w)).  w is packed [Cout][kh*kw][Cin] (onda_pack_weight_fwd).
  * Epilogue, in order: per-channel sum / sum-of-squares partials of the raw result into

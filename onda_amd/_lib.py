@@ -48,6 +48,7 @@ class OndaEmaEntry(Structure):
 # name -> (restype, argtypes); mirrors include/onda_hip.h one to one
 SIGNATURES = {
     "onda_conv_tiles_m": (I, [I]),
+    "onda_conv_tiles_mc": (I, [I, I]),
     "onda_conv_ws_floats": (L, []),
     "onda_conv2d_fwd": (I, [P, P, P, P, P, P, P, P, POINTER(OndaConv), P]),
     "onda_absmax": (I, [P, L, I, I, P, P]),

@@ -30,10 +30,13 @@ constexpr int LDS_ROW = 36;  // 32 floats + 4 pad: ds_read_b128 of 16 distinct r
 // instantiation -- the one most launches run -- grew to 296 registers: ONE wave per SIMD, nothing to cover a barrier, an LDS
 // round trip or the next step's global loads with, SQ_VALU_MFMA_BUSY 0.66 of the SIMD cycles on a board at 950 W and
 // 2.4 GHz (profiles/r06_d_f32_sq_counters.txt; round 6).
+// (The template also instantiates as 256 x 128 tiles on 8 waves -- conv_big_tile below, off: measured slower.)
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool SK>
-__global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const ConvK a) {
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void conv_fwd_kernel(const ConvK a) {
+  constexpr int NT = WAVES_M * WAVES_N * 64;   // threads: 8 per 32-channel row, NT / 8 rows per pass of the workgroup
+  constexpr int RP = NT / 8;
   constexpr int TM = BM / (32 * WAVES_M), TN = BN / (32 * WAVES_N);
-  constexpr int AL = BM / 32, BL = BN / 32;
+  constexpr int AL = BM / RP, BL = BN / RP;
   constexpr int STAGE = (BM + BN) * LDS_ROW;
   __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
 
@@ -72,7 +75,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const ConvK a) {
   int hi0[AL], wi0[AL], bH[AL];
 #pragma unroll
   for (int u = 0; u < AL; ++u) {
-    const int m = m0 + rbase + 32 * u;
+    const int m = m0 + rbase + RP * u;
     const bool vm = m < a.M;
     const int mm = vm ? m : 0;
     const int wo = mm % c.Wo, tq = mm / c.Wo;
@@ -86,7 +89,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const ConvK a) {
   const int wstride = a.taps * c.Cin;
 #pragma unroll
   for (int u = 0; u < BL; ++u) {
-    const int n = n0 + rbase + 32 * u;
+    const int n = n0 + rbase + RP * u;
     vn[u] = n < c.Cout;
     wrow[u] = static_cast<const float*>(a.w) + (size_t)(vn[u] ? n : 0) * wstride + ccol;
   }
@@ -115,9 +118,9 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const ConvK a) {
     float* Ab = lds + buf * STAGE;
     float* Bb = Ab + BM * LDS_ROW;
 #pragma unroll
-    for (int u = 0; u < AL; ++u) *reinterpret_cast<f32x4*>(&Ab[(rbase + 32 * u) * LDS_ROW + ccol]) = ar[u];
+    for (int u = 0; u < AL; ++u) *reinterpret_cast<f32x4*>(&Ab[(rbase + RP * u) * LDS_ROW + ccol]) = ar[u];
 #pragma unroll
-    for (int u = 0; u < BL; ++u) *reinterpret_cast<f32x4*>(&Bb[(rbase + 32 * u) * LDS_ROW + ccol]) = br[u];
+    for (int u = 0; u < BL; ++u) *reinterpret_cast<f32x4*>(&Bb[(rbase + RP * u) * LDS_ROW + ccol]) = br[u];
   };
 
   f32x16 acc[TM][TN];
@@ -607,6 +610,16 @@ extern "C" {
 
 int onda_conv_tiles_m(int M) { return (M + 127) / 128; }
 
+// the exact-fp32 forward / data-gradient tile of an (M, Cout) problem: 256 x 128 on 8 waves when that fills the chip
+static bool conv_big_tile(long long M, int Cout) {
+  // OFF: built on the idea that these kernels wait for operand delivery like their f16x2 counterparts; measured, the 256 x 128 tile
+  // is 2.4 % SLOWER at the step (292.8 / 293.2 against 286.0 / 286.5 ms, alternating runs) and 3 % per shape.  ONDA_F32_BIG_TILE=1.
+  static const int on = getenv("ONDA_F32_BIG_TILE") ? atoi(getenv("ONDA_F32_BIG_TILE")) : 0;
+  return on && Cout > 64 && ((M + 255) / 256) * ((Cout + 127) / 128) >= 200;
+}
+/* rows of the statistic partials onda_conv2d_fwd writes for an (M, Cout) problem (one per tile row of the kernel it runs on) */
+int onda_conv_tiles_mc(int M, int Cout) { return conv_big_tile(M, Cout) ? (M + 255) / 256 : (M + 127) / 128; }
+
 }  // extern "C"
 
 int conv_launch_fixup(const ConvK& k, int G, bool wide, hipStream_t st) {
@@ -682,17 +695,19 @@ int onda_conv2d_fwd(const float* x, const float* w, float* y, const float* scale
   k.M = (int)M;
   k.taps = c->kh * c->kw;
   k.kcper = c->Cin / 32;
-  k.tilesM = (k.M + 127) / 128;
+  const bool big = conv_big_tile(M, c->Cout) && ws != nullptr;
+  ONDA_REQUIRE(big || !conv_big_tile(M, c->Cout) || stats == nullptr);  // (the statistic rows follow onda_conv_tiles_mc)
+  k.tilesM = big ? (k.M + 255) / 256 : (k.M + 127) / 128;
   const bool wide = c->Cout > 64;
   k.tilesN = wide ? (c->Cout + 127) / 128 : (c->Cout + 63) / 64;
-  const int tiles = k.tilesM * k.tilesN, KT = k.taps * k.kcper, G = conv_resident_workgroups();
+  const int tiles = k.tilesM * k.tilesN, KT = k.taps * k.kcper, G = big ? conv_resident_workgroups() / 2 : conv_resident_workgroups();
   // One workgroup per tile wastes the last partial round of the G resident workgroups.  The
   // hybrid schedule runs the whole rounds tile-per-workgroup and spreads only the remaining
   // tiles evenly over all workgroups (stream-K); its price is the fix-up pass over those tiles.
   const int rem = tiles % G;
   k.tiles_dp = tiles - rem;
   const double t_tile_us = 2.0 * 128.0 * (wide ? 128.0 : 64.0) * k.taps * c->Cin / 0.2e6;  // one tile, half a CU, ~100 TF/s chip
-  const double fix_us = 8.0 + (G + 2.0 * rem) * (wide ? 0.03 : 0.015);  // partial tiles written + read
+  const double fix_us = 8.0 + (G + 2.0 * rem) * (big ? 0.06 : (wide ? 0.03 : 0.015));  // partial tiles written + read
   bool balanced = ws != nullptr && rem != 0 && KT >= 4 && t_tile_us * (1.0 - (double)rem / G) > fix_us;
   if (const int force = conv_sched_override()) {  // ONDA_CONV_SCHED: 1 tile-per-workgroup, 2 hybrid, 3 pure stream-K
     if (force == 1 || ws == nullptr) {
@@ -703,6 +718,14 @@ int onda_conv2d_fwd(const float* x, const float* w, float* y, const float* scale
     }
   }
   hipStream_t st = ONDA_STREAM(s);
+  if (big) {
+    if (balanced) {
+      hipLaunchKernelGGL((conv_fwd_kernel<256, 128, 4, 2, true>), dim3(G), dim3(512), 0, st, k);
+      return conv_launch_fixup_tile(k, G, 256, 128, st);
+    }
+    hipLaunchKernelGGL((conv_fwd_kernel<256, 128, 4, 2, false>), dim3(tiles), dim3(512), 0, st, k);
+    return ONDA_LAUNCH_RESULT();
+  }
   if (balanced) {
     if (wide)
       hipLaunchKernelGGL((conv_fwd_kernel<128, 128, 2, 2, true>), dim3(G), dim3(256), 0, st, k);

@@ -156,7 +156,7 @@ def conv_forward(x, wp, k, stride, dil, pad, cout, out=None, scale=None, shift=N
             raise RuntimeError("onda_amd: row groups (ops.row_groups) need the pre-split conv path")
         tile_rows = ctypes.c_int(0)
         tiles = (query("onda_conv_l2_tiles_m_split", B * Ho * Wo, cout, k * k, Cin, split, 0, byref(tile_rows)) if l2
-                 else query("onda_conv_tiles_m", B * Ho * Wo))
+                 else query("onda_conv_tiles_mc", B * Ho * Wo, cout))
         stats = torch.empty(tiles, stats_rows, cout, device=x.device, dtype=torch.float32)
         if l2:  # GEMM rows one partial row covers: depends on the kernel the problem runs on (the BatchNorm row groups need it)
             stats._onda_tile_rows = tile_rows.value
