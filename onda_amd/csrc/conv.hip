@@ -94,6 +94,8 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void conv_fwd_kernel(con
     wrow[u] = static_cast<const float*>(a.w) + (size_t)(vn[u] ? n : 0) * wstride + ccol;
   }
 
+  // (Per-tile skipping of filter taps that only see padding, as conv_l2_kernel does it, was tried here in round 6: these problems
+  //  run ONE round of 128 x 128 tiles, so the launch ends with the tiles in the middle of the image, which skip nothing.)
   long long aofs[AL];
   f32x4 ar[AL], br[BL];
   int tap = k_begin / a.kcper, c0 = (k_begin - tap * a.kcper) * BK;
@@ -339,7 +341,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK a) {
   const int li = lane & 31, lh = lane >> 5;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
 
-  int bid = blockIdx.x;
+  // workgroups are dealt round-robin over the 8 XCDs: hand each XCD a contiguous band of the (pixel range, tap, channel tile)
+  // order, so that the workgroups that stream the same dy rows (all input-channel tiles of a tap and pixel range) and the same
+  // x rows find them in ONE L2 instead of eight (as conv_wgrad_l2_kernel does; round 6: this kernel read 3.1 TB/s from the
+  // Infinity Cache for operands that eight L2s each fetched for themselves)
+  int bid;
+  {
+    const int nblk = gridDim.x, q = nblk >> 3, r = nblk & 7, xcd = blockIdx.x & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+  }
   const int tile_c = bid % a.tilesC;
   bid /= a.tilesC;
   const int tap = bid % a.taps;
@@ -359,6 +369,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK a) {
   const bool va = n0 + acol < c.Cout, vb = c0 + bcol < c.Cin;
 
   f32x4 ar[AL], br[BL];
+  int p_wo[BL], p_ho[BL], p_b[BL];  // this thread's x rows of the K-step gload() fetches next (it is called once per K-step, in order)
+#pragma unroll
+  for (int u = 0; u < BL; ++u) {
+    const int m = mbeg + brow + RPB * u;
+    p_wo[u] = m % c.Wo;
+    const int tq = m / c.Wo;
+    p_ho[u] = tq % c.Ho;
+    p_b[u] = tq / c.Ho;
+  }
   auto gload = [&](int mb) {
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -372,15 +391,63 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK a) {
       bool ok = vb && m < mend;
       size_t pix = m;
       if (!direct && ok) {
-        const int wo = m % c.Wo, tq = m / c.Wo;
-        const int ho = tq % c.Ho, b = tq / c.Ho;
-        const int hi = ho * c.stride + dh, wi = wo * c.stride + dw;
+        // (b, ho, wo) of this thread's row, WALKED from K-step to K-step (round 6): four divisions per row and K-step were 600
+        // VALU instructions in front of every K-step's MFMAs (3 x 3 filters 101 TFLOP/s, 1 x 1 -- no index arithmetic -- 120)
+        const int hi = p_ho[u] * c.stride + dh, wi = p_wo[u] * c.stride + dw;
         ok = (unsigned)hi < (unsigned)c.Hi && (unsigned)wi < (unsigned)c.Wi;
-        pix = ((size_t)b * c.Hi + hi) * c.Wi + wi;
+        pix = ((size_t)p_b[u] * c.Hi + hi) * c.Wi + wi;
       }
       br[u] = ok ? *reinterpret_cast<const f32x4*>(a.x + pix * c.ldx + c0 + bcol) : z;
     }
   };
+  auto advance = [&](int steps) {  // the walk, `steps` K-steps further
+    if (direct || steps <= 0) return;
+#pragma unroll
+    for (int u = 0; u < BL; ++u) {
+      p_wo[u] += steps * BK;
+      while (p_wo[u] >= c.Wo) {
+        p_wo[u] -= c.Wo;
+        if (++p_ho[u] == c.Ho) {
+          p_ho[u] = 0;
+          ++p_b[u];
+        }
+      }
+    }
+  };
+  // K-steps (32 pixels) whose output rows all map to input rows outside the image for this tap are exact zeros (whole rows of a
+  // dilated tap: up to a quarter of the ASPP weight-gradient work): skipped, as conv_wgrad_l2_kernel does.  Output row ho is live
+  // for this tap iff live_lo <= ho < live_hi; a dead step jumps straight to the step of the next live row.
+  const int live_lo = dh >= 0 ? 0 : (-dh + c.stride - 1) / c.stride;
+  const int live_hi = dh > c.Hi - 1 ? 0 : min(c.Ho, (c.Hi - 1 - dh) / c.stride + 1);
+  const bool all_live = direct || (live_lo == 0 && live_hi == c.Ho);  // (the centre row of taps, undilated filters: nothing to test)
+  // (output row, column) of the first pixel of the K-step `u_kt`, walked like the threads' own rows: no division per K-step
+  int u_kt = 0, u_wo = mbeg % c.Wo, u_ho = (mbeg / c.Wo) % c.Ho;
+  auto next_live = [&](int kt) {
+    if (all_live) return kt;
+    if (live_lo >= live_hi) return KT;
+    for (;;) {
+      while (u_kt < kt) {  // walk to K-step kt
+        u_wo += BK;
+        while (u_wo >= c.Wo) {
+          u_wo -= c.Wo;
+          if (++u_ho == c.Ho) u_ho = 0;
+        }
+        ++u_kt;
+      }
+      if (kt >= KT) return KT;
+      int left = u_wo + min(BK, mend - (mbeg + kt * BK)), ho = u_ho;  // the rows this step touches
+      bool lv = false;
+      for (;;) {
+        lv |= ho >= live_lo && ho < live_hi;
+        left -= c.Wo;
+        if (left <= 0) break;
+        if (++ho == c.Ho) ho = 0;
+      }
+      if (lv) return kt;
+      ++kt;
+    }
+  };
+
   auto sstore = [&](int buf) {
     float* Ab = lds + buf * STAGE;
     float* Bb = Ab + BK * SA;
@@ -398,32 +465,53 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK a) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  if (KT > 0) {
-    gload(mbeg);
+  int kt = next_live(0), walk = 0, cur = 0;
+  if (kt < KT) {
+    advance(kt - walk);
+    walk = kt;
+    gload(mbeg + kt * BK);
     sstore(0);
   }
   __syncthreads();
-  for (int kt = 0; kt < KT; ++kt) {
-    const int cur = kt & 1;
-    const bool more = kt + 1 < KT;
-    if (more) gload(mbeg + (kt + 1) * BK);
+  while (kt < KT) {
+    const int nx = next_live(kt + 1);
+    const bool more = nx < KT;
+    if (more) {
+      advance(nx - walk);
+      walk = nx;
+      gload(mbeg + nx * BK);
+    }
     const float* Ab = lds + cur * STAGE + lh * SA + wm * TM * 32 + li;
     const float* Bb = lds + cur * STAGE + BK * SA + lh * SB + wn * TN * 32 + li;
+    // the operands of step kk + 1 are read while the four MFMAs of step kk run (two register sets): left to the compiler every
+    // kk was "read, wait, multiply" -- sixteen exposed LDS round trips per K-step, MFMA busy 0.66 of the SIMD cycles (round 6)
+    float af[2][TM], bf[2][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) af[0][i] = Ab[i * 32];
+#pragma unroll
+    for (int i = 0; i < TN; ++i) bf[0][i] = Bb[i * 32];
 #pragma unroll
     for (int kk = 0; kk < BK / 2; ++kk) {
-      float af[TM], bf[TN];
+      const int cu = kk & 1, nx = cu ^ 1;
+      if (kk + 1 < BK / 2) {
 #pragma unroll
-      for (int i = 0; i < TM; ++i) af[i] = Ab[2 * kk * SA + i * 32];
+        for (int i = 0; i < TM; ++i) af[nx][i] = Ab[2 * (kk + 1) * SA + i * 32];
 #pragma unroll
-      for (int i = 0; i < TN; ++i) bf[i] = Bb[2 * kk * SB + i * 32];
+        for (int i = 0; i < TN; ++i) bf[nx][i] = Bb[2 * (kk + 1) * SB + i * 32];
+      }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int jn = 0; jn < TN; ++jn)
-          acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[jn], acc[i][jn], 0, 0, 0);
+          acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cu][i], bf[cu][jn], acc[i][jn], 0, 0, 0);
+      // (the scheduler sinks the reads behind the MFMAs otherwise: reads of step kk + 1 first, then the MFMAs of step kk)
+      __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
     }
     if (more) sstore(cur ^ 1);
     __syncthreads();
+    kt = nx;
+    cur ^= 1;
   }
 
 #pragma unroll
