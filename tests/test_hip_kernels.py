@@ -537,6 +537,49 @@ def test_batchnorm_train_limb_planes(C, H, W, relu, res, track):
         assert int(nbt) == 1
 
 
+@pytest.mark.parametrize("C,H,W,B,first,relu,res", [(256, 33, 65, 4, 0, True, True), (64, 17, 33, 3, 0, False, False),
+                                                    (128, 33, 41, 5, 2, True, True), (2048, 9, 17, 2, 0, True, False)])
+def test_batchnorm_statistics_inside_the_apply_launches(C, H, W, B, first, relu, res):
+    """onda_bn_train_l2 / onda_bn_bwd_l2(fuse_sums) (round 6: the small statistics passes run by the first workgroups of the apply
+    launches, everybody waiting for an atomic count; off by default since its step-level A/B, ops.FUSE_BN_FINALIZE) against the
+    separate launches: the same arithmetic in the same order, so limb rows, statistics, running buffers and gradients must be
+    IDENTICAL -- one row group, two row groups with a straddling statistics row, more finalizing workgroups than apply work."""
+    from onda_amd import ops
+    if not (ops.CONV_MODE == "f16x2" and ops.H2_PATH == "dma"):
+        pytest.skip("limb planes exist in the f16x2 / dma configuration only")
+    g = torch.Generator().manual_seed(C + H)
+    x = torch.randn(B, H, W, 64, generator=g).to(DEV)
+    w1 = (torch.randn(C, 64, 1, 1, generator=g) / 8).to(DEV)
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).to(DEV), torch.randn(C, generator=g).to(DEV)
+    r = (torch.randn(B, H, W, C, generator=g) * 3).to(DEV) if res else None
+    gy = torch.randn(B, H, W, C, generator=g).to(DEV)
+
+    def run(fused):
+        old, ops.FUSE_BN_FINALIZE = ops.FUSE_BN_FINALIZE, fused
+        try:
+            rm, rv, nbt = torch.zeros(C, device=DEV), torch.ones(C, device=DEV), torch.zeros((), dtype=torch.int64, device=DEV)
+            xd, wd = x.clone().requires_grad_(True), w1.clone().requires_grad_(True)
+            rd = r.clone().requires_grad_(True) if res else None
+            with ops.row_groups(first):
+                yd, stats = ops.Conv2dFn.apply(xd, wd, None, ops._PackCache(), 1, 1, 0, 4, None)
+                zd = ops.BNTrainLimbFn.apply(yd, stats, gamma, beta, rd, relu, (rm, rv, nbt), 0.1)
+                lb = ops.limbs_of(zd)
+                zd.backward(gy)  # BatchNorm backward (dx as limb rows) -> the conv's data and weight gradients
+            torch.cuda.synchronize()
+            # (the scale of a limb tensor = the maximum over its buffer's 64 slots, every 32nd float; floats 1..3 carry the fused
+            #  launch's hand-over counter and its "gave up" flag)
+            return (lb.planes.clone(), lb.amax[::32].max(), rm, rv, xd.grad.clone(), wd.grad.clone(),
+                    rd.grad.clone() if res else torch.zeros(1), lb.amax.view(torch.int32)[1:3].clone())
+        finally:
+            ops.FUSE_BN_FINALIZE = old
+
+    a, b = run(True), run(False)
+    for name, u, v in zip(("out limbs", "out scale", "running mean", "running var", "dx through the conv", "dw", "dres"), a, b):
+        assert torch.equal(u, v), name
+    assert int(a[7][0]) == (C + 15) // 16 * (2 if first else 1) and int(b[7][0]) == 0  # (the fused launch ran: its finalizers counted)
+    assert int(a[7][1]) == 0, "the hand-over's bounded wait gave up"
+
+
 @pytest.mark.parametrize("C,H,W,B,first,relu,res", [(256, 65, 129, 4, 2, True, True), (64, 33, 41, 5, 2, True, False),
                                                     (128, 16, 16, 4, 2, False, True), (256, 9, 17, 4, 1, True, False)])
 def test_batchnorm_row_groups(C, H, W, B, first, relu, res):

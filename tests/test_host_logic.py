@@ -31,6 +31,7 @@ def test_library_exports_every_declared_symbol():
     assert ctypes.sizeof(_lib.OndaConv) == 19 * 4 + 4 + 8 + 8 + 8 + 8 + 8 and ctypes.sizeof(_lib.OndaSgdEntry) == 48
     assert ctypes.sizeof(_lib.OndaSwitchCfg) == 16 + 6 * 8
     assert lib.onda_conv_tiles_m(33540) == 263
+    assert lib.onda_conv_tiles_mc(33540, 256) == 263 and lib.onda_conv_tiles_mc(33540, 64) == 263  # (256 x 128 fp32 tiles: off)
 
 
 def test_missing_library_fails_loudly(monkeypatch):
