@@ -135,15 +135,12 @@ __device__ __forceinline__ void grid_wait(float* amax_buf, int target) {
   if (threadIdx.x == 0) {
     int* flag = reinterpret_cast<int*>(amax_buf) + 1;
     int spins = 0;
-    // (few, widely spaced polls: ~2 000 resident workgroups asking for one line at device scope every 0.25 us -- s_sleep 8, the
-    //  first form -- cost 175 us per launch; a poll every ~4 us asks 1-2 times per workgroup)
-    __builtin_amdgcn_s_sleep(127);
     while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
-      if (++spins > (1 << 18)) {  // ~1 s of s_sleep: never seen; do not hang the box
+      if (++spins > (1 << 21)) {  // ~1 s of s_sleep: never seen; do not hang the box
         reinterpret_cast<int*>(amax_buf)[2] = 1;
         break;
       }
-      __builtin_amdgcn_s_sleep(127);
+      __builtin_amdgcn_s_sleep(8);
     }
   }
   __syncthreads();
