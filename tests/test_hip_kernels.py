@@ -767,6 +767,36 @@ def test_upsample_align_corners(h, w, H, W):
     assert (cls.long() != ref_cls).float().mean().item() < 1e-4
 
 
+@pytest.mark.parametrize("K,ld,hw,HW", [(19, 32, (9, 17), (64, 128)), (19, 19, (9, 17), (64, 128)), (19, 20, (5, 7), (11, 13)),
+                                        (40, 40, (5, 7), (33, 47)), (19, 32, (65, 129), (512, 1024))])
+def test_upsample_argmax_confusion_matrix(K, ld, hw, HW):
+    """The evaluation tail (adaptation_model.py:127-166, func.py:77-79 fast_hist): hist += confusion matrix of the upsampled
+    argmax against the labels, labels >= K ignored; counted per workgroup in LDS for K <= 32, per pixel in memory above;
+    16-byte and 4-byte class loads (row stride 32 / 20 / 19 floats) give the same class map."""
+    from onda_amd import ops
+    from onda_amd.framework.utils.func import fast_hist
+    (h, w), (H, W) = hw, HW
+    B = 8 if H == 512 else 2
+    g = torch.Generator().manual_seed(K * 1000 + ld)
+    rows = (torch.randn(B, h, w, ld, generator=g) * 3).to(DEV)
+    out = rows[..., :K].permute(0, 3, 1, 2)
+    assert ops.logits_rows(out)[1] == ld  # read in place, with this row stride
+    labels = torch.randint(0, K + 3, (B, H, W), generator=g).to(torch.uint8)
+    labels[labels >= K] = 255
+    labels[0, : H // 2] = 3  # a block of one class: many pixels of a workgroup in one cell
+    hist = torch.arange(K * K, dtype=torch.int64).reshape(K, K).to(DEV)  # accumulated INTO, not overwritten
+    before = hist.cpu().numpy().copy()
+    ops.upsample_argmax_hist(out, labels.to(DEV), hist, K)
+    cls = ops.upsample_argmax(out, (H, W)).cpu().numpy()
+    ref = F.interpolate(out.cpu().contiguous(), size=(H, W), mode="bilinear", align_corners=True)
+    top2 = ref.topk(2, dim=1)[0]
+    decided = ((top2[:, 0] - top2[:, 1]) > 1e-5).numpy()
+    assert np.array_equal(cls[decided], ref.argmax(1).numpy()[decided])
+    want = fast_hist(labels.numpy().flatten().astype(np.int64), cls.flatten().astype(np.int64), K)
+    assert np.array_equal(hist.cpu().numpy() - before, want.astype(np.int64))
+    assert int(want.sum()) == int((labels != 255).sum())
+
+
 @pytest.mark.parametrize("case", ["mixed", "none_ignored", "all_ignored"])
 def test_losses_golden(golden, case):
     """Fused CE/RCE/MRKLD kernel against the reference's own numbers (fixture G3)."""

@@ -38,6 +38,8 @@ def main():
     sys.argv = sys.argv[:1]
     args = bench.parse()
     torch.cuda.set_device(0)
+    if os.environ.get("EVAL"):  # the forward-only evaluation path (config 1) instead of the adaptation step
+        return eval_path(args)
     with tempfile.TemporaryDirectory() as tmp:
         da, src, trg = bench.build_adapter(args, "cuda:0", tmp, 1)
         for i in range(3):
@@ -53,6 +55,32 @@ def main():
             agg[(fn, where)] += n
         for (fn, where), n in agg.most_common(40):
             print(f"{n:5d}  {fn:28s} {where}")
+
+
+def eval_path(args):
+    from onda_amd import ops
+    from onda_amd.config import hybrid_switch_cfg
+    from onda_amd.framework.handlers import get_model
+    from onda_amd.synthetic import fill_state_dict, synth_batch
+    cfg, _ = hybrid_switch_cfg(args.width, args.height, "cuda:0", "NONE", batch_size=1)
+    model = get_model(cfg, 19)
+    fill_state_dict(model, 1, 3.0)
+    model.eval()
+    f = {k: v.to("cuda:0") for k, v in synth_batch(8, args.height, args.width, seed=4000).items()}
+    hist = torch.zeros(19, 19, dtype=torch.int64, device="cuda:0")
+    with torch.no_grad():
+        for _ in range(3):
+            ops.upsample_argmax_hist(model(f["image"])[1]["out"], f["label"], hist, 19)
+        torch.cuda.synchronize()
+        with Sites() as s:
+            ops.upsample_argmax_hist(model(f["image"])[1]["out"], f["label"], hist, 19)
+    torch.cuda.synchronize()
+    print(sum(s.hits.values()), "copy-like dispatches in one forward of 8 frames")
+    agg = collections.Counter()
+    for (fn, where, nb), n in s.hits.items():
+        agg[(fn, where, nb)] += n
+    for (fn, where, nb), n in agg.most_common(40):
+        print(f"{n:5d}  {fn:28s} {nb:10d} B  {where}")
 
 
 if __name__ == "__main__":

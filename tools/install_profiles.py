@@ -18,7 +18,7 @@ t["command"] = ("rocprofv3 --pmc FETCH_SIZE (and, separately, WRITE_SIZE) --kern
                 + t.get("workload", "python3 tools/one_pass.py") + "; tools/pmc_summary.py")
 json.dump(t, open(os.path.join(P, f"{tag}_hbm_traffic.json"), "w"), indent=1)
 import bench  # noqa: E402  (committed_traffic reads the file just written)
-lines = sorted(glob.glob(os.path.join(G, f"{tag}_bench_line*.json"))) + [os.path.join(G, f"{tag}_profiled_bench_line.json"),
+lines = sorted(glob.glob(os.path.join(G, f"{tag}_bench_line*.json"))) + sorted(glob.glob(os.path.join(G, f"{tag}_f32_bench_line.json"))) + [os.path.join(G, f"{tag}_profiled_bench_line.json"),
                                                                          os.path.join(G, f"{tag}_profiled_bench_line_one_stream.json")]
 for f in lines:
     j = json.load(open(f))
@@ -30,7 +30,7 @@ for f in lines:
     open(os.path.join(P, os.path.basename(f)), "w").write(json.dumps(j) + "\n")
     print(os.path.basename(f), j["ms_per_step"], j["value"], (j.get("roofline") or {}).get("frac"))
 for n in ("bench_kernel_stats.csv", "bench_kernel_stats_one_stream.csv", "sq_counters.txt", "conv_shapes.txt", "hbm_traffic_top.txt",
-          "step_kernel_table.txt", "power_summary.txt"):
+          "step_kernel_table.txt", "power_summary.txt", "f32_sq_counters.txt", "f32_conv_shapes.txt", "f32_power_summary.txt"):
     if os.path.exists(os.path.join(G, f"{tag}_{n}")):
         shutil.copy(os.path.join(G, f"{tag}_{n}"), os.path.join(P, f"{tag}_{n}"))
 print("library_src", src)

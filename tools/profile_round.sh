@@ -35,5 +35,12 @@ ONDA_SIDE_STREAMS=0 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format cs
 python3 tools/pmc_summary.py $G/prof_$tag/fetch $G/prof_$tag/write $G/${tag}_hbm_traffic.json "ONDA_SIDE_STREAMS=0 python3 $pmc_cmd (the bench step: 5 steps + set-up passes)" > $G/${tag}_hbm_traffic_top.txt
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $G/prof_$tag/sq -o sq -- python3 tools/one_pass.py > /dev/null 2> $G/prof_$tag/sq.err
 python3 tools/sq_summary.py $(find $G/prof_$tag/sq -name "*counter_collection.csv" | head -1) 12 > $G/${tag}_sq_counters.txt 2>&1
+# the exact-fp32 mode (ONDA_CONV_MODE=f32): bench line, per-shape rates, SQ counters, board power -- each in a run of its own
+ONDA_CONV_MODE=f32 python3 bench.py --steps 6 --warmup 2 $common --no-exact-f32 --no-roofline > $G/${tag}_f32_bench_line.json 2>/dev/null
+ONDA_CONV_MODE=f32 python3 tools/conv_shapes.py > $G/${tag}_f32_conv_shapes.txt 2>&1
+ONDA_CONV_MODE=f32 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $G/prof_$tag/sqf -o sq -- python3 tools/one_pass.py > /dev/null 2> $G/prof_$tag/sqf.err
+python3 tools/sq_summary.py $(find $G/prof_$tag/sqf -name "*counter_collection.csv" | head -1) 12 > $G/${tag}_f32_sq_counters.txt 2>&1
+ONDA_CONV_MODE=f32 python3 tools/power_log.py $G/${tag}_f32_power.csv -- python3 bench.py --steps 12 --warmup 3 $common --no-exact-f32 --no-roofline > /dev/null 2> $G/${tag}_f32_power_summary.txt
+rm -rf $G/${tag}_f32_power.csv $G/prof_$tag/sqf
 rm -rf $G/prof_$tag/fetch $G/prof_$tag/write $G/prof_$tag/sq $G/prof_$tag/kt $G/prof_$tag/kt1 $G/prof_$tag/tr   # (raw traces: hundreds of MB)
 head -c 400 $G/${tag}_bench_line.json; echo; head -12 $G/${tag}_bench_kernel_stats.csv; cat $G/${tag}_sq_counters.txt | head -8
