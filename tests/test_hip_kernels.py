@@ -797,6 +797,16 @@ def test_upsample_argmax_confusion_matrix(K, ld, hw, HW):
     assert int(want.sum()) == int((labels != 255).sum())
 
 
+def test_upsample_argmax_confusion_matrix_all_ignored():
+    """Every label outside [0, K): the matrix is left exactly as it was (fast_hist keeps nothing, func.py:77-79)."""
+    from onda_amd import ops
+    rows = torch.randn(1, 9, 17, 32, generator=torch.Generator().manual_seed(5)).to(DEV)
+    out = rows[..., :19].permute(0, 3, 1, 2)
+    hist = torch.arange(361, dtype=torch.int64).reshape(19, 19).to(DEV)
+    ops.upsample_argmax_hist(out, torch.full((1, 64, 128), 255, dtype=torch.uint8, device=DEV), hist, 19)
+    assert torch.equal(hist.cpu(), torch.arange(361, dtype=torch.int64).reshape(19, 19))
+
+
 @pytest.mark.parametrize("case", ["mixed", "none_ignored", "all_ignored"])
 def test_losses_golden(golden, case):
     """Fused CE/RCE/MRKLD kernel against the reference's own numbers (fixture G3)."""
